@@ -1,0 +1,142 @@
+/*
+ * gsr.h -- C-ABI of the MI355X-native Gaussian-splatting rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and sizes, no torch
+ * types.  Every entry point replaces one L0 interface of the reference
+ * (HuajianUP/Photo-SLAM); the LibTorch wrappers RasterizeGaussiansCUDA /
+ * RasterizeGaussiansBackwardCUDA / markVisible / distCUDA2 sit directly on top
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * All pointers are DEVICE pointers (gfx950 HBM) unless stated; fp32 throughout.
+ * A null pointer stands for an absent optional exactly as in the reference, where
+ * an empty tensor yields data_ptr()==nullptr (src/gaussian_rasterizer.cpp:209-219,
+ * cuda_rasterizer/forward.cu:205,241).
+ * The library owns no device memory: scratch comes from the caller through
+ * gsr_alloc_fn (the reference's std::function<char*(size_t)> resize callbacks,
+ * cuda_rasterizer/rasterizer.h:36-38, src/rasterize_points.cu:28-34).
+ * All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
+ * stream).  Functions return GSR_OK or a negative gsr_status; they never throw.
+ */
+#ifndef GSR_H
+#define GSR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gsr_status {
+	GSR_OK = 0,
+	GSR_ERR_INVALID_ARG = -1,   /* bad shape / forbidden null / inconsistent optional combination */
+	GSR_ERR_ALLOC = -2,         /* a gsr_alloc_fn returned NULL */
+	GSR_ERR_HIP = -3,           /* a HIP runtime call or kernel launch failed (see gsr_last_hip_error) */
+	GSR_ERR_UNSUPPORTED = -4    /* e.g. tile grid larger than 65535 in one dimension */
+} gsr_status;
+
+/* Resize-and-return-pointer callback; must return a device pointer to at least
+ * `bytes` bytes, 16-byte aligned (torch allocations are 512-byte aligned).
+ * Replaces std::function<char*(size_t)> of Rasterizer::forward
+ * (cuda_rasterizer/rasterizer.h:36-38). */
+typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
+
+/* Rasterizer::forward parameter list, cuda_rasterizer/rasterizer.h:35-59, 1:1. */
+typedef struct gsr_forward_args {
+	int P, D, M;                 /* #Gaussians, active SH degree, SH coeffs per channel stored */
+	const float* background;     /* [3] */
+	int width, height;
+	const float* means3D;        /* [P,3] */
+	const float* shs;            /* [P,M,3] or NULL */
+	const float* colors_precomp; /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+	const float* opacities;      /* [P] */
+	const float* scales;         /* [P,3] or NULL */
+	float scale_modifier;
+	const float* rotations;      /* [P,4] (r,x,y,z), NOT normalised in-kernel (forward.cu:127) */
+	const float* cov3D_precomp;  /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+	const float* viewmatrix;     /* [16] = W2C^T row-major, i.e. element (r,c) at [4c+r] */
+	const float* projmatrix;     /* [16] = (Proj W2C)^T */
+	const float* cam_pos;        /* [3] */
+	float tan_fovx, tan_fovy;
+	int prefiltered;
+	float* out_color;            /* [3,H,W] written for every pixel */
+	int* radii;                  /* [P] or NULL */
+} gsr_forward_args;
+
+/* Rasterizer::forward, cuda_rasterizer/rasterizer_impl.cu:198-336.
+ * Fills out_color and radii, returns the number of (tile, Gaussian) instances in
+ * *num_rendered.  The three scratch buffers are opaque and must be handed unchanged
+ * to gsr_backward.  One host synchronisation (to size the binning buffer), as the
+ * reference (rasterizer_impl.cu:281).  P == 0 is a valid no-op that leaves
+ * out_color untouched (src/rasterize_points.cu:81). */
+int gsr_forward(const gsr_forward_args* args,
+                gsr_alloc_fn geometryBuffer, void* geometry_ctx,
+                gsr_alloc_fn binningBuffer, void* binning_ctx,
+                gsr_alloc_fn imageBuffer, void* image_ctx,
+                void* stream, int* num_rendered);
+
+/* Rasterizer::backward parameter list, cuda_rasterizer/rasterizer.h:61-91. */
+typedef struct gsr_backward_args {
+	int P, D, M, R;
+	const float* background;
+	int width, height;
+	const float* means3D;
+	const float* shs;
+	const float* colors_precomp;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* cov3D_precomp;
+	const float* viewmatrix;
+	const float* projmatrix;
+	const float* campos;
+	float tan_fovx, tan_fovy;
+	const int* radii;            /* [P] or NULL (then the copy inside geom_buffer is used) */
+	char* geom_buffer;
+	char* binning_buffer;
+	char* image_buffer;
+	const float* dL_dpix;        /* [3,H,W] */
+	float* dL_dmean2D;           /* [P,3]  (.z stays 0) */
+	float* dL_dconic;            /* [P,4]  the reference's [P,2,2]; .z never written */
+	float* dL_dopacity;          /* [P]   */
+	float* dL_dcolor;            /* [P,3] */
+	float* dL_dmean3D;           /* [P,3] */
+	float* dL_dcov3D;            /* [P,6] */
+	float* dL_dsh;               /* [P,M,3] or NULL when shs is NULL */
+	float* dL_dscale;            /* [P,3] or NULL when scales is NULL */
+	float* dL_drot;              /* [P,4] or NULL when scales is NULL */
+} gsr_backward_args;
+
+/* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.
+ * Unlike the reference the gradient arrays need NOT be zero-filled by the caller:
+ * every element of every non-null output is written (zeros for culled Gaussians),
+ * which removes the reference's 300 B/Gaussian torch::zeros pass
+ * (src/rasterize_points.cu:149-157).  No host synchronisation. */
+int gsr_backward(const gsr_backward_args* args, void* stream);
+
+/* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
+ * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* SimpleKNN::knn, third_party/simple-knn/simple_knn.cu:185-221: meanDists[i] = mean of
+ * the squared distances from points[i] to its 3 nearest other points.  The reference
+ * cudaMalloc's internally; here scratch comes from the callback like everything else. */
+int gsr_knn_mean_dist2(int P, const float* points, float* meanDists,
+                       gsr_alloc_fn scratchBuffer, void* scratch_ctx, void* stream);
+
+/* Scratch sizes (bytes) gsr_forward will request, for callers that pre-allocate. */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_binning_bytes(int num_rendered);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_knn_scratch_bytes(int P);
+
+const char* gsr_strerror(int status);
+/* hipError_t of the last failing HIP call on this thread (0 if none), and its name. */
+int gsr_last_hip_error(void);
+const char* gsr_last_hip_error_string(void);
+/* "hip-gfx950" for the product library. */
+const char* gsr_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

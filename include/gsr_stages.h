@@ -1,0 +1,60 @@
+/*
+ * gsr_stages.h -- stage-level entry points of libgsr_hip.so, used by the parity tests
+ * to compare every intermediate of the pipeline with the oracle (tile rectangles, sort
+ * order, tile ranges, n_contrib, ...) and to exercise the scan / radix-sort building
+ * blocks at sizes the full pipeline does not reach in a unit test.
+ * Same conventions as gsr.h (device pointers, explicit stream, int status).
+ */
+#ifndef GSR_STAGES_H
+#define GSR_STAGES_H
+#include "gsr.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Typed views into the opaque scratch buffers of gsr_forward.  The layout is this
+ * library's own (it replaces GeometryState / BinningState / ImageState,
+ * cuda_rasterizer/rasterizer_impl.h:32-62); the reference's contract is only
+ * "same bytes back in backward". */
+typedef struct gsr_geometry_view {
+	uint32_t* depth_key;     /* [P]  float bits of view-space z; 0xFFFFFFFF if culled           */
+	uint32_t* tiles_touched; /* [P]                                                             */
+	int*      radii;         /* [P]  internal copy of radii                                     */
+	uint16_t* rect;          /* [P][4] tile rect (min.x, min.y, max.x, max.y), getRect output   */
+	float*    rec;           /* [P][12] blend record: x,y,conic.x,conic.y | conic.z,opacity,r,g | b,-,-,- */
+	float*    cov3D;         /* [P][6]                                                          */
+	uint8_t*  clamped;       /* [P]  bit c set = colour channel c was clamped                   */
+	uint32_t* order;         /* [P]  Gaussian ids in (depth, id) order                          */
+	uint32_t* offsets;       /* [P]  exclusive scan of tiles_touched[order[.]]                  */
+} gsr_geometry_view;
+typedef struct gsr_binning_view {
+	uint32_t* point_list;    /* [R] Gaussian id per instance, sorted by (tile, depth, id)       */
+	uint32_t* tile_keys;     /* [R] tile id per sorted instance                                 */
+} gsr_binning_view;
+typedef struct gsr_image_view {
+	float*    final_T;       /* [H*W] */
+	uint32_t* n_contrib;     /* [H*W] */
+	uint32_t* ranges;        /* [T][2] */
+} gsr_image_view;
+
+int gsr_view_geometry(char* geom_buffer, int P, gsr_geometry_view* out);
+int gsr_view_binning(char* binning_buffer, int R, int width, int height, gsr_binning_view* out);
+int gsr_view_image(char* image_buffer, int width, int height, gsr_image_view* out);
+
+/* Exclusive / inclusive prefix sum of n uint32 (the cub::DeviceScan::InclusiveSum
+ * replacement, rasterizer_impl.cu:276).  scratch: gsr_scan_scratch_bytes(n). */
+size_t gsr_scan_scratch_bytes(int n);
+int gsr_stage_scan_u32(const uint32_t* in, uint32_t* out, int n, int inclusive, char* scratch, void* stream);
+
+/* Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit,end_bit)
+ * (the cub::DeviceRadixSort::SortPairs replacement, rasterizer_impl.cu:303-308 and
+ * simple_knn.cu:210-213).  values_in == NULL means values = 0..n-1.  Inputs are only
+ * read; the result is in keys_out/values_out.  scratch: gsr_sort_scratch_bytes(n). */
+size_t gsr_sort_scratch_bytes(int n);
+int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
+                               int n, int begin_bit, int end_bit, char* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

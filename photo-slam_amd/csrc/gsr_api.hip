@@ -1,0 +1,319 @@
+// gsr_api.hip -- the C-ABI of libgsr_hip.so (include/gsr.h, include/gsr_stages.h):
+// argument validation, scratch carving, and the launch sequence of the forward and
+// backward passes on the caller's HIP stream.
+//
+// Forward launch sequence (reference: Rasterizer::forward, rasterizer_impl.cu:198-336):
+//   memset counters -> preprocess (+ per-wave atomic sum of tiles = num_rendered)
+//   -> async D2H of num_rendered + event            (the reference blocks here, :281)
+//   -> depth sort of the P Gaussians (4 x 8-bit passes) -> exclusive scan in depth order
+//   -> host waits for the event only now, sizes the binning buffer
+//   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
+#include "kernels.h"
+#include "../../include/gsr_stages.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace gsr {
+
+static thread_local int t_last_err = 0;
+static thread_local char t_last_what[256] = {0};
+void set_last_hip_error(int err, const char* what)
+{
+	t_last_err = err;
+	snprintf(t_last_what, sizeof(t_last_what), "%s: %s", what ? what : "?", hipGetErrorString((hipError_t)err));
+}
+
+// Pinned word + event used for the single device->host read of num_rendered; one per host
+// thread, so concurrent callers on different threads do not share state.
+struct HostSync {
+	uint32_t* pinned = nullptr;
+	hipEvent_t ev = nullptr;
+	int init()
+	{
+		if (pinned) return GSR_OK;
+		GSR_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
+		GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		return GSR_OK;
+	}
+};
+static thread_local HostSync t_sync;
+
+static inline size_t geometry_bytes(int P)
+{
+	size_t b = 0;
+	GeometryState::carve(nullptr, (size_t)P, &b);
+	return b;
+}
+static inline size_t binning_bytes(int R)
+{
+	size_t b = 0;
+	BinningState::carve(nullptr, (size_t)R, &b);
+	return b;
+}
+static inline size_t image_bytes(int W, int H)
+{
+	size_t b = 0;
+	const size_t T = (size_t)div_up(W, TILE) * div_up(H, TILE);
+	ImageState::carve(nullptr, (size_t)W * H, T, &b);
+	return b;
+}
+
+static int validate_common(int P, int D, int M, int W, int H, const void* shs, const void* colors, const void* scales,
+                           const void* rotations, const void* cov3D)
+{
+	if (P < 0 || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARG;
+	if ((shs == nullptr) == (colors == nullptr)) return GSR_ERR_INVALID_ARG;  // exactly one (gaussian_rasterizer.cpp:201-203)
+	const bool sr = scales != nullptr && rotations != nullptr;
+	if ((scales != nullptr) != (rotations != nullptr)) return GSR_ERR_INVALID_ARG;
+	if (sr == (cov3D != nullptr)) return GSR_ERR_INVALID_ARG;                 // exactly one (:205-207)
+	if (shs) {
+		if (D < 0 || D > 3) return GSR_ERR_UNSUPPORTED;
+		if (M < (D + 1) * (D + 1)) return GSR_ERR_INVALID_ARG;
+	}
+	if (div_up(W, TILE) > 65535 || div_up(H, TILE) > 65535) return GSR_ERR_UNSUPPORTED;
+	return GSR_OK;
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+size_t gsr_geometry_bytes(int P) { return geometry_bytes(P < 0 ? 0 : P); }
+size_t gsr_binning_bytes(int R) { return binning_bytes(R < 0 ? 0 : R); }
+size_t gsr_image_bytes(int W, int H) { return (W <= 0 || H <= 0) ? 0 : image_bytes(W, H); }
+size_t gsr_knn_scratch_bytes(int P) { return knn_scratch_bytes(P < 0 ? 0 : P); }
+size_t gsr_scan_scratch_bytes(int n) { return scan_scratch_elems(n < 0 ? 0 : n) * sizeof(uint32_t); }
+size_t gsr_sort_scratch_bytes(int n)
+{
+	const size_t m = (size_t)(n < 0 ? 0 : n);
+	return (sort_scratch_elems((int)m) + 2 * m + 64) * sizeof(uint32_t);  // histograms + one temp (key, value) buffer pair
+}
+
+const char* gsr_strerror(int status)
+{
+	switch (status) {
+		case GSR_OK: return "ok";
+		case GSR_ERR_INVALID_ARG: return "invalid argument";
+		case GSR_ERR_ALLOC: return "scratch allocation callback returned NULL";
+		case GSR_ERR_HIP: return "HIP runtime error";
+		case GSR_ERR_UNSUPPORTED: return "unsupported configuration";
+		default: return "unknown status";
+	}
+}
+int gsr_last_hip_error(void) { return t_last_err; }
+const char* gsr_last_hip_error_string(void) { return t_last_what; }
+const char* gsr_backend(void)
+{
+#ifdef GSR_EMU
+	return "emu-wave64";
+#else
+	return "hip-gfx950";
+#endif
+}
+
+int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* geometry_ctx, gsr_alloc_fn binningBuffer,
+                void* binning_ctx, gsr_alloc_fn imageBuffer, void* image_ctx, void* stream_, int* num_rendered)
+{
+	if (!a || !geometryBuffer || !binningBuffer || !imageBuffer || !num_rendered) return GSR_ERR_INVALID_ARG;
+	*num_rendered = 0;
+	int st = validate_common(a->P, a->D, a->M, a->width, a->height, a->shs, a->colors_precomp, a->scales, a->rotations,
+	                         a->cov3D_precomp);
+	if (a->P == 0) return GSR_OK;  // src/rasterize_points.cu:81
+	if (st != GSR_OK) return st;
+	if (!a->background || !a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->cam_pos || !a->out_color)
+		return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	const int P = a->P, W = a->width, H = a->height;
+	const int grid_x = div_up(W, TILE), grid_y = div_up(H, TILE), tiles = grid_x * grid_y;
+
+	char* geom_chunk = geometryBuffer(geometry_ctx, geometry_bytes(P));
+	if (!geom_chunk) return GSR_ERR_ALLOC;
+	GeometryState g = GeometryState::carve(geom_chunk, (size_t)P);
+	char* img_chunk = imageBuffer(image_ctx, image_bytes(W, H));
+	if (!img_chunk) return GSR_ERR_ALLOC;
+	ImageState im = ImageState::carve(img_chunk, (size_t)W * H, (size_t)tiles);
+
+	if ((st = t_sync.init()) != GSR_OK) return st;
+	GSR_HIP(hipMemsetAsync(g.counters, 0, 32 * sizeof(uint32_t), stream));
+
+	PreprocessParams pp;
+	pp.P = P; pp.D = a->D; pp.M = a->M;
+	pp.means3D = a->means3D; pp.scales = a->scales; pp.scale_modifier = a->scale_modifier; pp.rotations = a->rotations;
+	pp.opacities = a->opacities; pp.shs = a->shs; pp.cov3D_precomp = a->cov3D_precomp; pp.colors_precomp = a->colors_precomp;
+	pp.view = a->viewmatrix; pp.proj = a->projmatrix; pp.campos = a->cam_pos;
+	pp.W = W; pp.H = H; pp.tan_fovx = a->tan_fovx; pp.tan_fovy = a->tan_fovy;
+	pp.focal_y = H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:221-222
+	pp.focal_x = W / (2.0f * a->tan_fovx);
+	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
+	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
+
+	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	GSR_HIP(hipEventRecord(t_sync.ev, stream));
+
+	// depth order (stable: equal depths keep ascending Gaussian id)
+	uint32_t *kres = nullptr, *vres = nullptr;
+	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
+	                            g.sort_scratch, stream, &kres, &vres)) != GSR_OK)
+		return st;
+	// vres == g.order (4 passes end in the ping buffers)
+	if ((st = launch_scan_u32(g.tiles_touched, g.order, g.offsets, P, false, g.scan_scratch, stream)) != GSR_OK) return st;
+
+	GSR_HIP(hipEventSynchronize(t_sync.ev));
+	const int R = (int)*t_sync.pinned;
+	if (R < 0) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
+	char* bin_chunk = binningBuffer(binning_ctx, binning_bytes(R));
+	if (!bin_chunk) return GSR_ERR_ALLOC;
+	BinningState bs = BinningState::carve(bin_chunk, (size_t)R);
+
+	GSR_HIP(hipMemsetAsync(im.ranges, 0, (size_t)tiles * sizeof(uint2), stream));  // rasterizer_impl.cu:310
+	uint32_t* point_list = bs.vals_a;
+	if (R > 0) {
+		if ((st = launch_emit_instances(P, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;
+		const int bits = (int)higher_msb((uint32_t)tiles);
+		uint32_t* tkeys = nullptr;
+		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
+		                            bs.sort_scratch, stream, &tkeys, &point_list)) != GSR_OK)
+			return st;
+		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream)) != GSR_OK) return st;
+	}
+
+	BlendFwdParams bp;
+	bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
+	bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.out_color = a->out_color;
+	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
+	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
+	*num_rendered = R;
+	return GSR_OK;
+}
+
+int gsr_backward(const gsr_backward_args* a, void* stream_)
+{
+	if (!a) return GSR_ERR_INVALID_ARG;
+	int st = validate_common(a->P, a->D, a->M, a->width, a->height, a->shs, a->colors_precomp, a->scales, a->rotations,
+	                         a->cov3D_precomp);
+	if (a->P == 0) return GSR_OK;
+	if (st != GSR_OK) return st;
+	if (!a->background || !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos || !a->geom_buffer ||
+	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor ||
+	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
+		return GSR_ERR_INVALID_ARG;
+	if (a->shs && !a->dL_dsh) return GSR_ERR_INVALID_ARG;
+	if (a->scales && (!a->dL_dscale || !a->dL_drot)) return GSR_ERR_INVALID_ARG;
+	if (a->R > 0 && !a->binning_buffer) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	const int P = a->P, W = a->width, H = a->height, R = a->R;
+	const int grid_x = div_up(W, TILE), grid_y = div_up(H, TILE), tiles = grid_x * grid_y;
+	GeometryState g = GeometryState::carve(a->geom_buffer, (size_t)P);
+	ImageState im = ImageState::carve(a->image_buffer, (size_t)W * H, (size_t)tiles);
+	BinningState bs = BinningState::carve(a->binning_buffer, (size_t)R);
+	const int passes = tile_sort_passes(tiles);
+	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
+
+	// accumulators of the blend backward (44 B/Gaussian; everything else is written exactly once)
+	GSR_HIP(hipMemsetAsync(a->dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), stream));
+	GSR_HIP(hipMemsetAsync(a->dL_dconic, 0, (size_t)P * 4 * sizeof(float), stream));
+	GSR_HIP(hipMemsetAsync(a->dL_dopacity, 0, (size_t)P * sizeof(float), stream));
+	GSR_HIP(hipMemsetAsync(a->dL_dcolor, 0, (size_t)P * 3 * sizeof(float), stream));
+
+	if (R > 0) {
+		BlendBwdParams bp;
+		bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
+		bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.dL_dpix = a->dL_dpix;
+		bp.dL_dmean2D = a->dL_dmean2D; bp.dL_dconic = a->dL_dconic; bp.dL_dopacity = a->dL_dopacity;
+		bp.dL_dcolor = a->dL_dcolor;
+		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
+		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
+	}
+
+	PreprocessBwdParams pb;
+	pb.P = P; pb.D = a->D; pb.M = a->M;
+	pb.means3D = a->means3D; pb.radii = a->radii ? a->radii : g.radii; pb.shs = a->shs; pb.clamped = g.clamped;
+	pb.scales = a->scales; pb.rotations = a->rotations; pb.scale_modifier = a->scale_modifier;
+	pb.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
+	pb.view = a->viewmatrix; pb.proj = a->projmatrix; pb.campos = a->campos;
+	pb.focal_y = H / (2.0f * a->tan_fovy);
+	pb.focal_x = W / (2.0f * a->tan_fovx);
+	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
+	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dcolor = a->dL_dcolor;
+	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
+	pb.dL_drot = a->dL_drot;
+	return launch_preprocess_bwd(pb, stream);
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+	(void)projmatrix;  // the reference projects and discards (auxiliary.h:148-151); only view-space z decides
+	if (P < 0) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!means3D || !viewmatrix || !present) return GSR_ERR_INVALID_ARG;
+	return launch_check_frustum(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int gsr_knn_mean_dist2(int P, const float* points, float* meanDists, gsr_alloc_fn scratchBuffer, void* scratch_ctx,
+                       void* stream)
+{
+	if (P < 0) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!points || !meanDists || !scratchBuffer) return GSR_ERR_INVALID_ARG;
+	char* scratch = scratchBuffer(scratch_ctx, knn_scratch_bytes(P));
+	if (!scratch) return GSR_ERR_ALLOC;
+	return launch_knn(P, points, meanDists, scratch, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- gsr_stages.h
+int gsr_view_geometry(char* geom_buffer, int P, gsr_geometry_view* out)
+{
+	if (!geom_buffer || P < 0 || !out) return GSR_ERR_INVALID_ARG;
+	GeometryState g = GeometryState::carve(geom_buffer, (size_t)P);
+	out->depth_key = g.depth_key; out->tiles_touched = g.tiles_touched; out->radii = g.radii; out->rect = g.rect;
+	out->rec = reinterpret_cast<float*>(g.rec); out->cov3D = g.cov3D; out->clamped = g.clamped; out->order = g.order;
+	out->offsets = g.offsets;
+	return GSR_OK;
+}
+int gsr_view_binning(char* binning_buffer, int R, int width, int height, gsr_binning_view* out)
+{
+	if (!binning_buffer || R < 0 || !out || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
+	BinningState b = BinningState::carve(binning_buffer, (size_t)R);
+	const int passes = tile_sort_passes(div_up(width, TILE) * div_up(height, TILE));
+	out->point_list = (passes % 2) ? b.vals_b : b.vals_a;
+	out->tile_keys = (passes % 2) ? b.keys_b : b.keys_a;
+	return GSR_OK;
+}
+int gsr_view_image(char* image_buffer, int width, int height, gsr_image_view* out)
+{
+	if (!image_buffer || !out || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
+	const size_t T = (size_t)div_up(width, TILE) * div_up(height, TILE);
+	ImageState im = ImageState::carve(image_buffer, (size_t)width * height, T);
+	out->final_T = im.final_T; out->n_contrib = im.n_contrib; out->ranges = reinterpret_cast<uint32_t*>(im.ranges);
+	return GSR_OK;
+}
+int gsr_stage_scan_u32(const uint32_t* in, uint32_t* out, int n, int inclusive, char* scratch, void* stream)
+{
+	if (n < 0 || (n > 0 && (!in || !out || !scratch))) return GSR_ERR_INVALID_ARG;
+	return launch_scan_u32(in, nullptr, out, n, inclusive != 0, reinterpret_cast<uint32_t*>(scratch), (hipStream_t)stream);
+}
+int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out, int n,
+                               int begin_bit, int end_bit, char* scratch, void* stream_)
+{
+	if (n < 0 || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit) return GSR_ERR_INVALID_ARG;
+	if (n == 0) return GSR_OK;
+	if (!keys_in || !keys_out || !values_out || !scratch) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	const int passes = div_up(end_bit - begin_bit, RADIX_BITS);
+	// keys_in/values_in are only read; a temp pair carved from scratch is the other half of the
+	// ping-pong, arranged so that the final pass lands in (keys_out, values_out).
+	uint32_t* sc = reinterpret_cast<uint32_t*>(scratch);
+	uint32_t* tmp_k = sc + sort_scratch_elems(n);
+	uint32_t* tmp_v = tmp_k + n;
+	uint32_t *kp, *vp, *kq, *vq;  // ping, pong
+	if (passes % 2) { kq = keys_out; vq = values_out; kp = tmp_k; vp = tmp_v; }
+	else            { kp = keys_out; vp = values_out; kq = tmp_k; vq = tmp_v; }
+	uint32_t *kres, *vres;
+	return launch_radix_sort(keys_in, values_in, kp, vp, kq, vq, n, begin_bit, end_bit, sc, stream, &kres, &vres);
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// kernels.h -- parameter blocks and host-side launchers of every device stage.
+#pragma once
+#include "state.h"
+
+namespace gsr {
+
+struct PreprocessParams {
+	int P, D, M;
+	const float* means3D;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* opacities;
+	const float* shs;
+	const float* cov3D_precomp;
+	const float* colors_precomp;
+	const float* view;    // [16] device
+	const float* proj;    // [16] device
+	const float* campos;  // [3]  device
+	int W, H;
+	float tan_fovx, tan_fovy, focal_x, focal_y;
+	int grid_x, grid_y;
+	int* radii_out;  // caller's radii (nullable)
+};
+int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);
+int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
+
+int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
+
+struct BlendFwdParams {
+	const uint2* ranges;
+	const uint32_t* point_list;
+	const float4* rec;
+	const float* bg;
+	float* final_T;
+	uint32_t* n_contrib;
+	float* out_color;
+	int W, H, grid_x, tiles;
+};
+int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
+
+struct BlendBwdParams {
+	const uint2* ranges;
+	const uint32_t* point_list;
+	const float4* rec;
+	const float* bg;
+	const float* final_T;
+	const uint32_t* n_contrib;
+	const float* dL_dpix;   // [3,H,W]
+	float* dL_dmean2D;      // [P,3]
+	float* dL_dconic;       // [P,4]
+	float* dL_dopacity;     // [P]
+	float* dL_dcolor;       // [P,3]
+	int W, H, grid_x, tiles;
+};
+int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
+
+struct PreprocessBwdParams {
+	int P, D, M;
+	const float* means3D;
+	const int* radii;
+	const float* shs;
+	const uint8_t* clamped;
+	const float* scales;
+	const float* rotations;
+	float scale_modifier;
+	const float* cov3D;     // geom.cov3D or cov3D_precomp
+	const float* view;      // [16] device
+	const float* proj;      // [16] device
+	const float* campos;    // [3] device
+	float focal_x, focal_y, tan_fovx, tan_fovy;
+	const float* dL_dmean2D;  // [P,3]
+	const float* dL_dconic;   // [P,4]
+	const float* dL_dcolor;   // [P,3]
+	float* dL_dmean3D;        // [P,3]
+	float* dL_dcov3D;         // [P,6]
+	float* dL_dsh;            // [P,M,3] nullable
+	float* dL_dscale;         // [P,3] nullable
+	float* dL_drot;           // [P,4] nullable
+};
+int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
+
+// simple-knn
+size_t knn_scratch_bytes(int P);
+int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipStream_t stream);
+
+}  // namespace gsr

@@ -1,0 +1,255 @@
+// preprocess.hip -- per-Gaussian forward stage: cull, project, 3D->2D covariance (EWA),
+// conic, screen radius, tile rectangle, SH -> RGB, packed blend record.
+//
+// Semantics follow preprocessCUDA (cuda_rasterizer/forward.cu:155-256) and its helpers
+// (forward.cu:20-152, auxiliary.h:41-164).  This translation unit is compiled with
+// -ffp-contract=off and evaluates every expression in the reference's source order, so
+// that radii / tile rectangles / tiles_touched are bit-comparable with the CPU oracle
+// (nvcc, hipcc and gcc differ in FMA contraction by default).
+//
+// HBM traffic per Gaussian: reads 12 (mean) [+ 12 scale + 16 rot + 4 opacity + 12*K SH when
+// visible]; writes 12 (depth key, tiles, radius) [+ 48 record + 24 cov3D + 8 rect + 1 when
+// visible].  One thread per Gaussian; SH rows are read as 16-byte vectors.
+#include "state.h"
+#include "wave64.h"
+#include "kernels.h"
+
+namespace gsr {
+
+
+// SH constants, cuda_rasterizer/auxiliary.h:22-39
+__device__ static const float SH_C0 = 0.28209479177387814f;
+__device__ static const float SH_C1 = 0.4886025119029199f;
+__device__ static const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                         -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                         0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                         -0.5900435899266435f};
+
+// float -> int with the hardware's semantics (v_cvt_i32_f32: truncate, saturate, NaN -> 0)
+__device__ __forceinline__ int f2i(float f)
+{
+	if (f != f) return 0;
+	if (f >= 2147483648.0f) return 2147483647;
+	if (f <= -2147483648.0f) return (-2147483647 - 1);
+	return (int)f;
+}
+
+// auxiliary.h:41-44 (double because of the 1.0 / 0.5 literals)
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// One SH channel of computeColorFromSH, forward.cu:20-71.  sh points at coefficient 0 of the
+// Gaussian, channel stride 1, coefficient stride 3.
+__device__ __forceinline__ float sh_channel(const float* sh, int ch, int deg, float x, float y, float z)
+{
+#define SH(k) sh[3 * (k) + ch]
+	float result = SH_C0 * SH(0);
+	if (deg > 0) {
+		result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+		if (deg > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+			         SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+			if (deg > 2) {
+				result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+				         SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+				         SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+				         SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+				         SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+			}
+		}
+	}
+#undef SH
+	return result + 0.5f;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const bool in_range = idx < p.P;
+	uint32_t my_tiles = 0;
+
+	if (in_range) {
+		int radius_i = 0;
+		uint32_t depth_key = DEPTH_KEY_CULLED;
+		do {
+			const float px = p.means3D[3 * idx], py = p.means3D[3 * idx + 1], pz = p.means3D[3 * idx + 2];
+			const float* V = p.view;
+			const float* Pm = p.proj;
+			// in_frustum, auxiliary.h:139-164
+			const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+			if (vz <= 0.2f) break;
+			// transformPoint4x4 + perspective divide, forward.cu:199-201
+			const float hx = Pm[0] * px + Pm[4] * py + Pm[8] * pz + Pm[12];
+			const float hy = Pm[1] * px + Pm[5] * py + Pm[9] * pz + Pm[13];
+			const float hw = Pm[3] * px + Pm[7] * py + Pm[11] * pz + Pm[15];
+			const float p_w = 1.0f / (hw + 0.0000001f);
+			const float projx = hx * p_w, projy = hy * p_w;
+
+			// computeCov3D, forward.cu:118-152 (M = S*R with S diagonal: M[c][r] = s_r * R[c][r])
+			float c3[6];
+			if (p.cov3D_precomp != nullptr) {
+#pragma unroll
+				for (int i = 0; i < 6; i++) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
+			} else {
+				const float s0 = p.scale_modifier * p.scales[3 * idx], s1 = p.scale_modifier * p.scales[3 * idx + 1],
+				            s2 = p.scale_modifier * p.scales[3 * idx + 2];
+				const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+				const float r = q.x, x = q.y, y = q.z, z = q.w;
+				// R[c][r] (glm column-major) exactly as written at forward.cu:135-139
+				const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+				const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+				const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+				const float M00 = s0 * R00, M01 = s1 * R01, M02 = s2 * R02;
+				const float M10 = s0 * R10, M11 = s1 * R11, M12 = s2 * R12;
+				const float M20 = s0 * R20, M21 = s1 * R21, M22 = s2 * R22;
+				// Sigma = transpose(M) * M:  Sigma[c][r] = M[r][0]*M[c][0] + M[r][1]*M[c][1] + M[r][2]*M[c][2]
+				c3[0] = M00 * M00 + M01 * M01 + M02 * M02;
+				c3[1] = M10 * M00 + M11 * M01 + M12 * M02;
+				c3[2] = M20 * M00 + M21 * M01 + M22 * M02;
+				c3[3] = M10 * M10 + M11 * M11 + M12 * M12;
+				c3[4] = M20 * M10 + M21 * M11 + M22 * M12;
+				c3[5] = M20 * M20 + M21 * M21 + M22 * M22;
+#pragma unroll
+				for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c3[i];
+			}
+
+			// computeCov2D, forward.cu:74-113
+			float tx = V[0] * px + V[4] * py + V[8] * pz + V[12];
+			float ty = V[1] * px + V[5] * py + V[9] * pz + V[13];
+			const float tz = vz;
+			const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+			const float txtz = tx / tz, tytz = ty / tz;
+			tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+			ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+			const float J00 = p.focal_x / tz, J02 = -(p.focal_x * tx) / (tz * tz);
+			const float J11 = p.focal_y / tz, J12 = -(p.focal_y * ty) / (tz * tz);
+			// W[c][r] = view[4r + c] (glm::mat3 built row-wise from the column-major view matrix)
+			// T = W*J: T[0][r] = W[0][r]*J00 + W[2][r]*J02 ; T[1][r] = W[1][r]*J11 + W[2][r]*J12 ; T[2][r] = 0
+			// (the zero products of the glm expansion add exact zeros and are dropped)
+			const float T00 = V[0] * J00 + V[2] * J02, T01 = V[4] * J00 + V[6] * J02, T02 = V[8] * J00 + V[10] * J02;
+			const float T10 = V[1] * J11 + V[2] * J12, T11 = V[5] * J11 + V[6] * J12, T12 = V[9] * J11 + V[10] * J12;
+			// Vrk symmetric: V[c][r]: (c0 c1 c2 / c1 c3 c4 / c2 c4 c5)
+			// A = transpose(T) * transpose(Vrk):  A[c][r] = T[r][0]*Vrk[0][c] + T[r][1]*Vrk[1][c] + T[r][2]*Vrk[2][c]
+			const float A00 = T00 * c3[0] + T01 * c3[1] + T02 * c3[2];  // c=0,r=0
+			const float A10 = T00 * c3[1] + T01 * c3[3] + T02 * c3[4];  // c=1,r=0
+			const float A20 = T00 * c3[2] + T01 * c3[4] + T02 * c3[5];  // c=2,r=0
+			const float A01 = T10 * c3[0] + T11 * c3[1] + T12 * c3[2];  // c=0,r=1
+			const float A11 = T10 * c3[1] + T11 * c3[3] + T12 * c3[4];  // c=1,r=1
+			const float A21 = T10 * c3[2] + T11 * c3[4] + T12 * c3[5];  // c=2,r=1
+			// cov = A * T:  cov[c][r] = A[0][r]*T[c][0] + A[1][r]*T[c][1] + A[2][r]*T[c][2]
+			const float cov00 = (A00 * T00 + A10 * T01 + A20 * T02) + 0.3f;
+			const float cov01 = A01 * T00 + A11 * T01 + A21 * T02;
+			const float cov11 = (A01 * T10 + A11 * T11 + A21 * T12) + 0.3f;
+
+			// conic + radius, forward.cu:218-232
+			const float det = cov00 * cov11 - cov01 * cov01;
+			if (det == 0.0f) break;
+			const float det_inv = 1.f / det;
+			const float conx = cov11 * det_inv, cony = -cov01 * det_inv, conz = cov00 * det_inv;
+			const float mid = 0.5f * (cov00 + cov11);
+			const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+			const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+			const float pix = ndc2pix(projx, p.W), piy = ndc2pix(projy, p.H);
+			// getRect, auxiliary.h:46-56
+			const int mr = f2i(my_radius);
+			const int rminx = min(p.grid_x, max(0, f2i((pix - mr) / TILE)));
+			const int rminy = min(p.grid_y, max(0, f2i((piy - mr) / TILE)));
+			const int rmaxx = min(p.grid_x, max(0, f2i((pix + mr + TILE - 1) / TILE)));
+			const int rmaxy = min(p.grid_y, max(0, f2i((piy + mr + TILE - 1) / TILE)));
+			const uint32_t tiles = (uint32_t)(rmaxy - rminy) * (uint32_t)(rmaxx - rminx);
+			if (tiles == 0) break;
+
+			// colour, forward.cu:238-247
+			float cr, cg, cb;
+			uint8_t clamp_bits = 0;
+			if (p.colors_precomp == nullptr) {
+				float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+				const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+				dx = dx / len;
+				dy = dy / len;
+				dz = dz / len;
+				// SH row -> registers: 16-byte vector loads when the row is 16-byte aligned (M*3 % 4 == 0)
+				const float* sh = p.shs + (size_t)idx * p.M * 3;
+				const int nfl = 3 * (p.D + 1) * (p.D + 1);
+				float c[48];
+				if (((p.M * 3) & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0)) {
+					const float4* r4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+					for (int i = 0; i < 12; i++) {
+						if (4 * i < nfl) {
+							const float4 v = r4[i];
+							c[4 * i] = v.x;
+							c[4 * i + 1] = v.y;
+							c[4 * i + 2] = v.z;
+							c[4 * i + 3] = v.w;
+						}
+					}
+				} else {
+#pragma unroll
+					for (int i = 0; i < 48; i++)
+						if (i < nfl) c[i] = sh[i];
+				}
+				cr = sh_channel(c, 0, p.D, dx, dy, dz);
+				cg = sh_channel(c, 1, p.D, dx, dy, dz);
+				cb = sh_channel(c, 2, p.D, dx, dy, dz);
+				clamp_bits = (uint8_t)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+				cr = fmaxf(cr, 0.0f);
+				cg = fmaxf(cg, 0.0f);
+				cb = fmaxf(cb, 0.0f);
+			} else {
+				cr = p.colors_precomp[3 * (size_t)idx];
+				cg = p.colors_precomp[3 * (size_t)idx + 1];
+				cb = p.colors_precomp[3 * (size_t)idx + 2];
+			}
+
+			depth_key = __float_as_uint(vz);
+			radius_i = mr;
+			my_tiles = tiles;
+			g.rec[3 * (size_t)idx + 0] = make_float4(pix, piy, conx, cony);
+			g.rec[3 * (size_t)idx + 1] = make_float4(conz, p.opacities[idx], cr, cg);
+			g.rec[3 * (size_t)idx + 2] = make_float4(cb, 0.f, 0.f, 0.f);
+			g.clamped[idx] = clamp_bits;
+			reinterpret_cast<uint2*>(g.rect)[idx] =
+			    make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+		} while (0);
+		g.depth_key[idx] = depth_key;
+		g.tiles_touched[idx] = my_tiles;
+		g.radii[idx] = radius_i;
+		if (p.radii_out) p.radii_out[idx] = radius_i;
+	}
+	// num_rendered = sum of tiles_touched: one atomic per wave (replaces reading back the last
+	// element of the scan, rasterizer_impl.cu:281, so the host copy can overlap the depth sort)
+	const uint32_t wsum = wave_sum_u32(my_tiles);
+	if (lane_id() == 0 && wsum) atomicAdd(&g.counters[0], wsum);
+}
+
+// checkFrustum, cuda_rasterizer/rasterizer_impl.cu:54-66
+__global__ void __launch_bounds__(256)
+check_frustum_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (idx >= P) return;
+	const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+	const float vz = view[2] * px + view[6] * py + view[10] * pz + view[14];
+	present[idx] = vz <= 0.2f ? 0 : 1;
+}
+
+int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream)
+{
+	GSR_LAUNCH(preprocess_fwd_kernel, div_up(p.P, 256), 256, stream, p, g);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream)
+{
+	GSR_LAUNCH(check_frustum_kernel, div_up(P, 256), 256, stream, P, means3D, view, present);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+}  // namespace gsr

@@ -1,0 +1,244 @@
+// sort.hip -- prefix scan and stable LSD radix sort for gfx950 (wave64).
+//
+// Replaces cub::DeviceScan::InclusiveSum (cuda_rasterizer/rasterizer_impl.cu:276) and
+// cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:303-308, simple_knn.cu:210-213).
+// Both are HBM-streaming integer kernels: no MFMA, loads/stores coalesced per wave,
+// ranking by wave ballots (64-bit masks) instead of shared-memory atomics, and the
+// scatter goes through an LDS-staged locally sorted tile so that every digit run leaves
+// the workgroup as one contiguous burst.
+#include "state.h"
+#include "wave64.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------ scan
+// Block-wide exclusive scan of one value per thread (256 threads = 4 waves).
+// Returns the exclusive prefix; *total receives the block sum (valid in all threads).
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* s_wave /*[4]*/)
+{
+	const uint32_t incl = wave_incl_scan_u32(v);
+	const int w = wave_id(), l = lane_id();
+	__syncthreads();  // s_wave reuse across calls
+	if (l == 63) s_wave[w] = incl;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const uint32_t sw = s_wave[i];
+		if (i < w) base += sw;
+		tot += sw;
+	}
+	*total = tot;
+	return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ block_sums,
+                   int n, int items_per_block)
+{
+	__shared__ uint32_t s_wave[4];
+	const int base = blockIdx.x * items_per_block;
+	const int end = min(n, base + items_per_block);
+	uint32_t acc = 0;
+	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) acc += gather ? in[gather[i]] : in[i];
+	uint32_t tot;
+	block_excl_scan_256(acc, &tot, s_wave);
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// Single workgroup: in-place exclusive scan of the block sums (nblocks <= 1024 * 4).
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_spine_kernel(uint32_t* __restrict__ block_sums, int nblocks)
+{
+	__shared__ uint32_t s_wave[4];
+	uint32_t carry = 0;
+	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+		const int i = base + (int)threadIdx.x;
+		const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
+		if (i < nblocks) block_sums[i] = carry + ex;
+		carry += tot;
+	}
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ out,
+                  const uint32_t* __restrict__ block_sums, int n, int items_per_block, int inclusive)
+{
+	__shared__ uint32_t s_wave[4];
+	const int base = blockIdx.x * items_per_block;
+	const int end = min(n, base + items_per_block);
+	uint32_t carry = block_sums[blockIdx.x];
+	for (int b = base; b < end; b += SCAN_THREADS) {
+		const int i = b + (int)threadIdx.x;
+		const uint32_t v = i < end ? (gather ? in[gather[i]] : in[i]) : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
+		if (i < end) out[i] = carry + ex + (inclusive ? v : 0u);
+		carry += tot;
+	}
+}
+
+int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
+                    uint32_t* scratch, hipStream_t stream)
+{
+	if (n <= 0) return GSR_OK;
+	const int ipb = scan_items_per_block(n);
+	const int nb = div_up(n, ipb);
+	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, scratch, n, ipb);
+	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
+	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, in, gather, out, (const uint32_t*)scratch, n, ipb,
+	           inclusive ? 1 : 0);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// ------------------------------------------------------------------ radix sort
+// Pass structure (per 8-bit digit):  histogram -> exclusive scan of the [bin][block] table
+// -> scatter.  Block b always owns elements [b*4096, (b+1)*4096); wave w of the block owns
+// the 1024-element sub-range starting at w*1024 and walks it in 16 rounds of 64 lane-
+// consecutive elements, so the original order inside a digit is (wave, round, lane).
+
+__global__ void __launch_bounds__(SORT_THREADS)
+radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks)
+{
+	__shared__ uint32_t s_hist[RADIX_BINS];
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t dmask = (1u << nbits) - 1u;
+	const int wbase = blockIdx.x * SORT_CHUNK + wave_id() * SORT_ITEMS_PER_WAVE;
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const int i = wbase + r * 64 + lane_id();
+		const bool valid = i < n;
+		const uint32_t d = valid ? ((keys[i] >> shift) & dmask) : 0u;
+		const unsigned long long m = wave_match_digit(d, nbits, valid);
+		if (valid && (m & lanemask_lt()) == 0ull) atomicAdd(&s_hist[d], (uint32_t)__popcll(m));
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
+                     const uint32_t* __restrict__ hist_scanned, int nblocks)
+{
+	__shared__ uint32_t s_whist[4][RADIX_BINS];  // per-wave digit counts, then per-wave running write cursors
+	__shared__ uint32_t s_gbase[RADIX_BINS];     // global position of local element i of digit d = s_gbase[d] + i
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_keys[SORT_CHUNK];
+	__shared__ uint32_t s_vals[SORT_CHUNK];
+
+	const int w = wave_id(), l = lane_id();
+	const int tid = (int)threadIdx.x;
+	const uint32_t dmask = (1u << nbits) - 1u;
+	const int cbase = blockIdx.x * SORT_CHUNK;
+	const int wbase = cbase + w * SORT_ITEMS_PER_WAVE;
+
+#pragma unroll
+	for (int i = 0; i < 4; i++) s_whist[i][tid] = 0;
+	__syncthreads();
+
+	uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
+	// Phase A: load (coalesced 256 B per wave instruction) and count digits per wave.
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const int i = wbase + r * 64 + l;
+		const bool valid = i < n;
+		key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+		val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+		const uint32_t d = (key[r] >> shift) & dmask;
+		const unsigned long long m = wave_match_digit(d, nbits, valid);
+		// the lowest lane of each digit group adds the group size; groups of one wave touch distinct bins
+		if (valid && (m & lanemask_lt()) == 0ull) s_whist[w][d] += (uint32_t)__popcll(m);
+		wave_fence();
+	}
+	__syncthreads();
+
+	// Phase B: thread d owns digit d.  Local layout of the chunk = digits ascending, inside a digit
+	// waves ascending, inside a wave original order.
+	{
+		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
+		const uint32_t tot = c0 + c1 + c2 + c3;
+		uint32_t block_total;
+		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
+		s_whist[0][tid] = lstart;
+		s_whist[1][tid] = lstart + c0;
+		s_whist[2][tid] = lstart + c0 + c1;
+		s_whist[3][tid] = lstart + c0 + c1 + c2;
+		s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - lstart;
+	}
+	__syncthreads();
+
+	// Phase C: stable placement into the LDS tile.
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const int i = wbase + r * 64 + l;
+		const bool valid = i < n;
+		const uint32_t d = (key[r] >> shift) & dmask;
+		const unsigned long long m = wave_match_digit(d, nbits, valid);
+		const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+		uint32_t cursor = 0;
+		if (valid) cursor = s_whist[w][d];
+		wave_fence();  // every lane has read the cursor before the group leader advances it
+		if (valid) {
+			s_keys[cursor + rank] = key[r];
+			s_vals[cursor + rank] = val[r];
+			if (rank == 0) s_whist[w][d] = cursor + (uint32_t)__popcll(m);
+		}
+		wave_fence();
+	}
+	__syncthreads();
+
+	// Phase D: write the locally sorted tile; lanes of a digit run hit consecutive addresses.
+	const int count = min(SORT_CHUNK, n - cbase);
+	for (int i = tid; i < count; i += SORT_THREADS) {
+		const uint32_t k = s_keys[i];
+		const uint32_t d = (k >> shift) & dmask;
+		const uint32_t pos = s_gbase[d] + (uint32_t)i;
+		keys_out[pos] = k;
+		vals_out[pos] = s_vals[i];
+	}
+}
+
+int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
+                      uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res)
+{
+	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
+	*keys_res = (passes % 2) ? keys_pong : keys_ping;
+	*vals_res = (passes % 2) ? vals_pong : vals_ping;
+	if (n <= 0) return GSR_OK;
+	const int nb = sort_blocks(n);
+	const int hist_elems = RADIX_BINS * nb;
+	uint32_t* hist = scratch;
+	uint32_t* hist_scanned = scratch + hist_elems;
+	uint32_t* scan_scratch = scratch + 2 * (size_t)hist_elems;
+	if (passes == 0) {
+		// degenerate: nothing to sort on; result must still be materialised in the ping buffers
+		GSR_HIP(hipMemcpyAsync(keys_ping, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+		if (vals_in) GSR_HIP(hipMemcpyAsync(vals_ping, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+		else return GSR_ERR_INVALID_ARG;
+		return GSR_OK;
+	}
+	const uint32_t* kin = keys_in;
+	const uint32_t* vin = vals_in;
+	for (int p = 0; p < passes; p++) {
+		const int shift = begin_bit + p * RADIX_BITS;
+		const int nbits = min(RADIX_BITS, end_bit - shift);
+		uint32_t* kout = (p % 2 == 0) ? keys_pong : keys_ping;
+		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
+		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb);
+		int st = launch_scan_u32(hist, nullptr, hist_scanned, hist_elems, false, scan_scratch, stream);
+		if (st != GSR_OK) return st;
+		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
+		           (const uint32_t*)hist_scanned, nb);
+		kin = kout;
+		vin = vout;
+	}
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+}  // namespace gsr

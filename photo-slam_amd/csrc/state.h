@@ -1,0 +1,155 @@
+// state.h -- HBM layout of the three caller-owned scratch buffers and of the per-Gaussian
+// blend record.  This replaces GeometryState / BinningState / ImageState of the reference
+// (cuda_rasterizer/rasterizer_impl.h:32-62); callers treat the buffers as opaque bytes.
+#pragma once
+#include "rt.h"
+
+namespace gsr {
+
+constexpr int TILE = 16;              // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:16-17 (part of the parity contract)
+constexpr int TILE_PIXELS = TILE * TILE;
+constexpr uint32_t DEPTH_KEY_CULLED = 0xFFFFFFFFu;
+
+// Radix sort geometry: one workgroup (256 threads = 4 waves) ranks a 4096-element chunk;
+// each wave owns 1024 consecutive elements so that stability needs no cross-wave ordering.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS_PER_WAVE = 1024;
+constexpr int SORT_CHUNK = 4 * SORT_ITEMS_PER_WAVE;
+constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BINS = 1 << RADIX_BITS;
+
+constexpr int SCAN_THREADS = 256;
+
+static inline int sort_blocks(int n) { return n > 0 ? div_up(n, SORT_CHUNK) : 1; }
+// items per scan block: at least 2048, and large enough that the block-sum spine fits one block pass
+static inline int scan_items_per_block(int n)
+{
+	int ipb = 2048;
+	while ((long long)ipb * 1024 < (long long)n) ipb *= 2;
+	return ipb;
+}
+static inline int scan_blocks(int n) { return n > 0 ? div_up(n, scan_items_per_block(n)) : 1; }
+static inline size_t scan_scratch_elems(int n) { return (size_t)scan_blocks(n) + 64; }
+// histogram [RADIX_BINS][blocks] + its scanned copy + scan spine
+static inline size_t sort_scratch_elems(int n)
+{
+	size_t h = (size_t)RADIX_BINS * sort_blocks(n);
+	return 2 * h + scan_scratch_elems((int)h) + 64;
+}
+
+// The 48-byte per-Gaussian record the blend kernels gather (3 x float4):
+//   q0 = (mean2D.x, mean2D.y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, 0, 0, 0)
+// One record instead of the reference's three separate gathers (means2D / conic_opacity /
+// rgb, forward.cu:317-320,355).
+constexpr int REC_FLOAT4S = 3;
+
+struct GeometryState {
+	uint32_t* counters;       // [32]  [0] = total tiles touched (num_rendered)
+	uint32_t* depth_key;      // [P]
+	uint32_t* tiles_touched;  // [P]
+	int*      radii;          // [P]
+	uint16_t* rect;           // [4P]
+	float4*   rec;            // [3P]
+	float*    cov3D;          // [6P]
+	uint8_t*  clamped;        // [P]
+	uint32_t* order;          // [P]  final depth-sorted ids
+	uint32_t* offsets;        // [P]  exclusive scan of tiles_touched in depth order
+	uint32_t* sort_keys_a;    // [P]
+	uint32_t* sort_keys_b;    // [P]
+	uint32_t* sort_vals_b;    // [P]
+	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
+	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
+
+	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
+	{
+		GeometryState g;
+		Carver c(chunk);
+		g.counters = c.take<uint32_t>(32);
+		g.depth_key = c.take<uint32_t>(P);
+		g.tiles_touched = c.take<uint32_t>(P);
+		g.radii = c.take<int>(P);
+		g.rect = c.take<uint16_t>(4 * P);
+		g.rec = c.take<float4>(REC_FLOAT4S * P);
+		g.cov3D = c.take<float>(6 * P);
+		g.clamped = c.take<uint8_t>(P);
+		g.order = c.take<uint32_t>(P);
+		g.offsets = c.take<uint32_t>(P);
+		g.sort_keys_a = c.take<uint32_t>(P);
+		g.sort_keys_b = c.take<uint32_t>(P);
+		g.sort_vals_b = c.take<uint32_t>(P);
+		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
+		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
+		if (bytes) *bytes = c.used(chunk) + 128;
+		return g;
+	}
+};
+
+struct BinningState {
+	uint32_t* keys_a;        // [R] tile id per instance (ping)
+	uint32_t* vals_a;        // [R] Gaussian id per instance (ping)
+	uint32_t* keys_b;        // [R] (pong)
+	uint32_t* vals_b;        // [R] (pong)
+	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
+
+	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
+	{
+		BinningState b;
+		Carver c(chunk);
+		b.keys_a = c.take<uint32_t>(R);
+		b.vals_a = c.take<uint32_t>(R);
+		b.keys_b = c.take<uint32_t>(R);
+		b.vals_b = c.take<uint32_t>(R);
+		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
+		if (bytes) *bytes = c.used(chunk) + 128;
+		return b;
+	}
+};
+
+struct ImageState {
+	float*    final_T;    // [N]
+	uint32_t* n_contrib;  // [N]
+	uint2*    ranges;     // [T]
+
+	static ImageState carve(char* chunk, size_t N, size_t T, size_t* bytes = nullptr)
+	{
+		ImageState im;
+		Carver c(chunk);
+		im.final_T = c.take<float>(N);
+		im.n_contrib = c.take<uint32_t>(N);
+		im.ranges = c.take<uint2>(T);
+		if (bytes) *bytes = c.used(chunk) + 128;
+		return im;
+	}
+};
+
+// getHigherMsb, cuda_rasterizer/rasterizer_impl.cu:35-50: number of tile-id bits the sort covers.
+static inline uint32_t higher_msb(uint32_t n)
+{
+	uint32_t msb = sizeof(n) * 4;
+	uint32_t step = msb;
+	while (step > 1) {
+		step /= 2;
+		if (n >> msb) msb += step;
+		else msb -= step;
+	}
+	if (n >> msb) msb++;
+	return msb;
+}
+
+// After `passes` ping-pong radix passes starting in buffer A, where does the result live?
+static inline bool result_in_a(int passes) { return (passes % 2) == 0; }
+static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((uint32_t)tiles), RADIX_BITS); }
+
+// ---- device launchers (one per translation unit) ------------------------------------
+int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
+                    uint32_t* scratch, hipStream_t stream);
+// Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
+// Pass 0 reads (keys_in, vals_in) -- read-only, vals_in == nullptr means value = index -- and writes the
+// pong buffers; later passes alternate ping <- pong <- ping.  *keys_res / *vals_res receive the buffers
+// holding the result (pong for an odd number of passes, ping for an even one).
+int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
+                      uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res);
+
+}  // namespace gsr

@@ -1,0 +1,152 @@
+// wave64.h -- wavefront-level primitives for CDNA4 (wave = 64 lanes, SIMD-32 x 2 cycles).
+//
+// Every function must be called from wave-uniform control flow (all 64 lanes of the wave
+// reach the call).  Cross-lane reductions use DPP row operations (quad_perm, row mirrors,
+// row_bcast15/31 -- the gfx9/CDNA forms), which cost one VALU issue per step and no LDS
+// traffic; ballots land in an SGPR pair.
+#pragma once
+#include "rt.h"
+
+namespace gsr {
+
+#ifdef GSR_EMU
+// Emulator versions: implemented by rendezvous of the wave's lanes (tests/emu/hip_emu.h).
+using ::hipemu::wave_ballot;
+using ::hipemu::wave_fence;
+using ::hipemu::wave_incl_scan_u32;
+using ::hipemu::wave_max_u32;
+using ::hipemu::wave_reduce9_f32;
+using ::hipemu::wave_shfl_u32;
+using ::hipemu::wave_sum_u32;
+using ::hipemu::wave_uniform_u64;
+using ::hipemu::wave_uniform_u32;
+#else
+
+// Tell the compiler a value is wave-uniform (moves it to SGPRs: scalar loops, scalar LDS addresses).
+__device__ __forceinline__ uint32_t wave_uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __ballot(pred ? 1 : 0); }
+
+// Scheduling fence for intra-wave communication through LDS that relies on lock-step
+// execution (lanes read, then a leader lane writes).  The hardware issues a wave's LDS
+// operations in order, so no instruction is needed -- only the compiler must not move
+// memory operations across it.
+__device__ __forceinline__ void wave_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_shfl_u32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_CTRL = true>
+__device__ __forceinline__ float dpp_f32(float old_v, float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_v), __builtin_bit_cast(int, v),
+	                                                              CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND_CTRL = true>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old_v, uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)old_v, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL);
+}
+
+// DPP control encodings (LLVM AMDGPU: DppCtrl)
+constexpr int DPP_QUAD_PERM_1032 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_PERM_2301 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHR1 = 0x111;
+constexpr int DPP_ROW_SHR2 = 0x112;
+constexpr int DPP_ROW_SHR4 = 0x114;
+constexpr int DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+
+// Full-wave float sum; the total is valid in lane 63 (other lanes hold partials).
+__device__ __forceinline__ float wave_sum_f32_lane63(float v)
+{
+	v += dpp_f32<DPP_QUAD_PERM_1032>(0.f, v);
+	v += dpp_f32<DPP_QUAD_PERM_2301>(0.f, v);
+	v += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, v);
+	v += dpp_f32<DPP_ROW_MIRROR>(0.f, v);
+	// every lane of a 16-lane row now holds the row sum
+	v += dpp_f32<DPP_ROW_BCAST15, 0xa>(0.f, v);   // rows 1,3 += row 0,2 (lane 15 of previous row)
+	v += dpp_f32<DPP_ROW_BCAST31, 0xc>(0.f, v);   // rows 2,3 += lane 31
+	return v;
+}
+
+// Nine independent full-wave sums at once (the 9 per-Gaussian gradient components of the
+// backward blend); results valid in lane 63.  Interleaving the chains hides DPP latency.
+__device__ __forceinline__ void wave_reduce9_f32(float (&v)[9])
+{
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_QUAD_PERM_1032>(0.f, v[i]);
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_QUAD_PERM_2301>(0.f, v[i]);
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, v[i]);
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_MIRROR>(0.f, v[i]);
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_BCAST15, 0xa>(0.f, v[i]);
+#pragma unroll
+	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_BCAST31, 0xc>(0.f, v[i]);
+}
+
+// Inclusive prefix sum across the wave (Hillis-Steele on DPP row shifts + row broadcasts).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+	v += dpp_u32<DPP_ROW_SHR1>(0u, v);
+	v += dpp_u32<DPP_ROW_SHR2>(0u, v);
+	v += dpp_u32<DPP_ROW_SHR4>(0u, v);
+	v += dpp_u32<DPP_ROW_SHR8>(0u, v);
+	v += dpp_u32<DPP_ROW_BCAST15, 0xa>(0u, v);
+	v += dpp_u32<DPP_ROW_BCAST31, 0xc>(0u, v);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+	v = wave_incl_scan_u32(v);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+		v = v > o ? v : o;
+	}
+	return v;
+}
+#endif  // GSR_EMU
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+	return (1ull << (threadIdx.x & 63u)) - 1ull;
+}
+
+// For every lane, the set of lanes (among `valid` ones) holding the same `nbits`-bit digit.
+__device__ __forceinline__ unsigned long long wave_match_digit(uint32_t digit, int nbits, bool valid)
+{
+	unsigned long long m = wave_ballot(valid);
+	for (int b = 0; b < nbits; b++) {
+		const bool bit = (digit >> b) & 1u;
+		const unsigned long long s = wave_ballot(valid && bit);
+		m &= bit ? s : ~s;
+	}
+	return m;
+}
+
+}  // namespace gsr
