@@ -129,6 +129,16 @@ size_t gsr_binning_bytes(int num_rendered);
 size_t gsr_image_bytes(int width, int height);
 size_t gsr_knn_scratch_bytes(int P);
 
+/* Optional per-stage timing with HIP events recorded on the caller's stream (process-wide switch,
+ * meant for single-stream benchmarking).
+ * After gsr_profile_enable(1), every gsr_forward / gsr_backward records events between its
+ * stages; gsr_profile_read() waits for the last ones and returns milliseconds per stage
+ * (-1 for stages that did not run), indexed 0..gsr_profile_stage_count()-1. */
+int gsr_profile_enable(int on);
+int gsr_profile_stage_count(void);
+const char* gsr_profile_stage_name(int stage);
+int gsr_profile_read(float* ms, int count);
+
 const char* gsr_strerror(int status);
 /* hipError_t of the last failing HIP call on this thread (0 if none), and its name. */
 int gsr_last_hip_error(void);

@@ -1,0 +1,140 @@
+"""ctypes binding of the C-ABI (include/gsr.h, include/gsr_stages.h).
+
+The product library is photo-slam_amd/libgsr_hip.so (hand-written HIP for gfx950).  There is
+NO CPU fallback: if the library is missing, `load()` raises.  (The test-suite may pass the
+path of tests/emu/libgsr_emu.so explicitly to exercise kernel logic without a GPU; nothing
+in this package does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+GSR_OK = 0
+
+
+class GsrError(RuntimeError):
+    def __init__(self, lib, status, where):
+        msg = lib.gsr_strerror(status).decode()
+        hip = lib.gsr_last_hip_error_string().decode()
+        super().__init__(f"{where}: {msg} (status {status})" + (f" [{hip}]" if status == -3 and hip else ""))
+        self.status = status
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("background", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("scale_modifier", C.c_float), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
+                ("out_color", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("R", C.c_int), ("background", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("scales", C.c_void_p), ("scale_modifier", C.c_float),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("tan_fovx", C.c_float),
+                ("tan_fovy", C.c_float), ("radii", C.c_void_p), ("geom_buffer", C.c_void_p),
+                ("binning_buffer", C.c_void_p), ("image_buffer", C.c_void_p), ("dL_dpix", C.c_void_p),
+                ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p)]
+
+
+class GeometryView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("depth_key", "tiles_touched", "radii", "rect", "rec", "cov3D", "clamped",
+                                          "order", "offsets")]
+
+
+class BinningView(C.Structure):
+    _fields_ = [("point_list", C.c_void_p), ("tile_keys", C.c_void_p)]
+
+
+class ImageView(C.Structure):
+    _fields_ = [("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("ranges", C.c_void_p)]
+
+
+# every symbol include/gsr.h and include/gsr_stages.h declare
+EXPORTED_SYMBOLS = [
+    "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
+    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
+    "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
+    "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
+    "gsr_stage_scan_u32", "gsr_sort_scratch_bytes", "gsr_stage_radix_sort_pairs",
+]
+
+_libs = {}
+
+
+def load(path=None):
+    """Load the C-ABI library.  Default: the in-tree HIP build; raises if it does not exist."""
+    path = os.path.abspath(path or HIP_LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build the HIP extension first (python photo-slam_amd/build.py or "
+            f"__graft_entry__.build()); there is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    L.gsr_forward.restype = i32
+    L.gsr_forward.argtypes = [C.POINTER(ForwardArgs), ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, vp, C.POINTER(i32)]
+    L.gsr_backward.restype = i32
+    L.gsr_backward.argtypes = [C.POINTER(BackwardArgs), vp]
+    L.gsr_mark_visible.restype = i32
+    L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.gsr_knn_mean_dist2.restype = i32
+    L.gsr_knn_mean_dist2.argtypes = [i32, vp, vp, ALLOC_FN, vp, vp]
+    for n in ("gsr_geometry_bytes", "gsr_binning_bytes", "gsr_knn_scratch_bytes", "gsr_scan_scratch_bytes",
+              "gsr_sort_scratch_bytes"):
+        getattr(L, n).restype = sz
+        getattr(L, n).argtypes = [i32]
+    L.gsr_image_bytes.restype = sz
+    L.gsr_image_bytes.argtypes = [i32, i32]
+    L.gsr_strerror.restype = C.c_char_p
+    L.gsr_strerror.argtypes = [i32]
+    L.gsr_last_hip_error.restype = i32
+    L.gsr_last_hip_error_string.restype = C.c_char_p
+    L.gsr_backend.restype = C.c_char_p
+    L.gsr_profile_enable.restype = i32
+    L.gsr_profile_enable.argtypes = [i32]
+    L.gsr_profile_stage_count.restype = i32
+    L.gsr_profile_stage_name.restype = C.c_char_p
+    L.gsr_profile_stage_name.argtypes = [i32]
+    L.gsr_profile_read.restype = i32
+    L.gsr_profile_read.argtypes = [C.POINTER(f32), i32]
+    L.gsr_view_geometry.restype = i32
+    L.gsr_view_geometry.argtypes = [vp, i32, C.POINTER(GeometryView)]
+    L.gsr_view_binning.restype = i32
+    L.gsr_view_binning.argtypes = [vp, i32, i32, i32, C.POINTER(BinningView)]
+    L.gsr_view_image.restype = i32
+    L.gsr_view_image.argtypes = [vp, i32, i32, C.POINTER(ImageView)]
+    L.gsr_stage_scan_u32.restype = i32
+    L.gsr_stage_scan_u32.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.gsr_stage_radix_sort_pairs.restype = i32
+    L.gsr_stage_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    _libs[path] = L
+    return L
+
+
+def check(lib, status, where):
+    if status != GSR_OK:
+        raise GsrError(lib, status, where)
+
+
+def profile_enable(lib, on=True):
+    check(lib, lib.gsr_profile_enable(1 if on else 0), "gsr_profile_enable")
+
+
+def profile_read(lib):
+    """dict stage name -> milliseconds of the last forward/backward on this thread (-1 = did not run)"""
+    n = lib.gsr_profile_stage_count()
+    ms = (C.c_float * n)()
+    check(lib, lib.gsr_profile_read(ms, n), "gsr_profile_read")
+    return {lib.gsr_profile_stage_name(i).decode(): float(ms[i]) for i in range(n)}

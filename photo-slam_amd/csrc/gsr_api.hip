@@ -39,6 +39,34 @@ struct HostSync {
 };
 static thread_local HostSync t_sync;
 
+// Optional per-stage HIP-event timing (gsr_profile_*): events are recorded on the caller's
+// stream between the stages of gsr_forward / gsr_backward, so bench.py can price each kernel
+// group against its algorithmic bytes without a profiler attached.
+enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_OFFSET_SCAN, ST_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_BLEND_FWD,
+       ST_GRAD_MEMSET, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
+                                                    "tile_sort", "tile_ranges", "blend_fwd", "grad_memset",
+                                                    "blend_bwd", "preprocess_bwd"};
+struct Profiler {
+	bool on = false;
+	hipEvent_t fwd[8] = {};   // boundaries of the 7 forward stages
+	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
+	bool created = false, fwd_done = false, bwd_done = false;
+	int create()
+	{
+		if (created) return GSR_OK;
+		for (auto& e : fwd) GSR_HIP(hipEventCreate(&e));
+		for (auto& e : bwd) GSR_HIP(hipEventCreate(&e));
+		created = true;
+		return GSR_OK;
+	}
+};
+// process-wide (not per thread): PyTorch runs backward on an autograd worker thread, and the
+// benchmark reads the timings from the main thread.  Intended for single-stream benchmarking.
+static Profiler t_prof;
+#define PROF_FWD(i) do { if (t_prof.on) GSR_HIP(hipEventRecord(t_prof.fwd[i], stream)); } while (0)
+#define PROF_BWD(i) do { if (t_prof.on) GSR_HIP(hipEventRecord(t_prof.bwd[i], stream)); } while (0)
+
 static inline size_t geometry_bytes(int P)
 {
 	size_t b = 0;
@@ -137,7 +165,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	ImageState im = ImageState::carve(img_chunk, (size_t)W * H, (size_t)tiles);
 
 	if ((st = t_sync.init()) != GSR_OK) return st;
+	t_prof.fwd_done = false;
 	GSR_HIP(hipMemsetAsync(g.counters, 0, 32 * sizeof(uint32_t), stream));
+	PROF_FWD(0);
 
 	PreprocessParams pp;
 	pp.P = P; pp.D = a->D; pp.M = a->M;
@@ -150,6 +180,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
 	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
 
+	PROF_FWD(1);
 	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 	GSR_HIP(hipEventRecord(t_sync.ev, stream));
 
@@ -159,7 +190,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	                            g.sort_scratch, stream, &kres, &vres)) != GSR_OK)
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
+	PROF_FWD(2);
 	if ((st = launch_scan_u32(g.tiles_touched, g.order, g.offsets, P, false, g.scan_scratch, stream)) != GSR_OK) return st;
+	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));
 	const int R = (int)*t_sync.pinned;
@@ -172,19 +205,27 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	uint32_t* point_list = bs.vals_a;
 	if (R > 0) {
 		if ((st = launch_emit_instances(P, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;
+		PROF_FWD(4);
 		const int bits = (int)higher_msb((uint32_t)tiles);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
 		                            bs.sort_scratch, stream, &tkeys, &point_list)) != GSR_OK)
 			return st;
+		PROF_FWD(5);
 		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream)) != GSR_OK) return st;
+	} else {
+		PROF_FWD(4);
+		PROF_FWD(5);
 	}
+	PROF_FWD(6);
 
 	BlendFwdParams bp;
 	bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
 	bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.out_color = a->out_color;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
+	PROF_FWD(7);
+	t_prof.fwd_done = t_prof.on;
 	*num_rendered = R;
 	return GSR_OK;
 }
@@ -212,12 +253,15 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	const int passes = tile_sort_passes(tiles);
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
+	t_prof.bwd_done = false;
+	PROF_BWD(0);
 	// accumulators of the blend backward (44 B/Gaussian; everything else is written exactly once)
 	GSR_HIP(hipMemsetAsync(a->dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), stream));
 	GSR_HIP(hipMemsetAsync(a->dL_dconic, 0, (size_t)P * 4 * sizeof(float), stream));
 	GSR_HIP(hipMemsetAsync(a->dL_dopacity, 0, (size_t)P * sizeof(float), stream));
 	GSR_HIP(hipMemsetAsync(a->dL_dcolor, 0, (size_t)P * 3 * sizeof(float), stream));
 
+	PROF_BWD(1);
 	if (R > 0) {
 		BlendBwdParams bp;
 		bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
@@ -227,6 +271,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
 	}
+	PROF_BWD(2);
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;
@@ -240,7 +285,37 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dcolor = a->dL_dcolor;
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
-	return launch_preprocess_bwd(pb, stream);
+	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
+	PROF_BWD(3);
+	t_prof.bwd_done = t_prof.on;
+	return GSR_OK;
+}
+
+int gsr_profile_enable(int on)
+{
+	if (on) {
+		int st = t_prof.create();
+		if (st != GSR_OK) return st;
+	}
+	t_prof.on = on != 0;
+	t_prof.fwd_done = t_prof.bwd_done = false;
+	return GSR_OK;
+}
+int gsr_profile_stage_count(void) { return ST_COUNT; }
+const char* gsr_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
+int gsr_profile_read(float* ms, int count)
+{
+	if (!ms || count < ST_COUNT) return GSR_ERR_INVALID_ARG;
+	for (int i = 0; i < ST_COUNT; i++) ms[i] = -1.f;
+	if (t_prof.fwd_done) {
+		GSR_HIP(hipEventSynchronize(t_prof.fwd[7]));
+		for (int i = 0; i < 7; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
+	}
+	if (t_prof.bwd_done) {
+		GSR_HIP(hipEventSynchronize(t_prof.bwd[3]));
+		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
+	}
+	return GSR_OK;
 }
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

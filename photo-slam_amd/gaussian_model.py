@@ -1,0 +1,149 @@
+"""GaussianModel: the six learnable tensors, their activations, the 6-group Adam and the
+densification statistics -- the parts of src/gaussian_model.cpp the measured train step uses
+(activations :48-101, trainingSetup :477-510, addDensificationStats :817-831,
+exponLrFunc :1118-1131).  ATen ops on the HIP device; fused HIP versions are a "next" row
+(SURVEY.md 8f)."""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import rasterize_points as rp
+
+
+@dataclass
+class GaussianOptimizationParams:
+    """include/gaussian_parameters.h:61-96 defaults (cfg/gaussian_mapper/RGB-D/Replica/replica_rgbd.yaml)."""
+    iterations_: int = 30000
+    position_lr_init_: float = 0.00016
+    position_lr_final_: float = 0.0000016
+    position_lr_delay_mult_: float = 0.01
+    position_lr_max_steps_: int = 30000
+    feature_lr_: float = 0.0025
+    opacity_lr_: float = 0.05
+    scaling_lr_: float = 0.005
+    rotation_lr_: float = 0.001
+    percent_dense_: float = 0.01
+    lambda_dssim_: float = 0.2
+    densification_interval_: int = 100
+    opacity_reset_interval_: int = 3000
+    densify_from_iter_: int = 500
+    densify_until_iter_: int = 15000
+    densify_grad_threshold_: float = 0.0002
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianModel:
+    def __init__(self, sh_degree=3, device="cuda"):
+        self.max_sh_degree_ = sh_degree
+        self.active_sh_degree_ = 0
+        self.device_ = torch.device(device)
+        self.spatial_lr_scale_ = 1.0
+        self.optimizer_ = None
+
+    # ---- construction
+    @classmethod
+    def from_cloud(cls, cloud, device="cuda", sh_degree=3):
+        """Load a scene.Cloud (raw parameters) -- stands in for createFromPcd/loadPly in benchmarks."""
+        m = cls(sh_degree, device)
+        t = lambda a: torch.from_numpy(a).to(m.device_).contiguous().requires_grad_(True)
+        m.xyz_ = t(cloud.xyz)
+        m.features_dc_ = t(cloud.features_dc)
+        m.features_rest_ = t(cloud.features_rest)
+        m.scaling_ = t(cloud.scaling)
+        m.rotation_ = t(cloud.rotation)
+        m.opacity_ = t(cloud.opacity)
+        m.active_sh_degree_ = sh_degree
+        m.spatial_lr_scale_ = cloud.extent
+        P = m.xyz_.shape[0]
+        m.max_radii2D_ = torch.zeros(P, device=m.device_)
+        m.xyz_gradient_accum_ = torch.zeros((P, 1), device=m.device_)
+        m.denom_ = torch.zeros((P, 1), device=m.device_)
+        return m
+
+    def createFromPcd(self, points, colors, spatial_lr_scale):
+        """src/gaussian_model.cpp:114-191: scales from the simple-knn distance (distCUDA2)."""
+        self.spatial_lr_scale_ = spatial_lr_scale
+        pts = points.to(self.device_).float().contiguous()
+        n = pts.shape[0]
+        C0 = 0.28209479177387814
+        fused_color = (colors.to(self.device_).float() - 0.5) / C0  # RGB2SH, include/sh_utils.h:138
+        M = (self.max_sh_degree_ + 1) ** 2
+        features = torch.zeros((n, 3, M), device=self.device_)
+        features[:, :3, 0] = fused_color
+        dist2 = torch.clamp_min(rp.distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3)
+        rots = torch.zeros((n, 4), device=self.device_)
+        rots[:, 0] = 1
+        opacities = inverse_sigmoid(0.1 * torch.ones((n, 1), device=self.device_))
+        req = lambda a: a.contiguous().requires_grad_(True)
+        self.xyz_ = req(pts)
+        self.features_dc_ = req(features[:, :, 0:1].transpose(1, 2))
+        self.features_rest_ = req(features[:, :, 1:].transpose(1, 2))
+        self.scaling_ = req(scales)
+        self.rotation_ = req(rots)
+        self.opacity_ = req(opacities)
+        self.max_radii2D_ = torch.zeros(n, device=self.device_)
+        self.xyz_gradient_accum_ = torch.zeros((n, 1), device=self.device_)
+        self.denom_ = torch.zeros((n, 1), device=self.device_)
+
+    # ---- activations, src/gaussian_model.cpp:48-71
+    def getScalingActivation(self):
+        return torch.exp(self.scaling_)
+
+    def getRotationActivation(self):
+        return torch.nn.functional.normalize(self.rotation_)
+
+    def getXYZ(self):
+        return self.xyz_
+
+    def getFeatures(self):
+        return torch.cat((self.features_dc_.clone(), self.features_rest_.clone()), 1)
+
+    def getOpacityActivation(self):
+        return torch.sigmoid(self.opacity_)
+
+    def setShDegree(self, sh):
+        self.active_sh_degree_ = min(max(sh, 0), self.max_sh_degree_)
+
+    def params(self):
+        return [self.xyz_, self.features_dc_, self.features_rest_, self.opacity_, self.scaling_, self.rotation_]
+
+    # ---- optimizer, src/gaussian_model.cpp:477-510
+    def trainingSetup(self, opt):
+        self.percent_dense_ = opt.percent_dense_
+        self.opt_ = opt
+        groups = [
+            dict(params=[self.xyz_], lr=opt.position_lr_init_ * self.spatial_lr_scale_, name="xyz"),
+            dict(params=[self.features_dc_], lr=opt.feature_lr_, name="f_dc"),
+            dict(params=[self.features_rest_], lr=opt.feature_lr_ / 20.0, name="f_rest"),
+            dict(params=[self.opacity_], lr=opt.opacity_lr_, name="opacity"),
+            dict(params=[self.scaling_], lr=opt.scaling_lr_, name="scaling"),
+            dict(params=[self.rotation_], lr=opt.rotation_lr_, name="rotation"),
+        ]
+        self.optimizer_ = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    def exponLrFunc(self, step):
+        """src/gaussian_model.cpp:1118-1131"""
+        o = self.opt_
+        lr_init, lr_final = o.position_lr_init_ * self.spatial_lr_scale_, o.position_lr_final_ * self.spatial_lr_scale_
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        delay_rate = 1.0
+        t = min(max(step / o.position_lr_max_steps_, 0.0), 1.0)
+        log_lerp = math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+        return delay_rate * log_lerp
+
+    def updateLearningRate(self, step):
+        lr = self.exponLrFunc(step)
+        self.optimizer_.param_groups[0]["lr"] = lr
+        return lr
+
+    # ---- densification statistics, src/gaussian_model.cpp:817-831
+    def addDensificationStats(self, viewspace_point_tensor, update_filter):
+        g = viewspace_point_tensor.grad
+        self.xyz_gradient_accum_[update_filter] += torch.norm(g[update_filter][:, :2], dim=-1, keepdim=True)
+        self.denom_[update_filter] += 1

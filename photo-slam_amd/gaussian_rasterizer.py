@@ -1,0 +1,96 @@
+"""GaussianRasterizationSettings / GaussianRasterizerFunction / GaussianRasterizer.
+
+Mirror of include/gaussian_rasterizer.h:25-127 and src/gaussian_rasterizer.cpp:18-234: same
+member names, argument order, saved tensors, gradient order and std::runtime_error texts.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import rasterize_points as rp
+
+
+@dataclass
+class GaussianRasterizationSettings:
+    """include/gaussian_rasterizer.h:25-55"""
+    image_height_: int
+    image_width_: int
+    tanfovx_: float
+    tanfovy_: float
+    bg_: torch.Tensor
+    scale_modifier_: float
+    viewmatrix_: torch.Tensor
+    projmatrix_: torch.Tensor
+    sh_degree_: int
+    campos_: torch.Tensor
+    prefiltered_: bool
+
+
+class GaussianRasterizerFunction(torch.autograd.Function):
+    """src/gaussian_rasterizer.cpp:28-180"""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        s = raster_settings
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rp.RasterizeGaussiansCUDA(
+            s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_, cov3Ds_precomp,
+            s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_, s.image_height_, s.image_width_, sh, s.sh_degree_,
+            s.campos_, s.prefiltered_)
+        ctx.num_rendered = num_rendered
+        ctx.raster_settings = s
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        s = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+            ctx.saved_tensors
+        (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+         dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
+            s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
+            s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
+            ctx.num_rendered, binningBuffer, imgBuffer)
+        # order of src/gaussian_rasterizer.cpp:159-179
+        def g(t, like):
+            return t if like.numel() else None
+        return (dL_dmeans3D, dL_dmeans2D, g(dL_dsh, sh), g(dL_dcolors, colors_precomp), dL_dopacity,
+                g(dL_dscales, scales), g(dL_drotations, rotations), g(dL_dcov3D, cov3Ds_precomp), None)
+
+
+def rasterizeGaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    """include/gaussian_rasterizer.h:78-100"""
+    return GaussianRasterizerFunction.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                            cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """include/gaussian_rasterizer.h:102-127, src/gaussian_rasterizer.cpp:18-26,182-234"""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings_ = raster_settings
+
+    def markVisibleGaussians(self, positions):
+        with torch.no_grad():
+            s = self.raster_settings_
+            return rp.markVisible(positions, s.viewmatrix_, s.projmatrix_)
+
+    def forward(self, means3D, means2D, opacities, has_shs, has_colors_precomp, has_scales, has_rotations,
+                has_cov3D_precomp, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        if (not has_shs and not has_colors_precomp) or (has_shs and has_colors_precomp):
+            raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+        if ((not has_scales or not has_rotations) and not has_cov3D_precomp) or \
+                ((has_scales or has_rotations) and has_cov3D_precomp):
+            raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.empty(0, device=means3D.device)
+        shs = shs if has_shs else empty
+        colors_precomp = colors_precomp if has_colors_precomp else empty
+        scales = scales if has_scales else empty
+        rotations = rotations if has_rotations else empty
+        cov3D_precomp = cov3D_precomp if has_cov3D_precomp else empty
+        color, radii = rasterizeGaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                          cov3D_precomp, self.raster_settings_)
+        return color, radii

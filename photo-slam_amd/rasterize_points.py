@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's torch <-> kernel boundary for this path:
+
+  RasterizeGaussiansCUDA          src/rasterize_points.cu:36-114   (include/rasterize_points.h:18-37)
+  RasterizeGaussiansBackwardCUDA  src/rasterize_points.cu:116-193  (include/rasterize_points.h:39-60)
+  markVisible                     src/rasterize_points.cu:195-214
+  distCUDA2                       third_party/simple-knn/spatial.cu:15-26
+
+Same names, argument order, return tuples and error behaviour; torch supplies device memory
+and the current HIP stream only -- all compute happens in libgsr_hip.so behind the C-ABI.
+(The LibTorch C++ twin of this file lives in photo-slam_amd/host/.)
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+
+_LIB_OVERRIDE = None  # tests may point this at the emulator build
+
+
+def _lib():
+    return capi.load(_LIB_OVERRIDE)
+
+
+def _stream_ptr(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def _ptr(t):
+    """contiguous().data_ptr() with the reference's empty-tensor -> nullptr convention."""
+    if t is None or t.numel() == 0:
+        return None, None
+    t = t.contiguous()
+    return t, C.c_void_p(t.data_ptr())
+
+
+def _check_device(lib, *tensors):
+    backend = lib.gsr_backend()
+    for t in tensors:
+        if t is None:
+            continue
+        if backend == b"hip-gfx950" and not t.is_cuda:
+            raise RuntimeError("libgsr_hip.so needs device (torch 'cuda' = HIP) tensors; there is no CPU path")
+        if backend != b"hip-gfx950" and t.is_cuda:
+            raise RuntimeError("the emulator build works on host memory only")
+
+
+def _resize_functional(t):
+    """resizeFunctional, src/rasterize_points.cu:28-34."""
+    def fn(_ctx, nbytes):
+        t.resize_(int(nbytes))
+        return t.data_ptr()
+    return capi.ALLOC_FN(fn)
+
+
+def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                           viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                           prefiltered):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # AT_ERROR, rasterize_points.cu:57-59
+    lib = _lib()
+    _check_device(lib, means3D, background, viewmatrix, projmatrix, campos)
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    dev = means3D.device
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geomBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
+    binningBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
+    imgBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
+    rendered = 0
+    if P != 0:
+        M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
+        keep = []
+        a = capi.ForwardArgs()
+        a.P, a.D, a.M, a.width, a.height = P, int(degree), M, W, H
+        a.scale_modifier, a.tan_fovx, a.tan_fovy, a.prefiltered = float(scale_modifier), float(tan_fovx), float(tan_fovy), int(bool(prefiltered))
+        for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors),
+                        ("opacities", opacity), ("scales", scales), ("rotations", rotations),
+                        ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix),
+                        ("cam_pos", campos)):
+            k, p = _ptr(t.float() if t is not None and t.dtype != torch.float32 else t)
+            keep.append(k)
+            setattr(a, name, p)
+        a.out_color = out_color.data_ptr()
+        a.radii = radii.data_ptr()
+        cbs = [_resize_functional(b) for b in (geomBuffer, binningBuffer, imgBuffer)]
+        n = C.c_int(0)
+        st = lib.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream_ptr(means3D), C.byref(n))
+        capi.check(lib, st, "RasterizeGaussiansCUDA")
+        rendered = n.value
+    return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer
+
+
+def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                   viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                   geomBuffer, R, binningBuffer, imageBuffer):
+    lib = _lib()
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh is not None and sh.numel() != 0 else 0
+    dev = means3D.device
+    opts = dict(dtype=torch.float32, device=dev)
+    # torch::zeros in the reference (rasterize_points.cu:149-157); gsr_backward writes every element itself
+    dL_dmeans3D = torch.empty((P, 3), **opts)
+    dL_dmeans2D = torch.empty((P, 3), **opts)
+    dL_dcolors = torch.empty((P, 3), **opts)
+    dL_dconic = torch.empty((P, 2, 2), **opts)
+    dL_dopacity = torch.empty((P, 1), **opts)
+    dL_dcov3D = torch.empty((P, 6), **opts)
+    dL_dsh = torch.empty((P, M, 3), **opts)
+    dL_dscales = torch.empty((P, 3), **opts)
+    dL_drotations = torch.empty((P, 4), **opts)
+    if P != 0:
+        keep = []
+        a = capi.BackwardArgs()
+        a.P, a.D, a.M, a.R, a.width, a.height = P, int(degree), M, int(R), W, H
+        a.scale_modifier, a.tan_fovx, a.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+        for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors),
+                        ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp),
+                        ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos),
+                        ("radii", radii), ("geom_buffer", geomBuffer), ("binning_buffer", binningBuffer),
+                        ("image_buffer", imageBuffer), ("dL_dpix", dL_dout_color)):
+            k, p = _ptr(t)
+            keep.append(k)
+            setattr(a, name, p)
+        has_sh = a.shs is not None
+        has_scales = a.scales is not None
+        a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
+        a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
+        a.dL_dsh = dL_dsh.data_ptr() if has_sh and M else None
+        a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
+        a.dL_drot = dL_drotations.data_ptr() if has_scales else None
+        st = lib.gsr_backward(C.byref(a), _stream_ptr(means3D))
+        capi.check(lib, st, "RasterizeGaussiansBackwardCUDA")
+        if not has_sh:
+            dL_dsh.zero_()
+        if not has_scales:
+            dL_dscales.zero_()
+            dL_drotations.zero_()
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def markVisible(means3D, viewmatrix, projmatrix):
+    lib = _lib()
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        k1, p1 = _ptr(means3D)
+        k2, p2 = _ptr(viewmatrix)
+        k3, p3 = _ptr(projmatrix)
+        st = lib.gsr_mark_visible(P, p1, p2, p3, C.c_void_p(present.data_ptr()), _stream_ptr(means3D))
+        capi.check(lib, st, "markVisible")
+    return present
+
+
+def distCUDA2(points):
+    lib = _lib()
+    P = points.size(0)
+    means = torch.zeros((P,), dtype=torch.float32, device=points.device)
+    if P != 0:
+        scratch = torch.empty((0,), dtype=torch.uint8, device=points.device)
+        cb = _resize_functional(scratch)
+        k, p = _ptr(points)
+        st = lib.gsr_knn_mean_dist2(P, p, C.c_void_p(means.data_ptr()), cb, None, _stream_ptr(points))
+        capi.check(lib, st, "distCUDA2")
+    return means

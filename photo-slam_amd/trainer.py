@@ -1,0 +1,60 @@
+"""The measured train step: GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774)
+without the SLAM keyframe scheduling -- render -> mask -> L1 + lambda*(1-SSIM) -> backward ->
+densification statistics -> Adam -- plus the keyframe-batch data parallelism of SURVEY.md 8(e):
+one keyframe per rank, all-reduce (mean) of the six leaf gradients, SUM/MAX of the statistics."""
+import torch
+import torch.distributed as dist
+
+from . import loss_utils
+from .gaussian_renderer import GaussianRenderer
+
+
+class TrainStep:
+    def __init__(self, gaussians, opt, pipe, background, world_size=1):
+        self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
+        self.iteration_ = 0
+        self.world_size_ = world_size
+        self.ema_loss_for_log_ = 0.0
+
+    def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
+        g, opt = self.gaussians_, self.opt_
+        self.iteration_ += 1
+        it = self.iteration_
+        g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
+        rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
+            viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_)
+        masked_image = rendered_image * mask                             # :692
+        Ll1 = loss_utils.l1_loss(masked_image, gt_image)                 # :695
+        lam = opt.lambda_dssim_
+        loss = (1.0 - lam) * Ll1 + lam * (1.0 - loss_utils.ssim(masked_image.unsqueeze(0), gt_image.unsqueeze(0)))
+        loss.backward()                                                  # :699
+        with torch.no_grad():
+            if self.world_size_ > 1:
+                # keyframe-batch data parallelism: mean of the per-view gradients over RCCL
+                for p in g.params():
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                    p.grad.mul_(1.0 / self.world_size_)
+            if sync_loss:
+                self.ema_loss_for_log_ = 0.4 * loss.item() + 0.6 * self.ema_loss_for_log_   # :705 (host sync, as the reference)
+            if it < opt.densify_until_iter_:
+                if self.world_size_ == 1:
+                    g.max_radii2D_[visibility_filter] = torch.max(g.max_radii2D_[visibility_filter],
+                                                                 radii[visibility_filter].float())  # :714-717
+                    g.addDensificationStats(viewspace_point_tensor, visibility_filter)              # :719
+                else:
+                    # per-view increments (norm BEFORE the sum over views, gaussian_model.cpp:821-826), then SUM / MAX
+                    vis = visibility_filter
+                    gn = torch.zeros_like(g.xyz_gradient_accum_)
+                    gn[vis] = torch.norm(viewspace_point_tensor.grad[vis][:, :2], dim=-1, keepdim=True)
+                    cnt = vis.float().unsqueeze(1)
+                    rad = torch.where(vis, radii.float(), torch.zeros_like(g.max_radii2D_))
+                    dist.all_reduce(gn, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(rad, op=dist.ReduceOp.MAX)
+                    g.xyz_gradient_accum_ += gn
+                    g.denom_ += cnt
+                    g.max_radii2D_ = torch.max(g.max_radii2D_, rad)
+            if it < opt.iterations_:
+                g.optimizer_.step()                                      # :769-772
+                g.optimizer_.zero_grad(set_to_none=True)
+        return loss

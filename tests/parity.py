@@ -1,0 +1,176 @@
+"""Shared parity harness: run one view through a C-ABI build (HIP on the GPU, or the wave64
+emulator on the host) and through the CPU oracle, and compare every stage.
+
+Bars (BASELINE.md section 3 / north_star):
+  * integer / index work -- radii, tile rectangles, tiles_touched, sort order (point_list),
+    tile ranges, n_contrib -- bit-exact (n_contrib outside oracle-flagged fragile pixels,
+    where a skip/terminate decision sits inside exp() rounding noise);
+  * rendered RGB: mean |diff| <= 1e-4; gradients: relative L1 <= 1e-4 * (a small factor for the
+    undefined fp32 atomic order), tolerance written at each assert.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from photo_slam_amd import capi
+from photo_slam_amd import rasterize_points as rp
+
+RGB_L1_TOL = 1e-4
+GRAD_REL_L1_TOL = 2e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _slice(buf, ptr, count, dtype):
+    """typed view of `count` elements at device pointer `ptr` inside the uint8 tensor `buf`"""
+    if count == 0:
+        return np.zeros(0, dtype)
+    off = ptr - buf.data_ptr()
+    nbytes = count * np.dtype(dtype).itemsize
+    assert 0 <= off and off + nbytes <= buf.numel(), (off, nbytes, buf.numel())
+    return buf[off:off + nbytes].cpu().numpy().view(dtype).copy()
+
+
+class BackendResult:
+    pass
+
+
+def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
+                colors=None, cov3D=None, do_backward=True):
+    """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library."""
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        lib = capi.load(lib_path)
+        empty = torch.empty(0, device=dev)
+        P = cl.xyz.shape[0]
+        a = dict(background=_t(bg, dev), means3D=_t(cl.xyz, dev),
+                 colors=_t(colors, dev) if use_colors_precomp else empty, opacity=_t(cl.get_opacity(), dev),
+                 scales=empty if use_cov3D_precomp else _t(cl.get_scaling(), dev),
+                 rotations=empty if use_cov3D_precomp else _t(cl.get_rotation(), dev), scale_modifier=1.0,
+                 cov3D_precomp=_t(cov3D, dev) if use_cov3D_precomp else empty, viewmatrix=_t(cam.viewmatrix, dev),
+                 projmatrix=_t(cam.projmatrix, dev), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, image_height=cam.H,
+                 image_width=cam.W, sh=empty if use_colors_precomp else _t(cl.get_features(), dev), degree=sh_degree,
+                 campos=_t(cam.campos, dev), prefiltered=False)
+        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a)
+        r = BackendResult()
+        r.R, r.out_color, r.radii = R, color.cpu().numpy(), radii.cpu().numpy()
+        if P:
+            gv, bv, iv = capi.GeometryView(), capi.BinningView(), capi.ImageView()
+            capi.check(lib, lib.gsr_view_geometry(C.c_void_p(geom.data_ptr()), P, C.byref(gv)), "view_geometry")
+            capi.check(lib, lib.gsr_view_image(C.c_void_p(img.data_ptr()), cam.W, cam.H, C.byref(iv)), "view_image")
+            r.depth_key = _slice(geom, gv.depth_key, P, np.uint32)
+            r.tiles_touched = _slice(geom, gv.tiles_touched, P, np.uint32)
+            r.rect = _slice(geom, gv.rect, 4 * P, np.uint16).reshape(P, 4)
+            r.rec = _slice(geom, gv.rec, 12 * P, np.float32).reshape(P, 12)
+            r.cov3D = _slice(geom, gv.cov3D, 6 * P, np.float32).reshape(P, 6)
+            r.clamped = _slice(geom, gv.clamped, P, np.uint8)
+            r.order = _slice(geom, gv.order, P, np.uint32)
+            r.offsets = _slice(geom, gv.offsets, P, np.uint32)
+            T = ((cam.W + 15) // 16) * ((cam.H + 15) // 16)
+            r.final_T = _slice(img, iv.final_T, cam.W * cam.H, np.float32).reshape(cam.H, cam.W)
+            r.n_contrib = _slice(img, iv.n_contrib, cam.W * cam.H, np.uint32).reshape(cam.H, cam.W)
+            r.ranges = _slice(img, iv.ranges, 2 * T, np.uint32).reshape(T, 2)
+            if R:
+                capi.check(lib, lib.gsr_view_binning(C.c_void_p(binning.data_ptr()), R, cam.W, cam.H, C.byref(bv)), "view_binning")
+                r.point_list = _slice(binning, bv.point_list, R, np.uint32)
+                r.tile_keys = _slice(binning, bv.tile_keys, R, np.uint32)
+            else:
+                r.point_list = np.zeros(0, np.uint32)
+                r.tile_keys = np.zeros(0, np.uint32)
+        if do_backward:
+            dpix = _t(dL_dpix if dL_dpix is not None else np.ones((3, cam.H, cam.W), np.float32), dev)
+            g = rp.RasterizeGaussiansBackwardCUDA(a["background"], a["means3D"], radii, a["colors"], a["scales"],
+                                                  a["rotations"], 1.0, a["cov3D_precomp"], a["viewmatrix"],
+                                                  a["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, a["sh"], sh_degree,
+                                                  a["campos"], geom, R, binning, img)
+            names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+            r.grads = {n: t.cpu().numpy() for n, t in zip(names, g)}
+        return r
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def run_oracle(oracle, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
+               colors=None, cov3D=None, do_backward=True):
+    res, color, radii = oracle.forward(
+        bg, cl.xyz, cl.get_opacity(), cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, cam.H, cam.W,
+        shs=None if use_colors_precomp else cl.get_features(), sh_degree=sh_degree,
+        colors_precomp=colors if use_colors_precomp else None,
+        scales=None if use_cov3D_precomp else cl.get_scaling(), rotations=None if use_cov3D_precomp else cl.get_rotation(),
+        cov3D_precomp=cov3D if use_cov3D_precomp else None)
+    grads = None
+    if do_backward and res is not None:
+        grads = oracle.backward(res, dL_dpix if dL_dpix is not None else np.ones((3, cam.H, cam.W), np.float32))
+    return res, color, radii, grads
+
+
+def rel_l1(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).sum() / (np.abs(b.astype(np.float64)).sum() + 1e-30))
+
+
+def compare(r, ores, ocolor, oradii, ograds, cam, use_colors_precomp=False, use_cov3D_precomp=False, report=None):
+    """Asserts the parity bars; returns a dict of measured deviations."""
+    rep = {} if report is None else report
+    vis = oradii > 0
+    # ---- preprocess: integers exact
+    assert np.array_equal(r.radii, oradii), f"radii mismatch on {(r.radii != oradii).sum()} Gaussians"
+    assert np.array_equal(r.tiles_touched, ores.tiles_touched), "tiles_touched mismatch"
+    want_key = np.where(vis, ores.depths.view(np.uint32), np.uint32(0xFFFFFFFF))
+    assert np.array_equal(r.depth_key, want_key), "depth keys mismatch"
+    # tile rectangles: recompute getRect from the oracle's means2D/radii (auxiliary.h:46-56)
+    gx, gy = ores.grid
+    m2 = ores.means2D[vis].astype(np.float32)
+    rad = oradii[vis].astype(np.int32)
+    def trunc(v):
+        return np.clip(np.trunc(v.astype(np.float64)), -2**31, 2**31 - 1).astype(np.int64)
+    f32 = np.float32
+    rminx = np.minimum(gx, np.maximum(0, trunc((m2[:, 0] - rad.astype(f32)) / f32(16))))
+    rminy = np.minimum(gy, np.maximum(0, trunc((m2[:, 1] - rad.astype(f32)) / f32(16))))
+    rmaxx = np.minimum(gx, np.maximum(0, trunc(((m2[:, 0] + rad.astype(f32)) + f32(16) - f32(1)) / f32(16))))
+    rmaxy = np.minimum(gy, np.maximum(0, trunc(((m2[:, 1] + rad.astype(f32)) + f32(16) - f32(1)) / f32(16))))
+    want_rect = np.stack([rminx, rminy, rmaxx, rmaxy], 1).astype(np.uint16)
+    assert np.array_equal(r.rect[vis], want_rect), "tile rectangles mismatch"
+    # ---- preprocess: floats (same op order, contraction off on both sides -> expected identical)
+    rec = r.rec[vis]
+    rep["means2D_maxabs"] = float(np.abs(rec[:, 0:2] - ores.means2D[vis]).max(initial=0))
+    conic_b = np.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1)
+    rep["conic_opacity_rel"] = rel_l1(conic_b, ores.conic_opacity[vis])
+    rgb_o = ores.inputs[0]["colors_precomp"][vis] if use_colors_precomp else ores.rgb[vis]
+    rep["rgb_maxabs"] = float(np.abs(np.stack([rec[:, 6], rec[:, 7], rec[:, 8]], 1) - rgb_o).max(initial=0))
+    assert rep["means2D_maxabs"] <= 1e-4 and rep["conic_opacity_rel"] <= 1e-6 and rep["rgb_maxabs"] <= 1e-5, rep
+    if not use_cov3D_precomp:
+        rep["cov3D_rel"] = rel_l1(r.cov3D[vis], ores.cov3D[vis])
+        assert rep["cov3D_rel"] <= 1e-6, rep
+    if not use_colors_precomp:
+        cl_o = (ores.clamped[:, 0] | (ores.clamped[:, 1] << 1) | (ores.clamped[:, 2] << 2)).astype(np.uint8)
+        assert np.array_equal(r.clamped[vis], cl_o[vis]), "clamp mask mismatch"
+    # ---- binning: exact
+    assert r.R == ores.R, (r.R, ores.R)
+    assert np.array_equal(r.point_list, ores.point_list), "sorted instance list differs from the oracle"
+    assert np.array_equal(r.tile_keys, (ores.keys_sorted >> np.uint64(32)).astype(np.uint32)), "tile keys differ"
+    assert np.array_equal(r.ranges, ores.ranges), "tile ranges differ"
+    # ---- blend forward
+    rep["rgb_L1"] = float(np.abs(r.out_color - ocolor).mean())
+    assert rep["rgb_L1"] <= RGB_L1_TOL, rep
+    solid = ores.fragile == 0
+    rep["fragile_px"] = int((~solid).sum())
+    mism = (r.n_contrib != ores.n_contrib) & solid
+    rep["n_contrib_mismatch_nonfragile"] = int(mism.sum())
+    assert rep["n_contrib_mismatch_nonfragile"] == 0, rep
+    rep["final_T_maxabs"] = float(np.abs(r.final_T - ores.final_T)[solid].max(initial=0))
+    assert rep["final_T_maxabs"] <= 1e-5, rep
+    # ---- backward
+    if ograds is not None and hasattr(r, "grads"):
+        for name, g in r.grads.items():
+            if g.size == 0:
+                continue
+            ref = ograds[name]
+            rep["grad_" + name] = rel_l1(g, ref)
+            assert np.isfinite(g).all(), name
+            assert rep["grad_" + name] <= GRAD_REL_L1_TOL, (name, rep["grad_" + name])
+            # culled Gaussians: exact zeros
+            assert not np.any(g.reshape(g.shape[0], -1)[~vis]), f"{name} non-zero on culled Gaussians"
+    return rep

@@ -1,0 +1,29 @@
+"""Kernel-logic parity on the host: the product kernel sources, compiled against the wave64
+emulator (tests/emu), must reproduce the oracle stage by stage on small scenes.  (The same
+comparison runs on the real GPU build in test_gpu_parity.py, marked gpu.)"""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from photo_slam_amd import scene
+
+CPU = torch.device("cpu")
+
+
+def small_scene(P, W, H, seed, scale_k=0.35):
+    return scene.make_cloud(P, W, H, 0.8 * W, 0.8 * W, seed=seed, scale_k=scale_k)
+
+
+@pytest.mark.parametrize("P,W,H,seed", [(600, 64, 48, 1), (1500, 80, 70, 2)])
+def test_forward_backward_matches_oracle(emu_lib_path, oracle, P, W, H, seed):
+    cl = small_scene(P, W, H, seed)
+    cam = cl.cameras[0]
+    bg = np.array([0.2, 0.5, 0.1], np.float32)
+    rng = np.random.default_rng(seed)
+    dpix = rng.standard_normal((3, H, W)).astype(np.float32)
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+    assert ores.R > 0
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix)
+    rep = parity.compare(r, ores, ocolor, oradii, ograds, cam)
+    print(rep)

@@ -1,0 +1,146 @@
+"""Host logic of the measured train step (GaussianRenderer.render -> loss -> backward -> Adam) and of
+the keyframe-batch data parallelism, on the host: CPU tensors, kernels through the wave64 emulator,
+collectives through gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from photo_slam_amd import rasterize_points as rp
+from photo_slam_amd import scene
+from photo_slam_amd.gaussian_model import GaussianModel, GaussianOptimizationParams
+from photo_slam_amd.gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from photo_slam_amd.gaussian_renderer import GaussianKeyframe, GaussianPipelineParams, GaussianRenderer
+from photo_slam_amd.trainer import TrainStep
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def emu(emu_lib_path):
+    rp._LIB_OVERRIDE = emu_lib_path
+    yield emu_lib_path
+    rp._LIB_OVERRIDE = None
+
+
+def _setup(P=300, W=48, H=32, seed=3, n_views=1):
+    cl = scene.make_cloud(P, W, H, 40.0, 40.0, seed=seed, scale_k=0.35, n_views=n_views)
+    g = GaussianModel.from_cloud(cl, device="cpu")
+    g.trainingSetup(GaussianOptimizationParams())
+    kfs = [GaussianKeyframe.from_camera(c, "cpu") for c in cl.cameras]
+    return cl, g, kfs
+
+
+def test_render_returns_reference_tuple_and_grads_flow(emu):
+    cl, g, kfs = _setup()
+    bg = torch.zeros(3)
+    img, viewspace, vis, radii = GaussianRenderer.render(kfs[0], 32, 48, g, GaussianPipelineParams(), bg)
+    assert img.shape == (3, 32, 48) and viewspace.shape == (300, 3) and vis.dtype == torch.bool
+    assert torch.equal(vis, radii > 0) and radii.dtype == torch.int32
+    img.sum().backward()
+    for p in g.params():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert viewspace.grad is not None and not viewspace.grad[:, 2].any()
+    assert not g.xyz_.grad[~vis].any()
+
+
+def test_rasterizer_argument_validation(emu):
+    cl, g, kfs = _setup()
+    s = GaussianRasterizationSettings(32, 48, 1.0, 1.0, torch.zeros(3), 1.0, kfs[0].world_view_transform_,
+                                      kfs[0].full_proj_transform_, 3, kfs[0].camera_center_, False)
+    r = GaussianRasterizer(s)
+    with pytest.raises(RuntimeError, match="excatly one of either SHs or precomputed colors"):
+        r(g.getXYZ(), g.getXYZ(), g.getOpacityActivation(), False, False, True, True, False)
+    with pytest.raises(RuntimeError, match="exactly one of either scale/rotation pair"):
+        r(g.getXYZ(), g.getXYZ(), g.getOpacityActivation(), True, False, True, False, False, shs=g.getFeatures())
+    assert r.markVisibleGaussians(g.getXYZ()).dtype == torch.bool
+
+
+def test_train_step_reduces_loss(emu):
+    cl, g, kfs = _setup()
+    torch.manual_seed(0)
+    gt = torch.rand(3, 32, 48)
+    mask = torch.ones(3, 32, 48)
+    ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+    losses = [float(ts.trainForOneIteration(kfs[0], gt, mask)) for _ in range(8)]
+    assert losses[-1] < losses[0], losses
+    assert g.denom_.sum() > 0 and g.max_radii2D_.max() > 0
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as entry
+entry.load_package()
+from photo_slam_amd import rasterize_points as rp, scene
+from photo_slam_amd.gaussian_model import GaussianModel, GaussianOptimizationParams
+from photo_slam_amd.gaussian_renderer import GaussianKeyframe, GaussianPipelineParams
+from photo_slam_amd.trainer import TrainStep
+rp._LIB_OVERRIDE = sys.argv[2]
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+cl = scene.make_cloud(300, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=ws)
+g = GaussianModel.from_cloud(cl, device="cpu"); g.trainingSetup(GaussianOptimizationParams())
+kf = GaussianKeyframe.from_camera(cl.cameras[rank], "cpu")
+torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
+ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), world_size=ws)
+for _ in range(2): ts.trainForOneIteration(kf, gt, torch.ones(3, 32, 48))
+out = {n: p.detach().numpy() for n, p in zip(["xyz","f_dc","f_rest","opacity","scaling","rotation"], g.params())}
+out["accum"] = g.xyz_gradient_accum_.numpy(); out["denom"] = g.denom_.numpy(); out["maxr"] = g.max_radii2D_.numpy()
+np.savez(os.path.join(sys.argv[3], f"rank{rank}.npz"), **out)
+dist.barrier()
+'''
+
+
+def test_keyframe_batch_data_parallel_gloo(emu, tmp_path):
+    """2 ranks x 1 keyframe each == 1 process accumulating both keyframes' gradients (mean)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29511", str(script), ROOT, emu, str(tmp_path)],
+                          env=env, timeout=600)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"replicas diverged on {k}"
+    # single-process reference: mean gradient of the two views, same Adam
+    cl, g, kfs = _setup(n_views=2)
+    opt = GaussianOptimizationParams()
+    mask = torch.ones(3, 32, 48)
+    gts = []
+    for rank in range(2):
+        torch.manual_seed(100 + rank)
+        gts.append(torch.rand(3, 32, 48))
+    from photo_slam_amd import loss_utils
+    for it in range(1, 3):
+        g.updateLearningRate(it)
+        grads = None
+        stats = []
+        for kf, gt in zip(kfs, gts):
+            img, vsp, vis, radii = GaussianRenderer.render(kf, 32, 48, g, GaussianPipelineParams(), torch.zeros(3))
+            m = img * mask
+            loss = 0.8 * loss_utils.l1_loss(m, gt) + 0.2 * (1.0 - loss_utils.ssim(m.unsqueeze(0), gt.unsqueeze(0)))
+            loss.backward()
+            cur = [p.grad.clone() for p in g.params()]
+            for p in g.params():
+                p.grad = None
+            grads = cur if grads is None else [a + b for a, b in zip(grads, cur)]
+            gn = torch.zeros_like(g.xyz_gradient_accum_)
+            gn[vis] = torch.norm(vsp.grad[vis][:, :2], dim=-1, keepdim=True)
+            stats.append((gn, vis.float().unsqueeze(1), torch.where(vis, radii.float(), torch.zeros(300))))
+        with torch.no_grad():
+            for p, gr in zip(g.params(), grads):
+                p.grad = gr * 0.5
+            g.xyz_gradient_accum_ += stats[0][0] + stats[1][0]
+            g.denom_ += stats[0][1] + stats[1][1]
+            g.max_radii2D_ = torch.max(g.max_radii2D_, torch.max(stats[0][2], stats[1][2]))
+            g.optimizer_.step()
+            g.optimizer_.zero_grad(set_to_none=True)
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    for n, p in zip(names, g.params()):
+        assert np.allclose(r0[n], p.detach().numpy(), rtol=1e-5, atol=1e-7), n
+    assert np.allclose(r0["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
+    assert np.array_equal(r0["denom"], g.denom_.numpy()) and np.array_equal(r0["maxr"], g.max_radii2D_.numpy())
