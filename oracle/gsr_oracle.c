@@ -1017,3 +1017,100 @@ void gsro_knn_bruteforce(int P, const float* points, float* meanDists)
 		meanDists[i] = (best[0] + best[1] + best[2]) / 3.0f;
 	}
 }
+
+
+/* ---------------- analysis helper (not part of the reference): work statistics of the
+ * per-quad rejection used by the HIP blend kernels (csrc/blend.h quad_keep_bits restated),
+ * and a check that it never rejects a pair the reference would blend.
+ * out[0] = sum over tiles of list length            out[1] = sum over tiles of max n_contrib (entries staged by bwd)
+ * out[2] = (quad, entry) pairs visited by fwd        out[3] = (quad, entry) pairs visited by bwd
+ * out[4] = (pixel, entry) pairs blended (alpha>=1/255, before termination)
+ * out[5] = (pixel, entry) pairs evaluated by the reference fwd (until done)
+ * out[6] = number of blended pairs that the quad test would have rejected (must be 0)
+ * out[7] = (quad, entry) pairs without rejection in fwd (4 * entries until the quad is done) */
+static uint32_t quad_keep_bits_ref(const float* m2, const float* co, float tile_px0, float tile_py0)
+{
+	const float mx = m2[0], my = m2[1], A = co[0], B = co[1], C = co[2], o = co[3];
+	if (o < 1.0f / 255.0f) return 0u;
+	const float det = A * C - B * B;
+	if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;
+	const float thr = logf(255.0f * o);
+	uint32_t bits = 0;
+	const float invA = 1.0f / A, invC = 1.0f / C;
+	for (int q = 0; q < 4; q++) {
+		const float u0 = tile_px0 + (float)((q & 1) * 8) - mx, u1 = u0 + 7.0f;
+		const float v0 = tile_py0 + (float)((q >> 1) * 8) - my, v1 = v0 + 7.0f;
+		float qmin;
+		if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) qmin = 0.f;
+		else {
+			float e, vs = fminf(v1, fmaxf(v0, -B * u0 * invC));
+			qmin = 0.5f * (A * u0 * u0 + C * vs * vs) + B * u0 * vs;
+			vs = fminf(v1, fmaxf(v0, -B * u1 * invC));
+			e = 0.5f * (A * u1 * u1 + C * vs * vs) + B * u1 * vs; qmin = fminf(qmin, e);
+			float us = fminf(u1, fmaxf(u0, -B * v0 * invA));
+			e = 0.5f * (A * us * us + C * v0 * v0) + B * us * v0; qmin = fminf(qmin, e);
+			us = fminf(u1, fmaxf(u0, -B * v1 * invA));
+			e = 0.5f * (A * us * us + C * v1 * v1) + B * us * v1; qmin = fminf(qmin, e);
+		}
+		const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
+		const float mag = 0.5f * (A * um * um + C * vm * vm) + fabsf(B) * um * vm;
+		const float margin = 0.01f + 1e-4f * thr + 2e-5f * mag;
+		if (!(qmin > thr + margin)) bits |= (1u << q);
+	}
+	return bits;
+}
+
+void gsro_cull_stats(const gsro_state* st, double* out)
+{
+	for (int i = 0; i < 8; i++) out[i] = 0;
+	const int W = st->W, H = st->H;
+	const int T = st->grid_x * st->grid_y;
+	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7)
+	for (int t = 0; t < T; t++) {
+		const int tx = t % st->grid_x, ty = t / st->grid_x;
+		const uint32_t rs = st->ranges[2 * t], re = st->ranges[2 * t + 1];
+		const uint32_t n = re - rs;
+		o0 += n;
+		uint32_t qmaxc[4] = {0, 0, 0, 0}; /* deepest n_contrib per quad */
+		uint32_t qdone_at[4] = {0, 0, 0, 0}; /* entries the fwd quad walks before all its pixels are done */
+		for (int q = 0; q < 4; q++)
+			for (int l = 0; l < 64; l++) {
+				int px = tx * 16 + (q & 1) * 8 + (l & 7), py = ty * 16 + (q >> 1) * 8 + (l >> 3);
+				if (px >= W || py >= H) continue;
+				uint32_t nc = st->n_contrib[(size_t)py * W + px];
+				if (nc > qmaxc[q]) qmaxc[q] = nc;
+				/* forward walk length of this pixel: until termination or end of list */
+				float T_ = 1.f; uint32_t k;
+				for (k = 0; k < n; k++) {
+					uint32_t g = st->point_list[rs + k];
+					float dx = st->means2D[2 * g] - (float)px, dy = st->means2D[2 * g + 1] - (float)py;
+					const float* co = st->conic_opacity + 4 * (size_t)g;
+					float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+					o5 += 1;
+					if (power > 0.0f) continue;
+					float alpha = fminf(0.99f, co[3] * expf(power));
+					if (alpha < 1.0f / 255.0f) continue;
+					float test_T = T_ * (1 - alpha);
+					if (test_T < 0.0001f) { k++; break; }
+					T_ = test_T;
+					o4 += 1;
+					uint32_t bits = quad_keep_bits_ref(st->means2D + 2 * g, co, (float)(tx * 16), (float)(ty * 16));
+					if (!((bits >> q) & 1)) o6 += 1;
+				}
+				if (k > qdone_at[q]) qdone_at[q] = k;
+			}
+		uint32_t bmax = 0;
+		for (int q = 0; q < 4; q++) if (qmaxc[q] > bmax) bmax = qmaxc[q];
+		o1 += bmax;
+		for (uint32_t k = 0; k < n; k++) {
+			uint32_t g = st->point_list[rs + k];
+			uint32_t bits = quad_keep_bits_ref(st->means2D + 2 * g, st->conic_opacity + 4 * (size_t)g, (float)(tx * 16), (float)(ty * 16));
+			for (int q = 0; q < 4; q++) {
+				if (k < qdone_at[q]) { o7 += 1; if ((bits >> q) & 1) o2 += 1; }
+				if (k < qmaxc[q] && ((bits >> q) & 1)) o3 += 1;
+			}
+		}
+	}
+	out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
+}

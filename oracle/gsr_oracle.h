@@ -99,6 +99,10 @@ void gsro_knn(int P, const float* points, float* meanDists);
 /* Brute-force O(P^2) exact 3-NN mean of squared distances (pins gsro_knn). */
 void gsro_knn_bruteforce(int P, const float* points, float* meanDists);
 
+/* Analysis helper (not in the reference): work statistics of the per-quad rejection of the HIP
+ * blend kernels, and the count of blended pairs it would wrongly reject (must be 0).  out[8]. */
+void gsro_cull_stats(const gsro_state* st, double* out);
+
 /* getHigherMsb, rasterizer_impl.cu:35-50. */
 uint32_t gsro_higher_msb(uint32_t n);
 

@@ -56,6 +56,7 @@ def lib():
         L.gsro_knn_bruteforce.argtypes = [C.c_int, fp, fp]
         L.gsro_higher_msb.restype = C.c_uint32
         L.gsro_higher_msb.argtypes = [C.c_uint32]
+        L.gsro_cull_stats.argtypes = [C.POINTER(_State), C.POINTER(C.c_double)]
         L.gsro_set_threads.argtypes = [C.c_int]
         L.gsro_get_threads.restype = C.c_int
         _lib = L
@@ -208,3 +209,11 @@ def knn(points, bruteforce=False):
 
 def higher_msb(n):
     return int(lib().gsro_higher_msb(int(n)))
+
+
+def cull_stats(res):
+    out = (C.c_double * 8)()
+    lib().gsro_cull_stats(res._st, out)
+    names = ("list_entries", "bwd_staged_entries", "fwd_quad_visits", "bwd_quad_visits", "blended_pairs",
+             "reference_fwd_pair_evals", "wrongly_rejected_pairs", "fwd_quad_visits_without_rejection")
+    return dict(zip(names, [float(v) for v in out]))
