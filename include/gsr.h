@@ -95,7 +95,8 @@ typedef struct gsr_backward_args {
 	char* image_buffer;
 	const float* dL_dpix;        /* [3,H,W] */
 	float* dL_dmean2D;           /* [P,3]  (.z stays 0) */
-	float* dL_dconic;            /* [P,4]  the reference's [P,2,2]; .z never written */
+	float* dL_dconic;            /* [P,4]  the reference's [P,2,2] (.z = 0); internal to the reference's wrapper
+	                                (rasterize_points.cu:152), so NULL is accepted */
 	float* dL_dopacity;          /* [P]   */
 	float* dL_dcolor;            /* [P,3] */
 	float* dL_dmean3D;           /* [P,3] */

@@ -38,6 +38,9 @@ def _deps():
 
 
 def build(force=False, verbose=False, save_temps=False):
+    extra_env = os.environ.get("GSR_EXTRA_FLAGS", "").split()   # experiment switches (-DGSR_EXP_...)
+    if extra_env:
+        force = True
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
     bdir = os.path.join(HERE, "build")
@@ -45,7 +48,7 @@ def build(force=False, verbose=False, save_temps=False):
     procs, objs = [], []
     for src, extra in SOURCES:
         o = os.path.join(bdir, src + ".o")
-        cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", o]
+        cmd = [HIPCC] + COMMON + extra + extra_env + ["-c", os.path.join(CSRC, src), "-o", o]
         if save_temps:
             cmd += ["-save-temps=obj"]
         if verbose:

@@ -21,7 +21,7 @@ namespace gsr {
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint32_t* __restrict__ tiles_touched, const uint16_t* __restrict__ rect, int grid_x,
-                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float4* __restrict__ rec)
 {
 	__shared__ uint32_t s_off[4][64];
 	__shared__ uint32_t s_g[4][64];
@@ -32,6 +32,9 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
 	const uint32_t g = valid ? order[j] : 0u;
 	const uint32_t cnt = valid ? tiles_touched[g] : 0u;
 	const uint32_t off = valid ? offsets[j] : 0u;
+	// slot of the Gaussian's first instance = its emission offset (the backward blend writes its
+	// per-tile gradient partials there, preprocess_bwd sums the contiguous run)
+	if (cnt) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = off;
 	const uint32_t total = wave_sum_u32(cnt);
 	if (total == 0) return;  // wave-uniform
 	// wave base = offset of the first valid lane = min over lanes holding instances; offsets are
@@ -78,10 +81,76 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 	if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
+// Sum every Gaussian's contiguous run of per-instance gradient slots (written by the backward
+// blend) into one 48-byte record per Gaussian, in a fixed order (no atomics: bit-reproducible).
+// Thread = Gaussian (id order, so the few screen-filling splats are spread over many waves).
+// Runs of up to 64 slots are summed by their owner lane; longer runs are summed by the whole wave
+// (strided 48-byte slots, then a DPP reduction) so that a 3000-tile splat costs 50 iterations,
+// not 3000.
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
+                       const float* __restrict__ partials, float* __restrict__ grad_acc)
+{
+	const int l = lane_id();
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const bool valid = idx < P;
+	const uint32_t cnt = valid ? tiles_touched[idx] : 0u;
+	if (wave_ballot(cnt != 0u) == 0ull) return;  // wave-uniform
+	const uint32_t first = cnt ? __float_as_uint(rec[3 * (size_t)idx + 2].w) : 0u;
+	const float4* part4 = reinterpret_cast<const float4*>(partials);
+	float a[9];
+#pragma unroll
+	for (int c = 0; c < 9; c++) a[c] = 0.f;
+	if (cnt != 0u && cnt <= 64u) {
+		const float4* src = part4 + 3 * (size_t)first;
+		for (uint32_t i = 0; i < cnt; i++) {
+			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
+			const float z = src[3 * (size_t)i + 2].x;
+			a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+			a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
+			a[8] += z;
+		}
+	}
+	unsigned long long big = wave_ballot(cnt > 64u);
+	while (big) {
+		const int b = __ffsll((long long)big) - 1;
+		big &= big - 1ull;
+		const uint32_t bfirst = wave_readlane_u32(first, b), bcnt = wave_readlane_u32(cnt, b);
+		float v[9];
+#pragma unroll
+		for (int c = 0; c < 9; c++) v[c] = 0.f;
+		const float4* src = part4 + 3 * (size_t)bfirst;
+		for (uint32_t i = (uint32_t)l; i < bcnt; i += 64u) {
+			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
+			const float z = src[3 * (size_t)i + 2].x;
+			v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+			v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+			v[8] += z;
+		}
+		wave_reduce9_f32(v);  // totals in lane 63
+#pragma unroll
+		for (int c = 0; c < 9; c++) a[c] = wave_writelane_f32(a[c], wave_readlane_f32(v[c], 63), b);
+	}
+	if (cnt) {
+		float4* dst = reinterpret_cast<float4*>(grad_acc) + 3 * (size_t)idx;
+		dst[0] = make_float4(a[0], a[1], a[2], a[3]);
+		dst[1] = make_float4(a[4], a[5], a[6], a[7]);
+		dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
+	}
+}
+
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, hipStream_t stream)
+{
+	GSR_LAUNCH(reduce_partials_kernel, div_up(P, 256), 256, stream, P, (const float4*)g.rec, (const uint32_t*)g.tiles_touched,
+	           partials, grad_acc);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
 int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
 {
 	GSR_LAUNCH(emit_instances_kernel, div_up(P, 256), 256, stream, P, (const uint32_t*)g.order, (const uint32_t*)g.offsets,
-	           (const uint32_t*)g.tiles_touched, (const uint16_t*)g.rect, grid_x, keys, vals);
+	           (const uint32_t*)g.tiles_touched, (const uint16_t*)g.rect, grid_x, keys, vals, g.rec);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -1,30 +1,47 @@
 // blend.h -- pieces shared by the forward and backward alpha-blend kernels.
+//
+// Work decomposition: the 16x16 tile stays the unit of binning (tile ids are part of the parity
+// contract), but the unit of execution is one WAVE per 8x8 pixel quad: a 64-thread workgroup
+// owns quad q of a tile, lane l the pixel (l&7, l>>3) inside it.  The four quads of a tile walk
+// the same depth-sorted list independently -- no workgroup barriers.  Per batch of 64 list
+// entries lane j gathers entry j's 48-byte record, evaluates the per-quad rejection test for it
+// and parks the (pre-scaled) record in the wave's 3 KiB LDS slice; a ballot yields the 64-bit
+// survivor mask in an SGPR pair; the wave walks the set bits with scalar instructions and
+// fetches each survivor with LDS broadcast reads (same address in all lanes: conflict-free, and
+// on the LDS pipe instead of the VALU the blend math saturates).
 #pragma once
 #include "state.h"
 #include "wave64.h"
 
 namespace gsr {
 
-// Workgroup = one 16x16 tile (the tile grid is part of the parity contract); wave q of the
-// workgroup owns the 8x8 pixel quad q (quad origin = ((q&1)*8, (q>>1)*8)), lane l the pixel
-// (l&7, l>>3) inside it.  8x8 quads are the most compact 64-pixel footprint, which is what
-// makes the per-quad rejection below effective.
-__device__ __forceinline__ void quad_pixel(int tile_x, int tile_y, int& px, int& py)
-{
-	const int q = wave_id(), l = lane_id();
-	px = tile_x * TILE + (q & 1) * 8 + (l & 7);
-	py = tile_y * TILE + (q >> 1) * 8 + (l >> 3);
-}
+constexpr int QUADS_PER_TILE = 4;
+constexpr float LOG2E = 1.4426950408889634f;
 
-// XCD-aware tile assignment: workgroup b is dispatched to XCD b % 8 (observed, used for
-// speed only), so XCD k is given a contiguous band of tiles -- neighbouring tiles share
-// Gaussian records, which then stay in that XCD's 4 MiB L2.
-__device__ __forceinline__ int xcd_tile(int block, int tiles)
+// exp(power) = exp2(pw) with pw = A'dx^2 + C'dy^2 + B'dxdy and the conic pre-scaled once per staged
+// entry (A' = -0.5*log2(e)*A, C' likewise, B' = -log2(e)*B): the per-pixel chain is 8 VALU + v_exp_f32.
+__device__ __forceinline__ float4 prescale_q0(const float4 q0) { return make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w); }
+__device__ __forceinline__ float prescale_c(float c) { return -0.5f * LOG2E * c; }
+
+// XCD-aware work assignment: workgroup b is dispatched to XCD b % 8 (observed behaviour, used for
+// speed only).  Each XCD gets a contiguous band of tiles and, inside it, the four quads of a tile
+// are consecutive workgroups -- the tile's list and records are then served by one 4 MiB L2.
+__device__ __forceinline__ int tile_assignment(int block, int tiles)
 {
 	const int per = (tiles + 7) >> 3;
-	return (block & 7) * per + (block >> 3);
+	const int t = (block & 7) * per + (block >> 3);
+	return (block >> 3) >= per ? tiles : t;
 }
-static inline int xcd_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
+static inline int tile_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
+__device__ __forceinline__ void quad_assignment(int block, int tiles, int& tile, int& quad)
+{
+	const int per = (tiles + 7) >> 3;            // tiles per XCD band
+	const int in_xcd = block >> 3;
+	tile = (block & 7) * per + (in_xcd >> 2);
+	quad = in_xcd & 3;
+	if ((in_xcd >> 2) >= per) tile = tiles;      // padding workgroups of the last band
+}
+static inline int quad_grid(int tiles) { return ((tiles + 7) >> 3) * 8 * QUADS_PER_TILE; }
 
 // Conservative per-quad rejection.  A (pixel, Gaussian) pair is skipped by the reference
 // when alpha = min(0.99, o*exp(power)) < 1/255 (forward.cu:343-345, backward.cu:499-501),
@@ -34,45 +51,50 @@ static inline int xcd_grid(int tiles) { return ((tiles + 7) >> 3) * 8; }
 // exceeds the threshold (plus a rounding margin) no pixel of the quad can blend this
 // Gaussian and the whole wave skips it -- the skipped pairs are exactly pairs the
 // reference `continue`s over, so results are unchanged.
-// Returns a 4-bit mask: bit q set = quad q must evaluate this Gaussian.
-__device__ __forceinline__ uint32_t quad_keep_bits(const float4 q0, const float4 q1, float tile_px0, float tile_py0)
+// (x0, y0) = pixel coordinates of the quad's first pixel.
+__device__ __forceinline__ bool quad_keep(const float4 q0, const float4 q1, float x0, float y0)
 {
 	const float mx = q0.x, my = q0.y, A = q0.z, B = q0.w, C = q1.x, o = q1.y;
-	if (o < 1.0f / 255.0f) return 0u;             // alpha <= o < 1/255 everywhere (NaN opacity falls through: keep)
+	if (o < 1.0f / 255.0f) return false;          // alpha <= o < 1/255 everywhere (NaN opacity falls through: keep)
 	const float det = A * C - B * B;
-	if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;  // not positive definite (or NaN): no bound, keep
+	if (!(A > 0.f && C > 0.f && det > 0.f)) return true;  // not positive definite (or NaN): no bound, keep
 	const float thr = __logf(255.0f * o);
-	uint32_t bits = 0;
-	const float invA = 1.0f / A, invC = 1.0f / C;
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		const float u0 = tile_px0 + (float)((q & 1) * 8) - mx, u1 = u0 + 7.0f;
-		const float v0 = tile_py0 + (float)((q >> 1) * 8) - my, v1 = v0 + 7.0f;
-		float qmin;
-		if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) {
-			qmin = 0.f;
-		} else {
-			// edge u = const: minimise over v in [v0, v1];  edge v = const: minimise over u
-			float e;
-			float vs = fminf(v1, fmaxf(v0, -B * u0 * invC));
-			qmin = 0.5f * (A * u0 * u0 + C * vs * vs) + B * u0 * vs;
-			vs = fminf(v1, fmaxf(v0, -B * u1 * invC));
-			e = 0.5f * (A * u1 * u1 + C * vs * vs) + B * u1 * vs;
-			qmin = fminf(qmin, e);
-			float us = fminf(u1, fmaxf(u0, -B * v0 * invA));
-			e = 0.5f * (A * us * us + C * v0 * v0) + B * us * v0;
-			qmin = fminf(qmin, e);
-			us = fminf(u1, fmaxf(u0, -B * v1 * invA));
-			e = 0.5f * (A * us * us + C * v1 * v1) + B * us * v1;
-			qmin = fminf(qmin, e);
-		}
-		// rounding margin: fp32 evaluation error of `power` scales with the magnitude of its terms
-		const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
-		const float mag = 0.5f * (A * um * um + C * vm * vm) + fabsf(B) * um * vm;
-		const float margin = 0.01f + 1e-4f * thr + 2e-5f * mag;
-		if (!(qmin > thr + margin)) bits |= (1u << q);
+	const float u0 = x0 - mx, u1 = u0 + 7.0f;
+	const float v0 = y0 - my, v1 = v0 + 7.0f;
+	float qmin;
+	if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) {
+		qmin = 0.f;
+	} else {
+		const float invA = 1.0f / A, invC = 1.0f / C;
+		// edge u = const: minimise over v in [v0, v1];  edge v = const: minimise over u
+		float e;
+		float vs = fminf(v1, fmaxf(v0, -B * u0 * invC));
+		qmin = 0.5f * (A * u0 * u0 + C * vs * vs) + B * u0 * vs;
+		vs = fminf(v1, fmaxf(v0, -B * u1 * invC));
+		e = 0.5f * (A * u1 * u1 + C * vs * vs) + B * u1 * vs;
+		qmin = fminf(qmin, e);
+		float us = fminf(u1, fmaxf(u0, -B * v0 * invA));
+		e = 0.5f * (A * us * us + C * v0 * v0) + B * us * v0;
+		qmin = fminf(qmin, e);
+		us = fminf(u1, fmaxf(u0, -B * v1 * invA));
+		e = 0.5f * (A * us * us + C * v1 * v1) + B * us * v1;
+		qmin = fminf(qmin, e);
 	}
-	return bits;
+	// rounding margin: fp32 evaluation error of `power` scales with the magnitude of its terms
+	const float um = fmaxf(fabsf(u0), fabsf(u1)), vm = fmaxf(fabsf(v0), fabsf(v1));
+	const float mag = 0.5f * (A * um * um + C * vm * vm) + fabsf(B) * um * vm;
+	const float margin = 0.01f + 1e-4f * thr + 2e-5f * mag;
+	return !(qmin > thr + margin);
 }
+
+// Gradient hand-off without global atomics.  Every (tile, Gaussian) instance owns one 48-byte slot
+//   [0..2] dL_dcolor  [3..4] dL_dmean2D.xy  [5..7] dL_dconic (x, y, w)  [8] dL_dopacity  [9..11] unused
+// in `partials`, indexed by emission order: a Gaussian's instances were emitted contiguously
+// (row-major over its tile rectangle, binning.hip), so slot = first_slot + (ty-miny)*w + (tx-minx),
+// all of which ride in the spare words of the blend record.  The backward blend merges the four
+// quads of a tile in LDS and writes each touched slot once with plain stores; preprocess_bwd then
+// sums each Gaussian's contiguous run.  (The reference issues 9 atomics per pixel-Gaussian pair;
+// 33 M float atomics per view were measured to cost ~1 ms on MI355X at the C3 size.)
+constexpr int GRAD_ACC_FLOATS = 12;
 
 }  // namespace gsr

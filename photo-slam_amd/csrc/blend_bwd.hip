@@ -1,43 +1,45 @@
-// blend_bwd.hip -- backward of the alpha blend: per-pixel loss gradients -> per-Gaussian
-// gradients of colour, 2D mean, conic and opacity.
+// blend_bwd.hip -- backward of the alpha blend: per-pixel loss gradients -> per-instance
+// gradients of colour, 2D mean, conic and opacity.  One workgroup per tile, one wave per 8x8 quad.
 //
 // Per-pixel semantics are renderCUDA's backward (cuda_rasterizer/backward.cu:399-557): walk
 // the tile list back to front starting at each pixel's last contributor, recompute alpha,
 // un-blend T, and accumulate the nine partial derivatives.
 //
 // The reference issues nine global float atomics per contributing (pixel, Gaussian) pair
-// (backward.cu:523-554).  Here:
-//   * the same per-quad rejection masks as the forward pass remove whole-wave work;
-//   * list entries behind the deepest last-contributor of the tile are never staged, entries
-//     behind the wave's deepest one are never visited;
-//   * the nine terms are summed across the 64 pixels of a quad with DPP row operations (no
-//     LDS, no atomics), the four quad sums meet in LDS (ds_add_f32), and one thread per
-//     staged entry flushes them: 9 global atomics per (tile, Gaussian) instead of per
-//     (pixel, Gaussian) -- up to 256x fewer, and the order inside a tile is fixed.
+// (backward.cu:523-554).  Here there are none (see blend.h):
+//   * entries behind the deepest last-contributor of the quad are never loaded, and the
+//     per-quad rejection mask removes whole-wave work exactly as in the forward pass;
+//   * the per-pair arithmetic is branch-free; 1/(1-alpha) is one v_rcp_f32 shared by the two
+//     divisions of the reference;
+//   * the nine terms are summed across the 64 pixels of a quad with a packed DPP butterfly
+//     (wave64.h) that leaves the nine totals in lanes 0..3 of three registers; three
+//     ds_add_f32 (4 + 4 + 1 active lanes) add them to the tile's LDS accumulators, where the
+//     four quads of a tile meet;
+//   * at the end of a segment of 256 list entries the workgroup writes every touched entry's
+//     nine sums to that instance's private 48-byte slot with plain stores.
 #include "blend.h"
 #include "kernels.h"
 
 namespace gsr {
 
+constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB)
 
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
 {
-	__shared__ float4 s_q0[256];
-	__shared__ float4 s_q1[256];
-	__shared__ float s_b[256];
-	__shared__ uint32_t s_gid[256];
-	__shared__ float s_acc[9][256];
-	__shared__ uint32_t s_touched[256];
-	__shared__ unsigned long long s_mask[4][4];  // [quad][loader wave]
+	__shared__ float4 s_q0[4][64];   // per wave: x, y, A', B'
+	__shared__ float4 s_q1[4][64];   // C', opacity, r, g
+	__shared__ float4 s_q2[4][64];   // b, A, B, C
+	__shared__ float s_acc[9][BWD_SEG];
+	__shared__ uint32_t s_slot[BWD_SEG];
 	__shared__ uint32_t s_wmax[4];
 
-	const int tile = xcd_tile((int)blockIdx.x, p.tiles);
+	const int tile = tile_assignment((int)blockIdx.x, p.tiles);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
-	const int w = wave_id(), l = lane_id(), tid = (int)threadIdx.x;
-	int px, py;
-	quad_pixel(tile_x, tile_y, px, py);
+	const int quad = wave_id(), l = lane_id(), tid = (int)threadIdx.x;
+	const int qx0 = tile_x * TILE + (quad & 1) * 8, qy0 = tile_y * TILE + (quad >> 1) * 8;
+	const int px = qx0 + (l & 7), py = qy0 + (l >> 3);
 	const bool inside = px < p.W && py < p.H;
 	const float pxf = (float)px, pyf = (float)py;
 	const uint2 range = p.ranges[tile];
@@ -53,138 +55,135 @@ blend_bwd_kernel(const BlendBwdParams p)
 		dpg = p.dL_dpix[plane + pix];
 		dpb = p.dL_dpix[2 * plane + pix];
 	}
-	const float bg_dot_dpixel = p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb;
+	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
 	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
 	float last_alpha = 0.f, lcr = 0.f, lcg = 0.f, lcb = 0.f;
 	const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
 
-	// deepest contributor of the wave / of the tile
+	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
 	const uint32_t wmax = wave_max_u32(last_contributor);
-	if (l == 0) s_wmax[w] = wmax;
-#pragma unroll
-	for (int c = 0; c < 9; c++) s_acc[c][tid] = 0.f;
-	s_touched[tid] = 0u;
+	if (l == 0) s_wmax[quad] = wmax;
 	__syncthreads();
 	const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-	const int nbatches = (int)((bmax + 255u) >> 8);
+	const int nseg = (int)((bmax + BWD_SEG - 1) / BWD_SEG);
 
-	for (int b = nbatches - 1; b >= 0; b--) {
-		// ---- stage entries [b*256, b*256+256) below bmax
-		const uint32_t e = (uint32_t)(b << 8) + (uint32_t)tid;
-		uint32_t keep = 0;
-		if (e < bmax) {
-			const uint32_t gid = p.point_list[range.x + e];
-			const float4 q0 = p.rec[3 * (size_t)gid + 0];
-			const float4 q1 = p.rec[3 * (size_t)gid + 1];
-			const float4 q2 = p.rec[3 * (size_t)gid + 2];
-			s_q0[tid] = q0;
-			s_q1[tid] = q1;
-			s_b[tid] = q2.x;
-			s_gid[tid] = gid;
-			keep = quad_keep_bits(q0, q1, (float)(tile_x * TILE), (float)(tile_y * TILE));
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const unsigned long long m = wave_ballot((keep >> q) & 1u);
-			if (l == 0) s_mask[q][w] = m;
-		}
+	for (int seg = nseg - 1; seg >= 0; seg--) {
+		const uint32_t seg_lo = (uint32_t)seg * BWD_SEG;
+		const uint32_t seg_hi = min(bmax, seg_lo + BWD_SEG);
+		for (int i = tid; i < 9 * BWD_SEG; i += 256) (&s_acc[0][0])[i] = 0.f;
+		for (int i = tid; i < BWD_SEG; i += 256) s_slot[i] = 0xFFFFFFFFu;
 		__syncthreads();
 
-		// ---- consume back to front
-		if ((uint32_t)(b << 8) < wmax) {
-			for (int lw = 3; lw >= 0; lw--) {
-				unsigned long long m = wave_uniform_u64(s_mask[w][lw]);
-				// drop entries at or behind the wave's deepest contributor
-				const long long first = (long long)(b << 8) + (lw << 6);
-				const long long lim = (long long)wmax - first;  // entries with bit >= lim are not needed
-				if (lim <= 0) continue;
-				if (lim < 64) m &= (1ull << lim) - 1ull;
+		const uint32_t w_hi = min(wmax, seg_hi);   // this quad needs [seg_lo, w_hi) of the segment
+		if (w_hi > seg_lo) {
+			int base = (int)((w_hi - 1u) & ~63u);
+			uint32_t gid_next = ((uint32_t)(base + l) < w_hi) ? p.point_list[range.x + (uint32_t)(base + l)] : 0u;
+			for (; base >= (int)seg_lo; base -= 64) {
+				const bool have = (uint32_t)(base + l) < w_hi;
+				const uint32_t gid = gid_next;
+				if (base >= (int)seg_lo + 64) gid_next = p.point_list[range.x + (uint32_t)(base - 64 + l)];
+				bool keep = false;
+				uint32_t slot = 0xFFFFFFFFu;
+				if (have) {
+					const float4 q0 = p.rec[3 * (size_t)gid + 0];
+					const float4 q1 = p.rec[3 * (size_t)gid + 1];
+					const float4 q2 = p.rec[3 * (size_t)gid + 2];
+					keep = quad_keep(q0, q1, (float)qx0, (float)qy0);
+					s_q0[quad][l] = prescale_q0(q0);
+					s_q1[quad][l] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
+					s_q2[quad][l] = make_float4(q2.x, q0.z, q0.w, q1.x);
+					const uint32_t rlo = __float_as_uint(q2.y), rhi = __float_as_uint(q2.z);
+					const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu;
+					slot = __float_as_uint(q2.w) + ((uint32_t)tile_y - miny) * (maxx - minx) + ((uint32_t)tile_x - minx);
+					s_slot[base - (int)seg_lo + l] = slot;   // the quads of the tile write the same value
+				}
+				unsigned long long m = wave_ballot(keep);
+				wave_fence();
 				while (m) {
 					const int bit = 63 - __clzll((long long)m);
 					m &= ~(1ull << bit);
-					const int jj = (lw << 6) + bit;
-					const uint32_t pos = (uint32_t)(b << 8) + (uint32_t)jj;
-					const float4 q0 = s_q0[jj];
-					const float4 q1 = s_q1[jj];
-					const float cb = s_b[jj];
+					const uint32_t pos = (uint32_t)(base + bit);
+					const float4 g0 = s_q0[quad][bit];
+					const float4 g1 = s_q1[quad][bit];
+					const float4 g2 = s_q2[quad][bit];
+					const float dx = g0.x - pxf, dy = g0.y - pyf;
+					const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
+					const float G = __builtin_amdgcn_exp2f(pw);
+					const float alpha = fminf(0.99f, g1.y * G);
+					const bool ok = (pos < last_contributor) && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
+					if (wave_ballot(ok) == 0ull) continue;  // wave-uniform
+					const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+					const float Tn = T * rinv;
+					const float one_m_la = 1.f - last_alpha;
+					const float nar = last_alpha * lcr + one_m_la * acr;
+					const float nag = last_alpha * lcg + one_m_la * acg;
+					const float nab = last_alpha * lcb + one_m_la * acb;
+					float dL_dalpha = (g1.z - nar) * dpr + (g1.w - nag) * dpg + (g2.x - nab) * dpb;
+					dL_dalpha = dL_dalpha * Tn + neg_Tfinal_bg * rinv;
+					// masked quantities: lanes that do not blend this entry contribute exact zeros
+					const float Gm = ok ? G : 0.f;
+					const float dcol = ok ? alpha * Tn : 0.f;
+					const float dL_dG = g1.y * dL_dalpha;
+					const float gdx = Gm * dx, gdy = Gm * dy;
+					const float dG_ddelx = -gdx * g2.y - gdy * g2.z;
+					const float dG_ddely = -gdy * g2.w - gdx * g2.z;
 					float v[9];
-#pragma unroll
-					for (int c = 0; c < 9; c++) v[c] = 0.f;
-					bool contributes = false;
-					if (pos < last_contributor) {
-						const float dx = q0.x - pxf, dy = q0.y - pyf;
-						const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-						if (!(power > 0.0f)) {
-							const float G = __expf(power);
-							const float alpha = fminf(0.99f, q1.y * G);
-							if (!(alpha < 1.0f / 255.0f)) {
-								contributes = true;
-								T = T / (1.f - alpha);
-								const float dchannel_dcolor = alpha * T;
-								float dL_dalpha;
-								acr = last_alpha * lcr + (1.f - last_alpha) * acr;
-								lcr = q1.z;
-								dL_dalpha = (q1.z - acr) * dpr;
-								acg = last_alpha * lcg + (1.f - last_alpha) * acg;
-								lcg = q1.w;
-								dL_dalpha += (q1.w - acg) * dpg;
-								acb = last_alpha * lcb + (1.f - last_alpha) * acb;
-								lcb = cb;
-								dL_dalpha += (cb - acb) * dpb;
-								v[0] = dchannel_dcolor * dpr;
-								v[1] = dchannel_dcolor * dpg;
-								v[2] = dchannel_dcolor * dpb;
-								dL_dalpha *= T;
-								last_alpha = alpha;
-								dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-								const float dL_dG = q1.y * dL_dalpha;
-								const float gdx = G * dx, gdy = G * dy;
-								const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-								const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-								v[3] = dL_dG * dG_ddelx * ddelx_dx;
-								v[4] = dL_dG * dG_ddely * ddely_dy;
-								v[5] = -0.5f * gdx * dx * dL_dG;
-								v[6] = -0.5f * gdx * dy * dL_dG;
-								v[7] = -0.5f * gdy * dy * dL_dG;
-								v[8] = G * dL_dalpha;
-							}
+					v[0] = dcol * dpr;
+					v[1] = dcol * dpg;
+					v[2] = dcol * dpb;
+					v[3] = dL_dG * dG_ddelx * ddelx_dx;
+					v[4] = dL_dG * dG_ddely * ddely_dy;
+					v[5] = -0.5f * gdx * dx * dL_dG;
+					v[6] = -0.5f * gdx * dy * dL_dG;
+					v[7] = -0.5f * gdy * dy * dL_dG;
+					v[8] = Gm * dL_dalpha;
+					// per-pixel state advances only where the entry was blended
+					T = ok ? Tn : T;
+					acr = ok ? nar : acr;
+					acg = ok ? nag : acg;
+					acb = ok ? nab : acb;
+					lcr = ok ? g1.z : lcr;
+					lcg = ok ? g1.w : lcg;
+					lcb = ok ? g2.x : lcb;
+					last_alpha = ok ? alpha : last_alpha;
+#ifndef GSR_EXP_NO_REDUCE
+					wave_reduce9_packed_f32(v);
+#endif
+					// totals: value c sits in lane (c & 3) of v[c >> 2]
+					{
+						const int e = (int)pos - (int)seg_lo;
+						if (l < 4) {
+							atomicAdd(&s_acc[l][e], v[0]);
+							atomicAdd(&s_acc[4 + l][e], v[1]);
 						}
-					}
-					if (wave_ballot(contributes) == 0ull) continue;  // wave-uniform
-					wave_reduce9_f32(v);
-					if (l == 63) {
-#pragma unroll
-						for (int c = 0; c < 9; c++) atomicAdd(&s_acc[c][jj], v[c]);
-						s_touched[jj] = 1u;
+						if (l == 0) atomicAdd(&s_acc[8][e], v[2]);
 					}
 				}
+				wave_fence();  // all lanes have read this batch before the next one overwrites the slice
 			}
 		}
 		__syncthreads();
 
-		// ---- flush: thread t owns staged entry t
-		if (s_touched[tid]) {
-			const uint32_t gid = s_gid[tid];
-			atomicAdd(&p.dL_dcolor[3 * (size_t)gid + 0], s_acc[0][tid]);
-			atomicAdd(&p.dL_dcolor[3 * (size_t)gid + 1], s_acc[1][tid]);
-			atomicAdd(&p.dL_dcolor[3 * (size_t)gid + 2], s_acc[2][tid]);
-			atomicAdd(&p.dL_dmean2D[3 * (size_t)gid + 0], s_acc[3][tid]);
-			atomicAdd(&p.dL_dmean2D[3 * (size_t)gid + 1], s_acc[4][tid]);
-			atomicAdd(&p.dL_dconic[4 * (size_t)gid + 0], s_acc[5][tid]);
-			atomicAdd(&p.dL_dconic[4 * (size_t)gid + 1], s_acc[6][tid]);
-			atomicAdd(&p.dL_dconic[4 * (size_t)gid + 3], s_acc[7][tid]);
-			atomicAdd(&p.dL_dopacity[gid], s_acc[8][tid]);
+		// write every touched entry of the segment to its instance slot
+		for (int i = tid; i < (int)(seg_hi - seg_lo); i += 256) {
+			const uint32_t slot = s_slot[i];
+			float any = 0.f;
 #pragma unroll
-			for (int c = 0; c < 9; c++) s_acc[c][tid] = 0.f;
-			s_touched[tid] = 0u;
+			for (int c = 0; c < 9; c++) any += fabsf(s_acc[c][i]);
+			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries keep the memset zeros
+				float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * 12);
+				dst[0] = make_float4(s_acc[0][i], s_acc[1][i], s_acc[2][i], s_acc[3][i]);
+				dst[1] = make_float4(s_acc[4][i], s_acc[5][i], s_acc[6][i], s_acc[7][i]);
+				reinterpret_cast<float*>(dst + 2)[0] = s_acc[8][i];
+			}
 		}
-		// the next iteration's staging barrier orders these LDS writes before the next consume
+		__syncthreads();
 	}
 }
 
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_bwd_kernel, xcd_grid(p.tiles), 256, stream, p);
+	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.tiles), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

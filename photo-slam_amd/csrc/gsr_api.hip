@@ -238,7 +238,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	if (a->P == 0) return GSR_OK;
 	if (st != GSR_OK) return st;
 	if (!a->background || !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos || !a->geom_buffer ||
-	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor ||
+	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dopacity || !a->dL_dcolor ||
 	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
 		return GSR_ERR_INVALID_ARG;
 	if (a->shs && !a->dL_dsh) return GSR_ERR_INVALID_ARG;
@@ -255,21 +255,18 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 
 	t_prof.bwd_done = false;
 	PROF_BWD(0);
-	// accumulators of the blend backward (44 B/Gaussian; everything else is written exactly once)
-	GSR_HIP(hipMemsetAsync(a->dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), stream));
-	GSR_HIP(hipMemsetAsync(a->dL_dconic, 0, (size_t)P * 4 * sizeof(float), stream));
-	GSR_HIP(hipMemsetAsync(a->dL_dopacity, 0, (size_t)P * sizeof(float), stream));
-	GSR_HIP(hipMemsetAsync(a->dL_dcolor, 0, (size_t)P * 3 * sizeof(float), stream));
-
+	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
+	// every API output is written exactly once by preprocess_bwd
+	if (R > 0) GSR_HIP(hipMemsetAsync(bs.partials, 0, (size_t)R * 12 * sizeof(float), stream));
 	PROF_BWD(1);
 	if (R > 0) {
 		BlendBwdParams bp;
 		bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
 		bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.dL_dpix = a->dL_dpix;
-		bp.dL_dmean2D = a->dL_dmean2D; bp.dL_dconic = a->dL_dconic; bp.dL_dopacity = a->dL_dopacity;
-		bp.dL_dcolor = a->dL_dcolor;
+		bp.partials = bs.partials;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
+		if ((st = launch_reduce_partials(P, g, bs.partials, g.grad_acc, stream)) != GSR_OK) return st;
 	}
 	PROF_BWD(2);
 
@@ -282,7 +279,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_y = H / (2.0f * a->tan_fovy);
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
-	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dcolor = a->dL_dcolor;
+	pb.grad_acc = g.grad_acc;
+	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;

@@ -26,6 +26,7 @@ int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hip
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
 int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, hipStream_t stream);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
 
 struct BlendFwdParams {
@@ -48,10 +49,7 @@ struct BlendBwdParams {
 	const float* final_T;
 	const uint32_t* n_contrib;
 	const float* dL_dpix;   // [3,H,W]
-	float* dL_dmean2D;      // [P,3]
-	float* dL_dconic;       // [P,4]
-	float* dL_dopacity;     // [P]
-	float* dL_dcolor;       // [P,3]
+	float* partials;        // [R][12] per-instance gradient slots (blend.h), zeroed by the caller
 	int W, H, grid_x, tiles;
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
@@ -70,9 +68,11 @@ struct PreprocessBwdParams {
 	const float* proj;      // [16] device
 	const float* campos;    // [3] device
 	float focal_x, focal_y, tan_fovx, tan_fovy;
-	const float* dL_dmean2D;  // [P,3]
-	const float* dL_dconic;   // [P,4]
-	const float* dL_dcolor;   // [P,3]
+	const float* grad_acc;    // [P][12] per-Gaussian blend gradients (reduce_partials_kernel), valid where radii > 0
+	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)
+	float* dL_dconic;         // [P,4]  nullable
+	float* dL_dopacity;       // [P]
+	float* dL_dcolor;         // [P,3]
 	float* dL_dmean3D;        // [P,3]
 	float* dL_dcov3D;         // [P,6]
 	float* dL_dsh;            // [P,M,3] nullable

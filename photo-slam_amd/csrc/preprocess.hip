@@ -211,10 +211,10 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			my_tiles = tiles;
 			g.rec[3 * (size_t)idx + 0] = make_float4(pix, piy, conx, cony);
 			g.rec[3 * (size_t)idx + 1] = make_float4(conz, p.opacities[idx], cr, cg);
-			g.rec[3 * (size_t)idx + 2] = make_float4(cb, 0.f, 0.f, 0.f);
+			const uint32_t rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16), rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
+			g.rec[3 * (size_t)idx + 2] = make_float4(cb, __uint_as_float(rect_lo), __uint_as_float(rect_hi), 0.f);
 			g.clamped[idx] = clamp_bits;
-			reinterpret_cast<uint2*>(g.rect)[idx] =
-			    make_uint2((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16));
+			reinterpret_cast<uint2*>(g.rect)[idx] = make_uint2(rect_lo, rect_hi);
 		} while (0);
 		g.depth_key[idx] = depth_key;
 		g.tiles_touched[idx] = my_tiles;

@@ -48,6 +48,12 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	if (!(p.radii[idx] > 0)) {
 		// culled: the reference leaves the torch::zeros content
 #pragma unroll
+		for (int i = 0; i < 3; i++) p.dL_dmean2D[3 * (size_t)idx + i] = 0.f;
+#pragma unroll
+		for (int i = 0; i < 3; i++) p.dL_dcolor[3 * (size_t)idx + i] = 0.f;
+		p.dL_dopacity[idx] = 0.f;
+		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
 		for (int i = 0; i < 3; i++) p.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
 #pragma unroll
 		for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
@@ -75,7 +81,19 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	float c3[6];
 #pragma unroll
 	for (int i = 0; i < 6; i++) c3[i] = p.cov3D[6 * (size_t)idx + i];
-	const float gcx = p.dL_dconic[4 * (size_t)idx], gcy = p.dL_dconic[4 * (size_t)idx + 1], gcz = p.dL_dconic[4 * (size_t)idx + 3];
+	// blend-stage gradients of this Gaussian (colour 0..2, mean2D 3..4, conic 5..7, opacity 8)
+	const float4* ga = reinterpret_cast<const float4*>(p.grad_acc) + 3 * (size_t)idx;
+	const float4 ga0 = ga[0], ga1 = ga[1];
+	const float ga2x = ga[2].x;
+	const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
+	p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w;
+	p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x;
+	p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+	p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
+	p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
+	p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
+	p.dL_dopacity[idx] = ga2x;
+	if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
 	float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 	float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 	const float tz0 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
@@ -150,7 +168,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	{
 		const float hw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
 		const float m_w = 1.0f / (hw + 0.0000001f);
-		const float g2x = p.dL_dmean2D[3 * (size_t)idx], g2y = p.dL_dmean2D[3 * (size_t)idx + 1];
+		const float g2x = ga0.w, g2y = ga1.x;
 		const float mul1 = (Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12]) * m_w * m_w;
 		const float mul2 = (Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13]) * m_w * m_w;
 		gmx += (Pm[0] * m_w - Pm[3] * mul1) * g2x + (Pm[1] * m_w - Pm[3] * mul2) * g2y;
@@ -181,7 +199,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 				if (i < nfl) sh[i] = shrow[i];
 		}
 		const uint8_t cl = p.clamped[idx];
-		float dRGB[3] = {p.dL_dcolor[3 * (size_t)idx], p.dL_dcolor[3 * (size_t)idx + 1], p.dL_dcolor[3 * (size_t)idx + 2]};
+		float dRGB[3] = {ga0.x, ga0.y, ga0.z};
 		dRGB[0] *= (cl & 1) ? 0.f : 1.f;
 		dRGB[1] *= (cl & 2) ? 0.f : 1.f;
 		dRGB[2] *= (cl & 4) ? 0.f : 1.f;

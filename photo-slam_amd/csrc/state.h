@@ -39,7 +39,8 @@ static inline size_t sort_scratch_elems(int n)
 }
 
 // The 48-byte per-Gaussian record the blend kernels gather (3 x float4):
-//   q0 = (mean2D.x, mean2D.y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, 0, 0, 0)
+//   q0 = (mean2D.x, mean2D.y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)
+//   q2 = (b, bits(rect.min), bits(rect.max), bits(first instance slot))   [rect packed x | y<<16]
 // One record instead of the reference's three separate gathers (means2D / conic_opacity /
 // rgb, forward.cu:317-320,355).
 constexpr int REC_FLOAT4S = 3;
@@ -60,6 +61,7 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
+	float*    grad_acc;       // [12P] per-Gaussian blend gradients (backward only; written for visible Gaussians)
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -80,6 +82,7 @@ struct GeometryState {
 		g.sort_vals_b = c.take<uint32_t>(P);
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
+		g.grad_acc = c.take<float>(12 * P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
@@ -91,6 +94,7 @@ struct BinningState {
 	uint32_t* keys_b;        // [R] (pong)
 	uint32_t* vals_b;        // [R] (pong)
 	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
+	float*    partials;      // [12R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
 
 	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
 	{
@@ -101,6 +105,7 @@ struct BinningState {
 		b.keys_b = c.take<uint32_t>(R);
 		b.vals_b = c.take<uint32_t>(R);
 		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
+		b.partials = c.take<float>(12 * R);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}

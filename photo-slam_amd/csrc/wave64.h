@@ -20,7 +20,27 @@ using ::hipemu::wave_shfl_u32;
 using ::hipemu::wave_sum_u32;
 using ::hipemu::wave_uniform_u64;
 using ::hipemu::wave_uniform_u32;
+using ::hipemu::wave_readlane_f32;
+using ::hipemu::wave_readlane_u32;
+using ::hipemu::wave_writelane_f32;
+using ::hipemu::wave_reduce9_packed_f32;
+using ::hipemu::wave_packed9_total;
 #else
+
+// Broadcast lane `lane`'s value to the whole wave through an SGPR (v_readlane_b32): the value
+// becomes a scalar operand of the following VALU instructions -- no LDS, no VGPR.
+__device__ __forceinline__ float wave_readlane_f32(float v, int lane)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ uint32_t wave_readlane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+// Put a wave-uniform value into lane `lane` of a VGPR, other lanes keep `old` (v_cmp once per
+// target lane + one v_cndmask per value; v_writelane_b32 would need both operands on the
+// constant bus, which gfx9 does not allow).
+__device__ __forceinline__ float wave_writelane_f32(float old, float uniform_value, int lane)
+{
+	return ((int)(threadIdx.x & 63u) == lane) ? uniform_value : old;
+}
 
 // Tell the compiler a value is wave-uniform (moves it to SGPRs: scalar loops, scalar LDS addresses).
 __device__ __forceinline__ uint32_t wave_uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -99,6 +119,66 @@ __device__ __forceinline__ void wave_reduce9_f32(float (&v)[9])
 	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_BCAST15, 0xa>(0.f, v[i]);
 #pragma unroll
 	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_BCAST31, 0xc>(0.f, v[i]);
+}
+
+// Nine full-wave sums with a packed butterfly: the first two levels (lane xor 1, xor 2) halve the
+// number of live values -- each lane keeps the half its low lane bits select and hands the other
+// half to its partner -- so the remaining four levels (rotate-adds inside a row of 16, then the
+// gfx950 v_permlane16_swap / v_permlane32_swap across rows) run on 3 registers instead of 9:
+// ~38 VALU instead of ~72.  On return v[0..2] hold the packed totals; the total of value c is in
+// register v[c >> 2] of every lane whose (lane & 3) == (c & 3)  ->  wave_packed9_total(v, c).
+__device__ __forceinline__ float dpp_xor16_add(float s)
+{
+	const unsigned u = __builtin_bit_cast(unsigned, s);
+	const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float dpp_xor32_add(float s)
+{
+	const unsigned u = __builtin_bit_cast(unsigned, s);
+	const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ void wave_reduce9_packed_f32(float (&v)[9])
+{
+	const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;
+	float r[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const float keep = b0 ? v[2 * k + 1] : v[2 * k];
+		const float send = b0 ? v[2 * k] : v[2 * k + 1];
+		r[k] = keep + dpp_f32<DPP_QUAD_PERM_1032>(0.f, send);
+	}
+	float s2 = v[8] + dpp_f32<DPP_QUAD_PERM_1032>(0.f, v[8]);
+	float s0, s1;
+	{
+		const float keep = b1 ? r[1] : r[0], send = b1 ? r[0] : r[1];
+		s0 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
+	}
+	{
+		const float keep = b1 ? r[3] : r[2], send = b1 ? r[2] : r[3];
+		s1 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
+	}
+	s2 += dpp_f32<DPP_QUAD_PERM_2301>(0.f, s2);
+	// lanes with equal (lane & 3) hold partial sums of the same value: rotate-add inside each row of 16 ...
+	constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+	s0 += dpp_f32<DPP_ROW_ROR4>(0.f, s0);
+	s1 += dpp_f32<DPP_ROW_ROR4>(0.f, s1);
+	s2 += dpp_f32<DPP_ROW_ROR4>(0.f, s2);
+	s0 += dpp_f32<DPP_ROW_ROR8>(0.f, s0);
+	s1 += dpp_f32<DPP_ROW_ROR8>(0.f, s1);
+	s2 += dpp_f32<DPP_ROW_ROR8>(0.f, s2);
+	// ... then across the four rows (lane i <-> i+16, i <-> i+32 keep the residue class)
+	s0 = dpp_xor16_add(s0);
+	s1 = dpp_xor16_add(s1);
+	s2 = dpp_xor16_add(s2);
+	v[0] = dpp_xor32_add(s0);
+	v[1] = dpp_xor32_add(s1);
+	v[2] = dpp_xor32_add(s2);
+}
+__device__ __forceinline__ float wave_packed9_total(const float (&v)[9], int c)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c >> 2]), c & 3));
 }
 
 // Inclusive prefix sum across the wave (Hillis-Steele on DPP row shifts + row broadcasts).

@@ -126,6 +126,17 @@ static inline void wave_reduce9_f32(float (&v)[9])
 		v[c] = acc;  // the real primitive only guarantees lane 63
 	}
 }
+// packed variant: same sums, delivered in the packed layout of csrc/wave64.h
+static inline void wave_reduce9_packed_f32(float (&v)[9])
+{
+	float t[9];
+	for (int c = 0; c < 9; c++) t[c] = v[c];
+	wave_reduce9_f32(t);
+	const int r = lane() & 3;
+	v[0] = t[r];
+	v[1] = t[4 + r];
+	v[2] = t[8];
+}
 // asserts the value really is wave-uniform (the real primitive silently takes lane 0's)
 static inline unsigned long long wave_uniform_u64(unsigned long long v)
 {
@@ -139,6 +150,19 @@ static inline unsigned long long wave_uniform_u64(unsigned long long v)
 	return v;
 }
 static inline uint32_t wave_uniform_u32(uint32_t v) { return (uint32_t)wave_uniform_u64(v); }
+static inline uint32_t wave_readlane_u32(uint32_t v, int src) { return wave_shfl_u32(v, src); }
+static inline float wave_readlane_f32(float v, int src)
+{
+	uint32_t b;
+	memcpy(&b, &v, 4);
+	b = wave_shfl_u32(b, src);
+	float r;
+	memcpy(&r, &b, 4);
+	return r;
+}
+// `uniform_value` only needs to be right in lane 63 here (the HIP version reads it from an SGPR
+// that was itself filled by readlane(.., 63)); every lane passes its own copy, lane `lane` keeps it.
+static inline float wave_writelane_f32(float old, float uniform_value, int dst_lane) { return lane() == dst_lane ? uniform_value : old; }
 }  // namespace hipemu
 
 static inline void __syncthreads() { hipemu::syncthreads(); }
@@ -157,6 +181,13 @@ static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+
+namespace hipemu {
+static inline float wave_packed9_total(const float (&v)[9], int c) { return wave_readlane_f32(v[c >> 2], c & 3); }
+}  // namespace hipemu
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
