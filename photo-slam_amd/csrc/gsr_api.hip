@@ -32,7 +32,7 @@ struct HostSync {
 	int init()
 	{
 		if (pinned) return GSR_OK;
-		GSR_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
+		GSR_HIP(hipHostMalloc((void**)&pinned, NUM_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
 		GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		return GSR_OK;
 	}
@@ -166,7 +166,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
-	GSR_HIP(hipMemsetAsync(g.counters, 0, 32 * sizeof(uint32_t), stream));
+	GSR_HIP(hipMemsetAsync(g.counters, 0, NUM_COUNTERS * sizeof(uint32_t), stream));
 	PROF_FWD(0);
 
 	PreprocessParams pp;
@@ -181,7 +181,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
 
 	PROF_FWD(1);
-	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, NUM_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 	GSR_HIP(hipEventRecord(t_sync.ev, stream));
 
 	// depth order (stable: equal depths keep ascending Gaussian id)
@@ -195,8 +195,10 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));
-	const int R = (int)*t_sync.pinned;
-	if (R < 0) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
+	unsigned long long R64 = 0;
+	for (int i = 0; i < NUM_COUNTERS; i++) R64 += t_sync.pinned[i];
+	if (R64 > 0x7FFFFFFFull) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
+	const int R = (int)R64;
 	char* bin_chunk = binningBuffer(binning_ctx, binning_bytes(R));
 	if (!bin_chunk) return GSR_ERR_ALLOC;
 	BinningState bs = BinningState::carve(bin_chunk, (size_t)R);

@@ -13,6 +13,7 @@
 #include "state.h"
 #include "wave64.h"
 #include "kernels.h"
+#include "shrows.h"
 
 namespace gsr {
 
@@ -64,18 +65,31 @@ __device__ __forceinline__ float sh_channel(const float* sh, int ch, int deg, fl
 	return result + 0.5f;
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int PRE_THREADS = 128;   // 2 waves x 13 KiB of row staging per workgroup
+
+__global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 {
+	__shared__ float4 s_rows[PRE_THREADS / 64][64][ROW_F4_PAD];
+	__shared__ uint32_t s_list[PRE_THREADS / 64][64];
+
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int w = wave_id();
+	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
 	const bool in_range = idx < p.P;
 	uint32_t my_tiles = 0;
+	int radius_i = 0;
+	uint32_t depth_key = DEPTH_KEY_CULLED;
+	float px = 0.f, py = 0.f, pz = 0.f;
+	float pix = 0.f, piy = 0.f, conx = 0.f, cony = 0.f, conz = 0.f;
+	uint32_t rect_lo = 0, rect_hi = 0;
 
+	// ---------------- phase 1: geometry (per lane)
 	if (in_range) {
-		int radius_i = 0;
-		uint32_t depth_key = DEPTH_KEY_CULLED;
 		do {
-			const float px = p.means3D[3 * idx], py = p.means3D[3 * idx + 1], pz = p.means3D[3 * idx + 2];
+			px = p.means3D[3 * idx];
+			py = p.means3D[3 * idx + 1];
+			pz = p.means3D[3 * idx + 2];
 			const float* V = p.view;
 			const float* Pm = p.proj;
 			// in_frustum, auxiliary.h:139-164
@@ -131,7 +145,6 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			// (the zero products of the glm expansion add exact zeros and are dropped)
 			const float T00 = V[0] * J00 + V[2] * J02, T01 = V[4] * J00 + V[6] * J02, T02 = V[8] * J00 + V[10] * J02;
 			const float T10 = V[1] * J11 + V[2] * J12, T11 = V[5] * J11 + V[6] * J12, T12 = V[9] * J11 + V[10] * J12;
-			// Vrk symmetric: V[c][r]: (c0 c1 c2 / c1 c3 c4 / c2 c4 c5)
 			// A = transpose(T) * transpose(Vrk):  A[c][r] = T[r][0]*Vrk[0][c] + T[r][1]*Vrk[1][c] + T[r][2]*Vrk[2][c]
 			const float A00 = T00 * c3[0] + T01 * c3[1] + T02 * c3[2];  // c=0,r=0
 			const float A10 = T00 * c3[1] + T01 * c3[3] + T02 * c3[4];  // c=1,r=0
@@ -148,12 +161,15 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			const float det = cov00 * cov11 - cov01 * cov01;
 			if (det == 0.0f) break;
 			const float det_inv = 1.f / det;
-			const float conx = cov11 * det_inv, cony = -cov01 * det_inv, conz = cov00 * det_inv;
+			conx = cov11 * det_inv;
+			cony = -cov01 * det_inv;
+			conz = cov00 * det_inv;
 			const float mid = 0.5f * (cov00 + cov11);
 			const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
 			const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
 			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-			const float pix = ndc2pix(projx, p.W), piy = ndc2pix(projy, p.H);
+			pix = ndc2pix(projx, p.W);
+			piy = ndc2pix(projy, p.H);
 			// getRect, auxiliary.h:46-56
 			const int mr = f2i(my_radius);
 			const int rminx = min(p.grid_x, max(0, f2i((pix - mr) / TILE)));
@@ -162,69 +178,84 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			const int rmaxy = min(p.grid_y, max(0, f2i((piy + mr + TILE - 1) / TILE)));
 			const uint32_t tiles = (uint32_t)(rmaxy - rminy) * (uint32_t)(rmaxx - rminx);
 			if (tiles == 0) break;
-
-			// colour, forward.cu:238-247
-			float cr, cg, cb;
-			uint8_t clamp_bits = 0;
-			if (p.colors_precomp == nullptr) {
-				float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
-				const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-				dx = dx / len;
-				dy = dy / len;
-				dz = dz / len;
-				// SH row -> registers: 16-byte vector loads when the row is 16-byte aligned (M*3 % 4 == 0)
-				const float* sh = p.shs + (size_t)idx * p.M * 3;
-				const int nfl = 3 * (p.D + 1) * (p.D + 1);
-				float c[48];
-				if (((p.M * 3) & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0)) {
-					const float4* r4 = reinterpret_cast<const float4*>(sh);
-#pragma unroll
-					for (int i = 0; i < 12; i++) {
-						if (4 * i < nfl) {
-							const float4 v = r4[i];
-							c[4 * i] = v.x;
-							c[4 * i + 1] = v.y;
-							c[4 * i + 2] = v.z;
-							c[4 * i + 3] = v.w;
-						}
-					}
-				} else {
-#pragma unroll
-					for (int i = 0; i < 48; i++)
-						if (i < nfl) c[i] = sh[i];
-				}
-				cr = sh_channel(c, 0, p.D, dx, dy, dz);
-				cg = sh_channel(c, 1, p.D, dx, dy, dz);
-				cb = sh_channel(c, 2, p.D, dx, dy, dz);
-				clamp_bits = (uint8_t)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
-				cr = fmaxf(cr, 0.0f);
-				cg = fmaxf(cg, 0.0f);
-				cb = fmaxf(cb, 0.0f);
-			} else {
-				cr = p.colors_precomp[3 * (size_t)idx];
-				cg = p.colors_precomp[3 * (size_t)idx + 1];
-				cb = p.colors_precomp[3 * (size_t)idx + 2];
-			}
-
 			depth_key = __float_as_uint(vz);
 			radius_i = mr;
 			my_tiles = tiles;
+			rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16);
+			rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
+		} while (0);
+	}
+	const bool vis = my_tiles != 0;
+
+	// ---------------- phase 2: colour, forward.cu:238-247.  SH rows of the visible lanes are moved by
+	// the whole wave (shrows.h); unaligned row pitches fall back to per-lane loads.
+	float cr = 0.f, cg = 0.f, cb = 0.f;
+	uint8_t clamp_bits = 0;
+	if (p.colors_precomp == nullptr) {
+		const int nfl = 3 * (p.D + 1) * (p.D + 1);
+		const bool rows_ok = (p.M * 3 == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
+		float c[48];
+		if (rows_ok) {
+			const int nf4 = (nfl + 3) >> 2;
+			wave_load_rows(reinterpret_cast<const float4*>(p.shs), wave_first, nf4, vis, s_rows[w], s_list[w]);
+			if (vis) {
+#pragma unroll
+				for (int i = 0; i < 12; i++) {
+					if (4 * i < nfl) {
+						const float4 v = s_rows[w][lane_id()][i];
+						c[4 * i] = v.x;
+						c[4 * i + 1] = v.y;
+						c[4 * i + 2] = v.z;
+						c[4 * i + 3] = v.w;
+					}
+				}
+			}
+		} else if (vis) {
+			const float* sh = p.shs + (size_t)idx * p.M * 3;
+#pragma unroll
+			for (int i = 0; i < 48; i++)
+				if (i < nfl) c[i] = sh[i];
+		}
+		if (vis) {
+			float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+			const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+			dx = dx / len;
+			dy = dy / len;
+			dz = dz / len;
+			cr = sh_channel(c, 0, p.D, dx, dy, dz);
+			cg = sh_channel(c, 1, p.D, dx, dy, dz);
+			cb = sh_channel(c, 2, p.D, dx, dy, dz);
+			clamp_bits = (uint8_t)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+			cr = fmaxf(cr, 0.0f);
+			cg = fmaxf(cg, 0.0f);
+			cb = fmaxf(cb, 0.0f);
+		}
+	} else if (vis) {
+		cr = p.colors_precomp[3 * (size_t)idx];
+		cg = p.colors_precomp[3 * (size_t)idx + 1];
+		cb = p.colors_precomp[3 * (size_t)idx + 2];
+	}
+
+	// ---------------- phase 3: outputs
+	if (in_range) {
+		if (vis) {
 			g.rec[3 * (size_t)idx + 0] = make_float4(pix, piy, conx, cony);
 			g.rec[3 * (size_t)idx + 1] = make_float4(conz, p.opacities[idx], cr, cg);
-			const uint32_t rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16), rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
 			g.rec[3 * (size_t)idx + 2] = make_float4(cb, __uint_as_float(rect_lo), __uint_as_float(rect_hi), 0.f);
 			g.clamped[idx] = clamp_bits;
 			reinterpret_cast<uint2*>(g.rect)[idx] = make_uint2(rect_lo, rect_hi);
-		} while (0);
+		}
 		g.depth_key[idx] = depth_key;
 		g.tiles_touched[idx] = my_tiles;
 		g.radii[idx] = radius_i;
 		if (p.radii_out) p.radii_out[idx] = radius_i;
 	}
-	// num_rendered = sum of tiles_touched: one atomic per wave (replaces reading back the last
-	// element of the scan, rasterizer_impl.cu:281, so the host copy can overlap the depth sort)
+	// num_rendered = sum of tiles_touched: one atomic per wave, spread over NUM_COUNTERS words that the
+	// host adds up (same-address atomics serialise at ~12 ns each: 31 k waves on ONE word cost 0.37 ms).
+	// Replaces reading back the last element of the scan (rasterizer_impl.cu:281), so the host copy
+	// can overlap the depth sort.
 	const uint32_t wsum = wave_sum_u32(my_tiles);
-	if (lane_id() == 0 && wsum) atomicAdd(&g.counters[0], wsum);
+	if (lane_id() == 0 && wsum) atomicAdd(&g.counters[(blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS - 1)], wsum);
 }
 
 // checkFrustum, cuda_rasterizer/rasterizer_impl.cu:54-66
@@ -240,7 +271,7 @@ check_frustum_kernel(int P, const float* __restrict__ means3D, const float* __re
 
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream)
 {
-	GSR_LAUNCH(preprocess_fwd_kernel, div_up(p.P, 256), 256, stream, p, g);
+	GSR_LAUNCH(preprocess_fwd_kernel, div_up(p.P, PRE_THREADS), PRE_THREADS, stream, p, g);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -9,6 +9,7 @@ namespace gsr {
 constexpr int TILE = 16;              // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:16-17 (part of the parity contract)
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr uint32_t DEPTH_KEY_CULLED = 0xFFFFFFFFu;
+constexpr int NUM_COUNTERS = 1024;   // same-address atomics serialise (~12 ns each): spread the per-wave sums
 
 // Radix sort geometry: one workgroup (256 threads = 4 waves) ranks a 4096-element chunk;
 // each wave owns 1024 consecutive elements so that stability needs no cross-wave ordering.
@@ -46,7 +47,7 @@ static inline size_t sort_scratch_elems(int n)
 constexpr int REC_FLOAT4S = 3;
 
 struct GeometryState {
-	uint32_t* counters;       // [32]  [0] = total tiles touched (num_rendered)
+	uint32_t* counters;       // [NUM_COUNTERS] partial sums of tiles touched; their total is num_rendered
 	uint32_t* depth_key;      // [P]
 	uint32_t* tiles_touched;  // [P]
 	int*      radii;          // [P]
@@ -67,7 +68,7 @@ struct GeometryState {
 	{
 		GeometryState g;
 		Carver c(chunk);
-		g.counters = c.take<uint32_t>(32);
+		g.counters = c.take<uint32_t>(NUM_COUNTERS);
 		g.depth_key = c.take<uint32_t>(P);
 		g.tiles_touched = c.take<uint32_t>(P);
 		g.radii = c.take<int>(P);
