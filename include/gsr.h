@@ -124,6 +124,26 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 int gsr_knn_mean_dist2(int P, const float* points, float* meanDists,
                        gsr_alloc_fn scratchBuffer, void* scratch_ctx, void* stream);
 
+/* ---- train-step kernels next to the rasterizer (the largest non-raster costs) ----
+ *
+ * Masked L1 + SSIM loss of GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:692-698,
+ * include/loss_utils.h:28-124):  x = rendered * mask;
+ *   loss = (1-lambda) * mean|x - gt| + lambda * (1 - mean(ssim_map(x, gt)))    (11x11 window, sigma 1.5)
+ * Writes the scalar loss to *loss (device) and dloss/drendered to grad_rendered [3,H,W]; replaces
+ * 5 + 10 grouped conv2d of the autograd graph.  mask may be NULL (all ones).
+ * scratch: gsr_loss_scratch_bytes(width, height) device bytes. */
+size_t gsr_loss_scratch_bytes(int width, int height);
+int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, int width, int height,
+                     float lambda_dssim, float* grad_rendered, float* loss, char* scratch, void* stream);
+
+/* One torch::optim::Adam step (no amsgrad / weight decay; src/gaussian_model.cpp:477-510 uses eps 1e-15)
+ * on a flat fp32 tensor: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= (lr / (1-b1^step)) * m / (sqrt(v) / sqrt(1-b2^step) + eps).
+ * period/split/lr_tail: if period > 0, elements [split, period) of every period-element row use lr_tail
+ * (features_dc and features_rest live in one [P,16,3] buffer with learning rates lr and lr/20). */
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, int step, int period, int split, float lr_tail, void* stream);
+
 /* Scratch sizes (bytes) gsr_forward will request, for callers that pre-allocate. */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_binning_bytes(int num_rendered);

@@ -26,6 +26,7 @@ SOURCES = [
     ("binning.hip", []),
     ("blend_fwd.hip", []),
     ("blend_bwd.hip", []),
+    ("train_ops.hip", []),
 ]
 COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable"]

@@ -1,0 +1,323 @@
+// train_ops.hip -- the two largest non-rasterizer costs of the measured train step
+// (GaussianMapper::trainForOneIteration, src/gaussian_mapper.cpp:692-699,769-772), fused:
+//
+//  * masked L1 + SSIM loss with its gradient w.r.t. the rendered image.  The reference builds it
+//    from 5 grouped 11x11 conv2d + ~20 elementwise ATen ops and lets autograd run 10 more convs
+//    backward (include/loss_utils.h:28-124); on MI355X MIOpen spends ~12 ms per step on those
+//    depthwise convolutions at 1080p.  Here: two LDS-tiled passes with a separable 11-tap window
+//    (window2D = g (x) g, loss_utils.h:49-74), ~0.4 GB of HBM traffic in total.
+//  * Adam (torch::optim::Adam semantics, eps 1e-15, src/gaussian_model.cpp:477-510) as one
+//    streaming pass per tensor: 7 x 4 bytes per parameter instead of ~10 elementwise launches
+//    per parameter group.
+#include "state.h"
+#include "wave64.h"
+
+namespace gsr {
+
+constexpr int LT = 32;            // output tile
+constexpr int LH = 5;             // window half width (11 taps)
+constexpr int LR = LT + 2 * LH;   // 42: input tile with halo
+constexpr int LRP = LR + 1;       // padded pitch
+
+struct LossParams {
+	const float* rendered;  // [3,H,W]
+	const float* gt;        // [3,H,W]
+	const float* mask;      // [3,H,W] or null
+	int W, H;
+	float lambda_dssim;
+	float g[11];            // normalised 1-D window
+	float* dmaps;           // [3][3,H,W]: dL/dmu1, dL/de11, dL/de12 (already scaled by -lambda/N)
+	float* partial;         // [2][nblocks]: L1 sums, SSIM sums
+	float* grad;            // [3,H,W] dL/d rendered
+	float* loss;            // [1]
+	int nblocks;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* s4)
+{
+	// wave sum by shuffles-free DPP is overkill here; LDS tree over 4 wave partials
+	float w = v;
+#ifdef GSR_EMU
+	{
+		uint32_t b; memcpy(&b, &w, 4);
+		const uint64_t* s = ::hipemu::wave_exchange(b);
+		float acc = 0.f;
+		for (int i = 0; i < 64; i++) { uint32_t u = (uint32_t)s[i]; float f; memcpy(&f, &u, 4); acc += f; }
+		::hipemu::wave_sync();
+		w = acc;
+	}
+#else
+	w = wave_sum_f32_lane63(w);
+	w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 63));
+#endif
+	__syncthreads();
+	if (lane_id() == 0) s4[wave_id()] = w;
+	__syncthreads();
+	return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+// Pass 1: window statistics -> SSIM map value + the three derivative maps, and L1 / SSIM partial sums.
+__global__ void __launch_bounds__(256)
+loss_fwd_kernel(const LossParams p)
+{
+	__shared__ float s_x[LR][LRP], s_y[LR][LRP];
+	__shared__ float s_h[5][LR][LT + 1];
+	__shared__ float s_red[4];
+	const int ch = (int)blockIdx.z;
+	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LT;
+	const size_t plane = (size_t)p.W * p.H;
+	const float* R = p.rendered + ch * plane;
+	const float* G = p.gt + ch * plane;
+	const float* Mk = p.mask ? p.mask + ch * plane : nullptr;
+	const int tid = (int)threadIdx.x;
+	for (int i = tid; i < LR * LR; i += 256) {
+		const int r = i / LR, c = i - r * LR;
+		const int gx = x0 - LH + c, gy = y0 - LH + r;
+		float xv = 0.f, yv = 0.f;
+		if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.H) {
+			const size_t o = (size_t)gy * p.W + gx;
+			xv = R[o] * (Mk ? Mk[o] : 1.f);
+			yv = G[o];
+		}
+		s_x[r][c] = xv;
+		s_y[r][c] = yv;
+	}
+	__syncthreads();
+	// horizontal pass: LR rows x LT columns
+	for (int i = tid; i < LR * LT; i += 256) {
+		const int r = i / LT, c = i - r * LT;
+		float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+		for (int t = 0; t < 11; t++) {
+			const float xv = s_x[r][c + t], yv = s_y[r][c + t], gw = p.g[t];
+			a0 += gw * xv;
+			a1 += gw * yv;
+			a2 += gw * xv * xv;
+			a3 += gw * yv * yv;
+			a4 += gw * xv * yv;
+		}
+		s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+	}
+	__syncthreads();
+	const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+	const float inv_n = 1.0f / (3.0f * (float)plane);
+	float l1_sum = 0.f, ssim_sum = 0.f;
+	for (int i = tid; i < LT * LT; i += 256) {
+		const int r = i / LT, c = i - r * LT;
+		const int gx = x0 + c, gy = y0 + r;
+		if (gx < p.W && gy < p.H) {
+			float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+			for (int t = 0; t < 11; t++) {
+				const float gw = p.g[t];
+				mu1 += gw * s_h[0][r + t][c];
+				mu2 += gw * s_h[1][r + t][c];
+				e11 += gw * s_h[2][r + t][c];
+				e22 += gw * s_h[3][r + t][c];
+				e12 += gw * s_h[4][r + t][c];
+			}
+			const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+			const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
+			const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
+			const float invCD = 1.0f / (Cc * D);
+			const float S = A * B * invCD;
+			ssim_sum += S;
+			const float xv = s_x[r + LH][c + LH], yv = s_y[r + LH][c + LH];
+			l1_sum += fabsf(xv - yv);
+			// dL/dS = -lambda / N ; chain to (mu1, e11, e12)
+			const float gS = -p.lambda_dssim * inv_n;
+			const float dmu1 = 2.f * mu2 * (B - A) * invCD - 2.f * mu1 * S * (1.0f / Cc - 1.0f / D);
+			const size_t o = (size_t)gy * p.W + gx;
+			p.dmaps[(0 * 3 + ch) * plane + o] = gS * dmu1;
+			p.dmaps[(1 * 3 + ch) * plane + o] = gS * (-S / D);
+			p.dmaps[(2 * 3 + ch) * plane + o] = gS * (2.f * A * invCD);
+		}
+	}
+	const float t1 = block_sum_256(l1_sum, s_red);
+	const float t2 = block_sum_256(ssim_sum, s_red);
+	if (tid == 0) {
+		const int b = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+		p.partial[b] = t1;
+		p.partial[p.nblocks + b] = t2;
+	}
+}
+
+// Pass 2: dL/dx = G*(dL/dmu1) + 2x G*(dL/de11) + y G*(dL/de12) + (1-lambda)/N sign(x-y), times mask.
+__global__ void __launch_bounds__(256)
+loss_bwd_kernel(const LossParams p)
+{
+	__shared__ float s_d[3][LR][LRP];
+	__shared__ float s_h[3][LR][LT + 1];
+	const int ch = (int)blockIdx.z;
+	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LT;
+	const size_t plane = (size_t)p.W * p.H;
+	const int tid = (int)threadIdx.x;
+	for (int i = tid; i < LR * LR; i += 256) {
+		const int r = i / LR, c = i - r * LR;
+		const int gx = x0 - LH + c, gy = y0 - LH + r;
+		const bool in = gx >= 0 && gx < p.W && gy >= 0 && gy < p.H;
+		const size_t o = in ? (size_t)gy * p.W + gx : 0;
+#pragma unroll
+		for (int k = 0; k < 3; k++) s_d[k][r][c] = in ? p.dmaps[(k * 3 + ch) * plane + o] : 0.f;
+	}
+	__syncthreads();
+	for (int i = tid; i < LR * LT; i += 256) {
+		const int r = i / LT, c = i - r * LT;
+		float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+		for (int t = 0; t < 11; t++) {
+			const float gw = p.g[t];
+			a0 += gw * s_d[0][r][c + t];
+			a1 += gw * s_d[1][r][c + t];
+			a2 += gw * s_d[2][r][c + t];
+		}
+		s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
+	}
+	__syncthreads();
+	const float inv_n = 1.0f / (3.0f * (float)plane);
+	for (int i = tid; i < LT * LT; i += 256) {
+		const int r = i / LT, c = i - r * LT;
+		const int gx = x0 + c, gy = y0 + r;
+		if (gx < p.W && gy < p.H) {
+			float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+			for (int t = 0; t < 11; t++) {
+				const float gw = p.g[t];
+				c0 += gw * s_h[0][r + t][c];
+				c1 += gw * s_h[1][r + t][c];
+				c2 += gw * s_h[2][r + t][c];
+			}
+			const size_t o = ch * plane + (size_t)gy * p.W + gx;
+			const float m = p.mask ? p.mask[o] : 1.f;
+			const float xv = p.rendered[o] * m, yv = p.gt[o];
+			const float d = xv - yv;
+			const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+			const float gx_ = c0 + 2.f * xv * c1 + yv * c2 + (1.0f - p.lambda_dssim) * inv_n * sgn;
+			p.grad[o] = gx_ * m;
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256)
+loss_final_kernel(const LossParams p)
+{
+	__shared__ float s_red[4];
+	float a = 0.f, b = 0.f;
+	for (int i = (int)threadIdx.x; i < p.nblocks; i += 256) {
+		a += p.partial[i];
+		b += p.partial[p.nblocks + i];
+	}
+	const float l1 = block_sum_256(a, s_red);
+	const float ss = block_sum_256(b, s_red);
+	if (threadIdx.x == 0) {
+		const float inv_n = 1.0f / (3.0f * (float)p.W * (float)p.H);
+		p.loss[0] = (1.0f - p.lambda_dssim) * (l1 * inv_n) + p.lambda_dssim * (1.0f - ss * inv_n);
+	}
+}
+
+// ------------------------------------------------------------------ Adam
+// torch.optim.Adam / torch::optim::Adam step (no amsgrad, no weight decay):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
+            float* __restrict__ exp_avg_sq, long long n, float step_size, float b1, float b2, float eps,
+            float inv_sqrt_bc2, int period, int split, float step_size_tail)
+{
+	// period/split: elements [split, period) of every `period`-element row use step_size_tail (the SH buffer
+	// keeps features_dc (lr) and features_rest (lr/20) in one [P,16,3] tensor); period == 0: uniform.
+	const long long stride = (long long)gridDim.x * blockDim.x * 4;
+	for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+		if (i + 3 < n && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+		                   reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0) {
+			float4 pv = *reinterpret_cast<float4*>(param + i);
+			const float4 gv = *reinterpret_cast<const float4*>(grad + i);
+			float4 mv = *reinterpret_cast<float4*>(exp_avg + i);
+			float4 vv = *reinterpret_cast<float4*>(exp_avg_sq + i);
+			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const float ss = (period && (int)((i + k) % period) >= split) ? step_size_tail : step_size;
+				mp[k] = b1 * mp[k] + (1.f - b1) * gp[k];
+				vp[k] = b2 * vp[k] + (1.f - b2) * gp[k] * gp[k];
+				pp[k] -= ss * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
+			}
+			*reinterpret_cast<float4*>(param + i) = pv;
+			*reinterpret_cast<float4*>(exp_avg + i) = mv;
+			*reinterpret_cast<float4*>(exp_avg_sq + i) = vv;
+		} else {
+			for (long long k = i; k < n && k < i + 4; k++) {
+				const float ss = (period && (int)(k % period) >= split) ? step_size_tail : step_size;
+				const float g = grad[k];
+				const float m = b1 * exp_avg[k] + (1.f - b1) * g;
+				const float v = b2 * exp_avg_sq[k] + (1.f - b2) * g * g;
+				exp_avg[k] = m;
+				exp_avg_sq[k] = v;
+				param[k] -= ss * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+			}
+		}
+	}
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+size_t gsr_loss_scratch_bytes(int width, int height)
+{
+	if (width <= 0 || height <= 0) return 0;
+	const size_t plane = (size_t)width * height;
+	const size_t nb = (size_t)div_up(width, LT) * div_up(height, LT) * 3;
+	return (9 * plane + 2 * nb + 64) * sizeof(float);
+}
+
+int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, int width, int height, float lambda_dssim,
+                     float* grad_rendered, float* loss, char* scratch, void* stream_)
+{
+	if (!rendered || !gt || !grad_rendered || !loss || !scratch || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	LossParams p;
+	p.rendered = rendered; p.gt = gt; p.mask = mask; p.W = width; p.H = height; p.lambda_dssim = lambda_dssim;
+	// gaussian(11, 1.5) normalised, include/loss_utils.h:49-62
+	float sum = 0.f;
+	for (int x = 0; x < 11; x++) {
+		const int t = x - 5;
+		p.g[x] = expf(-(float)(t * t) / (2.0f * 1.5f * 1.5f));
+		sum += p.g[x];
+	}
+	for (int x = 0; x < 11; x++) p.g[x] /= sum;
+	const size_t plane = (size_t)width * height;
+	const int gx = div_up(width, LT), gy = div_up(height, LT);
+	p.nblocks = gx * gy * 3;
+	p.dmaps = reinterpret_cast<float*>(scratch);
+	p.partial = p.dmaps + 9 * plane;
+	p.grad = grad_rendered;
+	p.loss = loss;
+	GSR_LAUNCH(loss_fwd_kernel, dim3(gx, gy, 3), 256, stream, p);
+	GSR_LAUNCH(loss_bwd_kernel, dim3(gx, gy, 3), 256, stream, p);
+	GSR_LAUNCH(loss_final_kernel, 1, 256, stream, p);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                  float beta2, float eps, int step, int period, int split, float lr_tail, void* stream_)
+{
+	if (n < 0 || step < 1) return GSR_ERR_INVALID_ARG;
+	if (n == 0) return GSR_OK;
+	if (!param || !grad || !exp_avg || !exp_avg_sq) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+	const float step_size = (float)(lr / bc1), step_tail = (float)(lr_tail / bc1);
+	const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+	long long blocks = (n / 4 + 255) / 256;
+	if (blocks > 8192) blocks = 8192;
+	if (blocks < 1) blocks = 1;
+	GSR_LAUNCH(adam_kernel, (int)blocks, 256, stream, param, grad, exp_avg, exp_avg_sq, n, step_size, beta1, beta2, eps,
+	           inv_sqrt_bc2, period, split, step_tail);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+}  // extern "C"

@@ -8,7 +8,48 @@ from dataclasses import dataclass
 
 import torch
 
+from . import capi
 from . import rasterize_points as rp
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (the reference's torch::optim::Adam with eps 1e-15,
+    src/gaussian_model.cpp:477-510) as one HIP streaming pass per tensor (csrc/train_ops.hip).
+    A group may carry `period`/`split`/`lr_tail`: elements [split, period) of every row use lr_tail
+    (features_dc | features_rest share one [P,16,3] buffer with lr and lr/20)."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-15):
+        self.param_groups = groups
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self.step_count = 0
+
+    def step(self):
+        lib = rp._lib()
+        self.step_count += 1
+        with torch.no_grad():
+            for grp in self.param_groups:
+                for p in grp["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self.state.get(id(p))
+                    if st is None:
+                        st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                    g = p.grad.contiguous()
+                    capi.check(lib, lib.gsr_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                      st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]),
+                                                      self.betas[0], self.betas[1], self.eps, self.step_count,
+                                                      int(grp.get("period", 0)), int(grp.get("split", 0)),
+                                                      float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
+                               "gsr_adam_step")
+
+    def zero_grad(self, set_to_none=True):
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
 
 
 @dataclass
@@ -51,8 +92,8 @@ class GaussianModel:
         m = cls(sh_degree, device)
         t = lambda a: torch.from_numpy(a).to(m.device_).contiguous().requires_grad_(True)
         m.xyz_ = t(cloud.xyz)
-        m.features_dc_ = t(cloud.features_dc)
-        m.features_rest_ = t(cloud.features_rest)
+        import numpy as _np
+        m.features_ = t(_np.concatenate([cloud.features_dc, cloud.features_rest], axis=1))
         m.scaling_ = t(cloud.scaling)
         m.rotation_ = t(cloud.rotation)
         m.opacity_ = t(cloud.opacity)
@@ -81,8 +122,7 @@ class GaussianModel:
         opacities = inverse_sigmoid(0.1 * torch.ones((n, 1), device=self.device_))
         req = lambda a: a.contiguous().requires_grad_(True)
         self.xyz_ = req(pts)
-        self.features_dc_ = req(features[:, :, 0:1].transpose(1, 2))
-        self.features_rest_ = req(features[:, :, 1:].transpose(1, 2))
+        self.features_ = req(features.transpose(1, 2))
         self.scaling_ = req(scales)
         self.rotation_ = req(rots)
         self.opacity_ = req(opacities)
@@ -100,8 +140,20 @@ class GaussianModel:
     def getXYZ(self):
         return self.xyz_
 
+    # The reference keeps features_dc [P,1,3] and features_rest [P,15,3] as two leaves and rebuilds
+    # [P,16,3] with cat + 2 clones every step (src/gaussian_model.cpp:63-66: ~3 x 384 MB at 2 M Gaussians).
+    # Here ONE [P,16,3] leaf is the storage; dc / rest are views (for PLY I/O) and the two learning
+    # rates are applied per coefficient inside the fused Adam.
+    @property
+    def features_dc_(self):
+        return self.features_[:, 0:1, :]
+
+    @property
+    def features_rest_(self):
+        return self.features_[:, 1:, :]
+
     def getFeatures(self):
-        return torch.cat((self.features_dc_.clone(), self.features_rest_.clone()), 1)
+        return self.features_
 
     def getOpacityActivation(self):
         return torch.sigmoid(self.opacity_)
@@ -110,7 +162,7 @@ class GaussianModel:
         self.active_sh_degree_ = min(max(sh, 0), self.max_sh_degree_)
 
     def params(self):
-        return [self.xyz_, self.features_dc_, self.features_rest_, self.opacity_, self.scaling_, self.rotation_]
+        return [self.xyz_, self.features_, self.opacity_, self.scaling_, self.rotation_]
 
     # ---- optimizer, src/gaussian_model.cpp:477-510
     def trainingSetup(self, opt):
@@ -118,13 +170,13 @@ class GaussianModel:
         self.opt_ = opt
         groups = [
             dict(params=[self.xyz_], lr=opt.position_lr_init_ * self.spatial_lr_scale_, name="xyz"),
-            dict(params=[self.features_dc_], lr=opt.feature_lr_, name="f_dc"),
-            dict(params=[self.features_rest_], lr=opt.feature_lr_ / 20.0, name="f_rest"),
+            dict(params=[self.features_], lr=opt.feature_lr_, name="f_dc+f_rest", period=3 * (self.max_sh_degree_ + 1) ** 2,
+                 split=3, lr_tail=opt.feature_lr_ / 20.0),
             dict(params=[self.opacity_], lr=opt.opacity_lr_, name="opacity"),
             dict(params=[self.scaling_], lr=opt.scaling_lr_, name="scaling"),
             dict(params=[self.rotation_], lr=opt.rotation_lr_, name="rotation"),
         ]
-        self.optimizer_ = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer_ = FusedAdam(groups, eps=1e-15)
 
     def exponLrFunc(self, step):
         """src/gaussian_model.cpp:1118-1131"""

@@ -49,3 +49,42 @@ def ssim(img1, img2, window_size=11, size_average=True):
     channel = img1.size(-3)
     window = create_window(window_size, channel, img1.device).type_as(img1)
     return _ssim(img1, img2, window, window_size, channel, size_average)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused HIP version of the train-step loss (csrc/train_ops.hip, gsr_l1_ssim_loss):
+#   loss = (1 - lambda) * l1_loss(rendered * mask, gt) + lambda * (1 - ssim(rendered * mask, gt))
+# (src/gaussian_mapper.cpp:692-698) with its gradient w.r.t. `rendered`, in two LDS-tiled kernels.
+import ctypes as _C
+
+from . import rasterize_points as _rp
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rendered, gt, mask, lambda_dssim):
+        lib = _rp._lib()
+        _rp._check_device(lib, rendered, gt)
+        r = rendered.contiguous().float()
+        g = gt.contiguous().float()
+        m = None if mask is None else mask.contiguous().float()
+        _, H, W = r.shape
+        grad = torch.empty_like(r)
+        loss = torch.empty(1, dtype=torch.float32, device=r.device)
+        scratch = torch.empty(int(lib.gsr_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=r.device)
+        st = lib.gsr_l1_ssim_loss(r.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(), W, H,
+                                  float(lambda_dssim), grad.data_ptr(), loss.data_ptr(), scratch.data_ptr(),
+                                  _rp._stream_ptr(r))
+        from . import capi
+        capi.check(lib, st, "gsr_l1_ssim_loss")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_out, None, None, None
+
+
+def fused_l1_ssim_loss(rendered, gt, mask, lambda_dssim):
+    return _FusedL1SSIM.apply(rendered, gt, mask, lambda_dssim)

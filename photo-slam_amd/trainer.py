@@ -23,10 +23,8 @@ class TrainStep:
         g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
         rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
             viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_)
-        masked_image = rendered_image * mask                             # :692
-        Ll1 = loss_utils.l1_loss(masked_image, gt_image)                 # :695
-        lam = opt.lambda_dssim_
-        loss = (1.0 - lam) * Ll1 + lam * (1.0 - loss_utils.ssim(masked_image.unsqueeze(0), gt_image.unsqueeze(0)))
+        # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
+        loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_)
         loss.backward()                                                  # :699
         with torch.no_grad():
             if self.world_size_ > 1:

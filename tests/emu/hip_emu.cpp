@@ -109,9 +109,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 	gridDim = grid;
 	g_nthreads = nthreads;
 	const int nwaves = (nthreads + 63) / 64;
+	for (unsigned bz = 0; bz < grid.z; bz++)
 	for (unsigned by = 0; by < grid.y; by++)
 		for (unsigned bx = 0; bx < grid.x; bx++) {
-			blockIdx = dim3(bx, by, 0);
+			blockIdx = dim3(bx, by, bz);
 			g_alive = nthreads;
 			g_bar_count = 0;
 			for (int w = 0; w < nwaves; w++) {

@@ -60,6 +60,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+#include <math.h>
 
 namespace hipemu {
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);

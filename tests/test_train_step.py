@@ -88,7 +88,7 @@ kf = GaussianKeyframe.from_camera(cl.cameras[rank], "cpu")
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
 ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), world_size=ws)
 for _ in range(2): ts.trainForOneIteration(kf, gt, torch.ones(3, 32, 48))
-out = {n: p.detach().numpy() for n, p in zip(["xyz","f_dc","f_rest","opacity","scaling","rotation"], g.params())}
+out = {n: p.detach().numpy() for n, p in zip(["xyz","features","opacity","scaling","rotation"], g.params())}
 out["accum"] = g.xyz_gradient_accum_.numpy(); out["denom"] = g.denom_.numpy(); out["maxr"] = g.max_radii2D_.numpy()
 np.savez(os.path.join(sys.argv[3], f"rank{rank}.npz"), **out)
 dist.barrier()
@@ -121,8 +121,7 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path):
         stats = []
         for kf, gt in zip(kfs, gts):
             img, vsp, vis, radii = GaussianRenderer.render(kf, 32, 48, g, GaussianPipelineParams(), torch.zeros(3))
-            m = img * mask
-            loss = 0.8 * loss_utils.l1_loss(m, gt) + 0.2 * (1.0 - loss_utils.ssim(m.unsqueeze(0), gt.unsqueeze(0)))
+            loss = loss_utils.fused_l1_ssim_loss(img, gt, mask, 0.2)
             loss.backward()
             cur = [p.grad.clone() for p in g.params()]
             for p in g.params():
@@ -139,7 +138,7 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path):
             g.max_radii2D_ = torch.max(g.max_radii2D_, torch.max(stats[0][2], stats[1][2]))
             g.optimizer_.step()
             g.optimizer_.zero_grad(set_to_none=True)
-    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    names = ["xyz", "features", "opacity", "scaling", "rotation"]
     for n, p in zip(names, g.params()):
         assert np.allclose(r0[n], p.detach().numpy(), rtol=1e-5, atol=1e-7), n
     assert np.allclose(r0["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
