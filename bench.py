@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of Gaussians (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raster-only", action="store_true", help="time rasterizer fwd+bwd only (no loss/optimizer)")
+    ap.add_argument("--host", default="cpp", choices=["cpp", "py"],
+                    help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
     args = ap.parse_args()
 
     import torch
@@ -100,8 +102,28 @@ def main():
     pipe = GaussianPipelineParams()
     ts = TrainStep(g, opt, pipe, bg, world_size=world)
 
+    ops = None
+    if args.host == "cpp" and not args.raster_only:
+        sys.path.insert(0, os.path.join(ROOT, "photo-slam_amd", "host"))
+        import build_host
+        torch.ops.load_library(build_host.build("hip"))
+        ops = torch.ops.photoslam_amd
+        handle = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                                    g.rotation_.detach(), 3, float(cl.extent), bg)
+        import math
+        fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+
     def one_step():
-        if args.raster_only:
+        if ops is not None:
+            loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
+                                                   kf.camera_center_, fovx, fovy, H, W, gt, mask)
+            if world > 1:
+                for gr in ops.trainer_grads(handle):
+                    dist.all_reduce(gr, op=dist.ReduceOp.SUM)
+                    gr.mul_(1.0 / world)
+            loss.item()                       # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
+            ops.trainer_finish(handle)
+        elif args.raster_only:
             img, vsp, vis, radii = GaussianRenderer.render(kf, H, W, g, pipe, bg)
             img.backward(gt)
             g.optimizer_.zero_grad(set_to_none=True)
@@ -168,7 +190,8 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
-                       "raster_only": bool(args.raster_only)},
+                       "raster_only": bool(args.raster_only),
+                       "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }

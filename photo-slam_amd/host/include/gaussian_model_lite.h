@@ -1,0 +1,89 @@
+// gaussian_model_lite.h -- the slice of GaussianModel / GaussianKeyframe the measured train step
+// needs (include/gaussian_model.h:59-193, include/gaussian_keyframe.h:36-136 of the reference),
+// LibTorch only -- the reference classes pull in OpenCV, Eigen, Sophus and ORB-SLAM3, none of which
+// exist in this environment.  Member names follow the reference so GaussianRenderer::render is the
+// same code for both.
+#pragma once
+#include <torch/torch.h>
+
+#include <cmath>
+#include <memory>
+#include <vector>
+
+struct GaussianOptimizationParams {  // include/gaussian_parameters.h:61-96 defaults
+	int iterations_ = 30000;
+	float position_lr_init_ = 0.00016f, position_lr_final_ = 0.0000016f, position_lr_delay_mult_ = 0.01f;
+	int position_lr_max_steps_ = 30000;
+	float feature_lr_ = 0.0025f, opacity_lr_ = 0.05f, scaling_lr_ = 0.005f, rotation_lr_ = 0.001f;
+	float percent_dense_ = 0.01f, lambda_dssim_ = 0.2f;
+	int densification_interval_ = 100, opacity_reset_interval_ = 3000, densify_from_iter_ = 500,
+	    densify_until_iter_ = 15000;
+	float densify_grad_threshold_ = 0.0002f;
+};
+
+struct GaussianKeyframe {
+	int image_height_ = 0, image_width_ = 0;
+	float FoVx_ = 0.f, FoVy_ = 0.f;
+	torch::Tensor world_view_transform_, full_proj_transform_, camera_center_;
+};
+
+// One Adam parameter group of the fused optimizer (gsr_adam_step)
+struct AdamGroup {
+	torch::Tensor param, exp_avg, exp_avg_sq;
+	float lr = 0.f, lr_tail = 0.f;
+	int period = 0, split = 0;
+};
+
+class GaussianModel {
+public:
+	GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity, torch::Tensor scaling,
+	              torch::Tensor rotation, float spatial_lr_scale);
+
+	// activations, src/gaussian_model.cpp:48-71
+	torch::Tensor getXYZ() { return xyz_; }
+	torch::Tensor getScalingActivation() { return torch::exp(scaling_); }
+	torch::Tensor getRotationActivation() { return torch::nn::functional::normalize(rotation_); }
+	torch::Tensor getOpacityActivation() { return torch::sigmoid(opacity_); }
+	// one [P,16,3] leaf instead of cat(features_dc.clone(), features_rest.clone()) (gaussian_model.cpp:63-66)
+	torch::Tensor getFeatures() { return features_; }
+	torch::Tensor getCovarianceActivation();
+
+	void trainingSetup(const GaussianOptimizationParams& opt);   // src/gaussian_model.cpp:477-510
+	float updateLearningRate(int step);                          // :1118-1131 (exponLrFunc)
+	void optimizerStep();                                        // torch::optim::Adam semantics, fused
+	void zeroGrad();
+	void addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter);  // :817-831
+	std::vector<torch::Tensor> params() { return {xyz_, features_, opacity_, scaling_, rotation_}; }
+
+	int max_sh_degree_, active_sh_degree_;
+	float spatial_lr_scale_;
+	torch::Tensor xyz_, features_, opacity_, scaling_, rotation_;
+	torch::Tensor max_radii2D_, xyz_gradient_accum_, denom_;
+	GaussianOptimizationParams opt_;
+	std::vector<AdamGroup> groups_;
+	int adam_step_ = 0;
+};
+
+// GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774) without the SLAM keyframe
+// scheduling: render -> masked L1 + lambda (1 - SSIM) -> backward -> statistics -> Adam.
+class TrainStep {
+public:
+	TrainStep(std::shared_ptr<GaussianModel> g, torch::Tensor background) : gaussians_(g), background_(background) {}
+	// forward + backward only (gradients left on the leaves, statistics gathered): lets a data-parallel
+	// driver all-reduce before finishOneIteration()
+	torch::Tensor renderAndBackward(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask);
+	void finishOneIteration();
+	torch::Tensor trainForOneIteration(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
+	{
+		auto loss = renderAndBackward(kf, gt_image, mask);
+		finishOneIteration();
+		return loss;
+	}
+	std::shared_ptr<GaussianModel> gaussians_;
+	torch::Tensor background_;
+	int iteration_ = 0;
+	torch::Tensor last_viewspace_, last_visibility_, last_radii_;
+};
+
+// loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)
+torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim);

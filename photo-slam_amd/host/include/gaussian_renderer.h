@@ -1,0 +1,81 @@
+// gaussian_renderer.h -- GaussianRenderer::render (include/gaussian_renderer.h:29-42).
+//
+// Inside the Photo-SLAM tree this header is used with the reference's own gaussian_model.h /
+// gaussian_keyframe.h / gaussian_parameters.h (define PHOTOSLAM_TREE).  Stand-alone (this repo:
+// no OpenCV / Eigen / ORB-SLAM3 available) render() is a template over the model and keyframe
+// types and touches exactly the members the reference implementation touches
+// (src/gaussian_renderer.cpp:41-148): FoVx_, FoVy_, world_view_transform_, full_proj_transform_,
+// camera_center_ ; getXYZ(), getOpacityActivation(), getScalingActivation(),
+// getRotationActivation(), getCovarianceActivation(), getFeatures(), active_sh_degree_.
+#pragma once
+#include <torch/torch.h>
+
+#include <cmath>
+#include <memory>
+#include <tuple>
+
+#include "gaussian_rasterizer.h"
+
+#ifdef PHOTOSLAM_TREE
+#include "gaussian_keyframe.h"
+#include "gaussian_model.h"
+#include "gaussian_parameters.h"
+#else
+struct GaussianPipelineParams {
+	bool convert_SHs_ = false;
+	bool compute_cov3D_ = false;
+};
+#endif
+
+class GaussianRenderer {
+public:
+	// returns (render, viewspace_points, visibility_filter, radii)
+	template <class Keyframe, class Model>
+	static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> render(
+	    std::shared_ptr<Keyframe> viewpoint_camera, int image_height, int image_width, std::shared_ptr<Model> pc,
+	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
+	    float scaling_modifier = 1.0f, bool use_override_color = false)
+	{
+		// dummy input whose gradient is dL/dmean2D (the densification statistic)
+		auto screenspace_points = torch::zeros_like(pc->getXYZ(), torch::TensorOptions().requires_grad(true));
+		screenspace_points.retain_grad();
+
+		const float tanfovx = std::tan(viewpoint_camera->FoVx_ * 0.5f);
+		const float tanfovy = std::tan(viewpoint_camera->FoVy_ * 0.5f);
+		GaussianRasterizationSettings raster_settings(image_height, image_width, tanfovx, tanfovy, bg_color,
+		                                              scaling_modifier, viewpoint_camera->world_view_transform_,
+		                                              viewpoint_camera->full_proj_transform_, pc->active_sh_degree_,
+		                                              viewpoint_camera->camera_center_, false);
+		GaussianRasterizer rasterizer(raster_settings);
+
+		auto means3D = pc->getXYZ();
+		auto opacity = pc->getOpacityActivation();
+		bool has_scales = false, has_rotations = false, has_cov3D_precomp = false;
+		torch::Tensor scales, rotations, cov3D_precomp;
+		if (pipe.compute_cov3D_) {
+			cov3D_precomp = pc->getCovarianceActivation();
+			has_cov3D_precomp = true;
+		} else {
+			scales = pc->getScalingActivation();
+			rotations = pc->getRotationActivation();
+			has_scales = has_rotations = true;
+		}
+		bool has_shs = false, has_color_precomp = false;
+		torch::Tensor shs, colors_precomp;
+		if (use_override_color) {
+			colors_precomp = override_color;
+			has_color_precomp = true;
+		} else {
+			// convert_SHs_ (SH evaluated in torch, include/sh_utils.h) is not used by any shipped config;
+			// the rasterizer evaluates SH itself
+			shs = pc->getFeatures();
+			has_shs = true;
+		}
+		auto result = rasterizer.forward(means3D, screenspace_points, opacity, has_shs, has_color_precomp, has_scales,
+		                                 has_rotations, has_cov3D_precomp, shs, colors_precomp, scales, rotations,
+		                                 cov3D_precomp);
+		auto rendered_image = std::get<0>(result);
+		auto radii = std::get<1>(result);
+		return std::make_tuple(rendered_image, screenspace_points, radii > 0, radii);
+	}
+};

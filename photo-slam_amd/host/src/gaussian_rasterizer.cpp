@@ -1,0 +1,82 @@
+// gaussian_rasterizer.cpp -- autograd glue, counterpart of src/gaussian_rasterizer.cpp:18-234.
+#include "gaussian_rasterizer.h"
+
+#include <stdexcept>
+
+torch::Tensor GaussianRasterizer::markVisibleGaussians(torch::Tensor& positions)
+{
+	torch::NoGradGuard no_grad;
+	return markVisible(positions, raster_settings_.viewmatrix_, raster_settings_.projmatrix_);
+}
+
+torch::autograd::tensor_list GaussianRasterizerFunction::forward(
+    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+    torch::Tensor cov3Ds_precomp, GaussianRasterizationSettings s)
+{
+	(void)means2D;  // only its gradient slot matters
+	auto r = RasterizeGaussiansCUDA(s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_,
+	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
+	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_);
+	ctx->saved_data["num_rendered"] = std::get<0>(r);
+	ctx->saved_data["scale_modifier"] = static_cast<double>(s.scale_modifier_);
+	ctx->saved_data["tanfovx"] = static_cast<double>(s.tanfovx_);
+	ctx->saved_data["tanfovy"] = static_cast<double>(s.tanfovy_);
+	ctx->saved_data["sh_degree"] = s.sh_degree_;
+	auto color = std::get<1>(r);
+	auto radii = std::get<2>(r);
+	// same 14 tensors, same order as the reference (src/gaussian_rasterizer.cpp:87-100)
+	ctx->save_for_backward({s.bg_, s.viewmatrix_, s.projmatrix_, s.campos_, colors_precomp, means3D, scales, rotations,
+	                        cov3Ds_precomp, radii, sh, std::get<3>(r), std::get<4>(r), std::get<5>(r)});
+	ctx->mark_non_differentiable({radii});
+	return {color, radii};
+}
+
+torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autograd::AutogradContext* ctx,
+                                                                  torch::autograd::tensor_list grad_outputs)
+{
+	const int num_rendered = static_cast<int>(ctx->saved_data["num_rendered"].toInt());
+	const float scale_modifier = static_cast<float>(ctx->saved_data["scale_modifier"].toDouble());
+	const float tanfovx = static_cast<float>(ctx->saved_data["tanfovx"].toDouble());
+	const float tanfovy = static_cast<float>(ctx->saved_data["tanfovy"].toDouble());
+	const int sh_degree = static_cast<int>(ctx->saved_data["sh_degree"].toInt());
+	auto v = ctx->get_saved_variables();
+	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
+	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
+	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
+	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13]);
+	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
+	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
+		return (input.defined() && input.numel() != 0) ? grad : torch::Tensor();
+	};
+	return {std::get<3>(g) /*means3D*/,
+	        std::get<0>(g) /*means2D*/,
+	        opt(std::get<5>(g), v[10]) /*sh*/,
+	        opt(std::get<1>(g), v[4]) /*colors_precomp*/,
+	        std::get<2>(g) /*opacities*/,
+	        opt(std::get<6>(g), v[6]) /*scales*/,
+	        opt(std::get<7>(g), v[7]) /*rotations*/,
+	        opt(std::get<4>(g), v[8]) /*cov3Ds_precomp*/,
+	        torch::Tensor() /*raster_settings*/};
+}
+
+std::tuple<torch::Tensor, torch::Tensor> GaussianRasterizer::forward(
+    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, bool has_shs, bool has_colors_precomp,
+    bool has_scales, bool has_rotations, bool has_cov3D_precomp, torch::Tensor shs, torch::Tensor colors_precomp,
+    torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3D_precomp)
+{
+	if (has_shs == has_colors_precomp)
+		throw std::runtime_error("Please provide excatly one of either SHs or precomputed colors!");
+	if (((!has_scales || !has_rotations) && !has_cov3D_precomp) || ((has_scales || has_rotations) && has_cov3D_precomp))
+		throw std::runtime_error(
+		    "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+	auto empty = torch::empty({0}, means3D.options().dtype(torch::kFloat32));
+	if (!has_shs) shs = empty;
+	if (!has_colors_precomp) colors_precomp = empty;
+	if (!has_scales) scales = empty;
+	if (!has_rotations) rotations = empty;
+	if (!has_cov3D_precomp) cov3D_precomp = empty;
+	auto result = rasterizeGaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+	                                 raster_settings_);
+	return std::make_tuple(result[0], result[1]);
+}

@@ -1,0 +1,117 @@
+// ops_register.cpp -- exposes the C++ host layer to Python (torch.ops.photoslam_amd.*) so that the
+// test-suite and bench.py can drive the very code a C++ caller (gaussian_mapper) would link against.
+#include <torch/library.h>
+#include <torch/torch.h>
+
+#include <map>
+#include <mutex>
+
+#include "gaussian_model_lite.h"
+#include "gaussian_renderer.h"
+#include "spatial.h"
+
+namespace {
+
+std::tuple<torch::Tensor, torch::Tensor> rasterize_gaussians(torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+                                                             torch::Tensor colors_precomp, torch::Tensor opacities,
+                                                             torch::Tensor scales, torch::Tensor rotations,
+                                                             torch::Tensor cov3Ds_precomp, torch::Tensor bg,
+                                                             double scale_modifier, torch::Tensor viewmatrix,
+                                                             torch::Tensor projmatrix, double tanfovx, double tanfovy,
+                                                             int64_t image_height, int64_t image_width, int64_t sh_degree,
+                                                             torch::Tensor campos, bool prefiltered)
+{
+	GaussianRasterizationSettings s((int)image_height, (int)image_width, (float)tanfovx, (float)tanfovy, bg,
+	                                (float)scale_modifier, viewmatrix, projmatrix, (int)sh_degree, campos, prefiltered);
+	GaussianRasterizer r(s);
+	auto has = [](const torch::Tensor& t) { return t.defined() && t.numel() != 0; };
+	return r.forward(means3D, means2D, opacities, has(sh), has(colors_precomp), has(scales), has(rotations),
+	                 has(cov3Ds_precomp), sh, colors_precomp, scales, rotations, cov3Ds_precomp);
+}
+
+torch::Tensor mark_visible(torch::Tensor means3D, torch::Tensor viewmatrix, torch::Tensor projmatrix)
+{
+	return markVisible(means3D, viewmatrix, projmatrix);
+}
+torch::Tensor dist_cuda2(torch::Tensor points) { return distCUDA2(points); }
+torch::Tensor l1_ssim_loss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, double lambda_dssim)
+{
+	return fusedL1SSIMLoss(rendered, gt, mask, (float)lambda_dssim);
+}
+
+// ---- a C++ TrainStep behind an integer handle
+std::mutex g_mu;
+std::map<int64_t, std::shared_ptr<TrainStep>> g_trainers;
+int64_t g_next = 1;
+
+int64_t trainer_create(torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity, torch::Tensor scaling,
+                       torch::Tensor rotation, int64_t sh_degree, double spatial_lr_scale, torch::Tensor background)
+{
+	auto model = std::make_shared<GaussianModel>((int)sh_degree, xyz, features, opacity, scaling, rotation,
+	                                             (float)spatial_lr_scale);
+	model->trainingSetup(GaussianOptimizationParams());
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_trainers[g_next] = std::make_shared<TrainStep>(model, background);
+	return g_next++;
+}
+std::shared_ptr<TrainStep> get(int64_t h)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	auto it = g_trainers.find(h);
+	TORCH_CHECK(it != g_trainers.end(), "unknown trainer handle");
+	return it->second;
+}
+std::shared_ptr<GaussianKeyframe> make_kf(torch::Tensor view, torch::Tensor proj, torch::Tensor campos, double fovx,
+                                          double fovy, int64_t H, int64_t W)
+{
+	auto kf = std::make_shared<GaussianKeyframe>();
+	kf->image_height_ = (int)H;
+	kf->image_width_ = (int)W;
+	kf->FoVx_ = (float)fovx;
+	kf->FoVy_ = (float)fovy;
+	kf->world_view_transform_ = view;
+	kf->full_proj_transform_ = proj;
+	kf->camera_center_ = campos;
+	return kf;
+}
+torch::Tensor trainer_render_and_backward(int64_t h, torch::Tensor view, torch::Tensor proj, torch::Tensor campos,
+                                          double fovx, double fovy, int64_t H, int64_t W, torch::Tensor gt,
+                                          torch::Tensor mask)
+{
+	return get(h)->renderAndBackward(make_kf(view, proj, campos, fovx, fovy, H, W), gt, mask).detach();
+}
+void trainer_finish(int64_t h) { get(h)->finishOneIteration(); }
+std::vector<torch::Tensor> trainer_params(int64_t h) { return get(h)->gaussians_->params(); }
+std::vector<torch::Tensor> trainer_grads(int64_t h)
+{
+	std::vector<torch::Tensor> g;
+	for (auto& p : get(h)->gaussians_->params()) g.push_back(p.grad());
+	return g;
+}
+std::vector<torch::Tensor> trainer_stats(int64_t h)
+{
+	auto g = get(h)->gaussians_;
+	return {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
+}
+void trainer_destroy(int64_t h)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_trainers.erase(h);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(photoslam_amd, m)
+{
+	m.def("rasterize_gaussians", &rasterize_gaussians);
+	m.def("mark_visible", &mark_visible);
+	m.def("dist_cuda2", &dist_cuda2);
+	m.def("l1_ssim_loss", &l1_ssim_loss);
+	m.def("trainer_create", &trainer_create);
+	m.def("trainer_render_and_backward", &trainer_render_and_backward);
+	m.def("trainer_finish", &trainer_finish);
+	m.def("trainer_params", &trainer_params);
+	m.def("trainer_grads", &trainer_grads);
+	m.def("trainer_stats", &trainer_stats);
+	m.def("trainer_destroy", &trainer_destroy);
+}

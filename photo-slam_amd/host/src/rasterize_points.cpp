@@ -1,0 +1,207 @@
+// rasterize_points.cpp -- the torch <-> kernel boundary (replaces src/rasterize_points.cu:28-214 and
+// third_party/simple-knn/spatial.cu:15-26 of the reference) on top of the C-ABI of libgsr_hip.so.
+// LibTorch supplies device memory and the current stream only.
+#include "rasterize_points.h"
+#include "spatial.h"
+
+#include <string>
+
+#include "../../../include/gsr.h"
+
+#ifndef GSR_HOST_NO_HIP
+#include <c10/hip/HIPStream.h>
+#endif
+
+namespace {
+
+// resizeFunctional, src/rasterize_points.cu:28-34, as a plain C callback
+char* resize_tensor(void* ctx, size_t bytes)
+{
+	auto* t = static_cast<torch::Tensor*>(ctx);
+	t->resize_({static_cast<int64_t>(bytes)});
+	return reinterpret_cast<char*>(t->data_ptr());
+}
+
+void* current_stream(const torch::Tensor& t)
+{
+#ifndef GSR_HOST_NO_HIP
+	if (t.is_cuda()) return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+#endif
+	return nullptr;
+}
+
+// contiguous fp32 pointer, nullptr for an empty tensor (the reference's "absent optional")
+struct F32 {
+	torch::Tensor keep;
+	const float* ptr = nullptr;
+	explicit F32(const torch::Tensor& t)
+	{
+		if (t.defined() && t.numel() != 0) {
+			keep = t.contiguous();
+			ptr = keep.data_ptr<float>();
+		}
+	}
+};
+
+void check(int status, const char* where)
+{
+	if (status == GSR_OK) return;
+	std::string msg = std::string(where) + ": " + gsr_strerror(status);
+	if (status == GSR_ERR_HIP) msg += std::string(" [") + gsr_last_hip_error_string() + "]";
+	throw std::runtime_error(msg);
+}
+
+}  // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
+    const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+    const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+    const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
+    const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
+    const bool prefiltered)
+{
+	if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
+		AT_ERROR("means3D must have dimensions (num_points, 3)");
+	}
+	const int P = static_cast<int>(means3D.size(0));
+	const int H = image_height, W = image_width;
+	auto float_opts = means3D.options().dtype(torch::kFloat32);
+	torch::Tensor out_color = torch::zeros({3, H, W}, float_opts);
+	torch::Tensor radii = torch::zeros({P}, means3D.options().dtype(torch::kInt32));
+	auto byte_opts = means3D.options().dtype(torch::kByte);
+	torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
+	torch::Tensor binningBuffer = torch::empty({0}, byte_opts);
+	torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+
+	int rendered = 0;
+	if (P != 0) {
+		F32 bg(background), m3(means3D), col(colors), op(opacity), sc(scales), rot(rotations), cov(cov3D_precomp),
+		    view(viewmatrix), proj(projmatrix), shs(sh), cam(campos);
+		gsr_forward_args a{};
+		a.P = P;
+		a.D = degree;
+		a.M = (sh.defined() && sh.numel() != 0) ? static_cast<int>(sh.size(1)) : 0;
+		a.background = bg.ptr;
+		a.width = W;
+		a.height = H;
+		a.means3D = m3.ptr;
+		a.shs = shs.ptr;
+		a.colors_precomp = col.ptr;
+		a.opacities = op.ptr;
+		a.scales = sc.ptr;
+		a.scale_modifier = scale_modifier;
+		a.rotations = rot.ptr;
+		a.cov3D_precomp = cov.ptr;
+		a.viewmatrix = view.ptr;
+		a.projmatrix = proj.ptr;
+		a.cam_pos = cam.ptr;
+		a.tan_fovx = tan_fovx;
+		a.tan_fovy = tan_fovy;
+		a.prefiltered = prefiltered ? 1 : 0;
+		a.out_color = out_color.data_ptr<float>();
+		a.radii = radii.data_ptr<int>();
+		check(gsr_forward(&a, resize_tensor, &geomBuffer, resize_tensor, &binningBuffer, resize_tensor, &imgBuffer,
+		                  current_stream(means3D), &rendered),
+		      "RasterizeGaussiansCUDA");
+	}
+	return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	const int H = static_cast<int>(dL_dout_color.size(1));
+	const int W = static_cast<int>(dL_dout_color.size(2));
+	const int M = (sh.defined() && sh.numel() != 0) ? static_cast<int>(sh.size(1)) : 0;
+	auto o = means3D.options().dtype(torch::kFloat32);
+	const bool has_sh = M != 0, has_scales = scales.defined() && scales.numel() != 0;
+	// the reference zero-fills all nine (src/rasterize_points.cu:149-157); gsr_backward writes every
+	// element of every output it is given, so only the outputs it is NOT given need zeros
+	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
+	torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
+	torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
+	torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
+	torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
+	torch::Tensor dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
+	torch::Tensor dL_dscales = has_scales ? torch::empty({P, 3}, o) : torch::zeros({P, 3}, o);
+	torch::Tensor dL_drotations = has_scales ? torch::empty({P, 4}, o) : torch::zeros({P, 4}, o);
+
+	if (P != 0) {
+		F32 bg(background), m3(means3D), col(colors), sc(scales), rot(rotations), cov(cov3D_precomp), view(viewmatrix),
+		    proj(projmatrix), shs(sh), cam(campos), dpix(dL_dout_color);
+		torch::Tensor radii_c = radii.contiguous(), geom_c = geomBuffer.contiguous(), bin_c = binningBuffer.contiguous(),
+		              img_c = imageBuffer.contiguous();
+		gsr_backward_args a{};
+		a.P = P;
+		a.D = degree;
+		a.M = M;
+		a.R = R;
+		a.background = bg.ptr;
+		a.width = W;
+		a.height = H;
+		a.means3D = m3.ptr;
+		a.shs = shs.ptr;
+		a.colors_precomp = col.ptr;
+		a.scales = sc.ptr;
+		a.scale_modifier = scale_modifier;
+		a.rotations = rot.ptr;
+		a.cov3D_precomp = cov.ptr;
+		a.viewmatrix = view.ptr;
+		a.projmatrix = proj.ptr;
+		a.campos = cam.ptr;
+		a.tan_fovx = tan_fovx;
+		a.tan_fovy = tan_fovy;
+		a.radii = radii_c.numel() ? radii_c.data_ptr<int>() : nullptr;
+		a.geom_buffer = reinterpret_cast<char*>(geom_c.data_ptr());
+		a.binning_buffer = bin_c.numel() ? reinterpret_cast<char*>(bin_c.data_ptr()) : nullptr;
+		a.image_buffer = reinterpret_cast<char*>(img_c.data_ptr());
+		a.dL_dpix = dpix.ptr;
+		a.dL_dmean2D = dL_dmeans2D.data_ptr<float>();
+		a.dL_dconic = nullptr;  // internal to the reference's wrapper (rasterize_points.cu:152)
+		a.dL_dopacity = dL_dopacity.data_ptr<float>();
+		a.dL_dcolor = dL_dcolors.data_ptr<float>();
+		a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
+		a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
+		a.dL_dsh = has_sh ? dL_dsh.data_ptr<float>() : nullptr;
+		a.dL_dscale = has_scales ? dL_dscales.data_ptr<float>() : nullptr;
+		a.dL_drot = has_scales ? dL_drotations.data_ptr<float>() : nullptr;
+		check(gsr_backward(&a, current_stream(means3D)), "RasterizeGaussiansBackwardCUDA");
+	}
+	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+	                       dL_drotations);
+}
+
+torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	torch::Tensor present = torch::zeros({P}, means3D.options().dtype(at::kBool));
+	if (P != 0) {
+		F32 m3(means3D), view(viewmatrix), proj(projmatrix);
+		check(gsr_mark_visible(P, m3.ptr, view.ptr, proj.ptr, reinterpret_cast<uint8_t*>(present.data_ptr<bool>()),
+		                       current_stream(means3D)),
+		      "markVisible");
+	}
+	return present;
+}
+
+torch::Tensor distCUDA2(const torch::Tensor& points)
+{
+	const int P = static_cast<int>(points.size(0));
+	torch::Tensor means = torch::zeros({P}, points.options().dtype(torch::kFloat32));
+	if (P != 0) {
+		F32 pts(points);
+		torch::Tensor scratch = torch::empty({0}, points.options().dtype(torch::kByte));
+		check(gsr_knn_mean_dist2(P, pts.ptr, means.data_ptr<float>(), resize_tensor, &scratch, current_stream(points)),
+		      "distCUDA2");
+	}
+	return means;
+}

@@ -1,0 +1,173 @@
+// train_step.cpp -- LibTorch host code of the measured train step (see gaussian_model_lite.h).
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/gsr.h"
+#include "gaussian_model_lite.h"
+#include "gaussian_renderer.h"
+
+#ifndef GSR_HOST_NO_HIP
+#include <c10/hip/HIPStream.h>
+#endif
+
+namespace {
+void* stream_of(const torch::Tensor& t)
+{
+#ifndef GSR_HOST_NO_HIP
+	if (t.is_cuda()) return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+#endif
+	return nullptr;
+}
+void check(int status, const char* where)
+{
+	if (status != GSR_OK) throw std::runtime_error(std::string(where) + ": " + gsr_strerror(status));
+}
+
+class FusedL1SSIMFunction : public torch::autograd::Function<FusedL1SSIMFunction> {
+public:
+	static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor rendered, torch::Tensor gt,
+	                             torch::Tensor mask, double lambda_dssim)
+	{
+		auto r = rendered.contiguous(), g = gt.contiguous();
+		torch::Tensor m = mask.defined() && mask.numel() ? mask.contiguous() : torch::Tensor();
+		const int H = static_cast<int>(r.size(1)), W = static_cast<int>(r.size(2));
+		auto grad = torch::empty_like(r);
+		auto loss = torch::empty({1}, r.options());
+		auto scratch = torch::empty({static_cast<int64_t>(gsr_loss_scratch_bytes(W, H))}, r.options().dtype(torch::kByte));
+		check(gsr_l1_ssim_loss(r.data_ptr<float>(), g.data_ptr<float>(), m.defined() ? m.data_ptr<float>() : nullptr, W,
+		                       H, static_cast<float>(lambda_dssim), grad.data_ptr<float>(), loss.data_ptr<float>(),
+		                       reinterpret_cast<char*>(scratch.data_ptr()), stream_of(r)),
+		      "gsr_l1_ssim_loss");
+		ctx->save_for_backward({grad});
+		return loss[0];
+	}
+	static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list go)
+	{
+		auto grad = ctx->get_saved_variables()[0];
+		return {grad * go[0], torch::Tensor(), torch::Tensor(), torch::Tensor()};
+	}
+};
+}  // namespace
+
+torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim)
+{
+	return FusedL1SSIMFunction::apply(rendered, gt, mask, static_cast<double>(lambda_dssim));
+}
+
+GaussianModel::GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity,
+                             torch::Tensor scaling, torch::Tensor rotation, float spatial_lr_scale)
+    : max_sh_degree_(sh_degree), active_sh_degree_(sh_degree), spatial_lr_scale_(spatial_lr_scale)
+{
+	auto leaf = [](torch::Tensor t) { return t.detach().clone().contiguous().set_requires_grad(true); };
+	xyz_ = leaf(xyz);
+	features_ = leaf(features);
+	opacity_ = leaf(opacity);
+	scaling_ = leaf(scaling);
+	rotation_ = leaf(rotation);
+	const auto P = xyz_.size(0);
+	max_radii2D_ = torch::zeros({P}, xyz_.options());
+	xyz_gradient_accum_ = torch::zeros({P, 1}, xyz_.options());
+	denom_ = torch::zeros({P, 1}, xyz_.options());
+}
+
+torch::Tensor GaussianModel::getCovarianceActivation()
+{
+	throw std::runtime_error("compute_cov3D is not used by the shipped configs; pass scales/rotations");
+}
+
+void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)
+{
+	opt_ = opt;
+	groups_.clear();
+	auto add = [&](torch::Tensor& p, float lr, int period = 0, int split = 0, float lr_tail = 0.f) {
+		AdamGroup g;
+		g.param = p;
+		g.exp_avg = torch::zeros_like(p);
+		g.exp_avg_sq = torch::zeros_like(p);
+		g.lr = lr;
+		g.lr_tail = lr_tail;
+		g.period = period;
+		g.split = split;
+		groups_.push_back(g);
+	};
+	add(xyz_, opt.position_lr_init_ * spatial_lr_scale_);
+	// features_dc (lr) | features_rest (lr / 20) share the [P,16,3] buffer
+	add(features_, opt.feature_lr_, 3 * (max_sh_degree_ + 1) * (max_sh_degree_ + 1), 3, opt.feature_lr_ / 20.0f);
+	add(opacity_, opt.opacity_lr_);
+	add(scaling_, opt.scaling_lr_);
+	add(rotation_, opt.rotation_lr_);
+	adam_step_ = 0;
+}
+
+float GaussianModel::updateLearningRate(int step)
+{
+	const float lr_init = opt_.position_lr_init_ * spatial_lr_scale_, lr_final = opt_.position_lr_final_ * spatial_lr_scale_;
+	float lr = 0.f;
+	if (!(step < 0 || (lr_init == 0.0f && lr_final == 0.0f))) {
+		float t = static_cast<float>(step) / static_cast<float>(opt_.position_lr_max_steps_);
+		t = std::min(std::max(t, 0.0f), 1.0f);
+		lr = std::exp(std::log(lr_init) * (1 - t) + std::log(lr_final) * t);
+	}
+	groups_[0].lr = lr;
+	return lr;
+}
+
+void GaussianModel::optimizerStep()
+{
+	torch::NoGradGuard ng;
+	adam_step_++;
+	for (auto& g : groups_) {
+		auto grad = g.param.grad();
+		if (!grad.defined()) continue;
+		grad = grad.contiguous();
+		check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
+		                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, adam_step_,
+		                    g.period, g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
+		      "gsr_adam_step");
+	}
+}
+
+void GaussianModel::zeroGrad()
+{
+	for (auto& g : groups_) g.param.mutable_grad() = torch::Tensor();
+}
+
+void GaussianModel::addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter)
+{
+	auto g = viewspace_point_tensor.grad();
+	auto n = torch::norm(g.index({update_filter}).slice(1, 0, 2), 2, {-1}, true);
+	xyz_gradient_accum_.index_put_({update_filter}, xyz_gradient_accum_.index({update_filter}) + n);
+	denom_.index_put_({update_filter}, denom_.index({update_filter}) + 1);
+}
+
+torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
+{
+	auto& g = gaussians_;
+	iteration_++;
+	g->updateLearningRate(iteration_);
+	GaussianPipelineParams pipe;
+	torch::Tensor override_color;
+	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color);
+	auto rendered = std::get<0>(pkg);
+	last_viewspace_ = std::get<1>(pkg);
+	last_visibility_ = std::get<2>(pkg);
+	last_radii_ = std::get<3>(pkg);
+	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_);
+	loss.backward();
+	return loss;
+}
+
+void TrainStep::finishOneIteration()
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	if (iteration_ < g->opt_.densify_until_iter_) {
+		auto vis = last_visibility_;
+		g->max_radii2D_.index_put_({vis}, torch::max(g->max_radii2D_.index({vis}), last_radii_.index({vis}).to(torch::kFloat32)));
+		g->addDensificationStats(last_viewspace_, vis);
+	}
+	if (iteration_ < g->opt_.iterations_) {
+		g->optimizerStep();
+		g->zeroGrad();
+	}
+}
