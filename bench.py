@@ -195,10 +195,20 @@ def main():
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_C3_raster_only.json")
+        # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, scripts_gpu_pmc.sh), corrected as
+        # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only.
+        kernel_of = {"blend_bwd": "gsr::blend_bwd_kernel", "blend_fwd": "gsr::blend_fwd_kernel",
+                     "preprocess_fwd": "gsr::preprocess_fwd_kernel", "preprocess_bwd": "gsr::preprocess_bwd_kernel"}
+        if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(pmc_file):
+            pm = json.load(open(pmc_file)).get(kernel_of[dom])
+            if pm:
+                traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
         if dom:
             a = stages[dom]["GBps"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "raster_fwd_bwd_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
