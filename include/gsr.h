@@ -144,6 +144,12 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, int step, int period, int split, float lr_tail, void* stream);
 
+/* Per-view densification statistics (src/gaussian_mapper.cpp:714-719, src/gaussian_model.cpp:817-831) for
+ * vis = radii > 0:  max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmean2D.xy|; denom += 1.
+ * dL_dmean2D is the [P,3] viewspace gradient; accum/denom are [P] ([P,1]) floats, max_radii2D [P] floats. */
+int gsr_densify_stats(int P, const float* dL_dmean2D, const int* radii, float* xyz_gradient_accum, float* denom,
+                      float* max_radii2D, void* stream);
+
 /* Scratch sizes (bytes) gsr_forward will request, for callers that pre-allocate. */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_binning_bytes(int num_rendered);

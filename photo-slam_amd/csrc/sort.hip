@@ -108,10 +108,18 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 	__syncthreads();
 	const uint32_t dmask = (1u << nbits) - 1u;
 	const int wbase = blockIdx.x * SORT_CHUNK + wave_id() * SORT_ITEMS_PER_WAVE;
+	// all 16 loads in flight before the first ballot (one HBM latency per wave instead of sixteen)
+	uint32_t key[SORT_ROUNDS];
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const int i = wbase + r * 64 + lane_id();
+		key[r] = i < n ? keys[i] : 0u;
+	}
+#pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const int i = wbase + r * 64 + lane_id();
 		const bool valid = i < n;
-		const uint32_t d = valid ? ((keys[i] >> shift) & dmask) : 0u;
+		const uint32_t d = valid ? ((key[r] >> shift) & dmask) : 0u;
 		const unsigned long long m = wave_match_digit(d, nbits, valid);
 		if (valid && (m & lanemask_lt()) == 0ull) atomicAdd(&s_hist[d], (uint32_t)__popcll(m));
 	}
@@ -119,10 +127,30 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
 }
 
+// One workgroup per digit: exclusive scan of that digit's row hist[d][0..nblocks) in place, row total to
+// totals[d].  Together with a 256-entry scan of the totals inside the scatter kernel this replaces the
+// generic three-launch scan of the whole [256][nblocks] table (3 launches per pass instead of 5).
+__global__ void __launch_bounds__(SCAN_THREADS)
+radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
+{
+	__shared__ uint32_t s_wave[4];
+	uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+	uint32_t carry = 0;
+	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+		const int i = base + (int)threadIdx.x;
+		const uint32_t v = i < nblocks ? row[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
+		if (i < nblocks) row[i] = carry + ex;
+		carry += tot;
+	}
+	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
-                     const uint32_t* __restrict__ hist_scanned, int nblocks)
+                     const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks)
 {
 	__shared__ uint32_t s_whist[4][RADIX_BINS];  // per-wave digit counts, then per-wave running write cursors
 	__shared__ uint32_t s_gbase[RADIX_BINS];     // global position of local element i of digit d = s_gbase[d] + i
@@ -163,11 +191,13 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const uint32_t tot = c0 + c1 + c2 + c3;
 		uint32_t block_total;
 		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
+		uint32_t all;
+		const uint32_t digit_base = block_excl_scan_256(totals[tid], &all, s_wave);   // elements with a smaller digit
 		s_whist[0][tid] = lstart;
 		s_whist[1][tid] = lstart + c0;
 		s_whist[2][tid] = lstart + c0 + c1;
 		s_whist[3][tid] = lstart + c0 + c1 + c2;
-		s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - lstart;
+		s_gbase[tid] = digit_base + hist_rows[(size_t)tid * nblocks + blockIdx.x] - lstart;
 	}
 	__syncthreads();
 
@@ -213,8 +243,7 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 	const int nb = sort_blocks(n);
 	const int hist_elems = RADIX_BINS * nb;
 	uint32_t* hist = scratch;
-	uint32_t* hist_scanned = scratch + hist_elems;
-	uint32_t* scan_scratch = scratch + 2 * (size_t)hist_elems;
+	uint32_t* totals = scratch + hist_elems;
 	if (passes == 0) {
 		// degenerate: nothing to sort on; result must still be materialised in the ping buffers
 		GSR_HIP(hipMemcpyAsync(keys_ping, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
@@ -230,10 +259,9 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		uint32_t* kout = (p % 2 == 0) ? keys_pong : keys_ping;
 		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
 		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb);
-		int st = launch_scan_u32(hist, nullptr, hist_scanned, hist_elems, false, scan_scratch, stream);
-		if (st != GSR_OK) return st;
+		GSR_LAUNCH(radix_row_prefix_kernel, RADIX_BINS, SCAN_THREADS, stream, hist, totals, nb);
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
-		           (const uint32_t*)hist_scanned, nb);
+		           (const uint32_t*)hist, (const uint32_t*)totals, nb);
 		kin = kout;
 		vin = vout;
 	}

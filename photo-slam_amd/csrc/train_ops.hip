@@ -258,6 +258,25 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 	}
 }
 
+// Densification statistics of one view (src/gaussian_mapper.cpp:714-719, src/gaussian_model.cpp:817-831):
+//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]); xyz_gradient_accum[vis] += |dL/dmean2D.xy|; denom[vis] += 1
+// with vis = radii > 0.  The reference does this with boolean-mask gathers/scatters (nonzero + index_put_:
+// 8 partition kernels and a host sync per step); one pass over P here.
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const float* __restrict__ dL_dmean2D, const int* __restrict__ radii,
+                     float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ max_radii)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i >= P) return;
+	const int r = radii[i];
+	if (r > 0) {
+		const float gx = dL_dmean2D[3 * (size_t)i], gy = dL_dmean2D[3 * (size_t)i + 1];
+		accum[i] += sqrtf(gx * gx + gy * gy);
+		denom[i] += 1.0f;
+		max_radii[i] = fmaxf(max_radii[i], (float)r);
+	}
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -316,6 +335,18 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 	if (blocks < 1) blocks = 1;
 	GSR_LAUNCH(adam_kernel, (int)blocks, 256, stream, param, grad, exp_avg, exp_avg_sq, n, step_size, beta1, beta2, eps,
 	           inv_sqrt_bc2, period, split, step_tail);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+int gsr_densify_stats(int P, const float* dL_dmean2D, const int* radii, float* xyz_gradient_accum, float* denom,
+                      float* max_radii2D, void* stream_)
+{
+	if (P < 0) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!dL_dmean2D || !radii || !xyz_gradient_accum || !denom || !max_radii2D) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	GSR_LAUNCH(densify_stats_kernel, div_up(P, 256), 256, stream, P, dL_dmean2D, radii, xyz_gradient_accum, denom, max_radii2D);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -199,3 +199,13 @@ class GaussianModel:
         g = viewspace_point_tensor.grad
         self.xyz_gradient_accum_[update_filter] += torch.norm(g[update_filter][:, :2], dim=-1, keepdim=True)
         self.denom_[update_filter] += 1
+
+    def addViewStats(self, viewspace_point_tensor, radii):
+        """max_radii2D / xyz_gradient_accum / denom update of one view (gaussian_mapper.cpp:714-719) in one
+        HIP pass (gsr_densify_stats) instead of boolean-mask gathers and scatters."""
+        lib = rp._lib()
+        g = viewspace_point_tensor.grad.contiguous()
+        r = radii.contiguous()
+        capi.check(lib, lib.gsr_densify_stats(self.xyz_.shape[0], g.data_ptr(), r.data_ptr(), self.xyz_gradient_accum_.data_ptr(),
+                                              self.denom_.data_ptr(), self.max_radii2D_.data_ptr(), rp._stream_ptr(g)),
+                   "gsr_densify_stats")

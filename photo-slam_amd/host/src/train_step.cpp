@@ -162,9 +162,13 @@ void TrainStep::finishOneIteration()
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	if (iteration_ < g->opt_.densify_until_iter_) {
-		auto vis = last_visibility_;
-		g->max_radii2D_.index_put_({vis}, torch::max(g->max_radii2D_.index({vis}), last_radii_.index({vis}).to(torch::kFloat32)));
-		g->addDensificationStats(last_viewspace_, vis);
+		// :714-719 in one pass (gsr_densify_stats) instead of boolean-mask gathers/scatters + a host sync
+		auto grad = last_viewspace_.grad().contiguous();
+		auto radii = last_radii_.contiguous();
+		check(gsr_densify_stats(static_cast<int>(g->xyz_.size(0)), grad.data_ptr<float>(), radii.data_ptr<int>(),
+		                        g->xyz_gradient_accum_.data_ptr<float>(), g->denom_.data_ptr<float>(),
+		                        g->max_radii2D_.data_ptr<float>(), stream_of(grad)),
+		      "gsr_densify_stats");
 	}
 	if (iteration_ < g->opt_.iterations_) {
 		g->optimizerStep();

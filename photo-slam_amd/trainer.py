@@ -36,9 +36,7 @@ class TrainStep:
                 self.ema_loss_for_log_ = 0.4 * loss.item() + 0.6 * self.ema_loss_for_log_   # :705 (host sync, as the reference)
             if it < opt.densify_until_iter_:
                 if self.world_size_ == 1:
-                    g.max_radii2D_[visibility_filter] = torch.max(g.max_radii2D_[visibility_filter],
-                                                                 radii[visibility_filter].float())  # :714-717
-                    g.addDensificationStats(viewspace_point_tensor, visibility_filter)              # :719
+                    g.addViewStats(viewspace_point_tensor, radii)                                   # :714-719, fused
                 else:
                     # per-view increments (norm BEFORE the sum over views, gaussian_model.cpp:821-826), then SUM / MAX
                     vis = visibility_filter
