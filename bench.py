@@ -61,7 +61,11 @@ def main():
     ap.add_argument("--raster-only", action="store_true", help="time rasterizer fwd+bwd only (no loss/optimizer)")
     ap.add_argument("--host", default="cpp", choices=["cpp", "py"],
                     help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
+    ap.add_argument("--densify-interval", type=int, default=0,
+                    help="run densifyAndPrune every N steps inside the timed region (Python host only; 0 = off; reference: 100)")
     args = ap.parse_args()
+    if args.densify_interval:
+        args.host = "py"
 
     import torch
     import torch.distributed as dist
@@ -100,7 +104,9 @@ def main():
     gt = torch.nn.functional.avg_pool2d(torch.rand(3, H, W, generator=gen).unsqueeze(0), 5, 1, 2).squeeze(0).to(dev)
     mask = torch.ones(3, H, W, device=dev)
     pipe = GaussianPipelineParams()
-    ts = TrainStep(g, opt, pipe, bg, world_size=world)
+    if args.densify_interval:
+        opt.densification_interval_, opt.densify_from_iter_ = args.densify_interval, 0
+    ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent, densify=bool(args.densify_interval))
 
     ops = None
     if args.host == "cpp" and not args.raster_only:
@@ -190,7 +196,8 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
-                       "raster_only": bool(args.raster_only),
+                       "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
+                       "gaussians_after": int(g.xyz_.shape[0]) if ops is None else P,
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
             "raster_fwd_bwd_ms": round(raster_ms, 4),

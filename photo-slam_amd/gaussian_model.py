@@ -43,6 +43,21 @@ class FusedAdam:
                                                       float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
                                "gsr_adam_step")
 
+    def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):
+        """Swap a parameter tensor (densify / prune / opacity reset): the Adam moments are replaced by the given
+        tensors, or by zeros (replaceTensorToOptimizer, src/gaussian_model.cpp:567-586)."""
+        for grp in self.param_groups:
+            grp["params"] = [new if p is old else p for p in grp["params"]]
+        self.state.pop(id(old), None)
+        self.state[id(new)] = dict(exp_avg=torch.zeros_like(new) if exp_avg is None else exp_avg,
+                                   exp_avg_sq=torch.zeros_like(new) if exp_avg_sq is None else exp_avg_sq)
+
+    def moments(self, p):
+        st = self.state.get(id(p))
+        if st is None:
+            return torch.zeros_like(p), torch.zeros_like(p)
+        return st["exp_avg"], st["exp_avg_sq"]
+
     def zero_grad(self, set_to_none=True):
         for grp in self.param_groups:
             for p in grp["params"]:
@@ -209,3 +224,129 @@ class GaussianModel:
         capi.check(lib, lib.gsr_densify_stats(self.xyz_.shape[0], g.data_ptr(), r.data_ptr(), self.xyz_gradient_accum_.data_ptr(),
                                               self.denom_.data_ptr(), self.max_radii2D_.data_ptr(), rp._stream_ptr(g)),
                    "gsr_densify_stats")
+
+
+    # ------------------------------------------------------------------ densification (amortised 1/interval)
+    # src/gaussian_model.cpp:588-815.  Same selection rules, same resulting order
+    # [originals that were not split | clones | split children] and the same Adam-state surgery, but each
+    # tensor is rebuilt ONCE (the reference copies every tensor 4-6 times through clone -> cat -> split -> cat
+    # -> prune -> prune and then drops the allocator cache).
+    _PARAM_NAMES = ("xyz_", "features_", "opacity_", "scaling_", "rotation_")
+
+    def _rebuild(self, index, overrides=None):
+        """Gather all parameters / Adam moments with `index` (long tensor into the current arrays; -1 = new
+        entry whose moments are zero); overrides: {name: (positions, values)} applied after the gather."""
+        new_rows = index < 0
+        safe = index.clamp_min(0)
+        for name in self._PARAM_NAMES:
+            old = getattr(self, name)
+            m, v = self.optimizer_.moments(old) if self.optimizer_ is not None else (None, None)
+            with torch.no_grad():
+                new = old.detach()[safe].clone()
+                if overrides and name in overrides:
+                    pos, val = overrides[name]
+                    new[pos] = val
+                new.requires_grad_(True)
+                if m is not None:
+                    m2, v2 = m[safe].clone(), v[safe].clone()
+                    m2[new_rows] = 0
+                    v2[new_rows] = 0
+            setattr(self, name, new)
+            if self.optimizer_ is not None:
+                self.optimizer_.replace_param(old, new, m2, v2)
+        n = index.shape[0]
+        dev = self.xyz_.device
+        return n, dev
+
+    def prunePoints(self, mask):
+        """:588-642"""
+        keep = torch.nonzero(~mask).squeeze(1)
+        self._rebuild(keep)
+        self.xyz_gradient_accum_ = self.xyz_gradient_accum_[keep]
+        self.denom_ = self.denom_[keep]
+        self.max_radii2D_ = self.max_radii2D_[keep]
+
+    def densifyAndPrune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, N=2):
+        """:795-815 (densifyAndClone :763-793, densifyAndSplit :716-761, prunePoints :588-642) in one rebuild."""
+        with torch.no_grad():
+            grads = self.xyz_gradient_accum_ / self.denom_
+            grads[grads.isnan()] = 0.0
+            g = grads.squeeze(-1)
+            scal = self.getScalingActivation()
+            smax = scal.max(dim=1).values
+            big = smax > self.percent_dense_ * extent
+            clone_mask = (g.abs() >= max_grad) & ~big          # frobenius_norm over the last dim of [P,1]
+            split_mask = (g >= max_grad) & big
+            P = self.xyz_.shape[0]
+            ar = torch.arange(P, device=self.xyz_.device)
+            keep_idx, clone_idx, split_idx = ar[~split_mask], ar[clone_mask], ar[split_mask]
+            rep = split_idx.repeat(N)
+            # children: position sampled from the parent Gaussian, scale / (0.8 N)
+            stds = scal[rep]
+            samples = torch.normal(torch.zeros_like(stds), stds, generator=generator)
+            q = self.rotation_.detach()[rep]
+            q = q / q.norm(dim=1, keepdim=True)
+            r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                             2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                             2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+            child_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self.xyz_.detach()[rep]
+            child_scaling = torch.log(stds / (0.8 * N))
+            # new entries are marked by (-1 - source) so their Adam moments come out zero
+            index = torch.cat([keep_idx, clone_idx, rep])
+            is_new = torch.cat([torch.zeros_like(keep_idx, dtype=torch.bool), torch.ones_like(clone_idx, dtype=torch.bool),
+                                torch.ones_like(rep, dtype=torch.bool)])
+            # final prune (:805-813) evaluated on the would-be tensors
+            opac = torch.sigmoid(self.opacity_.detach()[index]).squeeze(-1)
+            prune = opac < min_opacity
+            if max_screen_size:
+                # max_radii2D is reset by densificationPostfix before the prune, so big_points_vs is always false
+                new_smax = torch.cat([smax[keep_idx], smax[clone_idx], torch.exp(child_scaling).max(dim=1).values])
+                prune = prune | (new_smax > 0.1 * extent)
+            sel = ~prune
+            child_pos_all = torch.arange(keep_idx.shape[0] + clone_idx.shape[0], index.shape[0], device=index.device)
+            new_pos = torch.cumsum(sel.to(torch.int64), 0) - 1
+            child_sel = sel[child_pos_all]
+            child_pos = new_pos[child_pos_all][child_sel]
+            index_f = index[sel]
+            is_new_f = is_new[sel]
+        gather_index = torch.where(is_new_f, -1 - index_f, index_f)
+        self._rebuild_with_sources(gather_index, {"xyz_": (child_pos, child_xyz[child_sel]),
+                                                  "scaling_": (child_pos, child_scaling[child_sel])})
+        n = gather_index.shape[0]
+        dev = self.xyz_.device
+        self.xyz_gradient_accum_ = torch.zeros((n, 1), device=dev)
+        self.denom_ = torch.zeros((n, 1), device=dev)
+        self.max_radii2D_ = torch.zeros(n, device=dev)
+        return dict(cloned=int(clone_idx.shape[0]), split=int(split_idx.shape[0]), pruned=int(prune.sum()), points=n)
+
+    def _rebuild_with_sources(self, gather_index, overrides):
+        """gather_index >= 0: existing row (keeps its Adam moments); < 0: copy of row (-1 - value) with zero moments."""
+        new_rows = gather_index < 0
+        src = torch.where(new_rows, -1 - gather_index, gather_index)
+        for name in self._PARAM_NAMES:
+            old = getattr(self, name)
+            m, v = self.optimizer_.moments(old) if self.optimizer_ is not None else (None, None)
+            with torch.no_grad():
+                new = old.detach()[src].clone()
+                if name in overrides:
+                    pos, val = overrides[name]
+                    new[pos] = val
+                new.requires_grad_(True)
+                if m is not None:
+                    m2, v2 = m[src].clone(), v[src].clone()
+                    m2[new_rows] = 0
+                    v2[new_rows] = 0
+            setattr(self, name, new)
+            if self.optimizer_ is not None:
+                self.optimizer_.replace_param(old, new, m2, v2)
+
+    def resetOpacity(self):
+        """src/gaussian_model.cpp:553-565: opacity <- inverse_sigmoid(min(opacity, 0.01)), zero Adam moments."""
+        with torch.no_grad():
+            new = inverse_sigmoid(torch.min(self.getOpacityActivation(), torch.ones_like(self.opacity_) * 0.01))
+        new = new.clone().requires_grad_(True)
+        old = self.opacity_
+        self.opacity_ = new
+        if self.optimizer_ is not None:
+            self.optimizer_.replace_param(old, new)

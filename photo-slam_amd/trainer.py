@@ -10,8 +10,15 @@ from .gaussian_renderer import GaussianRenderer
 
 
 class TrainStep:
-    def __init__(self, gaussians, opt, pipe, background, world_size=1):
+    def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
+                 densify_min_opacity=0.005, prune_big_point_after_iter=0, seed=0):
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
+        self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
+        self.densify_, self.densify_min_opacity_ = densify, densify_min_opacity
+        self.prune_big_point_after_iter_ = prune_big_point_after_iter
+        # every rank draws the same split samples: identical replicas without a broadcast
+        self.generator_ = torch.Generator(device=gaussians.xyz_.device).manual_seed(seed)
+        self.last_densify_ = None
         self.iteration_ = 0
         self.world_size_ = world_size
         self.ema_loss_for_log_ = 0.0
@@ -50,6 +57,15 @@ class TrainStep:
                     g.xyz_gradient_accum_ += gn
                     g.denom_ += cnt
                     g.max_radii2D_ = torch.max(g.max_radii2D_, rad)
+                if self.densify_:
+                    if it > opt.densify_from_iter_ and it % opt.densification_interval_ == 0:       # :721-730
+                        size_threshold = 20 if it > self.prune_big_point_after_iter_ > 0 else 0
+                        g.optimizer_.zero_grad(set_to_none=True)   # shapes change; this step's update is skipped
+                        self.last_densify_ = g.densifyAndPrune(opt.densify_grad_threshold_, self.densify_min_opacity_,
+                                                               self.cameras_extent_, size_threshold,
+                                                               generator=self.generator_)
+                    if opt.opacity_reset_interval_ and it % opt.opacity_reset_interval_ == 0:      # :732-735
+                        g.resetOpacity()
             if it < opt.iterations_:
                 g.optimizer_.step()                                      # :769-772
                 g.optimizer_.zero_grad(set_to_none=True)

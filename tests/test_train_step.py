@@ -143,3 +143,49 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path):
         assert np.allclose(r0[n], p.detach().numpy(), rtol=1e-5, atol=1e-7), n
     assert np.allclose(r0["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
     assert np.array_equal(r0["denom"], g.denom_.numpy()) and np.array_equal(r0["maxr"], g.max_radii2D_.numpy())
+
+
+def test_densify_and_prune_keeps_model_consistent(emu):
+    """densifyAndPrune (src/gaussian_model.cpp:716-815): selection rules, resulting order, Adam-state surgery."""
+    cl, g, kfs = _setup(P=400)
+    torch.manual_seed(0)
+    gt = torch.rand(3, 32, 48)
+    ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+    for _ in range(3):
+        ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+    P0 = g.xyz_.shape[0]
+    xyz0, op0, sc0 = g.xyz_.detach().clone(), g.opacity_.detach().clone(), g.scaling_.detach().clone()
+    m0 = g.optimizer_.moments(g.xyz_)[0].clone()
+    grads = (g.xyz_gradient_accum_ / g.denom_).nan_to_num(0.0).squeeze(-1)
+    thr = float(grads[grads > 0].median())
+    extent = 1.0
+    smax = torch.exp(sc0).max(dim=1).values
+    big = smax > g.percent_dense_ * extent
+    clone_mask, split_mask = (grads >= thr) & ~big, (grads >= thr) & big
+    gen = torch.Generator().manual_seed(5)
+    info = g.densifyAndPrune(thr, 0.005, extent, 0, generator=gen)
+    assert info["cloned"] == int(clone_mask.sum()) and info["split"] == int(split_mask.sum()) and info["split"] > 0
+    n_keep = P0 - info["split"]
+    # nothing is pruned by opacity here? compute expected survivors in reference order
+    order = torch.cat([torch.arange(P0)[~split_mask], torch.arange(P0)[clone_mask], torch.arange(P0)[split_mask].repeat(2)])
+    survive = torch.sigmoid(op0[order]).squeeze(-1) >= 0.005
+    assert g.xyz_.shape[0] == int(survive.sum()) == info["points"]
+    src = order[survive]
+    is_child = (torch.arange(order.shape[0]) >= n_keep + info["cloned"])[survive]
+    # originals and clones copy their source; children are displaced and shrunk by 1/(0.8*2)
+    assert torch.equal(g.xyz_.detach()[~is_child], xyz0[src][~is_child])
+    assert torch.allclose(g.scaling_.detach()[is_child], torch.log(torch.exp(sc0[src][is_child]) / 1.6), atol=1e-6)
+    assert not torch.equal(g.xyz_.detach()[is_child], xyz0[src][is_child])
+    # Adam moments: kept for originals, zero for every new Gaussian; statistics reset
+    is_orig = (torch.arange(order.shape[0]) < n_keep)[survive]
+    m1 = g.optimizer_.moments(g.xyz_)[0]
+    assert torch.equal(m1[is_orig], m0[src][is_orig]) and not m1[~is_orig].any()
+    for p in g.params():
+        assert p.shape[0] == g.xyz_.shape[0] and p.requires_grad and p.is_leaf
+    assert not g.denom_.any() and g.denom_.shape[0] == g.xyz_.shape[0]
+    # training continues on the new set; opacity reset clamps to 0.01
+    loss = ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+    assert torch.isfinite(loss)
+    g.resetOpacity()
+    assert float(torch.sigmoid(g.opacity_).max()) <= 0.01 + 1e-6
+    assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
