@@ -89,7 +89,7 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 // not 3000.
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
-                       const float* __restrict__ partials, float* __restrict__ grad_acc)
+                       const float* __restrict__ partials, float* __restrict__ grad_acc, float half_w, float half_h)
 {
 	const int l = lane_id();
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -132,17 +132,20 @@ reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __
 		for (int c = 0; c < 9; c++) a[c] = wave_writelane_f32(a[c], wave_readlane_f32(v[c], 63), b);
 	}
 	if (cnt) {
+		// constant factors the blend left out: dL_dG = opacity * dL_dalpha; d(mean2D) carries -W/2, -H/2
+		// (backward.cu:460-461,539-546), the conic terms -1/2 (:549-551)
+		const float o = rec[3 * (size_t)idx + 1].y;
 		float4* dst = reinterpret_cast<float4*>(grad_acc) + 3 * (size_t)idx;
-		dst[0] = make_float4(a[0], a[1], a[2], a[3]);
-		dst[1] = make_float4(a[4], a[5], a[6], a[7]);
+		dst[0] = make_float4(a[0], a[1], a[2], -o * half_w * a[3]);
+		dst[1] = make_float4(-o * half_h * a[4], -0.5f * o * a[5], -0.5f * o * a[6], -0.5f * o * a[7]);
 		dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
 	}
 }
 
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, hipStream_t stream)
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, int W, int H, hipStream_t stream)
 {
 	GSR_LAUNCH(reduce_partials_kernel, div_up(P, 256), 256, stream, P, (const float4*)g.rec, (const uint32_t*)g.tiles_touched,
-	           partials, grad_acc);
+	           partials, grad_acc, 0.5f * (float)W, 0.5f * (float)H);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -57,8 +57,6 @@ blend_bwd_kernel(const BlendBwdParams p)
 	}
 	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
 	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
-	float last_alpha = 0.f, lcr = 0.f, lcg = 0.f, lcb = 0.f;
-	const float ddelx_dx = 0.5f * (float)p.W, ddely_dy = 0.5f * (float)p.H;
 
 	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
 	const uint32_t wmax = wave_max_u32(last_contributor);
@@ -114,38 +112,31 @@ blend_bwd_kernel(const BlendBwdParams p)
 					if (wave_ballot(ok) == 0ull) continue;  // wave-uniform
 					const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
 					const float Tn = T * rinv;
-					const float one_m_la = 1.f - last_alpha;
-					const float nar = last_alpha * lcr + one_m_la * acr;
-					const float nag = last_alpha * lcg + one_m_la * acg;
-					const float nab = last_alpha * lcb + one_m_la * acb;
-					float dL_dalpha = (g1.z - nar) * dpr + (g1.w - nag) * dpg + (g2.x - nab) * dpb;
+					// accum_rec of the reference (backward.cu:509-511), advanced eagerly: acc <- acc + alpha (c - acc)
+					// (the reference delays the same update by one entry through last_alpha / last_color)
+					const float dcr = g1.z - acr, dcg = g1.w - acg, dcb = g2.x - acb;
+					float dL_dalpha = dcr * dpr + dcg * dpg + dcb * dpb;
 					dL_dalpha = dL_dalpha * Tn + neg_Tfinal_bg * rinv;
-					// masked quantities: lanes that do not blend this entry contribute exact zeros
-					const float Gm = ok ? G : 0.f;
-					const float dcol = ok ? alpha * Tn : 0.f;
-					const float dL_dG = g1.y * dL_dalpha;
-					const float gdx = Gm * dx, gdy = Gm * dy;
-					const float dG_ddelx = -gdx * g2.y - gdy * g2.z;
-					const float dG_ddely = -gdy * g2.w - gdx * g2.z;
+					// lanes that do not blend this entry contribute exact zeros and keep their state
+					const float am = ok ? alpha : 0.f;
+					const float dLm = ok ? dL_dalpha : 0.f;
+					const float dcol = am * Tn;
+					const float gdx = G * dx, gdy = G * dy;
 					float v[9];
 					v[0] = dcol * dpr;
 					v[1] = dcol * dpg;
 					v[2] = dcol * dpb;
-					v[3] = dL_dG * dG_ddelx * ddelx_dx;
-					v[4] = dL_dG * dG_ddely * ddely_dy;
-					v[5] = -0.5f * gdx * dx * dL_dG;
-					v[6] = -0.5f * gdx * dy * dL_dG;
-					v[7] = -0.5f * gdy * dy * dL_dG;
-					v[8] = Gm * dL_dalpha;
-					// per-pixel state advances only where the entry was blended
+					// the per-Gaussian constants (opacity, -1/2, W/2, H/2) are applied after the reduction (reduce_partials)
+					v[3] = dLm * (gdx * g2.y + gdy * g2.z);
+					v[4] = dLm * (gdy * g2.w + gdx * g2.z);
+					v[5] = dLm * gdx * dx;
+					v[6] = dLm * gdx * dy;
+					v[7] = dLm * gdy * dy;
+					v[8] = dLm * G;
 					T = ok ? Tn : T;
-					acr = ok ? nar : acr;
-					acg = ok ? nag : acg;
-					acb = ok ? nab : acb;
-					lcr = ok ? g1.z : lcr;
-					lcg = ok ? g1.w : lcg;
-					lcb = ok ? g2.x : lcb;
-					last_alpha = ok ? alpha : last_alpha;
+					acr += am * dcr;
+					acg += am * dcg;
+					acb += am * dcb;
 #ifndef GSR_EXP_NO_REDUCE
 					wave_reduce9_packed_f32(v);
 #endif

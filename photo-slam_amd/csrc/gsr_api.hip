@@ -268,7 +268,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.partials = bs.partials;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
-		if ((st = launch_reduce_partials(P, g, bs.partials, g.grad_acc, stream)) != GSR_OK) return st;
+		if ((st = launch_reduce_partials(P, g, bs.partials, g.grad_acc, W, H, stream)) != GSR_OK) return st;
 	}
 	PROF_BWD(2);
 

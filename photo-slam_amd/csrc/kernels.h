@@ -26,7 +26,7 @@ int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hip
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
 int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, hipStream_t stream);
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, int W, int H, hipStream_t stream);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
 
 struct BlendFwdParams {
