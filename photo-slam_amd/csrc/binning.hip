@@ -19,7 +19,8 @@ namespace gsr {
 // key/value stores are fully coalesced and a screen-filling splat is spread over all lanes
 // (duplicateWithKeys gives each Gaussian's whole run to one thread).
 __global__ void __launch_bounds__(256)
-emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted_keys,
+                      const uint32_t* __restrict__ offsets,
                       const uint32_t* __restrict__ tiles_touched, const uint16_t* __restrict__ rect, int grid_x,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float4* __restrict__ rec)
 {
@@ -28,7 +29,9 @@ emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t*
 	__shared__ uint2 s_rect[4][64];
 	const int w = wave_id(), l = lane_id();
 	const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	const bool valid = j < P;
+	// culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing: no gathers for them
+	const bool valid = j < P && sorted_keys[j] != DEPTH_KEY_CULLED;
+	if (wave_ballot(valid) == 0ull) return;  // wave-uniform
 	const uint32_t g = valid ? order[j] : 0u;
 	const uint32_t cnt = valid ? tiles_touched[g] : 0u;
 	const uint32_t off = valid ? offsets[j] : 0u;
@@ -152,7 +155,8 @@ int launch_reduce_partials(int P, const GeometryState& g, const float* partials,
 
 int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
 {
-	GSR_LAUNCH(emit_instances_kernel, div_up(P, 256), 256, stream, P, (const uint32_t*)g.order, (const uint32_t*)g.offsets,
+	GSR_LAUNCH(emit_instances_kernel, div_up(P, 256), 256, stream, P, (const uint32_t*)g.order, (const uint32_t*)g.sort_keys_a,
+	           (const uint32_t*)g.offsets,
 	           (const uint32_t*)g.tiles_touched, (const uint16_t*)g.rect, grid_x, keys, vals, g.rec);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
