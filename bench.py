@@ -124,8 +124,11 @@ def main():
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
             if world > 1:
-                for gr in ops.trainer_grads(handle):
-                    dist.all_reduce(gr, op=dist.ReduceOp.SUM)
+                grads = ops.trainer_grads(handle)
+                works = [dist.all_reduce(gr, op=dist.ReduceOp.SUM, async_op=True) for gr in grads]
+                for w in works:
+                    w.wait()
+                for gr in grads:
                     gr.mul_(1.0 / world)
             loss.item()                       # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
             ops.trainer_finish(handle)
