@@ -15,10 +15,19 @@ import torch
 
 from . import capi
 
-_LIB_OVERRIDE = None  # tests may point this at the emulator build
+# Test-suite hook ONLY: pytest points this at tests/emu/libgsr_emu.so (the same kernel sources compiled
+# against the wave64 emulator) so the host logic can be exercised without a GPU.  Anything else is
+# refused -- the product path is libgsr_hip.so or an exception, never a CPU implementation.
+_LIB_OVERRIDE = None
 
 
 def _lib():
+    if _LIB_OVERRIDE is not None:
+        import os
+        p = os.path.realpath(_LIB_OVERRIDE)
+        if os.path.basename(os.path.dirname(p)) != "emu" or os.path.basename(p) != "libgsr_emu.so" \
+                or "PYTEST_CURRENT_TEST" not in os.environ:
+            raise RuntimeError("_LIB_OVERRIDE is reserved for the test-suite's emulator build (tests/emu/libgsr_emu.so)")
     return capi.load(_LIB_OVERRIDE)
 
 
