@@ -59,7 +59,16 @@ typedef struct gsr_forward_args {
 	int prefiltered;
 	float* out_color;            /* [3,H,W] written for every pixel */
 	int* radii;                  /* [P] or NULL */
+	/* Extension (0 = the reference contract: activated inputs).  Bit mask of GSR_RAW_*: the corresponding input
+	 * holds the model's RAW parameter and the activation of GaussianModel (src/gaussian_model.cpp:48-62) is applied
+	 * in-kernel: sigmoid(opacity), exp(scaling), normalize(rotation).  Saves the ~13 elementwise ATen launches
+	 * (forward + autograd) GaussianRenderer::render otherwise spends per step. */
+	int raw_params;
 } gsr_forward_args;
+
+#define GSR_RAW_OPACITY 1   /* opacities are logits */
+#define GSR_RAW_SCALING 2   /* scales are log-scales */
+#define GSR_RAW_ROTATION 4  /* rotations are unnormalised quaternions (normalised with eps 1e-12 like F::normalize) */
 
 /* Rasterizer::forward, cuda_rasterizer/rasterizer_impl.cu:198-336.
  * Fills out_color and radii, returns the number of (tile, Gaussian) instances in
@@ -104,6 +113,9 @@ typedef struct gsr_backward_args {
 	float* dL_dsh;               /* [P,M,3] or NULL when shs is NULL */
 	float* dL_dscale;            /* [P,3] or NULL when scales is NULL */
 	float* dL_drot;              /* [P,4] or NULL when scales is NULL */
+	/* Same mask as gsr_forward_args.raw_params (must match the forward call): dL_dopacity / dL_dscale / dL_drot are
+	 * then gradients w.r.t. the RAW parameters (chain rule through sigmoid / exp / normalize applied in-kernel). */
+	int raw_params;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.

@@ -31,7 +31,7 @@ class ForwardArgs(C.Structure):
                 ("scale_modifier", C.c_float), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
-                ("out_color", C.c_void_p), ("radii", C.c_void_p)]
+                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("raw_params", C.c_int)]
 
 
 class BackwardArgs(C.Structure):
@@ -44,7 +44,9 @@ class BackwardArgs(C.Structure):
                 ("binning_buffer", C.c_void_p), ("image_buffer", C.c_void_p), ("dL_dpix", C.c_void_p),
                 ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p)]
+                ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int)]
+
+RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 
 
 class GeometryView(C.Structure):

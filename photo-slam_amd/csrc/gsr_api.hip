@@ -177,7 +177,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.W = W; pp.H = H; pp.tan_fovx = a->tan_fovx; pp.tan_fovy = a->tan_fovy;
 	pp.focal_y = H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:221-222
 	pp.focal_x = W / (2.0f * a->tan_fovx);
-	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
+	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii; pp.raw_params = a->raw_params;
 	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
 
 	PROF_FWD(1);
@@ -281,7 +281,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_y = H / (2.0f * a->tan_fovy);
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
-	pb.grad_acc = g.grad_acc;
+	pb.grad_acc = g.grad_acc; pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;

@@ -21,6 +21,7 @@ struct PreprocessParams {
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	int grid_x, grid_y;
 	int* radii_out;  // caller's radii (nullable)
+	int raw_params;  // GSR_RAW_* mask: activations applied in-kernel
 };
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
@@ -69,6 +70,7 @@ struct PreprocessBwdParams {
 	const float* campos;    // [3] device
 	float focal_x, focal_y, tan_fovx, tan_fovy;
 	const float* grad_acc;    // [P][12] per-Gaussian blend gradients (reduce_partials_kernel), valid where radii > 0
+	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)
 	float* dL_dconic;         // [P,4]  nullable
 	float* dL_dopacity;       // [P]
@@ -78,6 +80,7 @@ struct PreprocessBwdParams {
 	float* dL_dsh;            // [P,M,3] nullable
 	float* dL_dscale;         // [P,3] nullable
 	float* dL_drot;           // [P,4] nullable
+	int raw_params;           // GSR_RAW_* mask: outputs are gradients of the raw parameters
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 

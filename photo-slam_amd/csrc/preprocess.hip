@@ -108,9 +108,21 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 #pragma unroll
 				for (int i = 0; i < 6; i++) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
 			} else {
-				const float s0 = p.scale_modifier * p.scales[3 * idx], s1 = p.scale_modifier * p.scales[3 * idx + 1],
-				            s2 = p.scale_modifier * p.scales[3 * idx + 2];
-				const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+				float sx = p.scales[3 * idx], sy = p.scales[3 * idx + 1], sz = p.scales[3 * idx + 2];
+				if (p.raw_params & GSR_RAW_SCALING) {   // getScalingActivation, gaussian_model.cpp:48-51
+					sx = expf(sx);
+					sy = expf(sy);
+					sz = expf(sz);
+				}
+				const float s0 = p.scale_modifier * sx, s1 = p.scale_modifier * sy, s2 = p.scale_modifier * sz;
+				float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+				if (p.raw_params & GSR_RAW_ROTATION) {  // getRotationActivation: F::normalize (eps 1e-12), :53-56
+					const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+					q.x = q.x / qn;
+					q.y = q.y / qn;
+					q.z = q.z / qn;
+					q.w = q.w / qn;
+				}
 				const float r = q.x, x = q.y, y = q.z, z = q.w;
 				// R[c][r] (glm column-major) exactly as written at forward.cu:135-139
 				const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
@@ -240,7 +252,9 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	if (in_range) {
 		if (vis) {
 			g.rec[3 * (size_t)idx + 0] = make_float4(pix, piy, conx, cony);
-			g.rec[3 * (size_t)idx + 1] = make_float4(conz, p.opacities[idx], cr, cg);
+			float opac = p.opacities[idx];
+			if (p.raw_params & GSR_RAW_OPACITY) opac = 1.0f / (1.0f + expf(-opac));   // getOpacityActivation, :68-71
+			g.rec[3 * (size_t)idx + 1] = make_float4(conz, opac, cr, cg);
 			g.rec[3 * (size_t)idx + 2] = make_float4(cb, __uint_as_float(rect_lo), __uint_as_float(rect_hi), 0.f);
 			g.clamped[idx] = clamp_bits;
 			reinterpret_cast<uint2*>(g.rect)[idx] = make_uint2(rect_lo, rect_hi);

@@ -92,7 +92,13 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
 		p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
 		p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
-		p.dL_dopacity[idx] = ga2x;
+		// raw logit: d sigmoid = o (1 - o), o = the activated opacity kept in the blend record
+		if (p.raw_params & GSR_RAW_OPACITY) {
+			const float o = p.rec[3 * (size_t)idx + 1].y;
+			p.dL_dopacity[idx] = ga2x * o * (1.0f - o);
+		} else {
+			p.dL_dopacity[idx] = ga2x;
+		}
 		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
 		float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 		float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
@@ -295,10 +301,23 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 
 	// ------------------------------------------------------------------ cov3D backward, backward.cu:278-341
 	if (p.scales) {
-		const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+		float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+		float qn = 1.0f;
+		if (p.raw_params & GSR_RAW_ROTATION) {
+			qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+			q.x = q.x / qn;
+			q.y = q.y / qn;
+			q.z = q.z / qn;
+			q.w = q.w / qn;
+		}
 		const float r = q.x, x = q.y, y = q.z, z = q.w;
-		const float s0 = p.scale_modifier * p.scales[3 * (size_t)idx], s1 = p.scale_modifier * p.scales[3 * (size_t)idx + 1],
-		            s2 = p.scale_modifier * p.scales[3 * (size_t)idx + 2];
+		float sx = p.scales[3 * (size_t)idx], sy = p.scales[3 * (size_t)idx + 1], sz = p.scales[3 * (size_t)idx + 2];
+		if (p.raw_params & GSR_RAW_SCALING) {
+			sx = expf(sx);
+			sy = expf(sy);
+			sz = expf(sz);
+		}
+		const float s0 = p.scale_modifier * sx, s1 = p.scale_modifier * sy, s2 = p.scale_modifier * sz;
 		// R[c][r]
 		const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
 		const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
@@ -319,9 +338,14 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		float D20 = DM(0, 2), D21 = DM(1, 2), D22 = DM(2, 2);
 #undef DM
 		// Rt[c][r] = R[r][c];  dL_dscale.k = dot(Rt[k], dL_dMt[k])
-		p.dL_dscale[3 * (size_t)idx + 0] = R00 * D00 + R10 * D01 + R20 * D02;
-		p.dL_dscale[3 * (size_t)idx + 1] = R01 * D10 + R11 * D11 + R21 * D12;
-		p.dL_dscale[3 * (size_t)idx + 2] = R02 * D20 + R12 * D21 + R22 * D22;
+		// the reference writes dot(Rt[k], dL_dMt[k]) as the scale gradient (backward.cu:318-321); a raw log-scale
+		// adds d exp = the activated scale
+		const float ds0 = R00 * D00 + R10 * D01 + R20 * D02, ds1 = R01 * D10 + R11 * D11 + R21 * D12,
+		            ds2 = R02 * D20 + R12 * D21 + R22 * D22;
+		const bool raw_s = (p.raw_params & GSR_RAW_SCALING) != 0;
+		p.dL_dscale[3 * (size_t)idx + 0] = raw_s ? ds0 * sx : ds0;
+		p.dL_dscale[3 * (size_t)idx + 1] = raw_s ? ds1 * sy : ds1;
+		p.dL_dscale[3 * (size_t)idx + 2] = raw_s ? ds2 * sz : ds2;
 		D00 *= s0; D01 *= s0; D02 *= s0;
 		D10 *= s1; D11 *= s1; D12 *= s1;
 		D20 *= s2; D21 *= s2; D22 *= s2;
@@ -330,7 +354,16 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		dq.y = 2 * y * (D10 + D01) + 2 * z * (D20 + D02) + 2 * r * (D12 - D21) - 4 * x * (D22 + D11);
 		dq.z = 2 * x * (D10 + D01) + 2 * r * (D20 - D02) + 2 * z * (D12 + D21) - 4 * y * (D22 + D00);
 		dq.w = 2 * r * (D01 - D10) + 2 * x * (D20 + D02) + 2 * y * (D12 + D21) - 4 * z * (D11 + D00);
-		reinterpret_cast<float4*>(p.dL_drot)[idx] = dq;  // no normalisation Jacobian, backward.cu:340
+		// no normalisation Jacobian in the reference kernel (backward.cu:340: autograd's normalize supplies it);
+		// for a raw quaternion it is applied here: dL/dr = (g - q (q.g)) / |r|
+		if (p.raw_params & GSR_RAW_ROTATION) {
+			const float qg = r * dq.x + x * dq.y + y * dq.z + z * dq.w;
+			dq.x = (dq.x - r * qg) / qn;
+			dq.y = (dq.y - x * qg) / qn;
+			dq.z = (dq.z - y * qg) / qn;
+			dq.w = (dq.w - z * qg) / qn;
+		}
+		reinterpret_cast<float4*>(p.dL_drot)[idx] = dq;
 	}
 }
 

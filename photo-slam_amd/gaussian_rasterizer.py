@@ -24,6 +24,7 @@ class GaussianRasterizationSettings:
     sh_degree_: int
     campos_: torch.Tensor
     prefiltered_: bool
+    raw_params_: int = 0   # extension: GSR_RAW_* mask, activations fused into the rasterizer (include/gsr.h)
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -35,7 +36,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rp.RasterizeGaussiansCUDA(
             s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_, cov3Ds_precomp,
             s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_, s.image_height_, s.image_width_, sh, s.sh_degree_,
-            s.campos_, s.prefiltered_)
+            s.campos_, s.prefiltered_, s.raw_params_)
         ctx.num_rendered = num_rendered
         ctx.raster_settings = s
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -52,7 +53,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
          dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer)
+            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_)
         # order of src/gaussian_rasterizer.cpp:159-179
         def g(t, like):
             return t if like.numel() else None

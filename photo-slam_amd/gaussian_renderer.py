@@ -34,8 +34,12 @@ class GaussianKeyframe:
 class GaussianRenderer:
     @staticmethod
     def render(viewpoint_camera, image_height, image_width, pc, pipe, bg_color, override_color=None,
-               scaling_modifier=1.0, use_override_color=False):
-        """returns (render, viewspace_points, visibility_filter, radii)"""
+               scaling_modifier=1.0, use_override_color=False, fuse_activations=True):
+        """returns (render, viewspace_points, visibility_filter, radii)
+
+        fuse_activations (extension; False = the reference data flow): hand the raw opacity / scaling / rotation
+        leaves to the rasterizer, which applies sigmoid / exp / normalize in preprocess and their chain rule in the
+        backward preprocess -- same result, ~13 fewer elementwise launches and 3 fewer [P,*] temporaries per step."""
         screenspace_points = torch.zeros_like(pc.getXYZ(), requires_grad=True)
         try:
             screenspace_points.retain_grad()
@@ -44,15 +48,18 @@ class GaussianRenderer:
         raster_settings = GaussianRasterizationSettings(
             image_height, image_width, viewpoint_camera.tanfovx_, viewpoint_camera.tanfovy_, bg_color, scaling_modifier,
             viewpoint_camera.world_view_transform_, viewpoint_camera.full_proj_transform_, pc.active_sh_degree_,
-            viewpoint_camera.camera_center_, False)
+            viewpoint_camera.camera_center_, False, 7 if fuse_activations else 0)
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points
-        opacity = pc.getOpacityActivation()
         if pipe.compute_cov3D_:
             raise NotImplementedError("compute_cov3D: pass cov3D_precomp to GaussianRasterizer.forward directly")
-        scales = pc.getScalingActivation()
-        rotations = pc.getRotationActivation()
+        if fuse_activations:
+            opacity, scales, rotations = pc.opacity_, pc.scaling_, pc.rotation_
+        else:
+            opacity = pc.getOpacityActivation()
+            scales = pc.getScalingActivation()
+            rotations = pc.getRotationActivation()
         has_shs = has_color_precomp = False
         shs = colors_precomp = None
         if use_override_color:

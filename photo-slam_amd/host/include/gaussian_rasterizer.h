@@ -29,6 +29,7 @@ struct GaussianRasterizationSettings {
 	int sh_degree_;
 	torch::Tensor campos_;
 	bool prefiltered_;
+	int raw_params_ = 0;   // extension: GSR_RAW_* mask (activations fused into the rasterizer), see include/gsr.h
 };
 
 class GaussianRasterizerFunction : public torch::autograd::Function<GaussianRasterizerFunction> {

@@ -34,8 +34,10 @@ public:
 	static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> render(
 	    std::shared_ptr<Keyframe> viewpoint_camera, int image_height, int image_width, std::shared_ptr<Model> pc,
 	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
-	    float scaling_modifier = 1.0f, bool use_override_color = false)
+	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false)
 	{
+		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
+		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
 		// dummy input whose gradient is dL/dmean2D (the densification statistic)
 		auto screenspace_points = torch::zeros_like(pc->getXYZ(), torch::TensorOptions().requires_grad(true));
 		screenspace_points.retain_grad();
@@ -46,18 +48,19 @@ public:
 		                                              scaling_modifier, viewpoint_camera->world_view_transform_,
 		                                              viewpoint_camera->full_proj_transform_, pc->active_sh_degree_,
 		                                              viewpoint_camera->camera_center_, false);
+		raster_settings.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
 		GaussianRasterizer rasterizer(raster_settings);
 
 		auto means3D = pc->getXYZ();
-		auto opacity = pc->getOpacityActivation();
+		auto opacity = raster_settings.raw_params_ ? pc->opacity_ : pc->getOpacityActivation();
 		bool has_scales = false, has_rotations = false, has_cov3D_precomp = false;
 		torch::Tensor scales, rotations, cov3D_precomp;
 		if (pipe.compute_cov3D_) {
 			cov3D_precomp = pc->getCovarianceActivation();
 			has_cov3D_precomp = true;
 		} else {
-			scales = pc->getScalingActivation();
-			rotations = pc->getRotationActivation();
+			scales = raster_settings.raw_params_ ? pc->scaling_ : pc->getScalingActivation();
+			rotations = raster_settings.raw_params_ ? pc->rotation_ : pc->getRotationActivation();
 			has_scales = has_rotations = true;
 		}
 		bool has_shs = false, has_color_precomp = false;

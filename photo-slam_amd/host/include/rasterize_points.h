@@ -15,7 +15,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-    const bool prefiltered);
+    const bool prefiltered, const int raw_params = 0 /* extension: GSR_RAW_* mask, see include/gsr.h */);
 
 // (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -26,6 +26,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
-                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer);
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                               const int raw_params = 0);
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);

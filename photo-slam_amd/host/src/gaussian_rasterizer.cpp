@@ -17,12 +17,13 @@ torch::autograd::tensor_list GaussianRasterizerFunction::forward(
 	(void)means2D;  // only its gradient slot matters
 	auto r = RasterizeGaussiansCUDA(s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_,
 	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
-	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_);
+	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, s.raw_params_);
 	ctx->saved_data["num_rendered"] = std::get<0>(r);
 	ctx->saved_data["scale_modifier"] = static_cast<double>(s.scale_modifier_);
 	ctx->saved_data["tanfovx"] = static_cast<double>(s.tanfovx_);
 	ctx->saved_data["tanfovy"] = static_cast<double>(s.tanfovy_);
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
+	ctx->saved_data["raw_params"] = s.raw_params_;
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
 	// same 14 tensors, same order as the reference (src/gaussian_rasterizer.cpp:87-100)
@@ -40,11 +41,12 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 	const float tanfovx = static_cast<float>(ctx->saved_data["tanfovx"].toDouble());
 	const float tanfovy = static_cast<float>(ctx->saved_data["tanfovy"].toDouble());
 	const int sh_degree = static_cast<int>(ctx->saved_data["sh_degree"].toInt());
+	const int raw_params = static_cast<int>(ctx->saved_data["raw_params"].toInt());
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
 	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
-	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13]);
+	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0) ? grad : torch::Tensor();

@@ -59,7 +59,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-    const bool prefiltered)
+    const bool prefiltered, const int raw_params)
 {
 	if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
 		AT_ERROR("means3D must have dimensions (num_points, 3)");
@@ -99,6 +99,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 		a.tan_fovx = tan_fovx;
 		a.tan_fovy = tan_fovy;
 		a.prefiltered = prefiltered ? 1 : 0;
+		a.raw_params = raw_params;
 		a.out_color = out_color.data_ptr<float>();
 		a.radii = radii.data_ptr<int>();
 		check(gsr_forward(&a, resize_tensor, &geomBuffer, resize_tensor, &binningBuffer, resize_tensor, &imgBuffer,
@@ -116,7 +117,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
-                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                               const int raw_params)
 {
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = static_cast<int>(dL_dout_color.size(1));
@@ -174,6 +176,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		a.dL_dsh = has_sh ? dL_dsh.data_ptr<float>() : nullptr;
 		a.dL_dscale = has_scales ? dL_dscales.data_ptr<float>() : nullptr;
 		a.dL_drot = has_scales ? dL_drotations.data_ptr<float>() : nullptr;
+		a.raw_params = raw_params;
 		check(gsr_backward(&a, current_stream(means3D)), "RasterizeGaussiansBackwardCUDA");
 	}
 	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,

@@ -66,7 +66,9 @@ def _resize_functional(t):
 
 def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                           prefiltered):
+                           prefiltered, raw_params=0):
+    """raw_params (extension, default 0 = reference contract): GSR_RAW_* mask -- opacity / scales / rotations are the
+    model's raw parameters and are activated in-kernel (include/gsr.h)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # AT_ERROR, rasterize_points.cu:57-59
     lib = _lib()
@@ -85,6 +87,7 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
         a = capi.ForwardArgs()
         a.P, a.D, a.M, a.width, a.height = P, int(degree), M, W, H
         a.scale_modifier, a.tan_fovx, a.tan_fovy, a.prefiltered = float(scale_modifier), float(tan_fovx), float(tan_fovy), int(bool(prefiltered))
+        a.raw_params = int(raw_params)
         for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors),
                         ("opacities", opacity), ("scales", scales), ("rotations", rotations),
                         ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix),
@@ -104,7 +107,7 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                   geomBuffer, R, binningBuffer, imageBuffer):
+                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0):
     lib = _lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -126,6 +129,7 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         a = capi.BackwardArgs()
         a.P, a.D, a.M, a.R, a.width, a.height = P, int(degree), M, int(R), W, H
         a.scale_modifier, a.tan_fovx, a.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+        a.raw_params = int(raw_params)
         for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors),
                         ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp),
                         ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos),

@@ -189,3 +189,24 @@ def test_densify_and_prune_keeps_model_consistent(emu):
     g.resetOpacity()
     assert float(torch.sigmoid(g.opacity_).max()) <= 0.01 + 1e-6
     assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
+
+
+def test_fused_activations_match_the_reference_data_flow(emu):
+    """raw_params extension: sigmoid/exp/normalize applied inside the rasterizer == activating with torch first."""
+    cl, g, kfs = _setup(P=500)
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    torch.manual_seed(1)
+    dpix = torch.randn(3, 32, 48)
+    outs = []
+    for fuse in (False, True):
+        for p in g.params():
+            p.grad = None
+        img, vsp, vis, radii = GaussianRenderer.render(kfs[0], 32, 48, g, GaussianPipelineParams(), bg, fuse_activations=fuse)
+        (img * dpix).sum().backward()
+        outs.append((img.detach().clone(), radii.clone(), [p.grad.clone() for p in g.params()], vsp.grad.clone()))
+    (img0, r0, g0, v0), (img1, r1, g1, v1) = outs
+    assert (r0 != r1).float().mean() < 1e-3          # exp() ulp differences may flip a ceil() very rarely
+    assert (img0 - img1).abs().mean() < 1e-5
+    for a, b in zip(g0 + [v0], g1 + [v1]):
+        rel = (a - b).abs().sum() / (a.abs().sum() + 1e-30)
+        assert rel < 1e-4, rel
