@@ -24,7 +24,6 @@ using ::hipemu::wave_readlane_f32;
 using ::hipemu::wave_readlane_u32;
 using ::hipemu::wave_writelane_f32;
 using ::hipemu::wave_reduce9_packed_f32;
-using ::hipemu::wave_reduce9_rows_f32;
 using ::hipemu::wave_packed9_total;
 #else
 
@@ -140,40 +139,6 @@ __device__ __forceinline__ float dpp_xor32_add(float s)
 	const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
 	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
-// Row-level variant: stops after the in-row levels (26 VALU).  Every 16-lane row then holds ITS partial totals in
-// the packed layout; the caller adds the four rows in LDS (ds_add_f32 from lanes with (lane & 12) == 0: the LDS
-// pipe is idle in the blend kernels while the VALU is saturated, so the 4-way same-address adds are cheaper
-// than the 12 cross-row VALU instructions they replace).
-__device__ __forceinline__ void wave_reduce9_rows_f32(float (&v)[9])
-{
-	const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;
-	float r[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const float keep = b0 ? v[2 * k + 1] : v[2 * k];
-		const float send = b0 ? v[2 * k] : v[2 * k + 1];
-		r[k] = keep + dpp_f32<DPP_QUAD_PERM_1032>(0.f, send);
-	}
-	float s2 = v[8] + dpp_f32<DPP_QUAD_PERM_1032>(0.f, v[8]);
-	float s0, s1;
-	{
-		const float keep = b1 ? r[1] : r[0], send = b1 ? r[0] : r[1];
-		s0 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
-	}
-	{
-		const float keep = b1 ? r[3] : r[2], send = b1 ? r[2] : r[3];
-		s1 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
-	}
-	s2 += dpp_f32<DPP_QUAD_PERM_2301>(0.f, s2);
-	constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
-	s0 += dpp_f32<DPP_ROW_ROR4>(0.f, s0);
-	s1 += dpp_f32<DPP_ROW_ROR4>(0.f, s1);
-	s2 += dpp_f32<DPP_ROW_ROR4>(0.f, s2);
-	v[0] = s0 + dpp_f32<DPP_ROW_ROR8>(0.f, s0);
-	v[1] = s1 + dpp_f32<DPP_ROW_ROR8>(0.f, s1);
-	v[2] = s2 + dpp_f32<DPP_ROW_ROR8>(0.f, s2);
-}
-
 __device__ __forceinline__ void wave_reduce9_packed_f32(float (&v)[9])
 {
 	const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;

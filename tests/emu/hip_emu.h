@@ -127,30 +127,6 @@ static inline void wave_reduce9_f32(float (&v)[9])
 		v[c] = acc;  // the real primitive only guarantees lane 63
 	}
 }
-// row-level packed variant: partial totals per 16-lane row
-static inline void wave_reduce9_rows_f32(float (&v)[9])
-{
-	float t[9];
-	const int row = lane() >> 4;
-	for (int c = 0; c < 9; c++) {
-		uint32_t bits;
-		memcpy(&bits, &v[c], 4);
-		const uint64_t* s = wave_exchange(bits);
-		float acc = 0.f;
-		for (int i = row * 16; i < row * 16 + 16; i++) {
-			uint32_t b = (uint32_t)s[i];
-			float f;
-			memcpy(&f, &b, 4);
-			acc += f;
-		}
-		wave_sync();
-		t[c] = acc;
-	}
-	const int r = lane() & 3;
-	v[0] = t[r];
-	v[1] = t[4 + r];
-	v[2] = t[8];
-}
 // packed variant: same sums, delivered in the packed layout of csrc/wave64.h
 static inline void wave_reduce9_packed_f32(float (&v)[9])
 {
