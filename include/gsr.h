@@ -162,6 +162,30 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int gsr_densify_stats(int P, const float* dL_dmean2D, const int* radii, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream);
 
+/* ---- Photo-SLAM's point-cloud kernels ----
+ * transformPoints (src/operate_points.cu:73-93): out = M[:3,:4] * (p, 1), M = transformmatrix[16] with
+ * element (r,c) at [4c+r] (transformPoint4x3). */
+int gsr_transform_points(int P, const float* points, const float* transformmatrix, float* out_points, void* stream);
+/* scale_and_transform_points (src/operate_points.cu:52-71): for mask[i] != 0: out_points[i] = M * (scale * p_i),
+ * out_rots[i] = quaternion of (M[:3,:3] * R(q_i)), q stored (w, x, y, z).  Unmasked rows are NOT written.
+ * reference_rot_layout != 0 reproduces insert_rot_to_rots exactly as shipped (cuda_rasterizer/operate_points.h:
+ * 175-178 writes component +2 twice and never +3: the row becomes (w, x, z, <previous content>)); 0 writes the
+ * intended (w, x, y, z). */
+int gsr_scale_transform_points(int P, float scale, const float* points, const float* rots, const float* transformmatrix,
+                               const uint8_t* mask, float* out_points, float* out_rots, int reference_rot_layout,
+                               void* stream);
+/* reproject_depths_pinhole (src/stereo_vision.cu:39-61): pixel i = (u = i % width, v = i / width), for mask[i]:
+ * out = ((u-cx)*d/fx, (v-cy)*d/fy, d).  Unmasked rows are NOT written. */
+int gsr_reproject_depth_pinhole(int P, int width, float fx, float fy, float cx, float cy, const float* depths,
+                                const uint8_t* mask, float* out_points, void* stream);
+/* search_neighborhood_to_estimate_depth_and_reproject_pinhole (src/stereo_vision.cu:63-136): keypoints with a 3D
+ * point are copied; the others take the depth of the nearest (squared pixel distance <= max_pixel_dist, first wins)
+ * keypoint that has one and are re-projected, or get z = -1.  colors is indexed exactly as the reference does
+ * (colors[int(v*width+u) + 0..2]). */
+int gsr_neighborhood_depth_pinhole(int N, int width, float fx, float fy, float cx, float cy, float max_pixel_dist,
+                                   const float* pixels, const uint8_t* has3D, const float* point3D, const float* colors,
+                                   float* out_points, float* out_colors, void* stream);
+
 /* Scratch sizes (bytes) gsr_forward will request, for callers that pre-allocate. */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_binning_bytes(int num_rendered);

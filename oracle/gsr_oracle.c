@@ -1114,3 +1114,121 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 	}
 	out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
 }
+
+
+/* ---------------- Photo-SLAM point kernels ---------------- */
+/* transform_points, src/operate_points.cu:38-50 */
+void gsro_transform_points(int P, const float* pts, const float* m, float* out)
+{
+	for (int i = 0; i < P; i++) {
+		f3 p = pt(pts, (uint32_t)i);
+		f3 t = transformPoint4x3(p, m);
+		out[3 * (size_t)i] = t.x; out[3 * (size_t)i + 1] = t.y; out[3 * (size_t)i + 2] = t.z;
+	}
+}
+/* scale_and_transform_points, src/operate_points.cu:52-71 with the helpers of
+ * cuda_rasterizer/operate_points.h:55-179.  reference_rot_layout: see gsr.h. */
+void gsro_scale_transform_points(int P, float scale, const float* pts, const float* rots, const float* m,
+                                 const uint8_t* mask, float* out_pts, float* out_rots, int reference_rot_layout)
+{
+	for (int idx = 0; idx < P; idx++) {
+		if (!mask[idx]) continue;
+		f3 p = pt(pts, (uint32_t)idx);
+		p.x *= scale; p.y *= scale; p.z *= scale;
+		f3 t3 = transformPoint4x3(p, m);
+		out_pts[3 * (size_t)idx] = t3.x; out_pts[3 * (size_t)idx + 1] = t3.y; out_pts[3 * (size_t)idx + 2] = t3.z;
+		/* q_orig = {x = q[1], y = q[2], z = q[3], w = q[0]}, operate_points.h:77-80 */
+		float qx = rots[4 * (size_t)idx + 1], qy = rots[4 * (size_t)idx + 2], qz = rots[4 * (size_t)idx + 3], qw = rots[4 * (size_t)idx];
+		float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+		float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+		float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+		float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+		float R00 = 1.0f - (tyy + tzz), R01 = txy - twz, R02 = txz + twy;
+		float R10 = txy + twz, R11 = 1.0f - (txx + tzz), R12 = tyz - twx;
+		float R20 = txz - twy, R21 = tyz + twx, R22 = 1.0f - (txx + tyy);
+		float R[3][3];
+		R[0][0] = m[0] * R00 + m[4] * R10 + m[8] * R20;
+		R[0][1] = m[0] * R01 + m[4] * R11 + m[8] * R21;
+		R[0][2] = m[0] * R02 + m[4] * R12 + m[8] * R22;
+		R[1][0] = m[1] * R00 + m[5] * R10 + m[9] * R20;
+		R[1][1] = m[1] * R01 + m[5] * R11 + m[9] * R21;
+		R[1][2] = m[1] * R02 + m[5] * R12 + m[9] * R22;
+		R[2][0] = m[2] * R00 + m[6] * R10 + m[10] * R20;
+		R[2][1] = m[2] * R01 + m[6] * R11 + m[10] * R21;
+		R[2][2] = m[2] * R02 + m[6] * R12 + m[10] * R22;
+		float ow, ox, oy, oz;
+		float t = R[0][0] + R[1][1] + R[2][2];
+		if (t > 0.0f) {
+			t = sqrtf(t + 1.0f);
+			ow = 0.5f * t;
+			t = 0.5f / t;
+			ox = (R[2][1] - R[1][2]) * t;
+			oy = (R[0][2] - R[2][0]) * t;
+			oz = (R[1][0] - R[0][1]) * t;
+		} else {
+			int i = 0;
+			if (R[1][1] > R[0][0]) i = 1;
+			if (R[2][2] > R[i][i]) i = 2;
+			int j = (i + 1) % 3, k = (j + 1) % 3;
+			t = sqrtf(R[i][i] - R[j][j] - R[k][k] + 1.0f);
+			float xyz[3];
+			xyz[i] = 0.5f * t;
+			t = 0.5f / t;
+			ow = (R[k][j] - R[j][k]) * t;
+			xyz[j] = (R[j][i] + R[i][j]) * t;
+			xyz[k] = (R[k][i] + R[i][k]) * t;
+			ox = xyz[0]; oy = xyz[1]; oz = xyz[2];
+		}
+		float* r = out_rots + 4 * (size_t)idx;
+		r[0] = ow; r[1] = ox;
+		if (reference_rot_layout) { r[2] = oy; r[2] = oz; } /* operate_points.h:175-178 verbatim: +2 twice, +3 never */
+		else { r[2] = oy; r[3] = oz; }
+	}
+}
+/* reproject_depths_pinhole, src/stereo_vision.cu:39-61 */
+void gsro_reproject_depth_pinhole(int P, int width, float fx, float fy, float cx, float cy, const float* depths,
+                                  const uint8_t* mask, float* points)
+{
+	for (int idx = 0; idx < P; idx++) {
+		if (!mask[idx]) continue;
+		int v = idx / width, u = idx - v * width;
+		float depth = depths[idx];
+		points[3 * (size_t)idx] = (u - cx) * depth / fx;
+		points[3 * (size_t)idx + 1] = (v - cy) * depth / fy;
+		points[3 * (size_t)idx + 2] = depth;
+	}
+}
+/* search_neighborhood_to_estimate_depth_and_reproject_pinhole, src/stereo_vision.cu:63-136 */
+void gsro_neighborhood_depth_pinhole(int N, int width, float fx, float fy, float cx, float cy, float max_pixel_dist,
+                                     const float* pixels, const uint8_t* has3D, const float* p3d, const float* colors,
+                                     float* out_p, float* out_c)
+{
+	for (int idx = 0; idx < N; idx++) {
+		float u = pixels[2 * idx], v = pixels[2 * idx + 1];
+		int ptidx = idx * 3;
+		int px = (int)(v * width + u);
+		if (has3D[idx]) {
+			out_p[ptidx] = p3d[ptidx]; out_p[ptidx + 1] = p3d[ptidx + 1]; out_p[ptidx + 2] = p3d[ptidx + 2];
+			out_c[ptidx] = colors[px]; out_c[ptidx + 1] = colors[px + 1]; out_c[ptidx + 2] = colors[px + 2];
+			continue;
+		}
+		float min_dist = FLT_MAX, depth = -1.0f;
+		for (int i = 0; i < N; ++i) {
+			if (!has3D[i] || i == idx) continue;
+			float du = u - pixels[2 * i], dv = v - pixels[2 * i + 1];
+			float dist = du * du + dv * dv;
+			if (dist > max_pixel_dist || dist >= min_dist) continue;
+			min_dist = dist;
+			depth = p3d[i * 3 + 2];
+		}
+		if (depth > 0.0f) {
+			int ui = (int)u, vi = (int)v;
+			out_p[ptidx] = (ui - cx) * depth / fx;
+			out_p[ptidx + 1] = (vi - cy) * depth / fy;
+			out_p[ptidx + 2] = depth;
+			out_c[ptidx] = colors[px]; out_c[ptidx + 1] = colors[px + 1]; out_c[ptidx + 2] = colors[px + 2];
+		} else {
+			out_p[ptidx + 2] = -1.0f;
+		}
+	}
+}

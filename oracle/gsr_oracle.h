@@ -99,6 +99,18 @@ void gsro_knn(int P, const float* points, float* meanDists);
 /* Brute-force O(P^2) exact 3-NN mean of squared distances (pins gsro_knn). */
 void gsro_knn_bruteforce(int P, const float* points, float* meanDists);
 
+/* Photo-SLAM point kernels: src/operate_points.cu:38-71 (+ cuda_rasterizer/operate_points.h:39-179) and
+ * src/stereo_vision.cu:39-136 (+ cuda_rasterizer/stereo_vision.h:39-53).  Outputs must be pre-zeroed by the caller
+ * like the reference's torch::zeros_like; unmasked rows are left untouched. */
+void gsro_transform_points(int P, const float* pts, const float* m, float* out);
+void gsro_scale_transform_points(int P, float scale, const float* pts, const float* rots, const float* m,
+                                 const uint8_t* mask, float* out_pts, float* out_rots, int reference_rot_layout);
+void gsro_reproject_depth_pinhole(int P, int width, float fx, float fy, float cx, float cy, const float* depths,
+                                  const uint8_t* mask, float* points);
+void gsro_neighborhood_depth_pinhole(int N, int width, float fx, float fy, float cx, float cy, float max_pixel_dist,
+                                     const float* pixels, const uint8_t* has3D, const float* p3d, const float* colors,
+                                     float* out_p, float* out_c);
+
 /* Analysis helper (not in the reference): work statistics of the per-quad rejection of the HIP
  * blend kernels, and the count of blended pairs it would wrongly reject (must be 0).  out[8]. */
 void gsro_cull_stats(const gsro_state* st, double* out);

@@ -56,6 +56,11 @@ def lib():
         L.gsro_knn_bruteforce.argtypes = [C.c_int, fp, fp]
         L.gsro_higher_msb.restype = C.c_uint32
         L.gsro_higher_msb.argtypes = [C.c_uint32]
+        u8 = C.POINTER(C.c_uint8)
+        L.gsro_transform_points.argtypes = [C.c_int, fp, fp, fp]
+        L.gsro_scale_transform_points.argtypes = [C.c_int, C.c_float, fp, fp, fp, u8, fp, fp, C.c_int]
+        L.gsro_reproject_depth_pinhole.argtypes = [C.c_int, C.c_int] + [C.c_float] * 4 + [fp, u8, fp]
+        L.gsro_neighborhood_depth_pinhole.argtypes = [C.c_int, C.c_int] + [C.c_float] * 5 + [fp, u8, fp, fp, fp, fp]
         L.gsro_cull_stats.argtypes = [C.POINTER(_State), C.POINTER(C.c_double)]
         L.gsro_set_threads.argtypes = [C.c_int]
         L.gsro_get_threads.restype = C.c_int
@@ -217,3 +222,40 @@ def cull_stats(res):
     names = ("list_entries", "bwd_staged_entries", "fwd_quad_visits", "bwd_quad_visits", "blended_pairs",
              "reference_fwd_pair_evals", "wrongly_rejected_pairs", "fwd_quad_visits_without_rejection")
     return dict(zip(names, [float(v) for v in out]))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def transform_points(points, m):
+    k1, p1 = _f(points); k2, p2 = _f(m)
+    out = np.zeros_like(k1)
+    lib().gsro_transform_points(k1.shape[0], p1, p2, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def scale_transform_points(scale, points, rots, m, mask, reference_rot_layout=True):
+    k1, p1 = _f(points); k2, p2 = _f(rots); k3, p3 = _f(m); k4, p4 = _u8(mask)
+    op, orot = np.zeros_like(k1), np.zeros_like(k2)
+    fp = C.POINTER(C.c_float)
+    lib().gsro_scale_transform_points(k1.shape[0], scale, p1, p2, p3, p4, op.ctypes.data_as(fp), orot.ctypes.data_as(fp),
+                                      int(reference_rot_layout))
+    return op, orot
+
+
+def reproject_depth_pinhole(depth, mask, intr, width):
+    k1, p1 = _f(depth); k2, p2 = _u8(mask)
+    out = np.zeros((k1.shape[0], 3), np.float32)
+    lib().gsro_reproject_depth_pinhole(k1.shape[0], width, *[float(x) for x in intr], p1, p2, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def neighborhood_depth_pinhole(pixels, has3D, p3d, colors, max_pixel_dist, intr, width):
+    k1, p1 = _f(pixels); k2, p2 = _u8(has3D); k3, p3 = _f(p3d); k4, p4 = _f(colors)
+    op, oc = np.zeros_like(k3), np.zeros_like(k3)
+    fp = C.POINTER(C.c_float)
+    lib().gsro_neighborhood_depth_pinhole(k1.shape[0], width, *[float(x) for x in intr], float(max_pixel_dist), p1, p2, p3, p4,
+                                          op.ctypes.data_as(fp), oc.ctypes.data_as(fp))
+    return op, oc

@@ -22,6 +22,7 @@ SOURCES = [
     ("preprocess.hip", ["-ffp-contract=off"]),
     ("preprocess_bwd.hip", ["-ffp-contract=off"]),
     ("knn.hip", ["-ffp-contract=off"]),
+    ("points.hip", ["-ffp-contract=off"]),
     ("sort.hip", []),
     ("binning.hip", []),
     ("blend_fwd.hip", []),

@@ -67,7 +67,8 @@ EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
     "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
-    "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
+    "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
+    "gsr_neighborhood_depth_pinhole", "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
     "gsr_stage_scan_u32", "gsr_sort_scratch_bytes", "gsr_stage_radix_sort_pairs",
 ]
 
@@ -119,6 +120,14 @@ def load(path=None):
     L.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_longlong, f32, f32, f32, f32, i32, i32, i32, f32, vp]
     L.gsr_densify_stats.restype = i32
     L.gsr_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.gsr_transform_points.restype = i32
+    L.gsr_transform_points.argtypes = [i32, vp, vp, vp, vp]
+    L.gsr_scale_transform_points.restype = i32
+    L.gsr_scale_transform_points.argtypes = [i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.gsr_reproject_depth_pinhole.restype = i32
+    L.gsr_reproject_depth_pinhole.argtypes = [i32, i32, f32, f32, f32, f32, vp, vp, vp, vp]
+    L.gsr_neighborhood_depth_pinhole.restype = i32
+    L.gsr_neighborhood_depth_pinhole.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp]
     L.gsr_view_geometry.restype = i32
     L.gsr_view_geometry.argtypes = [vp, i32, C.POINTER(GeometryView)]
     L.gsr_view_binning.restype = i32

@@ -145,6 +145,27 @@ class GaussianModel:
         self.xyz_gradient_accum_ = torch.zeros((n, 1), device=self.device_)
         self.denom_ = torch.zeros((n, 1), device=self.device_)
 
+    # ---- checkpoint interchange, src/gaussian_model.cpp:838-1047
+    def savePly(self, path):
+        from . import ply_io
+        n = lambda t: t.detach().cpu().numpy()
+        ply_io.save_ply(path, n(self.xyz_), n(self.features_), n(self.opacity_), n(self.scaling_), n(self.rotation_))
+
+    @classmethod
+    def loadPly(cls, path, device="cuda", sh_degree=3):
+        from . import ply_io
+        d = ply_io.load_ply(path, sh_degree)
+        m = cls(sh_degree, device)
+        t = lambda a: torch.from_numpy(a).to(m.device_).contiguous().requires_grad_(True)
+        m.xyz_, m.features_, m.opacity_, m.scaling_, m.rotation_ = (t(d["xyz"]), t(d["features"]), t(d["opacity"]),
+                                                                   t(d["scaling"]), t(d["rotation"]))
+        m.active_sh_degree_ = sh_degree   # loadPly sets the active degree to the maximum (:953)
+        P = m.xyz_.shape[0]
+        m.max_radii2D_ = torch.zeros(P, device=m.device_)
+        m.xyz_gradient_accum_ = torch.zeros((P, 1), device=m.device_)
+        m.denom_ = torch.zeros((P, 1), device=m.device_)
+        return m
+
     # ---- activations, src/gaussian_model.cpp:48-71
     def getScalingActivation(self):
         return torch.exp(self.scaling_)

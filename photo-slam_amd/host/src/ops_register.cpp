@@ -8,7 +8,9 @@
 
 #include "gaussian_model_lite.h"
 #include "gaussian_renderer.h"
+#include "operate_points.h"
 #include "spatial.h"
+#include "stereo_vision.h"
 
 namespace {
 
@@ -37,6 +39,32 @@ torch::Tensor dist_cuda2(torch::Tensor points) { return distCUDA2(points); }
 torch::Tensor l1_ssim_loss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, double lambda_dssim)
 {
 	return fusedL1SSIMLoss(rendered, gt, mask, (float)lambda_dssim);
+}
+
+torch::Tensor transform_points(torch::Tensor points, torch::Tensor transformmatrix)
+{
+	transformPoints(points, transformmatrix);
+	return points;
+}
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, int64_t> scale_transform_mark_visible(
+    torch::Tensor points, torch::Tensor rots, torch::Tensor not_transformed, torch::Tensor unstable, torch::Tensor transform,
+    torch::Tensor view, torch::Tensor proj, int64_t num_transformed, double scale)
+{
+	int n = (int)num_transformed;
+	scaleAndTransformThenMarkVisiblePoints(points, rots, not_transformed, unstable, transform, view, proj, n, (float)scale);
+	return std::make_tuple(points, rots, not_transformed, (int64_t)n);
+}
+torch::Tensor reproject_depth_pinhole(torch::Tensor depth, torch::Tensor mask, std::vector<double> intr, int64_t width)
+{
+	std::vector<float> f(intr.begin(), intr.end());
+	return reprojectDepthPinhole(depth, mask, f, (int)width);
+}
+std::tuple<torch::Tensor, torch::Tensor> neighborhood_keypoints(torch::Tensor px, torch::Tensor has, torch::Tensor p3,
+                                                                torch::Tensor colors, double max_dist, std::vector<double> intr,
+                                                                int64_t width)
+{
+	std::vector<float> f(intr.begin(), intr.end());
+	return monocularPinholeInactiveGeoDensifyBySearchingNeighborhoodKeypoints(px, has, p3, colors, (float)max_dist, f, (int)width);
 }
 
 // ---- a C++ TrainStep behind an integer handle
@@ -107,6 +135,10 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("mark_visible", &mark_visible);
 	m.def("dist_cuda2", &dist_cuda2);
 	m.def("l1_ssim_loss", &l1_ssim_loss);
+	m.def("transform_points", &transform_points);
+	m.def("scale_transform_mark_visible", &scale_transform_mark_visible);
+	m.def("reproject_depth_pinhole", &reproject_depth_pinhole);
+	m.def("neighborhood_keypoints", &neighborhood_keypoints);
 	m.def("trainer_create", &trainer_create);
 	m.def("trainer_render_and_backward", &trainer_render_and_backward);
 	m.def("trainer_finish", &trainer_finish);

@@ -125,3 +125,33 @@ def test_cpp_host_layer_on_gpu():
     ops = load_host("hip")
     run_rasterize_checks(ops, torch.device("cuda:0"), None)
     run_trainer_checks(ops, torch.device("cuda:0"), None)
+
+
+def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
+    ops = load_host("emu")
+    from photo_slam_amd import operate_points as op
+    rng = np.random.default_rng(0)
+    P = 500
+    pts = torch.from_numpy(rng.standard_normal((P, 3)).astype(np.float32))
+    rots = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((P, 4)).astype(np.float32)))
+    M = torch.eye(4)
+    M[3, :3] = torch.tensor([0.3, -0.2, 0.5])
+    cl = scene.make_cloud(P, 64, 48, 50.0, 50.0, seed=5)
+    cam = cl.cameras[0]
+    view, proj = torch.from_numpy(cam.viewmatrix), torch.from_numpy(cam.projmatrix)
+    assert torch.equal(ops.transform_points(pts.clone(), M), torch.from_numpy(oracle.transform_points(pts.numpy(), M.numpy())))
+    a = torch.from_numpy(rng.random(P) < 0.7)
+    b = torch.from_numpy(rng.random(P) < 0.8)
+    xyz = torch.from_numpy(cl.xyz)
+    p1, r1, m1, n1 = ops.scale_transform_mark_visible(xyz.clone(), rots.clone(), a.clone(), b, M, view, proj, 3, 1.25)
+    rp._LIB_OVERRIDE = emu_lib_path
+    try:
+        p2, r2, m2 = xyz.clone(), rots.clone(), a.clone()
+        n2 = op.scaleAndTransformThenMarkVisiblePoints(p2, r2, m2, b, M, view, proj, 3, scale=1.25)
+    finally:
+        rp._LIB_OVERRIDE = None
+    assert n1 == n2 and torch.equal(p1, p2) and torch.equal(r1, r2) and torch.equal(m1, m2)
+    d = torch.from_numpy((rng.random(40 * 30) * 4).astype(np.float32))
+    mk = torch.from_numpy(rng.random(40 * 30) < 0.5)
+    assert torch.equal(ops.reproject_depth_pinhole(d, mk, [50.0, 52.0, 19.5, 14.5], 40),
+                       torch.from_numpy(oracle.reproject_depth_pinhole(d.numpy(), mk.numpy(), [50.0, 52.0, 19.5, 14.5], 40)))
