@@ -208,65 +208,44 @@ __device__ __forceinline__ void update3(float px, float py, float pz, float qx, 
 	}
 }
 
-// boxMeanDist, simple_knn.cu:147-183.  Thread = one point (in Morton order); a workgroup of 256
-// Morton-consecutive points walks the boxes in order; a box any of them still needs is staged
-// once in LDS and scanned from there with broadcast reads.
+// boxMeanDist, simple_knn.cu:147-183.  Thread = one point (in Morton order).  Every thread walks the boxes in
+// order (the box AABBs are wave-uniform loads) and scans a box only if its AABB distance can still improve the
+// point's 3rd-best; the 64 lanes of a wave are Morton neighbours, so they mostly scan the same boxes and the
+// contiguous, pre-gathered points of a box are fetched once per wave (same-address loads).  No barriers, no LDS.
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_mean_dist_kernel(int P, const float* __restrict__ spts, const uint32_t* __restrict__ indices,
                      const float* __restrict__ boxes, int nbox, float* __restrict__ dists)
 {
-	__shared__ float s_box[KNN_BOX * 3];
-	__shared__ int s_need[4];
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	const bool valid = idx < P;
-	float px = 0.f, py = 0.f, pz = 0.f;
+	if (idx >= P) return;
+	const float px = spts[3 * (size_t)idx], py = spts[3 * (size_t)idx + 1], pz = spts[3 * (size_t)idx + 2];
 	float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-	float reject = FLT_MAX;
-	if (valid) {
-		px = spts[3 * (size_t)idx];
-		py = spts[3 * (size_t)idx + 1];
-		pz = spts[3 * (size_t)idx + 2];
-		for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
-			if (i == idx) continue;
-			update3(px, py, pz, spts[3 * (size_t)i], spts[3 * (size_t)i + 1], spts[3 * (size_t)i + 2], best);
-		}
-		reject = best[2];
-		best[0] = FLT_MAX;
-		best[1] = FLT_MAX;
-		best[2] = FLT_MAX;
+	for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
+		if (i == idx) continue;
+		update3(px, py, pz, spts[3 * (size_t)i], spts[3 * (size_t)i + 1], spts[3 * (size_t)i + 2], best);
 	}
+	const float reject = best[2];
+	best[0] = FLT_MAX;
+	best[1] = FLT_MAX;
+	best[2] = FLT_MAX;
 	for (int b = 0; b < nbox; b++) {
 		// distBoxPoint, simple_knn.cu:119-129
-		bool need = false;
-		if (valid) {
-			const float bnx = boxes[6 * (size_t)b], bny = boxes[6 * (size_t)b + 1], bnz = boxes[6 * (size_t)b + 2];
-			const float bxx = boxes[6 * (size_t)b + 3], bxy = boxes[6 * (size_t)b + 4], bxz = boxes[6 * (size_t)b + 5];
-			float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-			if (px < bnx || px > bxx) ddx = fminf(fabsf(px - bnx), fabsf(px - bxx));
-			if (py < bny || py > bxy) ddy = fminf(fabsf(py - bny), fabsf(py - bxy));
-			if (pz < bnz || pz > bxz) ddz = fminf(fabsf(pz - bnz), fabsf(pz - bxz));
-			const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
-			need = !(dist > reject || dist > best[2]);
+		const float bnx = boxes[6 * (size_t)b], bny = boxes[6 * (size_t)b + 1], bnz = boxes[6 * (size_t)b + 2];
+		const float bxx = boxes[6 * (size_t)b + 3], bxy = boxes[6 * (size_t)b + 4], bxz = boxes[6 * (size_t)b + 5];
+		float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+		if (px < bnx || px > bxx) ddx = fminf(fabsf(px - bnx), fabsf(px - bxx));
+		if (py < bny || py > bxy) ddy = fminf(fabsf(py - bny), fabsf(py - bxy));
+		if (pz < bnz || pz > bxz) ddz = fminf(fabsf(pz - bnz), fabsf(pz - bxz));
+		const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+		if (dist > reject || dist > best[2]) continue;
+		const int bbase = b * KNN_BOX;
+		const int cnt = min(KNN_BOX, P - bbase);
+		for (int i = 0; i < cnt; i++) {
+			if (bbase + i == idx) continue;
+			update3(px, py, pz, spts[3 * (size_t)(bbase + i)], spts[3 * (size_t)(bbase + i) + 1], spts[3 * (size_t)(bbase + i) + 2], best);
 		}
-		const bool wave_need = wave_ballot(need) != 0ull;
-		if (lane_id() == 0) s_need[wave_id()] = wave_need ? 1 : 0;
-		__syncthreads();
-		const bool any = (s_need[0] | s_need[1] | s_need[2] | s_need[3]) != 0;
-		if (any) {
-			const int bbase = b * KNN_BOX;
-			const int cnt = min(KNN_BOX, P - bbase);
-			for (int i = (int)threadIdx.x; i < cnt * 3; i += KNN_THREADS) s_box[i] = spts[3 * (size_t)bbase + i];
-			__syncthreads();
-			if (need) {
-				for (int i = 0; i < cnt; i++) {
-					if (bbase + i == idx) continue;
-					update3(px, py, pz, s_box[3 * i], s_box[3 * i + 1], s_box[3 * i + 2], best);
-				}
-			}
-		}
-		__syncthreads();
 	}
-	if (valid) dists[indices[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
+	dists[indices[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
 int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipStream_t stream)
