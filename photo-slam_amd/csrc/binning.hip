@@ -137,10 +137,13 @@ reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __
 	if (cnt) {
 		// constant factors the blend left out: dL_dG = opacity * dL_dalpha; d(mean2D) carries -W/2, -H/2
 		// (backward.cu:460-461,539-546), the conic terms -1/2 (:549-551)
-		const float o = rec[3 * (size_t)idx + 1].y;
+		// a[3], a[4] = sum dL_dG*G*dx, sum dL_dG*G*dy: dG_ddelx = -G (dx A + dy B), dG_ddely = -G (dy C + dx B)
+		const float4 q0 = rec[3 * (size_t)idx];
+		const float4 q1 = rec[3 * (size_t)idx + 1];
+		const float A = q0.z, B = q0.w, C = q1.x, o = q1.y;
 		float4* dst = reinterpret_cast<float4*>(grad_acc) + 3 * (size_t)idx;
-		dst[0] = make_float4(a[0], a[1], a[2], -o * half_w * a[3]);
-		dst[1] = make_float4(-o * half_h * a[4], -0.5f * o * a[5], -0.5f * o * a[6], -0.5f * o * a[7]);
+		dst[0] = make_float4(a[0], a[1], a[2], -o * half_w * (a[3] * A + a[4] * B));
+		dst[1] = make_float4(-o * half_h * (a[4] * C + a[3] * B), -0.5f * o * a[5], -0.5f * o * a[6], -0.5f * o * a[7]);
 		dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
 	}
 }

@@ -11,10 +11,14 @@
 //     per-quad rejection mask removes whole-wave work exactly as in the forward pass;
 //   * the per-pair arithmetic is branch-free; 1/(1-alpha) is one v_rcp_f32 shared by the two
 //     divisions of the reference;
-//   * the nine terms are summed across the 64 pixels of a quad with a packed DPP butterfly
-//     (wave64.h) that leaves the nine totals in lanes 0..3 of three registers; three
-//     ds_add_f32 (4 + 4 + 1 active lanes) add them to the tile's LDS accumulators, where the
-//     four quads of a tile meet;
+//   * the nine terms are summed across the 64 pixels of a quad with a butterfly packed from the
+//     top through v_permlane32_swap / v_permlane16_swap (wave64.h, 24 VALU) that leaves eight
+//     totals in one register (one per 8-lane group) and the ninth in lane 63; ONE ds_add_f32
+//     with nine active lanes adds them to the tile's LDS accumulators, where the four quads
+//     of a tile meet;
+//   * the two mean2D terms are reduced as sum(dL_dG*G*dx), sum(dL_dG*G*dy); their conic
+//     combination (backward.cu:539-546) is linear in them and applied once per Gaussian in
+//     reduce_partials;
 //   * at the end of a segment of 256 list entries the workgroup writes every touched entry's
 //     nine sums to that instance's private 48-byte slot with plain stores.
 #include "blend.h"
@@ -27,9 +31,7 @@ constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
 {
-	__shared__ float4 s_q0[4][64];   // per wave: x, y, A', B'
-	__shared__ float4 s_q1[4][64];   // C', opacity, r, g
-	__shared__ float4 s_q2[4][64];   // b, A, B, C
+	__shared__ float4 s_rec[4][64][3];   // per wave and entry: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
 	__shared__ float s_acc[9][BWD_SEG];
 	__shared__ uint32_t s_slot[BWD_SEG];
 	__shared__ uint32_t s_wmax[4];
@@ -37,7 +39,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const int tile = tile_assignment((int)blockIdx.x, p.tiles);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
-	const int quad = wave_id(), l = lane_id(), tid = (int)threadIdx.x;
+	const int quad = (int)wave_uniform_u32((uint32_t)wave_id());   // scalar: the LDS record address is SGPR arithmetic
+	const int l = lane_id(), tid = (int)threadIdx.x;
 	const int qx0 = tile_x * TILE + (quad & 1) * 8, qy0 = tile_y * TILE + (quad >> 1) * 8;
 	const int px = qx0 + (l & 7), py = qy0 + (l >> 3);
 	const bool inside = px < p.W && py < p.H;
@@ -55,14 +58,19 @@ blend_bwd_kernel(const BlendBwdParams p)
 		dpg = p.dL_dpix[plane + pix];
 		dpb = p.dL_dpix[2 * plane + pix];
 	}
+	// lanes 0, 8, .., 56 deliver the eight packed totals, lanes 1, 17, 33, 49 the four row sums of the ninth
+	// (wave_reduce9_swap_f32): one ds_add_f32 with twelve active lanes
+	const bool red_ninth = (l & 15) == 1;
+	const bool red_lane = ((l & 7) == 0) || red_ninth;
+	const int red_off = (red_ninth ? 8 : wave_swap9_component(l)) * BWD_SEG;
 	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
 	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
 
 	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
-	const uint32_t wmax = wave_max_u32(last_contributor);
+	const uint32_t wmax = wave_uniform_u32(wave_max_u32(last_contributor));
 	if (l == 0) s_wmax[quad] = wmax;
 	__syncthreads();
-	const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+	const uint32_t bmax = wave_uniform_u32(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
 	const int nseg = (int)((bmax + BWD_SEG - 1) / BWD_SEG);
 
 	for (int seg = nseg - 1; seg >= 0; seg--) {
@@ -87,9 +95,9 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float4 q1 = p.rec[3 * (size_t)gid + 1];
 					const float4 q2 = p.rec[3 * (size_t)gid + 2];
 					keep = quad_keep(q0, q1, (float)qx0, (float)qy0);
-					s_q0[quad][l] = prescale_q0(q0);
-					s_q1[quad][l] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
-					s_q2[quad][l] = make_float4(q2.x, q0.z, q0.w, q1.x);
+					s_rec[quad][l][0] = prescale_q0(q0);
+					s_rec[quad][l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
+					s_rec[quad][l][2].x = q2.x;
 					const uint32_t rlo = __float_as_uint(q2.y), rhi = __float_as_uint(q2.z);
 					const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu;
 					slot = __float_as_uint(q2.w) + ((uint32_t)tile_y - miny) * (maxx - minx) + ((uint32_t)tile_x - minx);
@@ -101,9 +109,9 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const int bit = 63 - __clzll((long long)m);
 					m &= ~(1ull << bit);
 					const uint32_t pos = (uint32_t)(base + bit);
-					const float4 g0 = s_q0[quad][bit];
-					const float4 g1 = s_q1[quad][bit];
-					const float4 g2 = s_q2[quad][bit];
+					const float4 g0 = s_rec[quad][bit][0];
+					const float4 g1 = s_rec[quad][bit][1];
+					const float gb = s_rec[quad][bit][2].x;
 					const float dx = g0.x - pxf, dy = g0.y - pyf;
 					const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
 					const float G = __builtin_amdgcn_exp2f(pw);
@@ -114,41 +122,34 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float Tn = T * rinv;
 					// accum_rec of the reference (backward.cu:509-511), advanced eagerly: acc <- acc + alpha (c - acc)
 					// (the reference delays the same update by one entry through last_alpha / last_color)
-					const float dcr = g1.z - acr, dcg = g1.w - acg, dcb = g2.x - acb;
+					const float dcr = g1.z - acr, dcg = g1.w - acg, dcb = gb - acb;
 					float dL_dalpha = dcr * dpr + dcg * dpg + dcb * dpb;
 					dL_dalpha = dL_dalpha * Tn + neg_Tfinal_bg * rinv;
 					// lanes that do not blend this entry contribute exact zeros and keep their state
 					const float am = ok ? alpha : 0.f;
 					const float dLm = ok ? dL_dalpha : 0.f;
 					const float dcol = am * Tn;
-					const float gdx = G * dx, gdy = G * dy;
 					float v[9];
 					v[0] = dcol * dpr;
 					v[1] = dcol * dpg;
 					v[2] = dcol * dpb;
-					// the per-Gaussian constants (opacity, -1/2, W/2, H/2) are applied after the reduction (reduce_partials)
-					v[3] = dLm * (gdx * g2.y + gdy * g2.z);
-					v[4] = dLm * (gdy * g2.w + gdx * g2.z);
-					v[5] = dLm * gdx * dx;
-					v[6] = dLm * gdx * dy;
-					v[7] = dLm * gdy * dy;
-					v[8] = dLm * G;
+					// the per-Gaussian constants (opacity, -1/2, W/2, H/2, the conic in the mean2D terms) are applied
+					// after the reduction (reduce_partials)
+					const float wG = dLm * G;
+					const float tdx = wG * dx, tdy = wG * dy;
+					v[3] = tdx;
+					v[4] = tdy;
+					v[5] = tdx * dx;
+					v[6] = tdx * dy;
+					v[7] = tdy * dy;
+					v[8] = wG;
 					T = ok ? Tn : T;
 					acr += am * dcr;
 					acg += am * dcg;
 					acb += am * dcb;
-#ifndef GSR_EXP_NO_REDUCE
-					wave_reduce9_packed_f32(v);
-#endif
-					// totals: value c sits in lane (c & 3) of v[c >> 2]
-					{
-						const int e = (int)pos - (int)seg_lo;
-						if (l < 4) {
-							atomicAdd(&s_acc[l][e], v[0]);
-							atomicAdd(&s_acc[4 + l][e], v[1]);
-						}
-						if (l == 0) atomicAdd(&s_acc[8][e], v[2]);
-					}
+					float packed, ninth_row;
+					wave_reduce9_swap_f32(v, packed, ninth_row);
+					if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
 				}
 				wave_fence();  // all lanes have read this batch before the next one overwrites the slice
 			}

@@ -138,6 +138,31 @@ static inline void wave_reduce9_packed_f32(float (&v)[9])
 	v[1] = t[4 + r];
 	v[2] = t[8];
 }
+// top-packed variant (csrc/wave64.h wave_reduce9_swap_f32): lane group g = lane >> 3 receives the total of value bitrev3(g)
+static inline int wave_swap9_component(int lane_)
+{
+	const int g = lane_ >> 3;
+	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);
+}
+static inline void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
+{
+	float t[9];
+	for (int c = 0; c < 9; c++) t[c] = v[c];
+	uint32_t bits;
+	memcpy(&bits, &v[8], 4);
+	const uint64_t* s = wave_exchange(bits);
+	float row = 0.f;
+	for (int i = 0; i < 16; i++) {
+		uint32_t b = (uint32_t)s[(lane() & ~15) + i];
+		float f;
+		memcpy(&f, &b, 4);
+		row += f;
+	}
+	wave_sync();
+	wave_reduce9_f32(t);
+	packed = t[wave_swap9_component(lane())];
+	ninth_row = row;
+}
 // asserts the value really is wave-uniform (the real primitive silently takes lane 0's)
 static inline unsigned long long wave_uniform_u64(unsigned long long v)
 {
