@@ -41,7 +41,9 @@ def _deps():
 
 def build(force=False, verbose=False, save_temps=False):
     extra_env = os.environ.get("GSR_EXTRA_FLAGS", "").split()   # experiment switches (-DGSR_EXP_...)
-    if extra_env:
+    stamp = OUT + ".flags"   # a library built with experiment switches must never be mistaken for the product build
+    built_with = open(stamp).read() if os.path.exists(stamp) else ""
+    if " ".join(extra_env) != built_with:
         force = True
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
         return OUT
@@ -61,6 +63,8 @@ def build(force=False, verbose=False, save_temps=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs)
+    with open(stamp, "w") as f:
+        f.write(" ".join(extra_env))
     return OUT
 
 

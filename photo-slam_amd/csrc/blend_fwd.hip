@@ -16,9 +16,7 @@ namespace gsr {
 __global__ void __launch_bounds__(64)
 blend_fwd_kernel(const BlendFwdParams p)
 {
-	__shared__ float4 s_q0[64];
-	__shared__ float4 s_q1[64];
-	__shared__ float s_b[64];
+	__shared__ float4 s_rec[64][3];   // per staged entry: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
 
 	int tile, quad;
 	quad_assignment((int)blockIdx.x, p.tiles, tile, quad);
@@ -33,13 +31,16 @@ blend_fwd_kernel(const BlendFwdParams p)
 	const int n = (int)(range.y - range.x);
 
 	float T = 1.0f;
-	float Cr = 0.f, Cg = 0.f, Cb = 0.f;
+	typedef float v2f __attribute__((vector_size(8)));
+	v2f Crg = {0.f, 0.f};   // red and green ride in one v_pk_fma_f32
+	float Cb = 0.f;
 	uint32_t last_contributor = 0;
-	bool done = !inside;
+	// pixel state predicates live as 64-bit lane masks in SGPR pairs; their logic is scalar
+	unsigned long long done_m = wave_ballot(!inside);
 
 	uint32_t gid_next = (l < n) ? p.point_list[range.x + (uint32_t)l] : 0u;
 	for (int base = 0; base < n; base += 64) {
-		if (wave_ballot(!done) == 0ull) break;
+		if (~done_m == 0ull) break;
 		const bool have = base + l < n;
 		const uint32_t gid = gid_next;
 		const int e_next = base + 64 + l;
@@ -50,9 +51,9 @@ blend_fwd_kernel(const BlendFwdParams p)
 			const float4 q1 = p.rec[3 * (size_t)gid + 1];
 			const float cb = p.rec[3 * (size_t)gid + 2].x;
 			keep = quad_keep(q0, q1, (float)qx0, (float)qy0);
-			s_q0[l] = prescale_q0(q0);
-			s_q1[l] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
-			s_b[l] = cb;
+			s_rec[l][0] = prescale_q0(q0);
+			s_rec[l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
+			s_rec[l][2].x = cb;
 		}
 		unsigned long long m = wave_ballot(keep);
 		wave_fence();
@@ -60,24 +61,23 @@ blend_fwd_kernel(const BlendFwdParams p)
 		while (m) {
 			const int bit = __ffsll((long long)m) - 1;
 			m &= m - 1ull;
-			const float4 g0 = s_q0[bit];
-			const float4 g1 = s_q1[bit];
-			const float gb = s_b[bit];
+			const float4 g0 = s_rec[bit][0];
+			const float4 g1 = s_rec[bit][1];
+			const float gb = s_rec[bit][2].x;
 			const float dx = g0.x - pxf, dy = g0.y - pyf;
 			const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;   // log2(e) * power
 			const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(pw));
-			const bool ok = !done && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
+			const unsigned long long ok_m = wave_ballot(!(pw > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
 			const float test_T = T * (1.f - alpha);
-			const bool term = ok && (test_T < 0.0001f);
-			const bool upd = ok && !term;
-			const float wgt = upd ? alpha * T : 0.f;
-			Cr += g1.z * wgt;
-			Cg += g1.w * wgt;
+			const unsigned long long below_m = wave_ballot(test_T < 0.0001f);
+			const unsigned long long upd_m = ok_m & ~below_m;
+			done_m |= ok_m & below_m;
+			const float wgt = mask_select0_f32(upd_m, alpha * T);
+			Crg += (v2f){g1.z, g1.w} * (v2f){wgt, wgt};
 			Cb += gb * wgt;
-			T = upd ? test_T : T;
-			last_contributor = upd ? (uint32_t)(base + bit + 1) : last_contributor;
-			done = done || term;
-			if (wave_ballot(!done) == 0ull) {
+			T = mask_select_f32(upd_m, test_T, T);
+			last_contributor = mask_select_u32(upd_m, (uint32_t)(base + bit + 1), last_contributor);
+			if (~done_m == 0ull) {
 				wave_done = true;
 				break;
 			}
@@ -91,8 +91,8 @@ blend_fwd_kernel(const BlendFwdParams p)
 		const size_t plane = (size_t)p.H * p.W;
 		p.final_T[pix] = T;
 		p.n_contrib[pix] = last_contributor;
-		p.out_color[pix] = Cr + T * p.bg[0];
-		p.out_color[plane + pix] = Cg + T * p.bg[1];
+		p.out_color[pix] = Crg[0] + T * p.bg[0];
+		p.out_color[plane + pix] = Crg[1] + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];
 	}
 }

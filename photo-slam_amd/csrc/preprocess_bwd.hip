@@ -26,6 +26,11 @@ __device__ static const float BSH_C3[] = {-0.5900435899266435f, 2.89061144264055
                                           0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                           -0.5900435899266435f};
 
+#ifdef GSR_EXP_NO_SMALL_STORES   // traffic experiment: drop every output but dL_dsh
+#define GSR_SMALL_STORE(x) for (int i_ = 0; i_ < 0; i_++) {}
+#else
+#define GSR_SMALL_STORE(x) x
+#endif
 constexpr int PRB_THREADS = 128;   // 2 waves x 13 KiB of row staging per workgroup
 
 __global__ void __launch_bounds__(PRB_THREADS)
@@ -33,6 +38,10 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 {
 	__shared__ float4 s_rows[PRB_THREADS / 64][64][ROW_F4_PAD];
 	__shared__ uint32_t s_list[PRB_THREADS / 64][64];
+#ifdef GSR_EXP_LDS_PAD   // occupancy experiment
+	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
+	if (p.P < 0) s_pad[threadIdx.x] = 1, p.dL_dopacity[0] = (float)s_pad[threadIdx.x ^ 1];
+#endif
 
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
@@ -47,21 +56,21 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	if (in_range && !vis) {
 		// culled: the reference leaves the torch::zeros content
 #pragma unroll
-		for (int i = 0; i < 3; i++) p.dL_dmean2D[3 * (size_t)idx + i] = 0.f;
+		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dmean2D[3 * (size_t)idx + i] = 0.f);
 #pragma unroll
-		for (int i = 0; i < 3; i++) p.dL_dcolor[3 * (size_t)idx + i] = 0.f;
-		p.dL_dopacity[idx] = 0.f;
-		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dcolor[3 * (size_t)idx + i] = 0.f);
+		GSR_SMALL_STORE(p.dL_dopacity[idx] = 0.f);
+		GSR_SMALL_STORE(if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-		for (int i = 0; i < 3; i++) p.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
+		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dmean3D[3 * (size_t)idx + i] = 0.f);
 #pragma unroll
-		for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+		GSR_SMALL_STORE(for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = 0.f);
 		if (out_sh && !rows_ok)
 			for (int i = 0; i < M3; i++) out_sh[i] = 0.f;
 		if (p.dL_dscale) {
 #pragma unroll
-			for (int i = 0; i < 3; i++) p.dL_dscale[3 * (size_t)idx + i] = 0.f;
-			reinterpret_cast<float4*>(p.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+			GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dscale[3 * (size_t)idx + i] = 0.f);
+			GSR_SMALL_STORE(reinterpret_cast<float4*>(p.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f));
 		}
 	}
 
@@ -86,20 +95,20 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		const float4 ga1 = ga[1];
 		const float ga2x = ga[2].x;
 		const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
-		p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w;
-		p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x;
-		p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-		p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
-		p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
-		p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
+		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w);
+		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x);
+		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f);
+		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x);
+		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y);
+		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z);
 		// raw logit: d sigmoid = o (1 - o), o = the activated opacity kept in the blend record
 		if (p.raw_params & GSR_RAW_OPACITY) {
 			const float o = p.rec[3 * (size_t)idx + 1].y;
-			p.dL_dopacity[idx] = ga2x * o * (1.0f - o);
+			GSR_SMALL_STORE(p.dL_dopacity[idx] = ga2x * o * (1.0f - o));
 		} else {
-			p.dL_dopacity[idx] = ga2x;
+			GSR_SMALL_STORE(p.dL_dopacity[idx] = ga2x);
 		}
-		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
+		GSR_SMALL_STORE(if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz));
 		float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 		float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 		const float tz0 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
@@ -142,7 +151,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
 		}
 #pragma unroll
-		for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+		GSR_SMALL_STORE(for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i]);
 
 		const float dL_dT00 = 2 * (T00 * V00 + T01 * V01 + T02 * V02) * dL_da + (T10 * V00 + T11 * V01 + T12 * V02) * dL_db;
 		const float dL_dT01 = 2 * (T00 * V10 + T01 * V11 + T02 * V12) * dL_da + (T10 * V10 + T11 * V11 + T12 * V12) * dL_db;
@@ -295,9 +304,9 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		}
 	}
 	if (!vis) return;
-	p.dL_dmean3D[3 * (size_t)idx + 0] = gmx;
-	p.dL_dmean3D[3 * (size_t)idx + 1] = gmy;
-	p.dL_dmean3D[3 * (size_t)idx + 2] = gmz;
+	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 0] = gmx);
+	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 1] = gmy);
+	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 2] = gmz);
 
 	// ------------------------------------------------------------------ cov3D backward, backward.cu:278-341
 	if (p.scales) {
@@ -343,9 +352,9 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		const float ds0 = R00 * D00 + R10 * D01 + R20 * D02, ds1 = R01 * D10 + R11 * D11 + R21 * D12,
 		            ds2 = R02 * D20 + R12 * D21 + R22 * D22;
 		const bool raw_s = (p.raw_params & GSR_RAW_SCALING) != 0;
-		p.dL_dscale[3 * (size_t)idx + 0] = raw_s ? ds0 * sx : ds0;
-		p.dL_dscale[3 * (size_t)idx + 1] = raw_s ? ds1 * sy : ds1;
-		p.dL_dscale[3 * (size_t)idx + 2] = raw_s ? ds2 * sz : ds2;
+		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 0] = raw_s ? ds0 * sx : ds0);
+		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 1] = raw_s ? ds1 * sy : ds1);
+		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 2] = raw_s ? ds2 * sz : ds2);
 		D00 *= s0; D01 *= s0; D02 *= s0;
 		D10 *= s1; D11 *= s1; D12 *= s1;
 		D20 *= s2; D21 *= s2; D22 *= s2;
@@ -363,7 +372,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			dq.z = (dq.z - y * qg) / qn;
 			dq.w = (dq.w - z * qg) / qn;
 		}
-		reinterpret_cast<float4*>(p.dL_drot)[idx] = dq;
+		GSR_SMALL_STORE(reinterpret_cast<float4*>(p.dL_drot)[idx] = dq);
 	}
 }
 

@@ -27,6 +27,9 @@ using ::hipemu::wave_reduce9_packed_f32;
 using ::hipemu::wave_packed9_total;
 using ::hipemu::wave_reduce9_swap_f32;
 using ::hipemu::wave_swap9_component;
+using ::hipemu::mask_select_f32;
+using ::hipemu::mask_select_u32;
+using ::hipemu::mask_select0_f32;
 #else
 
 // Broadcast lane `lane`'s value to the whole wave through an SGPR (v_readlane_b32): the value
@@ -53,7 +56,29 @@ __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long lon
 	return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __ballot(pred ? 1 : 0); }
+// the builtin takes the i1 directly: a predicate that already lives in an SGPR pair costs no VALU
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
+// Selects driven by an explicit 64-bit lane mask held in an SGPR pair (v_cndmask_b32 with a scalar mask operand):
+// predicates that are combined with scalar logic (and, andn2, or on ballots) never round-trip through the VALU.
+__device__ __forceinline__ float mask_select_f32(unsigned long long mask, float if_set, float if_clear)
+{
+	float r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+	return r;
+}
+__device__ __forceinline__ uint32_t mask_select_u32(unsigned long long mask, uint32_t if_set, uint32_t if_clear)
+{
+	uint32_t r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+	return r;
+}
+__device__ __forceinline__ float mask_select0_f32(unsigned long long mask, float if_set)
+{
+	float r;
+	asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
+	return r;
+}
 
 // Scheduling fence for intra-wave communication through LDS that relies on lock-step
 // execution (lanes read, then a leader lane writes).  The hardware issues a wave's LDS
@@ -198,6 +223,7 @@ __device__ __forceinline__ float swap16_add(float a, float b)
 	const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
 	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
+template <bool LAST_LEVEL = true>
 __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	constexpr int DPP_ROW_ROR8 = 0x128;
@@ -213,13 +239,13 @@ __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float
 	asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(r) : "v"(q1));
 	r += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, r);
 	r += dpp_f32<DPP_QUAD_PERM_2301>(0.f, r);
-	r += dpp_f32<DPP_QUAD_PERM_1032>(0.f, r);
+	if (LAST_LEVEL) r += dpp_f32<DPP_QUAD_PERM_1032>(0.f, r);   // without it: lanes 0 and 1 of a group hold the two halves
 	packed = r;
 	float n = v[8];
 	n += dpp_f32<DPP_QUAD_PERM_1032>(0.f, n);
 	n += dpp_f32<DPP_QUAD_PERM_2301>(0.f, n);
 	n += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, n);
-	n += dpp_f32<DPP_ROW_MIRROR>(0.f, n);
+	if (LAST_LEVEL) n += dpp_f32<DPP_ROW_MIRROR>(0.f, n);       // without it: sums over the lane's half row
 	ninth_row = n;
 }
 // the value whose total `packed` holds in this lane

@@ -138,12 +138,16 @@ static inline void wave_reduce9_packed_f32(float (&v)[9])
 	v[1] = t[4 + r];
 	v[2] = t[8];
 }
+static inline float mask_select_f32(unsigned long long mask, float if_set, float if_clear) { return ((mask >> lane()) & 1ull) ? if_set : if_clear; }
+static inline uint32_t mask_select_u32(unsigned long long mask, uint32_t if_set, uint32_t if_clear) { return ((mask >> lane()) & 1ull) ? if_set : if_clear; }
+static inline float mask_select0_f32(unsigned long long mask, float if_set) { return ((mask >> lane()) & 1ull) ? if_set : 0.f; }
 // top-packed variant (csrc/wave64.h wave_reduce9_swap_f32): lane group g = lane >> 3 receives the total of value bitrev3(g)
 static inline int wave_swap9_component(int lane_)
 {
 	const int g = lane_ >> 3;
 	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);
 }
+template <bool LAST_LEVEL = true>
 static inline void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	float t[9];
@@ -162,6 +166,10 @@ static inline void wave_reduce9_swap_f32(const float (&v)[9], float& packed, flo
 	wave_reduce9_f32(t);
 	packed = t[wave_swap9_component(lane())];
 	ninth_row = row;
+	if (!LAST_LEVEL) {   // the two halves: everything in the even lane / first half row, zero in the other
+		if (lane() & 1) packed = 0.f;
+		if (lane() & 8) ninth_row = 0.f;
+	}
 }
 // asserts the value really is wave-uniform (the real primitive silently takes lane 0's)
 static inline unsigned long long wave_uniform_u64(unsigned long long v)
