@@ -19,8 +19,8 @@ ARCH = "gfx950"
 # (source, extra flags)
 SOURCES = [
     ("gsr_api.hip", []),
-    ("preprocess.hip", ["-ffp-contract=off"]),
-    ("preprocess_bwd.hip", ["-ffp-contract=off"]),
+    ("preprocess.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),       # SLP packing inflates live ranges: see shrows.h
+    ("preprocess_bwd.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("knn.hip", ["-ffp-contract=off"]),
     ("points.hip", ["-ffp-contract=off"]),
     ("sort.hip", []),

@@ -18,15 +18,6 @@
 namespace gsr {
 
 
-// SH constants, cuda_rasterizer/auxiliary.h:22-39
-__device__ static const float SH_C0 = 0.28209479177387814f;
-__device__ static const float SH_C1 = 0.4886025119029199f;
-__device__ static const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                         -1.0925484305920792f, 0.5462742152960396f};
-__device__ static const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                         0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                         -0.5900435899266435f};
-
 // float -> int with the hardware's semantics (v_cvt_i32_f32: truncate, saturate, NaN -> 0)
 __device__ __forceinline__ int f2i(float f)
 {
@@ -39,38 +30,12 @@ __device__ __forceinline__ int f2i(float f)
 // auxiliary.h:41-44 (double because of the 1.0 / 0.5 literals)
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
-// One SH channel of computeColorFromSH, forward.cu:20-71.  sh points at coefficient 0 of the
-// Gaussian, channel stride 1, coefficient stride 3.
-__device__ __forceinline__ float sh_channel(const float* sh, int ch, int deg, float x, float y, float z)
-{
-#define SH(k) sh[3 * (k) + ch]
-	float result = SH_C0 * SH(0);
-	if (deg > 0) {
-		result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
-		if (deg > 1) {
-			const float xx = x * x, yy = y * y, zz = z * z;
-			const float xy = x * y, yz = y * z, xz = x * z;
-			result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
-			         SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
-			if (deg > 2) {
-				result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
-				         SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
-				         SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
-				         SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
-				         SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
-			}
-		}
-	}
-#undef SH
-	return result + 0.5f;
-}
-
-constexpr int PRE_THREADS = 128;   // 2 waves x 13 KiB of row staging per workgroup
+constexpr int PRE_THREADS = 128;   // 2 waves x 6.5 KiB of row staging per workgroup
 
 __global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 {
-	__shared__ float4 s_rows[PRE_THREADS / 64][64][ROW_F4_PAD];
+	__shared__ float4 s_rows[PRE_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[PRE_THREADS / 64][64];
 #ifdef GSR_EXP_LDS_PAD   // occupancy experiment
 	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
@@ -203,44 +168,51 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	}
 	const bool vis = my_tiles != 0;
 
-	// ---------------- phase 2: colour, forward.cu:238-247.  SH rows of the visible lanes are moved by
-	// the whole wave (shrows.h); unaligned row pitches fall back to per-lane loads.
+	// ---------------- phase 2: colour, forward.cu:238-247 (computeColorFromSH :20-71).  The SH rows of the visible
+	// lanes are fetched by the whole wave in passes of STAGE_ROWS rows, ranked by visible lane (shrows.h), and each
+	// owner streams its row out of LDS; unaligned row pitches fall back to per-lane loads.
 	float cr = 0.f, cg = 0.f, cb = 0.f;
 	uint8_t clamp_bits = 0;
 	if (p.colors_precomp == nullptr) {
-		const int nfl = 3 * (p.D + 1) * (p.D + 1);
+		const int ncoef = (p.D + 1) * (p.D + 1);
 		const bool rows_ok = (p.M * 3 == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
-		float c[48];
+		float rgb[3] = {0.f, 0.f, 0.f};
+		ShDir d = sh_dir(0.f, 0.f, 1.f);
+		if (vis) {
+			float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+			const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+			d = sh_dir(dx / len, dy / len, dz / len);
+		}
 		if (rows_ok) {
-			const int nf4 = (nfl + 3) >> 2;
-			wave_load_rows(reinterpret_cast<const float4*>(p.shs), wave_first, nf4, vis, s_rows[w], s_list[w]);
-			if (vis) {
-#pragma unroll
-				for (int i = 0; i < 12; i++) {
-					if (4 * i < nfl) {
-						const float4 v = s_rows[w][lane_id()][i];
-						c[4 * i] = v.x;
-						c[4 * i + 1] = v.y;
-						c[4 * i + 2] = v.z;
-						c[4 * i + 3] = v.w;
-					}
-				}
+			const unsigned long long vmask = wave_ballot(vis);
+			const int nvis = __popcll(vmask);
+			const int rank = __popcll(vmask & lanemask_lt());
+			if (vis) s_list[w][rank] = (uint32_t)lane_id();
+			wave_fence();
+			const int nf4 = (3 * ncoef + 3) >> 2;
+			for (int r0 = 0; r0 < nvis; r0 += STAGE_ROWS) {
+				const int count = (nvis - r0) < STAGE_ROWS ? (nvis - r0) : STAGE_ROWS;
+				wave_load_listed_rows(reinterpret_cast<const float4*>(p.shs), wave_first, nf4, r0, count, s_rows[w], s_list[w]);
+				if (vis && rank >= r0 && rank < r0 + count) sh_row_to_rgb(s_rows[w][rank - r0], ncoef, d, rgb);
+				wave_fence();  // the next pass overwrites the slice
 			}
 		} else if (vis) {
 			const float* sh = p.shs + (size_t)idx * p.M * 3;
 #pragma unroll
-			for (int i = 0; i < 48; i++)
-				if (i < nfl) c[i] = sh[i];
+			for (int k = 0; k < 16; k++) {
+				if (k < ncoef) {
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) {
+						const float t = sh_basis(k, d) * sh[3 * k + ch];
+						rgb[ch] = (k == 0) ? t : rgb[ch] + t;
+					}
+				}
+			}
 		}
 		if (vis) {
-			float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
-			const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-			dx = dx / len;
-			dy = dy / len;
-			dz = dz / len;
-			cr = sh_channel(c, 0, p.D, dx, dy, dz);
-			cg = sh_channel(c, 1, p.D, dx, dy, dz);
-			cb = sh_channel(c, 2, p.D, dx, dy, dz);
+			cr = rgb[0] + 0.5f;
+			cg = rgb[1] + 0.5f;
+			cb = rgb[2] + 0.5f;
 			clamp_bits = (uint8_t)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
 			cr = fmaxf(cr, 0.0f);
 			cg = fmaxf(cg, 0.0f);

@@ -1,15 +1,21 @@
-// preprocess_bwd.hip -- per-Gaussian backward stage, one fused kernel.
+// preprocess_bwd.hip -- per-Gaussian backward stage.
 //
-// Fuses computeCov2DCUDA (cuda_rasterizer/backward.cu:144-274) and the backward
-// preprocessCUDA (backward.cu:346-396, with the SH backward :20-139 and the cov3D backward
-// :278-341) into one pass over the Gaussians, so dL_dcov3D and the partial dL_dmean3D never
-// round-trip through HBM between two launches, and writes EVERY output element (zeros for
-// culled Gaussians) so the caller does not need the reference's torch::zeros pass
-// (src/rasterize_points.cu:149-157, 300 B/Gaussian).
+// Two kernels for the reference model's layout (48-float, 16-byte aligned SH rows):
+//   * sh_bwd_rows_kernel: the SH backward (cuda_rasterizer/backward.cu:20-139).  Rows move through LDS
+//     (shrows.h); it writes dL_dsh for EVERY Gaussian (zeros for culled ones) and parks the
+//     view-direction term of dL_dmean3D in that output array;
+//   * preprocess_bwd_kernel: computeCov2DCUDA (backward.cu:144-274) fused with the projection and
+//     cov3D backward of preprocessCUDA (backward.cu:346-396, :278-341), so dL_dcov3D and the partial
+//     dL_dmean3D never round-trip through HBM; it adds the parked SH term last (the reference's order)
+//     and writes every remaining output element, so the caller does not need the reference's
+//     torch::zeros pass (src/rasterize_points.cu:149-157, 300 B/Gaussian).
+// They were one kernel until its 140+ VGPRs capped it at three waves per SIMD; both halves are
+// latency-bound (measured: time ~ 1/occupancy), and apart they run at 6-8 waves.  Other SH layouts take the
+// fused instantiation with per-lane row access.
 //
-// HBM per Gaussian: culled: 4 read (radius) + (55+3M)*4 written zeros; visible: reads mean 12,
-// cov3D 24, conic grad 16, mean2D grad 12, colour grad 12, SH 12K, scale 12, rot 16, clamp 1;
-// writes mean3D 12, cov3D 24, SH 12M, scale 12, rot 16.
+// HBM per Gaussian: culled: 4 read (radius) + (55+3M)*4 written zeros; visible: reads mean 12 (x2),
+// cov3D 24, conic grad 16, mean2D grad 12, colour grad 12 (x2), SH 12K, scale 12, rot 16, clamp 1;
+// writes mean3D 12 (+12 parked and re-read), cov3D 24, SH 12M, scale 12, rot 16.
 #include "state.h"
 #include "wave64.h"
 #include "kernels.h"
@@ -18,39 +24,106 @@
 namespace gsr {
 
 
-__device__ static const float BSH_C0 = 0.28209479177387814f;
-__device__ static const float BSH_C1 = 0.4886025119029199f;
-__device__ static const float BSH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                          -1.0925484305920792f, 0.5462742152960396f};
-__device__ static const float BSH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                          -0.5900435899266435f};
-
 #ifdef GSR_EXP_NO_SMALL_STORES   // traffic experiment: drop every output but dL_dsh
 #define GSR_SMALL_STORE(x) for (int i_ = 0; i_ < 0; i_++) {}
 #else
 #define GSR_SMALL_STORE(x) x
 #endif
-constexpr int PRB_THREADS = 128;   // 2 waves x 13 KiB of row staging per workgroup
+constexpr int PRB_THREADS = 128;
+constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per workgroup
 
-__global__ void __launch_bounds__(PRB_THREADS)
-preprocess_bwd_kernel(const PreprocessBwdParams p)
+// SH backward for aligned 48-float rows; DEG = active SH degree.
+template <int DEG>
+__global__ void __launch_bounds__(SHB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs (3 dwords of scratch at degree 3)
+sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
-	__shared__ float4 s_rows[PRB_THREADS / 64][64][ROW_F4_PAD];
-	__shared__ uint32_t s_list[PRB_THREADS / 64][64];
+	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
+	__shared__ uint32_t s_list[SHB_THREADS / 64][STAGE_ROWS];
 #ifdef GSR_EXP_LDS_PAD   // occupancy experiment
 	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
 	if (p.P < 0) s_pad[threadIdx.x] = 1, p.dL_dopacity[0] = (float)s_pad[threadIdx.x ^ 1];
 #endif
-
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
 	const bool in_range = idx < p.P;
 	const bool vis = in_range && (p.radii[idx] > 0);
+	constexpr int ncoef = (DEG + 1) * (DEG + 1);
+	float dRGB[3] = {0.f, 0.f, 0.f};
+	float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};  // dRGBdx/dy/dz
+	float ox = 0.f, oy = 0.f, oz = 1.f;
+	if (vis) {
+		ox = p.means3D[3 * (size_t)idx] - p.campos[0];
+		oy = p.means3D[3 * (size_t)idx + 1] - p.campos[1];
+		oz = p.means3D[3 * (size_t)idx + 2] - p.campos[2];
+		const float4 ga0 = reinterpret_cast<const float4*>(p.grad_acc)[3 * (size_t)idx];   // colour gradient in x, y, z
+		const uint8_t cl = p.clamped[idx];
+		dRGB[0] = ga0.x * ((cl & 1) ? 0.f : 1.f);
+		dRGB[1] = ga0.y * ((cl & 2) ? 0.f : 1.f);
+		dRGB[2] = ga0.z * ((cl & 4) ? 0.f : 1.f);
+	}
+	// The wave handles its 64 rows in two halves of STAGE_ROWS: the SH rows of the half's visible lanes are fetched
+	// by the whole wave into LDS, each owner turns its row into the gradient row IN PLACE (zeros for culled
+	// Gaussians) while accumulating dRGB/d(direction), and the half leaves as one contiguous 6 KiB burst.
+	{
+		{
+			const int nf4 = (3 * ncoef + 3) >> 2;
+#pragma unroll 1
+			for (int h = 0; h < 64 / STAGE_ROWS; h++) {
+				const size_t half_first = wave_first + (size_t)(h * STAGE_ROWS);
+				const long long left = (long long)p.P - (long long)half_first;
+				if (left <= 0) break;   // wave-uniform
+				const bool mine = (l / STAGE_ROWS) == h;
+				const unsigned long long m = wave_ballot(vis && mine);
+				if (vis && mine) s_list[w][__popcll(m & lanemask_lt())] = (uint32_t)(l % STAGE_ROWS);
+				wave_fence();
+				wave_load_listed_rows<true>(reinterpret_cast<const float4*>(p.shs), half_first, nf4, 0, __popcll(m), s_rows[w], s_list[w]);
+				if (mine && in_range) {
+					float4* row = s_rows[w][l % STAGE_ROWS];
+					if (vis) {
+						// the direction is made opaque per pass: otherwise the ~50 basis / derivative factors are hoisted out
+						// of the loop as invariants and stay live across it
+						float ux = ox, uy = oy, uz = oz;
+						GSR_OPAQUE_F32(ux);
+						GSR_OPAQUE_F32(uy);
+						GSR_OPAQUE_F32(uz);
+						const float len = sqrtf(ux * ux + uy * uy + uz * uz);
+						const ShDir d = sh_dir(ux / len, uy / len, uz / len);
+						sh_row_backward(row, ncoef, d, dRGB, ddx, ddy, ddz);
+					} else {
+#pragma unroll
+						for (int i = 0; i < ROW_F4; i++) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+					}
+				}
+				wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+			}
+		}
+	}
+	if (vis) {
+		const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+		const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+		const float dLz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+		// dnormvdv, auxiliary.h:107-117; parked in dL_dmean3D, preprocess_bwd_kernel adds the covariance and projection terms
+		const float sum2 = ox * ox + oy * oy + oz * oz;
+		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+		p.dL_dmean3D[3 * (size_t)idx + 0] = ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
+		p.dL_dmean3D[3 * (size_t)idx + 1] = (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
+		p.dL_dmean3D[3 * (size_t)idx + 2] = (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+	}
+}
+
+// ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel has
+// run and parked its dL_dmean3D term; otherwise the SH backward happens here with per-lane scalar row access.
+template <bool ROWS_OK>
+__global__ void __launch_bounds__(PRB_THREADS)
+preprocess_bwd_kernel(const PreprocessBwdParams p)
+{
+
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const bool in_range = idx < p.P;
+	const bool vis = in_range && (p.radii[idx] > 0);
 	const int M3 = 3 * p.M;
-	const bool rows_ok = p.dL_dsh && (M3 == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0) &&
-	                     ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
+	constexpr bool rows_ok = ROWS_OK;
 	float* out_sh = (p.dL_dsh && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
 	if (in_range && !vis) {
@@ -85,13 +158,67 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		mx = p.means3D[3 * (size_t)idx];
 		my = p.means3D[3 * (size_t)idx + 1];
 		mz = p.means3D[3 * (size_t)idx + 2];
+		ga0 = reinterpret_cast<const float4*>(p.grad_acc)[3 * (size_t)idx];   // colour gradient (x, y, z), mean2D.x (w)
+	}
+	float shx = 0.f, shy = 0.f, shz = 0.f;   // d(loss)/d(mean) through the view direction of the SH colour
+
+	// ------------------------------------------------------------------ SH backward, backward.cu:20-139
+	if (p.shs) {   // wave-uniform
+		if (rows_ok) {
+			if (vis) {   // computed and parked by sh_bwd_rows_kernel
+				shx = p.dL_dmean3D[3 * (size_t)idx + 0];
+				shy = p.dL_dmean3D[3 * (size_t)idx + 1];
+				shz = p.dL_dmean3D[3 * (size_t)idx + 2];
+			}
+		} else {
+			const int ncoef = (p.D + 1) * (p.D + 1);
+			float dRGB[3] = {0.f, 0.f, 0.f};
+			float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};  // dRGBdx/dy/dz
+			if (vis) {
+				const float ox = mx - p.campos[0], oy = my - p.campos[1], oz = mz - p.campos[2];
+				const uint8_t cl = p.clamped[idx];
+				dRGB[0] = ga0.x * ((cl & 1) ? 0.f : 1.f);
+				dRGB[1] = ga0.y * ((cl & 2) ? 0.f : 1.f);
+				dRGB[2] = ga0.z * ((cl & 4) ? 0.f : 1.f);
+				const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+				const ShDir d = sh_dir(ox / len, oy / len, oz / len);
+				const float* shrow = p.shs + (size_t)idx * M3;
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					if (k < ncoef && k < p.M) {
+						float gx, gy, gz;
+						const int nz = sh_basis_grad(k, d, gx, gy, gz);
+#pragma unroll
+						for (int ch = 0; ch < 3; ch++) {
+							const float v = shrow[3 * k + ch];
+							out_sh[3 * k + ch] = sh_basis(k, d) * dRGB[ch];
+							if (nz & 1) ddx[ch] += gx * v;
+							if (nz & 2) ddy[ch] += gy * v;
+							if (nz & 4) ddz[ch] += gz * v;
+						}
+					}
+				}
+				for (int i = 3 * (ncoef < p.M ? ncoef : p.M); i < M3; i++) out_sh[i] = 0.f;   // keep the row fully written
+				const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+				const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+				const float dLz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+				// dnormvdv, auxiliary.h:107-117
+				const float sum2 = ox * ox + oy * oy + oz * oz;
+				const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+				shx = ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
+				shy = (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
+				shz = (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+			}
+		}
+	}
+
+	if (vis) {
 		// ------------------------------------------------------------------ computeCov2DCUDA, backward.cu:144-274
 		float c3[6];
 #pragma unroll
 		for (int i = 0; i < 6; i++) c3[i] = p.cov3D[6 * (size_t)idx + i];
 		// blend-stage gradients of this Gaussian (colour 0..2, mean2D 3..4, conic 5..7, opacity 8)
 		const float4* ga = reinterpret_cast<const float4*>(p.grad_acc) + 3 * (size_t)idx;
-		ga0 = ga[0];
 		const float4 ga1 = ga[1];
 		const float ga2x = ga[2].x;
 		const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
@@ -188,121 +315,9 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		}
 	}
 
-	// ------------------------------------------------------------------ SH backward, backward.cu:20-139
-	if (p.shs) {   // wave-uniform
-		const int deg = p.D;
-		const int nfl = 3 * (deg + 1) * (deg + 1);
-		float sh[48];
-		if (rows_ok) {
-			wave_load_rows(reinterpret_cast<const float4*>(p.shs), wave_first, (nfl + 3) >> 2, vis, s_rows[w], s_list[w]);
-			if (vis) {
-#pragma unroll
-				for (int i = 0; i < 12; i++)
-					if (4 * i < nfl) {
-						const float4 v = s_rows[w][l][i];
-						sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-					}
-			}
-			wave_fence();  // rows are re-used for the gradient below
-		} else if (vis) {
-			const float* shrow = p.shs + (size_t)idx * M3;
-#pragma unroll
-			for (int i = 0; i < 48; i++)
-				if (i < nfl) sh[i] = shrow[i];
-		}
-		float dsh[48];
-#pragma unroll
-		for (int i = 0; i < 48; i++) dsh[i] = 0.f;
-		if (vis) {
-			const float ox = mx - p.campos[0], oy = my - p.campos[1], oz = mz - p.campos[2];
-			const float len = sqrtf(ox * ox + oy * oy + oz * oz);
-			const float x = ox / len, y = oy / len, z = oz / len;
-			const uint8_t cl = p.clamped[idx];
-			float dRGB[3] = {ga0.x, ga0.y, ga0.z};
-			dRGB[0] *= (cl & 1) ? 0.f : 1.f;
-			dRGB[1] *= (cl & 2) ? 0.f : 1.f;
-			dRGB[2] *= (cl & 4) ? 0.f : 1.f;
-			float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};  // dRGBdx/dy/dz
-#define SHK(k) sh[3 * (k) + ch]
-#define DSH(k, val)                                                 \
-	{                                                               \
-		const float t_ = (val);                                     \
-		dsh[3 * (k)] = t_ * dRGB[0];                                \
-		dsh[3 * (k) + 1] = t_ * dRGB[1];                            \
-		dsh[3 * (k) + 2] = t_ * dRGB[2];                            \
-	}
-			DSH(0, BSH_C0);
-			if (deg > 0) {
-				DSH(1, -BSH_C1 * y);
-				DSH(2, BSH_C1 * z);
-				DSH(3, -BSH_C1 * x);
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) {
-					ddx[ch] = -BSH_C1 * SHK(3);
-					ddy[ch] = -BSH_C1 * SHK(1);
-					ddz[ch] = BSH_C1 * SHK(2);
-				}
-				if (deg > 1) {
-					const float xx = x * x, yy = y * y, zz = z * z;
-					const float xy = x * y, yz = y * z, xz = x * z;
-					DSH(4, BSH_C2[0] * xy);
-					DSH(5, BSH_C2[1] * yz);
-					DSH(6, BSH_C2[2] * (2.f * zz - xx - yy));
-					DSH(7, BSH_C2[3] * xz);
-					DSH(8, BSH_C2[4] * (xx - yy));
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) {
-						ddx[ch] += BSH_C2[0] * y * SHK(4) + BSH_C2[2] * 2.f * -x * SHK(6) + BSH_C2[3] * z * SHK(7) + BSH_C2[4] * 2.f * x * SHK(8);
-						ddy[ch] += BSH_C2[0] * x * SHK(4) + BSH_C2[1] * z * SHK(5) + BSH_C2[2] * 2.f * -y * SHK(6) + BSH_C2[4] * 2.f * -y * SHK(8);
-						ddz[ch] += BSH_C2[1] * y * SHK(5) + BSH_C2[2] * 2.f * 2.f * z * SHK(6) + BSH_C2[3] * x * SHK(7);
-					}
-					if (deg > 2) {
-						DSH(9, BSH_C3[0] * y * (3.f * xx - yy));
-						DSH(10, BSH_C3[1] * xy * z);
-						DSH(11, BSH_C3[2] * y * (4.f * zz - xx - yy));
-						DSH(12, BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-						DSH(13, BSH_C3[4] * x * (4.f * zz - xx - yy));
-						DSH(14, BSH_C3[5] * z * (xx - yy));
-						DSH(15, BSH_C3[6] * x * (xx - 3.f * yy));
-#pragma unroll
-						for (int ch = 0; ch < 3; ch++) {
-							ddx[ch] += (BSH_C3[0] * SHK(9) * 3.f * 2.f * xy + BSH_C3[1] * SHK(10) * yz + BSH_C3[2] * SHK(11) * -2.f * xy +
-							            BSH_C3[3] * SHK(12) * -3.f * 2.f * xz + BSH_C3[4] * SHK(13) * (-3.f * xx + 4.f * zz - yy) +
-							            BSH_C3[5] * SHK(14) * 2.f * xz + BSH_C3[6] * SHK(15) * 3.f * (xx - yy));
-							ddy[ch] += (BSH_C3[0] * SHK(9) * 3.f * (xx - yy) + BSH_C3[1] * SHK(10) * xz +
-							            BSH_C3[2] * SHK(11) * (-3.f * yy + 4.f * zz - xx) + BSH_C3[3] * SHK(12) * -3.f * 2.f * yz +
-							            BSH_C3[4] * SHK(13) * -2.f * xy + BSH_C3[5] * SHK(14) * -2.f * yz +
-							            BSH_C3[6] * SHK(15) * -3.f * 2.f * xy);
-							ddz[ch] += (BSH_C3[1] * SHK(10) * xy + BSH_C3[2] * SHK(11) * 4.f * 2.f * yz +
-							            BSH_C3[3] * SHK(12) * 3.f * (2.f * zz - xx - yy) + BSH_C3[4] * SHK(13) * 4.f * 2.f * xz +
-							            BSH_C3[5] * SHK(14) * (xx - yy));
-						}
-					}
-				}
-			}
-#undef SHK
-#undef DSH
-			const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
-			const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
-			const float dLz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
-			// dnormvdv, auxiliary.h:107-117
-			const float sum2 = ox * ox + oy * oy + oz * oz;
-			const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-			gmx += ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
-			gmy += (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
-			gmz += (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
-		}
-		// the gradient rows (zeros for culled Gaussians) leave the wave as one contiguous 12 KiB burst
-		if (rows_ok) {
-#pragma unroll
-			for (int i = 0; i < 12; i++) s_rows[w][l][i] = make_float4(dsh[4 * i], dsh[4 * i + 1], dsh[4 * i + 2], dsh[4 * i + 3]);
-			const long long left = (long long)p.P - (long long)wave_first;
-			wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), wave_first, (int)(left > 64 ? 64 : (left < 0 ? 0 : left)), s_rows[w]);
-		} else if (vis) {
-			for (int i = 0; i < (M3 < 48 ? M3 : 48); i++) out_sh[i] = dsh[i];
-			for (int i = 48; i < M3; i++) out_sh[i] = 0.f;  // M > 16 is not produced by the reference model; keep the row fully written
-		}
-	}
+	gmx += shx;   // same order as the reference: covariance, projection, then the SH direction term
+	gmy += shy;
+	gmz += shz;
 	if (!vis) return;
 	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 0] = gmx);
 	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 1] = gmy);
@@ -378,7 +393,24 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(preprocess_bwd_kernel, div_up(p.P, PRB_THREADS), PRB_THREADS, stream, p);
+	const bool rows_ok = p.dL_dsh && p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0) &&
+	                     ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
+	const int grid = div_up(p.P, PRB_THREADS);
+	if (rows_ok && p.D >= 0 && p.D <= 3) {
+		const int g = div_up(p.P, SHB_THREADS);
+		if (p.D == 3)
+			GSR_LAUNCH(sh_bwd_rows_kernel<3>, g, SHB_THREADS, stream, p);
+		else if (p.D == 2)
+			GSR_LAUNCH(sh_bwd_rows_kernel<2>, g, SHB_THREADS, stream, p);
+		else if (p.D == 1)
+			GSR_LAUNCH(sh_bwd_rows_kernel<1>, g, SHB_THREADS, stream, p);
+		else
+			GSR_LAUNCH(sh_bwd_rows_kernel<0>, g, SHB_THREADS, stream, p);
+		GSR_CHECK_LAUNCH();
+		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
+	} else {
+		GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
+	}
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -1,14 +1,22 @@
 // shrows.h -- coalesced access to per-Gaussian rows of 16-byte vectors (SH coefficients and their
-// gradients: 48 floats = 192 bytes per Gaussian at degree 3).
+// gradients: 48 floats = 192 bytes per Gaussian at degree 3), and the SH basis shared by the forward and
+// backward per-Gaussian kernels.
 //
 // One thread per Gaussian reading "its" 192-byte row issues 12 loads whose 64 lanes hit 64
 // different cache lines each; with ~20 waves per CU the 12 KiB-per-wave footprint thrashes the
 // 32 KiB L1 and lines are re-fetched from L2 (measured: 0.9 TB/s effective in preprocess_fwd).
 // Here the wave moves whole rows instead: consecutive lanes move consecutive 16-byte pieces of
-// the same row (5 rows of 12 vectors per wave instruction), through a per-wave LDS slice whose
+// the same row (4 rows of 12 vectors per wave instruction), through a per-wave LDS slice whose
 // rows are padded to 13 vectors so that both the row-wise fill and the lane-wise drain are
 // bank-conflict free.  Only the rows of lanes that want them are touched (culled Gaussians cost
 // no SH traffic in the forward pass).
+//
+// The slice holds STAGE_ROWS = 32 rows (6.5 KiB per wave), not 64: both kernels are latency-bound and their
+// occupancy is set by LDS (measured: halving the resident waves doubles their time), so a wave stages its rows
+// in passes of 32 and the owner lanes stream them out of LDS one 16-byte vector at a time -- the 48 coefficients
+// never sit in registers together.  (The two translation units that include this file are built with
+// -fno-slp-vectorize: the SLP vectoriser pairs the per-coefficient products of different coefficients into
+// v_pk_mul_f32 and thereby keeps a whole row live -- 138 instead of 80 VGPRs in the SH backward.)
 #pragma once
 #include "state.h"
 #include "wave64.h"
@@ -17,43 +25,168 @@ namespace gsr {
 
 constexpr int ROW_F4 = 12;        // 48 floats
 constexpr int ROW_F4_PAD = 13;    // LDS row pitch in float4
+constexpr int STAGE_ROWS = 32;    // rows staged per pass
 
-// Fill s_rows[lane][0..nf4) with the first nf4 vectors of row (first_row + lane) for every lane with
-// `want`.  gbase points at row 0; row pitch is ROW_F4 vectors.  s_list is a 64-entry scratch.
-__device__ __forceinline__ void wave_load_rows(const float4* __restrict__ gbase, size_t first_row, int nf4, bool want,
-                                               float4 (*s_rows)[ROW_F4_PAD], uint32_t* s_list)
+// Both movers give 16 lanes to a row (12 of them active at degree 3): four rows per wave instruction, and every index
+// is a shift or a compile-time offset -- the 5-rows-per-instruction packing needed divisions by 12 whose results
+// (one set per unrolled step) stayed live across the callers' loops and cost ~40 VGPRs.
+//
+// Fill s_rows[j][0..nf4) for j = 0 .. count-1 with the first nf4 vectors of row (first_row + s_list[list_first + j])
+// (BY_SOURCE: the row lands in s_rows[s_list[..]] instead, i.e. at its owner's position).
+// gbase points at row 0; row pitch is ROW_F4 vectors.  count <= STAGE_ROWS.  Wave-uniform arguments.
+template <bool BY_SOURCE = false>
+__device__ __forceinline__ void wave_load_listed_rows(const float4* __restrict__ gbase, size_t first_row, int nf4, int list_first,
+                                                      int count, float4 (*s_rows)[ROW_F4_PAD], const uint32_t* s_list)
 {
 	const int l = lane_id();
-	const unsigned long long mask = wave_ballot(want);
-	const int nvis = __popcll(mask);
-	if (nvis == 0) return;  // wave-uniform
-	if (want) s_list[__popcll(mask & lanemask_lt())] = (uint32_t)l;
-	wave_fence();
-	const int per = 64 / nf4;          // rows per wave instruction
-	const int slot = l / nf4, col = l - slot * nf4;
-	for (int it = 0; it * per < nvis; it++) {
-		const int r = it * per + slot;
-		if (slot < per && r < nvis) {
-			const uint32_t src = s_list[r];
-			s_rows[src][col] = gbase[(first_row + src) * ROW_F4 + col];
+	const int slot = l >> 4, col = l & 15;
+	for (int j0 = 0; j0 < count; j0 += 4) {
+		const int j = j0 + slot;
+		if (col < nf4 && j < count) {
+			const uint32_t src = s_list[list_first + j];
+			s_rows[BY_SOURCE ? (int)src : j][col] = gbase[(first_row + src) * ROW_F4 + col];
 		}
 	}
 	wave_fence();
 }
 
-// Write rows [first_row, first_row + nrows) (nrows <= 64) from s_rows to global, fully coalesced.
+// Write rows [first_row, first_row + nrows) (nrows <= STAGE_ROWS) from s_rows to global: each instruction writes four
+// whole rows = 768 contiguous bytes.
 __device__ __forceinline__ void wave_store_rows(float4* __restrict__ gbase, size_t first_row, int nrows,
                                                 float4 (*s_rows)[ROW_F4_PAD])
 {
 	const int l = lane_id();
+	const int slot = l >> 4, col = l & 15;
 	wave_fence();
+	float4* dst = gbase + (first_row + slot) * ROW_F4 + col;
+	const float4* src = &s_rows[slot][col];
 #pragma unroll
-	for (int k = 0; k < ROW_F4; k++) {
-		const int i = l + 64 * k;
-		const int row = i / ROW_F4, col = i - row * ROW_F4;
-		if (row < nrows) gbase[first_row * ROW_F4 + i] = s_rows[row][col];
+	for (int k = 0; k < STAGE_ROWS / 4; k++) {
+		if (col < ROW_F4 && 4 * k + slot < nrows) dst[4 * k * ROW_F4] = src[4 * k * ROW_F4_PAD];
 	}
 	wave_fence();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SH basis, cuda_rasterizer/auxiliary.h:22-39 + forward.cu:20-71 / backward.cu:20-139.
+__device__ static const float SHB_C0 = 0.28209479177387814f;
+__device__ static const float SHB_C1 = 0.4886025119029199f;
+__device__ static const float SHB_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SHB_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+struct ShDir {
+	float x, y, z, xx, yy, zz, xy, yz, xz;
+};
+__device__ __forceinline__ ShDir sh_dir(float x, float y, float z)
+{
+	ShDir d;
+	d.x = x; d.y = y; d.z = z;
+	d.xx = x * x; d.yy = y * y; d.zz = z * z;
+	d.xy = x * y; d.yz = y * z; d.xz = x * z;
+	return d;
+}
+
+// Basis value of coefficient k, written with the operand order of the reference so that (basis * sh) summed in
+// coefficient order reproduces computeColorFromSH bit for bit under -ffp-contract=off (the signs of degree 1 are
+// folded into the basis: (-a)*b == -(a*b) and r + (-t) == r - t exactly).  k is a compile-time constant after
+// unrolling.
+__device__ __forceinline__ float sh_basis(int k, const ShDir& d)
+{
+	switch (k) {
+	case 0: return SHB_C0;
+	case 1: return -SHB_C1 * d.y;
+	case 2: return SHB_C1 * d.z;
+	case 3: return -SHB_C1 * d.x;
+	case 4: return SHB_C2[0] * d.xy;
+	case 5: return SHB_C2[1] * d.yz;
+	case 6: return SHB_C2[2] * (2.0f * d.zz - d.xx - d.yy);
+	case 7: return SHB_C2[3] * d.xz;
+	case 8: return SHB_C2[4] * (d.xx - d.yy);
+	case 9: return SHB_C3[0] * d.y * (3.0f * d.xx - d.yy);
+	case 10: return SHB_C3[1] * d.xy * d.z;
+	case 11: return SHB_C3[2] * d.y * (4.0f * d.zz - d.xx - d.yy);
+	case 12: return SHB_C3[3] * d.z * (2.0f * d.zz - 3.0f * d.xx - 3.0f * d.yy);
+	case 13: return SHB_C3[4] * d.x * (4.0f * d.zz - d.xx - d.yy);
+	case 14: return SHB_C3[5] * d.z * (d.xx - d.yy);
+	default: return SHB_C3[6] * d.x * (d.xx - 3.0f * d.yy);
+	}
+}
+
+// d(basis k)/d(x, y, z) of the unit direction, backward.cu:63-127 (the factors that multiply sh[k] in dRGBdx/dy/dz).
+// Returns which of the three are non-zero (bit 0: x, 1: y, 2: z) so that the caller adds nothing for the others.
+__device__ __forceinline__ int sh_basis_grad(int k, const ShDir& d, float& gx, float& gy, float& gz)
+{
+	gx = gy = gz = 0.f;
+	switch (k) {
+	case 0: return 0;
+	case 1: gy = -SHB_C1; return 2;
+	case 2: gz = SHB_C1; return 4;
+	case 3: gx = -SHB_C1; return 1;
+	case 4: gx = SHB_C2[0] * d.y; gy = SHB_C2[0] * d.x; return 3;
+	case 5: gy = SHB_C2[1] * d.z; gz = SHB_C2[1] * d.y; return 6;
+	case 6: gx = SHB_C2[2] * 2.f * -d.x; gy = SHB_C2[2] * 2.f * -d.y; gz = SHB_C2[2] * 2.f * 2.f * d.z; return 7;
+	case 7: gx = SHB_C2[3] * d.z; gz = SHB_C2[3] * d.x; return 5;
+	case 8: gx = SHB_C2[4] * 2.f * d.x; gy = SHB_C2[4] * 2.f * -d.y; return 3;
+	case 9: gx = SHB_C3[0] * 3.f * 2.f * d.xy; gy = SHB_C3[0] * 3.f * (d.xx - d.yy); return 3;
+	case 10: gx = SHB_C3[1] * d.yz; gy = SHB_C3[1] * d.xz; gz = SHB_C3[1] * d.xy; return 7;
+	case 11: gx = SHB_C3[2] * -2.f * d.xy; gy = SHB_C3[2] * (-3.f * d.yy + 4.f * d.zz - d.xx); gz = SHB_C3[2] * 4.f * 2.f * d.yz; return 7;
+	case 12: gx = SHB_C3[3] * -3.f * 2.f * d.xz; gy = SHB_C3[3] * -3.f * 2.f * d.yz; gz = SHB_C3[3] * 3.f * (2.f * d.zz - d.xx - d.yy); return 7;
+	case 13: gx = SHB_C3[4] * (-3.f * d.xx + 4.f * d.zz - d.yy); gy = SHB_C3[4] * -2.f * d.xy; gz = SHB_C3[4] * 4.f * 2.f * d.xz; return 7;
+	case 14: gx = SHB_C3[5] * 2.f * d.xz; gy = SHB_C3[5] * -2.f * d.yz; gz = SHB_C3[5] * (d.xx - d.yy); return 7;
+	default: gx = SHB_C3[6] * 3.f * (d.xx - d.yy); gy = SHB_C3[6] * -3.f * 2.f * d.xy; return 3;
+	}
+}
+
+// computeColorFromSH before the +0.5 / clamp: streams the row one vector at a time (ncoef = (deg+1)^2, wave-uniform).
+__device__ __forceinline__ void sh_row_to_rgb(const float4* row, int ncoef, const ShDir& d, float (&rgb)[3])
+{
+	rgb[0] = rgb[1] = rgb[2] = 0.f;
+#pragma unroll
+	for (int i = 0; i < ROW_F4; i++) {
+		if ((4 * i) / 3 < ncoef) {
+			const float4 v = row[i];
+			const float in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int j = 4 * i + c, k = j / 3, ch = j - 3 * k;
+				if (k < ncoef) {
+					const float t = sh_basis(k, d) * in[c];
+					rgb[ch] = (k == 0) ? t : rgb[ch] + t;
+				}
+			}
+		}
+	}
+}
+
+// SH backward in place: the row holds sh on entry and dL_dsh = basis * dRGB on exit (zeros beyond ncoef);
+// dd{x,y,z}[ch] accumulate dRGB/d(direction).
+__device__ __forceinline__ void sh_row_backward(float4* row, int ncoef, const ShDir& d, const float (&dRGB)[3], float (&ddx)[3],
+                                                float (&ddy)[3], float (&ddz)[3])
+{
+#pragma unroll
+	for (int i = 0; i < ROW_F4; i++) {
+		float out[4] = {0.f, 0.f, 0.f, 0.f};
+		if ((4 * i) / 3 < ncoef) {
+			const float4 v = row[i];
+			const float in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int j = 4 * i + c, k = j / 3, ch = j - 3 * k;
+				if (k < ncoef) {
+					out[c] = sh_basis(k, d) * dRGB[ch];
+					float gx, gy, gz;
+					const int nz = sh_basis_grad(k, d, gx, gy, gz);
+					if (nz & 1) ddx[ch] += gx * in[c];
+					if (nz & 2) ddy[ch] += gy * in[c];
+					if (nz & 4) ddz[ch] += gz * in[c];
+				}
+			}
+		}
+		row[i] = make_float4(out[0], out[1], out[2], out[3]);
+	}
 }
 
 }  // namespace gsr

@@ -30,6 +30,8 @@ using ::hipemu::wave_swap9_component;
 using ::hipemu::mask_select_f32;
 using ::hipemu::mask_select_u32;
 using ::hipemu::mask_select0_f32;
+#define GSR_OPAQUE_F32(x) asm volatile("" : "+x"(x))
+#define GSR_SCHED_BARRIER() ((void)0)
 #else
 
 // Broadcast lane `lane`'s value to the whole wave through an SGPR (v_readlane_b32): the value
@@ -79,6 +81,15 @@ __device__ __forceinline__ float mask_select0_f32(unsigned long long mask, float
 	asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
 	return r;
 }
+
+// Make a value opaque to the optimiser (no instruction): stops loop-invariant hoisting of everything computed from it.
+#define GSR_OPAQUE_F32(x) asm volatile("" : "+v"(x))
+// No memory access may be moved across this point by the optimiser and no instruction by the machine scheduler.
+#define GSR_SCHED_BARRIER()                \
+	do {                                   \
+		asm volatile("" ::: "memory");     \
+		__builtin_amdgcn_sched_barrier(0); \
+	} while (0)
 
 // Scheduling fence for intra-wave communication through LDS that relies on lock-step
 // execution (lanes read, then a leader lane writes).  The hardware issues a wave's LDS
