@@ -24,11 +24,6 @@
 namespace gsr {
 
 
-#ifdef GSR_EXP_NO_SMALL_STORES   // traffic experiment: drop every output but dL_dsh
-#define GSR_SMALL_STORE(x) for (int i_ = 0; i_ < 0; i_++) {}
-#else
-#define GSR_SMALL_STORE(x) x
-#endif
 constexpr int PRB_THREADS = 128;
 constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per workgroup
 
@@ -126,39 +121,45 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	constexpr bool rows_ok = ROWS_OK;
 	float* out_sh = (p.dL_dsh && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
-	if (in_range && !vis) {
-		// culled: the reference leaves the torch::zeros content
-#pragma unroll
-		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dmean2D[3 * (size_t)idx + i] = 0.f);
-#pragma unroll
-		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dcolor[3 * (size_t)idx + i] = 0.f);
-		GSR_SMALL_STORE(p.dL_dopacity[idx] = 0.f);
-		GSR_SMALL_STORE(if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f));
-#pragma unroll
-		GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dmean3D[3 * (size_t)idx + i] = 0.f);
-#pragma unroll
-		GSR_SMALL_STORE(for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = 0.f);
-		if (out_sh && !rows_ok)
-			for (int i = 0; i < M3; i++) out_sh[i] = 0.f;
-		if (p.dL_dscale) {
-#pragma unroll
-			GSR_SMALL_STORE(for (int i = 0; i < 3; i++) p.dL_dscale[3 * (size_t)idx + i] = 0.f);
-			GSR_SMALL_STORE(reinterpret_cast<float4*>(p.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f));
-		}
-	}
+	// Culled Gaussians take the same store instructions as visible ones, with zeros (the reference leaves the
+	// torch::zeros content): every output leaves the wave as full contiguous lines.  Separate zero / value stores,
+	// each under its own half-empty lane mask, write every line twice partially (measured: 1.6x write traffic).
+	if (!rows_ok && out_sh && !vis)
+		for (int i = 0; i < M3; i++) out_sh[i] = 0.f;
 
 	const float* V = p.view;
 	const float* Pm = p.proj;
 	float mx = 0.f, my = 0.f, mz = 0.f;
 	float gmx = 0.f, gmy = 0.f, gmz = 0.f;
 	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-	float4 ga0 = make_float4(0.f, 0.f, 0.f, 0.f);
+	// blend-stage gradients of this Gaussian (colour 0..2, mean2D 3..4, conic 5..7, opacity 8)
+	float4 ga0 = make_float4(0.f, 0.f, 0.f, 0.f), ga1 = make_float4(0.f, 0.f, 0.f, 0.f);
+	float g_opacity = 0.f;
 
 	if (vis) {
 		mx = p.means3D[3 * (size_t)idx];
 		my = p.means3D[3 * (size_t)idx + 1];
 		mz = p.means3D[3 * (size_t)idx + 2];
-		ga0 = reinterpret_cast<const float4*>(p.grad_acc)[3 * (size_t)idx];   // colour gradient (x, y, z), mean2D.x (w)
+		const float4* ga = reinterpret_cast<const float4*>(p.grad_acc) + 3 * (size_t)idx;
+		ga0 = ga[0];
+		ga1 = ga[1];
+		g_opacity = ga[2].x;
+		// raw logit: d sigmoid = o (1 - o), o = the activated opacity kept in the blend record
+		if (p.raw_params & GSR_RAW_OPACITY) {
+			const float o = p.rec[3 * (size_t)idx + 1].y;
+			g_opacity = g_opacity * o * (1.0f - o);
+		}
+	}
+	const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
+	if (in_range) {
+		p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w;
+		p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x;
+		p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+		p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
+		p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
+		p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
+		p.dL_dopacity[idx] = g_opacity;
+		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
 	}
 	float shx = 0.f, shy = 0.f, shz = 0.f;   // d(loss)/d(mean) through the view direction of the SH colour
 
@@ -217,25 +218,6 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		float c3[6];
 #pragma unroll
 		for (int i = 0; i < 6; i++) c3[i] = p.cov3D[6 * (size_t)idx + i];
-		// blend-stage gradients of this Gaussian (colour 0..2, mean2D 3..4, conic 5..7, opacity 8)
-		const float4* ga = reinterpret_cast<const float4*>(p.grad_acc) + 3 * (size_t)idx;
-		const float4 ga1 = ga[1];
-		const float ga2x = ga[2].x;
-		const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
-		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w);
-		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x);
-		GSR_SMALL_STORE(p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f);
-		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x);
-		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y);
-		GSR_SMALL_STORE(p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z);
-		// raw logit: d sigmoid = o (1 - o), o = the activated opacity kept in the blend record
-		if (p.raw_params & GSR_RAW_OPACITY) {
-			const float o = p.rec[3 * (size_t)idx + 1].y;
-			GSR_SMALL_STORE(p.dL_dopacity[idx] = ga2x * o * (1.0f - o));
-		} else {
-			GSR_SMALL_STORE(p.dL_dopacity[idx] = ga2x);
-		}
-		GSR_SMALL_STORE(if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz));
 		float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 		float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 		const float tz0 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
@@ -277,8 +259,6 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			dcov[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
 			dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
 		}
-#pragma unroll
-		GSR_SMALL_STORE(for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i]);
 
 		const float dL_dT00 = 2 * (T00 * V00 + T01 * V01 + T02 * V02) * dL_da + (T10 * V00 + T11 * V01 + T12 * V02) * dL_db;
 		const float dL_dT01 = 2 * (T00 * V10 + T01 * V11 + T02 * V12) * dL_da + (T10 * V10 + T11 * V11 + T12 * V12) * dL_db;
@@ -318,13 +298,18 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	gmx += shx;   // same order as the reference: covariance, projection, then the SH direction term
 	gmy += shy;
 	gmz += shz;
-	if (!vis) return;
-	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 0] = gmx);
-	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 1] = gmy);
-	GSR_SMALL_STORE(p.dL_dmean3D[3 * (size_t)idx + 2] = gmz);
+	if (in_range) {
+		p.dL_dmean3D[3 * (size_t)idx + 0] = gmx;
+		p.dL_dmean3D[3 * (size_t)idx + 1] = gmy;
+		p.dL_dmean3D[3 * (size_t)idx + 2] = gmz;
+#pragma unroll
+		for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+	}
 
 	// ------------------------------------------------------------------ cov3D backward, backward.cu:278-341
-	if (p.scales) {
+	float g_scale[3] = {0.f, 0.f, 0.f};
+	float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (vis && p.scales) {
 		float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
 		float qn = 1.0f;
 		if (p.raw_params & GSR_RAW_ROTATION) {
@@ -367,13 +352,12 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		const float ds0 = R00 * D00 + R10 * D01 + R20 * D02, ds1 = R01 * D10 + R11 * D11 + R21 * D12,
 		            ds2 = R02 * D20 + R12 * D21 + R22 * D22;
 		const bool raw_s = (p.raw_params & GSR_RAW_SCALING) != 0;
-		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 0] = raw_s ? ds0 * sx : ds0);
-		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 1] = raw_s ? ds1 * sy : ds1);
-		GSR_SMALL_STORE(p.dL_dscale[3 * (size_t)idx + 2] = raw_s ? ds2 * sz : ds2);
+		g_scale[0] = raw_s ? ds0 * sx : ds0;
+		g_scale[1] = raw_s ? ds1 * sy : ds1;
+		g_scale[2] = raw_s ? ds2 * sz : ds2;
 		D00 *= s0; D01 *= s0; D02 *= s0;
 		D10 *= s1; D11 *= s1; D12 *= s1;
 		D20 *= s2; D21 *= s2; D22 *= s2;
-		float4 dq;
 		dq.x = 2 * z * (D01 - D10) + 2 * y * (D20 - D02) + 2 * x * (D12 - D21);
 		dq.y = 2 * y * (D10 + D01) + 2 * z * (D20 + D02) + 2 * r * (D12 - D21) - 4 * x * (D22 + D11);
 		dq.z = 2 * x * (D10 + D01) + 2 * r * (D20 - D02) + 2 * z * (D12 + D21) - 4 * y * (D22 + D00);
@@ -387,7 +371,12 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			dq.z = (dq.z - y * qg) / qn;
 			dq.w = (dq.w - z * qg) / qn;
 		}
-		GSR_SMALL_STORE(reinterpret_cast<float4*>(p.dL_drot)[idx] = dq);
+	}
+	if (in_range && p.dL_dscale) {
+		p.dL_dscale[3 * (size_t)idx + 0] = g_scale[0];
+		p.dL_dscale[3 * (size_t)idx + 1] = g_scale[1];
+		p.dL_dscale[3 * (size_t)idx + 2] = g_scale[2];
+		reinterpret_cast<float4*>(p.dL_drot)[idx] = dq;
 	}
 }
 

@@ -8,8 +8,8 @@ for flags in "$@"; do
   python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/kp/**/*kernel_stats.csv", recursive=True)
-rows = [r for r in csv.DictReader(open(f[0])) if r["Name"].startswith("gsr::")]
+rows = [r for r in csv.DictReader(open(f[0])) if "gsr::" in r["Name"]]
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
-    print(f'{r["Name"].split("(")[0]:40s} calls {int(r["Calls"]):5d}  avg {float(r["AverageNs"])/1e3:9.1f} us  total {float(r["TotalDurationNs"])/1e6:8.2f} ms')
+    print(f'{r["Name"].split("(")[0].replace("void ",""):44s} calls {int(r["Calls"]):5d}  avg {float(r["AverageNs"])/1e3:9.1f} us  total {float(r["TotalDurationNs"])/1e6:8.2f} ms')
 PY
 done
