@@ -15,53 +15,58 @@
 
 namespace gsr {
 
-// One wave emits the instances of 64 depth-consecutive Gaussians, lane-consecutively, so the
-// key/value stores are fully coalesced and a screen-filling splat is spread over all lanes
-// (duplicateWithKeys gives each Gaussian's whole run to one thread).
+// Instance emission, load-balanced over SLOTS (duplicateWithKeys, rasterizer_impl.cu:70-111, gives each Gaussian's
+// whole run to one thread).  Every wave owns EMIT_SLOTS consecutive instance slots, whatever Gaussians they
+// belong to: a 64-ary search over the depth-ordered exclusive offsets (four dependent, fully parallel probes
+// for 2 M Gaussians) finds the Gaussian holding the wave's first slot, the next EMIT_SLOTS + 1 offsets go to LDS
+// (every visible Gaussian owns >= 1 slot, so the window always suffices; culled ones sort to the end with
+// offset == R and are never selected), and each lane locates its slot's Gaussian with an 8-step LDS binary
+// search.  Screen-filling splats near the camera are consecutive in depth order; a per-Gaussian decomposition
+// left a single wave with >100 k instances of them (the kernel's tail was 80 % of its time).
+constexpr int EMIT_SLOTS = 256;
+
 __global__ void __launch_bounds__(256)
-emit_instances_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted_keys,
-                      const uint32_t* __restrict__ offsets,
-                      const uint32_t* __restrict__ tiles_touched, const uint16_t* __restrict__ rect, int grid_x,
-                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float4* __restrict__ rec)
+emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                      const uint16_t* __restrict__ rect, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                      float4* __restrict__ rec)
 {
-	__shared__ uint32_t s_off[4][64];
-	__shared__ uint32_t s_g[4][64];
-	__shared__ uint2 s_rect[4][64];
+	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
 	const int w = wave_id(), l = lane_id();
-	const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	// culled Gaussians sort to the end (key 0xFFFFFFFF) and emit nothing: no gathers for them
-	const bool valid = j < P && sorted_keys[j] != DEPTH_KEY_CULLED;
-	if (wave_ballot(valid) == 0ull) return;  // wave-uniform
-	const uint32_t g = valid ? order[j] : 0u;
-	const uint32_t cnt = valid ? tiles_touched[g] : 0u;
-	const uint32_t off = valid ? offsets[j] : 0u;
-	// slot of the Gaussian's first instance = its emission offset (the backward blend writes its
-	// per-tile gradient partials there, preprocess_bwd sums the contiguous run)
-	if (cnt) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = off;
-	const uint32_t total = wave_sum_u32(cnt);
-	if (total == 0) return;  // wave-uniform
-	// wave base = offset of the first valid lane = min over lanes holding instances; offsets are
-	// monotone in j, invalid lanes sit at the end, so lane 0 always holds the base.
-	const uint32_t base = wave_shfl_u32(off, 0);
-	s_off[w][l] = valid ? off - base : 0xFFFFFFFFu;
-	s_g[w][l] = g;
-	s_rect[w][l] = valid ? reinterpret_cast<const uint2*>(rect)[g] : make_uint2(0u, 0u);
+	const uint32_t s0 = ((uint32_t)blockIdx.x * 4u + (uint32_t)w) * (uint32_t)EMIT_SLOTS;
+	if (s0 >= R) return;   // wave-uniform
+	const uint32_t n = (R - s0) < (uint32_t)EMIT_SLOTS ? (R - s0) : (uint32_t)EMIT_SLOTS;
+	// r0 = last depth rank whose offset is <= s0 (offsets[0] == 0 keeps the invariant offsets[lo] <= s0)
+	uint32_t lo = 0, hi = (uint32_t)P;
+	while (hi - lo > 1u) {
+		const uint32_t step = (hi - lo + 63u) >> 6;
+		const uint32_t probe = lo + (uint32_t)l * step;
+		const bool le = probe < hi && offsets[probe] <= s0;
+		const uint32_t c = (uint32_t)__popcll(wave_ballot(le));   // monotone: lanes 0 .. c-1
+		lo = wave_uniform_u32(lo + (c - 1u) * step);
+		hi = wave_uniform_u32(min(hi, lo + step));
+	}
+	const uint32_t r0 = lo;
+	for (uint32_t i = (uint32_t)l; i <= (uint32_t)EMIT_SLOTS; i += 64u)
+		s_off[w][i] = (i <= n && r0 + i < (uint32_t)P) ? offsets[r0 + i] : 0xFFFFFFFFu;
 	wave_fence();
-	for (uint32_t i = (uint32_t)l; i < total; i += 64u) {
-		// last lane whose (relative, exclusive) offset is <= i; zero-count lanes share their
-		// successor's offset, so "last" skips them.
-		int lo = 0;
+	for (uint32_t i = (uint32_t)l; i < n; i += 64u) {
+		const uint32_t slot = s0 + i;
+		uint32_t j = 0;   // last window entry whose offset is <= slot
 #pragma unroll
-		for (int step = 32; step >= 1; step >>= 1)
-			if (s_off[w][lo + step] <= i) lo += step;
-		const uint32_t k = i - s_off[w][lo];
-		const uint2 r = s_rect[w][lo];
+		for (uint32_t step = EMIT_SLOTS / 2; step >= 1u; step >>= 1)
+			if (s_off[w][j + step] <= slot) j += step;
+		const uint32_t k = slot - s_off[w][j];
+		const uint32_t g = order[r0 + j];
+		const uint2 r = reinterpret_cast<const uint2*>(rect)[g];
 		const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
 		const uint32_t wdt = maxx - minx;
 		const uint32_t yy = k / wdt;
 		const uint32_t xx = k - yy * wdt;
-		keys[base + i] = (miny + yy) * (uint32_t)grid_x + (minx + xx);
-		vals[base + i] = s_g[w][lo];
+		keys[slot] = (miny + yy) * (uint32_t)grid_x + (minx + xx);
+		vals[slot] = g;
+		// slot of the Gaussian's first instance = its emission offset (the backward blend writes its per-tile gradient
+		// partials there, reduce_partials sums the contiguous run)
+		if (k == 0u) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = slot;
 	}
 }
 
@@ -92,7 +97,8 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 // not 3000.
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
-                       const float* __restrict__ partials, float* __restrict__ grad_acc, float half_w, float half_h)
+                       const float* __restrict__ partials, const uint8_t* __restrict__ touched, float* __restrict__ grad_acc,
+                       float half_w, float half_h)
 {
 	const int l = lane_id();
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -105,8 +111,24 @@ reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __
 #pragma unroll
 	for (int c = 0; c < 9; c++) a[c] = 0.f;
 	if (cnt != 0u && cnt <= 64u) {
+		// the run's flags, 16 bytes per load, squeezed to one bit per slot: the loop below then runs once per TOUCHED
+		// slot (~1 in 5) and its loads do not wait for one another (a byte-flag test per slot serialises on memory latency)
+		unsigned long long live = 0ull;
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			if (16u * c < cnt) {
+				uint4 f;
+				__builtin_memcpy(&f, touched + first + 16 * c, 16);   // unaligned 16-byte load
+				const uint32_t bits = (((f.x * 0x01020408u) >> 24) & 0xFu) | ((((f.y * 0x01020408u) >> 24) & 0xFu) << 4) |
+				                      ((((f.z * 0x01020408u) >> 24) & 0xFu) << 8) | ((((f.w * 0x01020408u) >> 24) & 0xFu) << 12);
+				live |= (unsigned long long)bits << (16 * c);
+			}
+		}
+		if (cnt < 64u) live &= (1ull << cnt) - 1ull;
 		const float4* src = part4 + 3 * (size_t)first;
-		for (uint32_t i = 0; i < cnt; i++) {
+		while (live) {
+			const int i = __ffsll((long long)live) - 1;
+			live &= live - 1ull;
 			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
 			const float z = src[3 * (size_t)i + 2].x;
 			a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
@@ -124,6 +146,7 @@ reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __
 		for (int c = 0; c < 9; c++) v[c] = 0.f;
 		const float4* src = part4 + 3 * (size_t)bfirst;
 		for (uint32_t i = (uint32_t)l; i < bcnt; i += 64u) {
+			if (!touched[bfirst + i]) continue;
 			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
 			const float z = src[3 * (size_t)i + 2].x;
 			v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
@@ -148,19 +171,20 @@ reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __
 	}
 }
 
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, int W, int H, hipStream_t stream)
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, const uint8_t* touched, float* grad_acc, int W, int H,
+                           hipStream_t stream)
 {
 	GSR_LAUNCH(reduce_partials_kernel, div_up(P, 256), 256, stream, P, (const float4*)g.rec, (const uint32_t*)g.tiles_touched,
-	           partials, grad_acc, 0.5f * (float)W, 0.5f * (float)H);
+	           partials, touched, grad_acc, 0.5f * (float)W, 0.5f * (float)H);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
 
-int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
+int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
 {
-	GSR_LAUNCH(emit_instances_kernel, div_up(P, 256), 256, stream, P, (const uint32_t*)g.order, (const uint32_t*)g.sort_keys_a,
-	           (const uint32_t*)g.offsets,
-	           (const uint32_t*)g.tiles_touched, (const uint16_t*)g.rect, grid_x, keys, vals, g.rec);
+	if (R <= 0) return GSR_OK;
+	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
+	           (const uint32_t*)g.offsets, (const uint16_t*)g.rect, grid_x, keys, vals, g.rec);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

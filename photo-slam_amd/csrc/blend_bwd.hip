@@ -60,13 +60,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 	}
 	// lanes 0, 8, .., 56 deliver the eight packed totals, lanes 1, 17, 33, 49 the four row sums of the ninth
 	// (wave_reduce9_swap_f32): one ds_add_f32 with twelve active lanes
-#ifdef GSR_BWD_HALVES   // skip the last butterfly level: two lanes per value (twelve -> twenty-four active lanes)
-	const bool red_ninth = (l & 7) == 2;
-	const bool red_lane = ((l & 7) < 2) || red_ninth;
-#else
 	const bool red_ninth = (l & 15) == 1;
 	const bool red_lane = ((l & 7) == 0) || red_ninth;
-#endif
 	const int red_off = (red_ninth ? 8 : wave_swap9_component(l)) * BWD_SEG;
 	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
 	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
@@ -153,11 +148,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 					acg += am * dcg;
 					acb += am * dcb;
 					float packed, ninth_row;
-#ifdef GSR_BWD_HALVES
-					wave_reduce9_swap_f32<false>(v, packed, ninth_row);
-#else
 					wave_reduce9_swap_f32(v, packed, ninth_row);
-#endif
 					if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
 				}
 				wave_fence();  // all lanes have read this batch before the next one overwrites the slice
@@ -171,7 +162,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 			float any = 0.f;
 #pragma unroll
 			for (int c = 0; c < 9; c++) any += fabsf(s_acc[c][i]);
-			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries keep the memset zeros
+			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries stay unflagged: reduce_partials skips them
+				p.touched[slot] = 1;
 				float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * 12);
 				dst[0] = make_float4(s_acc[0][i], s_acc[1][i], s_acc[2][i], s_acc[3][i]);
 				dst[1] = make_float4(s_acc[4][i], s_acc[5][i], s_acc[6][i], s_acc[7][i]);

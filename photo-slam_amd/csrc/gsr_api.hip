@@ -206,7 +206,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	GSR_HIP(hipMemsetAsync(im.ranges, 0, (size_t)tiles * sizeof(uint2), stream));  // rasterizer_impl.cu:310
 	uint32_t* point_list = bs.vals_a;
 	if (R > 0) {
-		if ((st = launch_emit_instances(P, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;
 		PROF_FWD(4);
 		const int bits = (int)higher_msb((uint32_t)tiles);
 		uint32_t* tkeys = nullptr;
@@ -259,16 +259,18 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
 	// every API output is written exactly once by preprocess_bwd
-	if (R > 0) GSR_HIP(hipMemsetAsync(bs.partials, 0, (size_t)R * 12 * sizeof(float), stream));
+	// R bytes of flags instead of 48 R bytes of slots (+ the 64 pad bytes: the reader's byte->bit squeeze needs every byte 0/1)
+	if (R > 0) GSR_HIP(hipMemsetAsync(bs.touched, 0, (size_t)R + 64, stream));
 	PROF_BWD(1);
 	if (R > 0) {
 		BlendBwdParams bp;
 		bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
 		bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.dL_dpix = a->dL_dpix;
 		bp.partials = bs.partials;
+		bp.touched = bs.touched;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
-		if ((st = launch_reduce_partials(P, g, bs.partials, g.grad_acc, W, H, stream)) != GSR_OK) return st;
+		if ((st = launch_reduce_partials(P, g, bs.partials, bs.touched, g.grad_acc, W, H, stream)) != GSR_OK) return st;
 	}
 	PROF_BWD(2);
 

@@ -26,8 +26,9 @@ struct PreprocessParams {
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
-int launch_emit_instances(int P, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, float* grad_acc, int W, int H, hipStream_t stream);
+int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_reduce_partials(int P, const GeometryState& g, const float* partials, const uint8_t* touched, float* grad_acc, int W, int H,
+                           hipStream_t stream);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
 
 struct BlendFwdParams {
@@ -50,7 +51,8 @@ struct BlendBwdParams {
 	const float* final_T;
 	const uint32_t* n_contrib;
 	const float* dL_dpix;   // [3,H,W]
-	float* partials;        // [R][12] per-instance gradient slots (blend.h), zeroed by the caller
+	float* partials;        // [R][12] per-instance gradient slots (blend.h); only slots flagged in `touched` are meaningful
+	uint8_t* touched;       // [R] zeroed by the caller; set to 1 for every slot written
 	int W, H, grid_x, tiles;
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);

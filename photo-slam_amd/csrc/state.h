@@ -96,6 +96,7 @@ struct BinningState {
 	uint32_t* vals_b;        // [R] (pong)
 	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
 	float*    partials;      // [12R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
+	uint8_t*  touched;       // [R] 1 where the backward blend wrote the slot (cleared per backward; the slots themselves are not)
 
 	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
 	{
@@ -107,6 +108,7 @@ struct BinningState {
 		b.vals_b = c.take<uint32_t>(R);
 		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
 		b.partials = c.take<float>(12 * R);
+		b.touched = c.take<uint8_t>(R + 64);   // readers fetch flags 16 bytes at a time
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}

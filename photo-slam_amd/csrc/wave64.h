@@ -234,7 +234,6 @@ __device__ __forceinline__ float swap16_add(float a, float b)
 	const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
 	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
-template <bool LAST_LEVEL = true>
 __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	constexpr int DPP_ROW_ROR8 = 0x128;
@@ -250,13 +249,13 @@ __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float
 	asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(r) : "v"(q1));
 	r += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, r);
 	r += dpp_f32<DPP_QUAD_PERM_2301>(0.f, r);
-	if (LAST_LEVEL) r += dpp_f32<DPP_QUAD_PERM_1032>(0.f, r);   // without it: lanes 0 and 1 of a group hold the two halves
+	r += dpp_f32<DPP_QUAD_PERM_1032>(0.f, r);
 	packed = r;
 	float n = v[8];
 	n += dpp_f32<DPP_QUAD_PERM_1032>(0.f, n);
 	n += dpp_f32<DPP_QUAD_PERM_2301>(0.f, n);
 	n += dpp_f32<DPP_ROW_HALF_MIRROR>(0.f, n);
-	if (LAST_LEVEL) n += dpp_f32<DPP_ROW_MIRROR>(0.f, n);       // without it: sums over the lane's half row
+	n += dpp_f32<DPP_ROW_MIRROR>(0.f, n);
 	ninth_row = n;
 }
 // the value whose total `packed` holds in this lane

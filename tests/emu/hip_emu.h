@@ -39,6 +39,7 @@ struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
@@ -147,7 +148,6 @@ static inline int wave_swap9_component(int lane_)
 	const int g = lane_ >> 3;
 	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);
 }
-template <bool LAST_LEVEL = true>
 static inline void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	float t[9];
@@ -166,10 +166,6 @@ static inline void wave_reduce9_swap_f32(const float (&v)[9], float& packed, flo
 	wave_reduce9_f32(t);
 	packed = t[wave_swap9_component(lane())];
 	ninth_row = row;
-	if (!LAST_LEVEL) {   // the two halves: everything in the even lane / first half row, zero in the other
-		if (lane() & 1) packed = 0.f;
-		if (lane() & 8) ninth_row = 0.f;
-	}
 }
 // asserts the value really is wave-uniform (the real primitive silently takes lane 0's)
 static inline unsigned long long wave_uniform_u64(unsigned long long v)
