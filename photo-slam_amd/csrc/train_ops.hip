@@ -226,17 +226,25 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 	// period/split: elements [split, period) of every `period`-element row use step_size_tail (the SH buffer
 	// keeps features_dc (lr) and features_rest (lr/20) in one [P,16,3] tensor); period == 0: uniform.
 	const long long stride = (long long)gridDim.x * blockDim.x * 4;
-	for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-		if (i + 3 < n && ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
-		                   reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0) {
+	const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+	                       reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+	// position inside the `period`-element row, carried in 32 bits (one 64-bit modulo per thread, not per element)
+	const uint32_t per = (uint32_t)period;
+	uint32_t r = per ? (uint32_t)(i0 % (long long)per) : 0u;
+	const uint32_t dr = per ? (uint32_t)(stride % (long long)per) : 0u;
+	for (long long i = i0; i < n; i += stride) {
+		if (i + 3 < n && aligned) {
 			float4 pv = *reinterpret_cast<float4*>(param + i);
-			const float4 gv = *reinterpret_cast<const float4*>(grad + i);
+			const float4 gv = load_stream_f4(reinterpret_cast<const float4*>(grad + i));
 			float4 mv = *reinterpret_cast<float4*>(exp_avg + i);
 			float4 vv = *reinterpret_cast<float4*>(exp_avg_sq + i);
 			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const float ss = (period && (int)((i + k) % period) >= split) ? step_size_tail : step_size;
+				uint32_t rk = r + (uint32_t)k;
+				if (rk >= per) rk -= per;
+				const float ss = (per && rk >= (uint32_t)split) ? step_size_tail : step_size;
 				mp[k] = b1 * mp[k] + (1.f - b1) * gp[k];
 				vp[k] = b2 * vp[k] + (1.f - b2) * gp[k] * gp[k];
 				pp[k] -= ss * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
@@ -246,7 +254,9 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 			*reinterpret_cast<float4*>(exp_avg_sq + i) = vv;
 		} else {
 			for (long long k = i; k < n && k < i + 4; k++) {
-				const float ss = (period && (int)(k % period) >= split) ? step_size_tail : step_size;
+				uint32_t rk = r + (uint32_t)(k - i);
+				if (rk >= per) rk -= per;
+				const float ss = (per && rk >= (uint32_t)split) ? step_size_tail : step_size;
 				const float g = grad[k];
 				const float m = b1 * exp_avg[k] + (1.f - b1) * g;
 				const float v = b2 * exp_avg_sq[k] + (1.f - b2) * g * g;
@@ -255,6 +265,8 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 				param[k] -= ss * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
 			}
 		}
+		r += dr;
+		if (r >= per) r -= per;
 	}
 }
 
@@ -331,7 +343,8 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 	const float step_size = (float)(lr / bc1), step_tail = (float)(lr_tail / bc1);
 	const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
 	long long blocks = (n / 4 + 255) / 256;
-	if (blocks > 8192) blocks = 8192;
+	// one float4 per thread: measured 609 us per step at C3 against 729 us for an 8192-block grid-stride loop
+	if (blocks > 0x7FFFFFFFll) blocks = 0x7FFFFFFFll;
 	if (blocks < 1) blocks = 1;
 	GSR_LAUNCH(adam_kernel, (int)blocks, 256, stream, param, grad, exp_avg, exp_avg_sq, n, step_size, beta1, beta2, eps,
 	           inv_sqrt_bc2, period, split, step_tail);

@@ -31,6 +31,7 @@ using ::hipemu::mask_select_f32;
 using ::hipemu::mask_select_u32;
 using ::hipemu::mask_select0_f32;
 #define GSR_OPAQUE_F32(x) asm volatile("" : "+x"(x))
+static inline float4 load_stream_f4(const float4* p) { return *p; }
 #define GSR_SCHED_BARRIER() ((void)0)
 #else
 
@@ -80,6 +81,14 @@ __device__ __forceinline__ float mask_select0_f32(unsigned long long mask, float
 	float r;
 	asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
 	return r;
+}
+
+// 16-byte load of data that is read exactly once (streaming: no reuse to keep in the caches).
+__device__ __forceinline__ float4 load_stream_f4(const float4* p)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+	return make_float4(t.x, t.y, t.z, t.w);
 }
 
 // Make a value opaque to the optimiser (no instruction): stops loop-invariant hoisting of everything computed from it.
