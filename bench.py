@@ -44,7 +44,7 @@ def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2):
         "tile_sort": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 8 * T,
         "blend_fwd": 40 * R + 20 * Npix,
-        "grad_memset": 44 * P,
+        "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
         "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V),
     }

@@ -67,8 +67,10 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = image_height, W = image_width;
 	auto float_opts = means3D.options().dtype(torch::kFloat32);
-	torch::Tensor out_color = torch::zeros({3, H, W}, float_opts);
-	torch::Tensor radii = torch::zeros({P}, means3D.options().dtype(torch::kInt32));
+	// torch::full(0) in the reference (rasterize_points.cu:68-69); gsr_forward writes every pixel and every radius itself,
+	// so only the P == 0 no-op needs the zeros
+	torch::Tensor out_color = P != 0 ? torch::empty({3, H, W}, float_opts) : torch::zeros({3, H, W}, float_opts);
+	torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
 	auto byte_opts = means3D.options().dtype(torch::kByte);
 	torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
 	torch::Tensor binningBuffer = torch::empty({0}, byte_opts);

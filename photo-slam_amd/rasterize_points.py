@@ -75,8 +75,10 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
     _check_device(lib, means3D, background, viewmatrix, projmatrix, campos)
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     dev = means3D.device
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # torch::full(0) in the reference (rasterize_points.cu:68-69); gsr_forward writes every pixel and every radius itself,
+    # so only the P == 0 no-op needs the zeros
+    out_color = (torch.empty if P != 0 else torch.zeros)((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
     geomBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
     binningBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
     imgBuffer = torch.empty((0,), dtype=torch.uint8, device=dev)
