@@ -206,7 +206,7 @@ def main():
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_C3_raster_only.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_C3_raster_only.json")
         # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, tools/gpu_pmc.sh), corrected as
         # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only.
         kernel_of = {"blend_bwd": "gsr::blend_bwd_kernel", "blend_fwd": "gsr::blend_fwd_kernel",

@@ -19,8 +19,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     with open(fs[0]) as f:
         for r in csv.DictReader(f):
-            if r.get("Counter_Name") == c and r["Kernel_Name"].startswith("gsr::"):
-                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            if r.get("Counter_Name") == c and "gsr::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out.setdefault(k, {})[c] = sum(v) / len(v)
         out[k]["launches_" + c] = len(v)

@@ -8,8 +8,17 @@ import csv, glob, collections
 fs = glob.glob("/tmp/sq/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(fs[0])):
-    if r["Kernel_Name"].startswith("gsr::blend") or r["Kernel_Name"].startswith("gsr::preprocess") or r["Kernel_Name"].startswith("gsr::radix_scatter"):
-        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, d in acc.items():
-    print(k, {c: f"{sum(v)/len(v):.3g}" for c, v in d.items()})
+    if "gsr::" in r["Kernel_Name"]:
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+for k, d in out.items():
+    # VALU pipe utilisation: cycles the VALU executes an instruction / (busy cycles x 4 SIMDs per CU are already summed by the counter)
+    if d.get("SQ_BUSY_CYCLES"):
+        d["valu_active_per_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_BUSY_CYCLES"]
+    if d.get("SQ_INSTS_VALU"):
+        d["valu_cycles_per_inst"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_INSTS_VALU"]
+json.dump(out, open("gpurun_out/sq_counters.json", "w"), indent=1)
+for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:8]:
+    print(k, {c: f"{v:.3g}" for c, v in d.items()})
 PY
