@@ -74,7 +74,7 @@ def main():
     from photo_slam_amd import capi, scene
     from photo_slam_amd.gaussian_model import GaussianModel, GaussianOptimizationParams
     from photo_slam_amd.gaussian_renderer import GaussianKeyframe, GaussianPipelineParams, GaussianRenderer
-    from photo_slam_amd.trainer import TrainStep
+    from photo_slam_amd.trainer import TrainStep, allreduce_mean
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,11 +84,19 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # GSR_BENCH_SHARE_GPU=1 + GSR_BENCH_BACKEND=gloo: every rank on device 0 over gloo -- a functional check of the
+    # multi-rank path on a 1-GPU box (tools/gpu_dist_smoke.sh); the measured configuration is one rank per GPU over RCCL
+    if os.environ.get("GSR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     lib = capi.load()  # raises if libgsr_hip.so is missing
 
     cfg = scene.CONFIGS[args.config]
@@ -124,12 +132,7 @@ def main():
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
             if world > 1:
-                grads = ops.trainer_grads(handle)
-                works = [dist.all_reduce(gr, op=dist.ReduceOp.SUM, async_op=True) for gr in grads]
-                for w in works:
-                    w.wait()
-                for gr in grads:
-                    gr.mul_(1.0 / world)
+                allreduce_mean(ops.trainer_grads(handle), world)
             loss.item()                       # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
             ops.trainer_finish(handle)
         elif args.raster_only:

@@ -9,6 +9,19 @@ from . import loss_utils
 from .gaussian_renderer import GaussianRenderer
 
 
+def allreduce_mean(tensors, world_size):
+    """In-place mean over the ranks, all reductions in flight together.  RCCL averages inside the collective
+    (ncclAvg); gloo has no AVG, so the CPU test path sums and scales (one more pass over the 472 MB of gradients)."""
+    avg = dist.get_backend() == "nccl"
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    works = [dist.all_reduce(t, op=op, async_op=True) for t in tensors]
+    for w in works:
+        w.wait()
+    if not avg:
+        for t in tensors:
+            t.mul_(1.0 / world_size)
+
+
 class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
                  densify_min_opacity=0.005, prune_big_point_after_iter=0, seed=0):
@@ -37,11 +50,7 @@ class TrainStep:
             if self.world_size_ > 1:
                 # keyframe-batch data parallelism: mean of the per-view gradients over RCCL
                 # all five reductions in flight together (the [P,16,3] SH gradient is 81 % of the bytes)
-                works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True) for p in g.params()]
-                for w in works:
-                    w.wait()
-                for p in g.params():
-                    p.grad.mul_(1.0 / self.world_size_)
+                allreduce_mean([p.grad for p in g.params()], self.world_size_)
             if sync_loss:
                 self.ema_loss_for_log_ = 0.4 * loss.item() + 0.6 * self.ema_loss_for_log_   # :705 (host sync, as the reference)
             if it < opt.densify_until_iter_:
