@@ -44,7 +44,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const int qx0 = tile_x * TILE + (quad & 1) * 8, qy0 = tile_y * TILE + (quad >> 1) * 8;
 	const int px = qx0 + (l & 7), py = qy0 + (l >> 3);
 	const bool inside = px < p.W && py < p.H;
-	const float pxf = (float)px, pyf = (float)py;
+	typedef float v2f __attribute__((vector_size(8)));
+	const v2f pxy = {(float)px, (float)py};
 	const uint2 range = p.ranges[tile];
 	const size_t pix = (size_t)py * p.W + px;
 	const size_t plane = (size_t)p.H * p.W;
@@ -63,6 +64,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const bool red_ninth = (l & 15) == 1;
 	const bool red_lane = ((l & 7) == 0) || red_ninth;
 	const int red_off = (red_ninth ? 8 : wave_swap9_component(l)) * BWD_SEG;
+	const v2f dprg = {dpr, dpg};
 	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
 	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
 
@@ -112,7 +114,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float4 g0 = s_rec[quad][bit][0];
 					const float4 g1 = s_rec[quad][bit][1];
 					const float gb = s_rec[quad][bit][2].x;
-					const float dx = g0.x - pxf, dy = g0.y - pyf;
+					const v2f dxy = (v2f){g0.x, g0.y} - pxy;
+					const float dx = dxy[0], dy = dxy[1];
 					const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
 					const float G = __builtin_amdgcn_exp2f(pw);
 					const float alpha = fminf(0.99f, g1.y * G);
@@ -129,19 +132,21 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float am = ok ? alpha : 0.f;
 					const float dLm = ok ? dL_dalpha : 0.f;
 					const float dcol = am * Tn;
-					float v[9];
-					v[0] = dcol * dpr;
-					v[1] = dcol * dpg;
-					v[2] = dcol * dpb;
 					// the per-Gaussian constants (opacity, -1/2, W/2, H/2, the conic in the mean2D terms) are applied
-					// after the reduction (reduce_partials)
+					// after the reduction (reduce_partials); pairs of products ride in v_pk_mul_f32
 					const float wG = dLm * G;
-					const float tdx = wG * dx, tdy = wG * dy;
-					v[3] = tdx;
-					v[4] = tdy;
-					v[5] = tdx * dx;
-					v[6] = tdx * dy;
-					v[7] = tdy * dy;
+					const v2f c01 = dprg * (v2f){dcol, dcol};
+					const v2f t = dxy * (v2f){wG, wG};          // sum w dx, sum w dy
+					const v2f m56 = dxy * (v2f){t[0], t[0]};    // sum w dx dx, sum w dx dy
+					float v[9];
+					v[0] = c01[0];
+					v[1] = c01[1];
+					v[2] = dcol * dpb;
+					v[3] = t[0];
+					v[4] = t[1];
+					v[5] = m56[0];
+					v[6] = m56[1];
+					v[7] = t[1] * dy;
 					v[8] = wG;
 					T = ok ? Tn : T;
 					acr += am * dcr;
@@ -149,6 +154,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 					acb += am * dcb;
 					float packed, ninth_row;
 					wave_reduce9_swap_f32(v, packed, ninth_row);
+					GSR_OPAQUE_F32(packed);      // keep the last butterfly adds fused with their DPP moves (the compiler otherwise
+					GSR_OPAQUE_F32(ninth_row);   // sinks them into the 12-lane branch as mov_dpp + add)
 					if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
 				}
 				wave_fence();  // all lanes have read this batch before the next one overwrites the slice
