@@ -1062,16 +1062,17 @@ static uint32_t quad_keep_bits_ref(const float* m2, const float* co, float tile_
 
 void gsro_cull_stats(const gsro_state* st, double* out)
 {
-	for (int i = 0; i < 8; i++) out[i] = 0;
+	for (int i = 0; i < 10; i++) out[i] = 0;
 	const int W = st->W, H = st->H;
 	const int T = st->grid_x * st->grid_y;
-	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7)
+	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7, o8, o9)
 	for (int t = 0; t < T; t++) {
 		const int tx = t % st->grid_x, ty = t / st->grid_x;
 		const uint32_t rs = st->ranges[2 * t], re = st->ranges[2 * t + 1];
 		const uint32_t n = re - rs;
 		o0 += n;
+		uint8_t* used = (uint8_t*)calloc((size_t)n + 1, 1); /* bit q: some pixel of quad q blends entry k */
 		uint32_t qmaxc[4] = {0, 0, 0, 0}; /* deepest n_contrib per quad */
 		uint32_t qdone_at[4] = {0, 0, 0, 0}; /* entries the fwd quad walks before all its pixels are done */
 		for (int q = 0; q < 4; q++)
@@ -1095,6 +1096,7 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 					if (test_T < 0.0001f) { k++; break; }
 					T_ = test_T;
 					o4 += 1;
+					used[k] |= (uint8_t)(1u << q);
 					uint32_t bits = quad_keep_bits_ref(st->means2D + 2 * g, co, (float)(tx * 16), (float)(ty * 16));
 					if (!((bits >> q) & 1)) o6 += 1;
 				}
@@ -1109,9 +1111,13 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 			for (int q = 0; q < 4; q++) {
 				if (k < qdone_at[q]) { o7 += 1; if ((bits >> q) & 1) o2 += 1; }
 				if (k < qmaxc[q] && ((bits >> q) & 1)) o3 += 1;
+				if ((used[k] >> q) & 1) o8 += 1;   /* (quad, entry) visits with at least one blending pixel */
 			}
+			if (used[k]) o9 += 1;                   /* (tile, entry) instances with at least one blending pixel */
 		}
+		free(used);
 	}
+	out[8] = o8; out[9] = o9;
 	out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
 }
 

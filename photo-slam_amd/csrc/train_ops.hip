@@ -56,6 +56,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* s4)
 	return s4[0] + s4[1] + s4[2] + s4[3];
 }
 
+// Both passes are separable 11-tap convolutions over a 32x32 output tile with a 5-pixel halo.  Every thread produces
+// FOUR consecutive outputs of a row (horizontal pass) or of a column (vertical pass) from 14 inputs held in
+// registers: 3.5 LDS reads per output and tap set instead of 11 (the first version, one output per thread, was
+// LDS-issue bound: 86 k ds_read_b32 per tile).
+constexpr int LG = 4;             // outputs per thread and pass
+constexpr int LW = LG + 2 * LH;   // 14 inputs feed them
+
 // Pass 1: window statistics -> SSIM map value + the three derivative maps, and L1 / SSIM partial sums.
 __global__ void __launch_bounds__(256)
 loss_fwd_kernel(const LossParams p)
@@ -83,54 +90,73 @@ loss_fwd_kernel(const LossParams p)
 		s_y[r][c] = yv;
 	}
 	__syncthreads();
-	// horizontal pass: LR rows x LT columns
-	for (int i = tid; i < LR * LT; i += 256) {
-		const int r = i / LT, c = i - r * LT;
-		float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+	// horizontal pass: LR rows x (LT / LG) groups of LG columns
+	for (int u = tid; u < LR * (LT / LG); u += 256) {
+		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
+		float xv[LW], yv[LW];
 #pragma unroll
-		for (int t = 0; t < 11; t++) {
-			const float xv = s_x[r][c + t], yv = s_y[r][c + t], gw = p.g[t];
-			a0 += gw * xv;
-			a1 += gw * yv;
-			a2 += gw * xv * xv;
-			a3 += gw * yv * yv;
-			a4 += gw * xv * yv;
+		for (int t = 0; t < LW; t++) {
+			xv[t] = s_x[r][c0 + t];
+			yv[t] = s_y[r][c0 + t];
 		}
-		s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+#pragma unroll
+		for (int o = 0; o < LG; o++) {
+			float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+			for (int t = 0; t < 11; t++) {
+				const float x = xv[o + t], y = yv[o + t], gw = p.g[t];
+				a0 += gw * x;
+				a1 += gw * y;
+				a2 += gw * x * x;
+				a3 += gw * y * y;
+				a4 += gw * x * y;
+			}
+			s_h[0][r][c0 + o] = a0; s_h[1][r][c0 + o] = a1; s_h[2][r][c0 + o] = a2; s_h[3][r][c0 + o] = a3; s_h[4][r][c0 + o] = a4;
+		}
 	}
 	__syncthreads();
 	const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 	const float inv_n = 1.0f / (3.0f * (float)plane);
 	float l1_sum = 0.f, ssim_sum = 0.f;
-	for (int i = tid; i < LT * LT; i += 256) {
-		const int r = i / LT, c = i - r * LT;
-		const int gx = x0 + c, gy = y0 + r;
-		if (gx < p.W && gy < p.H) {
-			float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+	{
+		// vertical pass: thread = (column c, group of LG rows)
+		const int c = tid & (LT - 1), r0 = (tid >> 5) * LG;
+		float st[5][LG];
 #pragma unroll
-			for (int t = 0; t < 11; t++) {
-				const float gw = p.g[t];
-				mu1 += gw * s_h[0][r + t][c];
-				mu2 += gw * s_h[1][r + t][c];
-				e11 += gw * s_h[2][r + t][c];
-				e22 += gw * s_h[3][r + t][c];
-				e12 += gw * s_h[4][r + t][c];
+		for (int k = 0; k < 5; k++) {
+			float col[LW];
+#pragma unroll
+			for (int t = 0; t < LW; t++) col[t] = s_h[k][r0 + t][c];
+#pragma unroll
+			for (int o = 0; o < LG; o++) {
+				float a = 0.f;
+#pragma unroll
+				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
+				st[k][o] = a;
 			}
-			const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-			const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
-			const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
-			const float invCD = 1.0f / (Cc * D);
-			const float S = A * B * invCD;
-			ssim_sum += S;
-			const float xv = s_x[r + LH][c + LH], yv = s_y[r + LH][c + LH];
-			l1_sum += fabsf(xv - yv);
-			// dL/dS = -lambda / N ; chain to (mu1, e11, e12)
-			const float gS = -p.lambda_dssim * inv_n;
-			const float dmu1 = 2.f * mu2 * (B - A) * invCD - 2.f * mu1 * S * (1.0f / Cc - 1.0f / D);
-			const size_t o = (size_t)gy * p.W + gx;
-			p.dmaps[(0 * 3 + ch) * plane + o] = gS * dmu1;
-			p.dmaps[(1 * 3 + ch) * plane + o] = gS * (-S / D);
-			p.dmaps[(2 * 3 + ch) * plane + o] = gS * (2.f * A * invCD);
+		}
+		const int gx = x0 + c;
+#pragma unroll
+		for (int o = 0; o < LG; o++) {
+			const int gy = y0 + r0 + o;
+			if (gx < p.W && gy < p.H) {
+				const float mu1 = st[0][o], mu2 = st[1][o], e11 = st[2][o], e22 = st[3][o], e12 = st[4][o];
+				const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+				const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
+				const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
+				const float invCD = 1.0f / (Cc * D);
+				const float S = A * B * invCD;
+				ssim_sum += S;
+				const float xv = s_x[r0 + o + LH][c + LH], yv = s_y[r0 + o + LH][c + LH];
+				l1_sum += fabsf(xv - yv);
+				// dL/dS = -lambda / N ; chain to (mu1, e11, e12)
+				const float gS = -p.lambda_dssim * inv_n;
+				const float dmu1 = 2.f * mu2 * (B - A) * invCD - 2.f * mu1 * S * (1.0f / Cc - 1.0f / D);
+				const size_t oo = (size_t)gy * p.W + gx;
+				p.dmaps[(0 * 3 + ch) * plane + oo] = gS * dmu1;
+				p.dmaps[(1 * 3 + ch) * plane + oo] = gS * (-S / D);
+				p.dmaps[(2 * 3 + ch) * plane + oo] = gS * (2.f * A * invCD);
+			}
 		}
 	}
 	const float t1 = block_sum_256(l1_sum, s_red);
@@ -161,39 +187,53 @@ loss_bwd_kernel(const LossParams p)
 		for (int k = 0; k < 3; k++) s_d[k][r][c] = in ? p.dmaps[(k * 3 + ch) * plane + o] : 0.f;
 	}
 	__syncthreads();
-	for (int i = tid; i < LR * LT; i += 256) {
-		const int r = i / LT, c = i - r * LT;
-		float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+	for (int u = tid; u < LR * (LT / LG); u += 256) {
+		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
 #pragma unroll
-		for (int t = 0; t < 11; t++) {
-			const float gw = p.g[t];
-			a0 += gw * s_d[0][r][c + t];
-			a1 += gw * s_d[1][r][c + t];
-			a2 += gw * s_d[2][r][c + t];
+		for (int k = 0; k < 3; k++) {
+			float v[LW];
+#pragma unroll
+			for (int t = 0; t < LW; t++) v[t] = s_d[k][r][c0 + t];
+#pragma unroll
+			for (int o = 0; o < LG; o++) {
+				float a = 0.f;
+#pragma unroll
+				for (int t = 0; t < 11; t++) a += p.g[t] * v[o + t];
+				s_h[k][r][c0 + o] = a;
+			}
 		}
-		s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
 	}
 	__syncthreads();
 	const float inv_n = 1.0f / (3.0f * (float)plane);
-	for (int i = tid; i < LT * LT; i += 256) {
-		const int r = i / LT, c = i - r * LT;
-		const int gx = x0 + c, gy = y0 + r;
-		if (gx < p.W && gy < p.H) {
-			float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+	{
+		const int c = tid & (LT - 1), r0 = (tid >> 5) * LG;
+		float cv[3][LG];
 #pragma unroll
-			for (int t = 0; t < 11; t++) {
-				const float gw = p.g[t];
-				c0 += gw * s_h[0][r + t][c];
-				c1 += gw * s_h[1][r + t][c];
-				c2 += gw * s_h[2][r + t][c];
+		for (int k = 0; k < 3; k++) {
+			float col[LW];
+#pragma unroll
+			for (int t = 0; t < LW; t++) col[t] = s_h[k][r0 + t][c];
+#pragma unroll
+			for (int o = 0; o < LG; o++) {
+				float a = 0.f;
+#pragma unroll
+				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
+				cv[k][o] = a;
 			}
-			const size_t o = ch * plane + (size_t)gy * p.W + gx;
-			const float m = p.mask ? p.mask[o] : 1.f;
-			const float xv = p.rendered[o] * m, yv = p.gt[o];
-			const float d = xv - yv;
-			const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-			const float gx_ = c0 + 2.f * xv * c1 + yv * c2 + (1.0f - p.lambda_dssim) * inv_n * sgn;
-			p.grad[o] = gx_ * m;
+		}
+		const int gx = x0 + c;
+#pragma unroll
+		for (int o = 0; o < LG; o++) {
+			const int gy = y0 + r0 + o;
+			if (gx < p.W && gy < p.H) {
+				const size_t oo = ch * plane + (size_t)gy * p.W + gx;
+				const float m = p.mask ? p.mask[oo] : 1.f;
+				const float xv = p.rendered[oo] * m, yv = p.gt[oo];
+				const float d = xv - yv;
+				const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+				const float gx_ = cv[0][o] + 2.f * xv * cv[1][o] + yv * cv[2][o] + (1.0f - p.lambda_dssim) * inv_n * sgn;
+				p.grad[oo] = gx_ * m;
+			}
 		}
 	}
 }
