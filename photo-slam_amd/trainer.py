@@ -10,16 +10,26 @@ from .gaussian_renderer import GaussianRenderer
 
 
 def allreduce_mean(tensors, world_size):
-    """In-place mean over the ranks, all reductions in flight together.  RCCL averages inside the collective
-    (ncclAvg); gloo has no AVG, so the CPU test path sums and scales (one more pass over the 472 MB of gradients)."""
-    avg = dist.get_backend() == "nccl"
-    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-    works = [dist.all_reduce(t, op=op, async_op=True) for t in tensors]
+    """In-place mean over the ranks.  RCCL: the reductions are issued as ONE group (a single fused collective launch, no
+    flattening copy) and averaged inside the collective (ncclAvg).  gloo (the CPU test path) has neither: it sums the
+    tensors one by one and scales (one more pass over the 472 MB of gradients)."""
+    if dist.get_backend() == "nccl":
+        try:
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(device=tensors[0].device, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            cm.wait()
+        except ImportError:   # older torch: five collectives in flight together
+            works = [dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True) for t in tensors]
+            for w in works:
+                w.wait()
+        return
+    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True) for t in tensors]
     for w in works:
         w.wait()
-    if not avg:
-        for t in tensors:
-            t.mul_(1.0 / world_size)
+    for t in tensors:
+        t.mul_(1.0 / world_size)
 
 
 class TrainStep:

@@ -38,8 +38,15 @@ class BackendResult:
     pass
 
 
+def _features(cl, sh_coeffs):
+    """[P,16,3] SH buffer of the cloud, or its first `sh_coeffs` coefficients as a compact [P,M,3] tensor (rows that are
+    not 48 floats take the kernels' per-lane row access instead of the LDS row movers)."""
+    f = cl.get_features()
+    return f if sh_coeffs is None else np.ascontiguousarray(f[:, :sh_coeffs])
+
+
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True):
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None):
     """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library."""
     rp._LIB_OVERRIDE = lib_path
     try:
@@ -52,7 +59,7 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                  rotations=empty if use_cov3D_precomp else _t(cl.get_rotation(), dev), scale_modifier=1.0,
                  cov3D_precomp=_t(cov3D, dev) if use_cov3D_precomp else empty, viewmatrix=_t(cam.viewmatrix, dev),
                  projmatrix=_t(cam.projmatrix, dev), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, image_height=cam.H,
-                 image_width=cam.W, sh=empty if use_colors_precomp else _t(cl.get_features(), dev), degree=sh_degree,
+                 image_width=cam.W, sh=empty if use_colors_precomp else _t(_features(cl, sh_coeffs), dev), degree=sh_degree,
                  campos=_t(cam.campos, dev), prefiltered=False)
         R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a)
         r = BackendResult()
@@ -94,10 +101,10 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
 
 
 def run_oracle(oracle, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-               colors=None, cov3D=None, do_backward=True):
+               colors=None, cov3D=None, do_backward=True, sh_coeffs=None):
     res, color, radii = oracle.forward(
         bg, cl.xyz, cl.get_opacity(), cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, cam.H, cam.W,
-        shs=None if use_colors_precomp else cl.get_features(), sh_degree=sh_degree,
+        shs=None if use_colors_precomp else _features(cl, sh_coeffs), sh_degree=sh_degree,
         colors_precomp=colors if use_colors_precomp else None,
         scales=None if use_cov3D_precomp else cl.get_scaling(), rotations=None if use_cov3D_precomp else cl.get_rotation(),
         cov3D_precomp=cov3D if use_cov3D_precomp else None)

@@ -107,6 +107,20 @@ def test_lower_sh_degrees(emu_lib_path, oracle, degree):
     assert not r.grads["dL_dsh"][:, k:, :].any(), "coefficients above the active degree must get zero gradient"
 
 
+@pytest.mark.parametrize("degree,coeffs", [(0, 1), (1, 4), (2, 9), (1, 9)])
+def test_compact_sh_layouts(emu_lib_path, oracle, degree, coeffs):
+    # SH tensors that are not [P,16,3] (rows of 3, 12 or 27 floats): the kernels' per-lane row access instead of the LDS movers
+    cl = _scene(seed=9)
+    cam = cl.cameras[0]
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, sh_degree=degree, sh_coeffs=coeffs)
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, sh_degree=degree, sh_coeffs=coeffs)
+    parity.compare(r, ores, ocolor, oradii, ograds, cam)
+    assert r.grads["dL_dsh"].shape[1] == coeffs
+    k = (degree + 1) ** 2
+    assert not r.grads["dL_dsh"][:, k:, :].any()
+
+
 def test_empty_and_tiny_inputs(emu_lib_path, oracle):
     rp._LIB_OVERRIDE = emu_lib_path
     try:

@@ -55,6 +55,14 @@ def test_lower_sh_degrees(oracle, dev, degree):
     _check(oracle, dev, cl, cl.cameras[0], np.ones(3, np.float32), sh_degree=degree)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,coeffs", [(0, 1), (1, 4), (2, 9)])
+def test_compact_sh_layouts(oracle, dev, degree, coeffs):
+    # SH tensors that are not [P,16,3]: per-lane row access in preprocess fwd / bwd instead of the LDS row movers
+    cl = scene.make_cloud(20000, 256, 192, 200.0, 200.0, seed=10, scale_k=0.15)
+    _check(oracle, dev, cl, cl.cameras[0], np.array([0.2, 0.4, 0.6], np.float32), sh_degree=degree, sh_coeffs=coeffs)
+
+
 def test_precomputed_colors_and_cov3D(oracle, dev):
     cl = scene.make_cloud(30000, 256, 192, 200.0, 200.0, seed=9, scale_k=0.15)
     cam = cl.cameras[0]
