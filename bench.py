@@ -46,6 +46,7 @@ def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2):
         "blend_fwd": 40 * R + 20 * Npix,
         "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
+        "reduce_partials": R + 48 * V,               # slot flags + one gradient record per visible Gaussian (implementation stage)
         "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V),
     }
 
@@ -218,10 +219,17 @@ def main():
             pm = json.load(open(pmc_file)).get(kernel_of[dom])
             if pm:
                 traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
+        # the blend kernels are VALU-bound: their VALU issue utilisation from the SQ counters (tools/gpu_sq.sh, C3 only) rides along
+        valu = None
+        sq_file = os.path.join(ROOT, "profiles", "r01_d_sq_counters_C3_raster_only.json")
+        if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(sq_file):
+            sq = json.load(open(sq_file)).get(kernel_of[dom])
+            if sq and "valu_issue_utilisation" in sq:
+                valu = round(sq["valu_issue_utilisation"], 3)
         if dom:
             a = stages[dom]["GBps"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "valu_issue_utilisation": valu,
                                "raster_fwd_bwd_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "stages": stages}
         if world == 1 and not args.no_cpu_baseline:

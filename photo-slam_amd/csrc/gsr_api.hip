@@ -43,14 +43,14 @@ static thread_local HostSync t_sync;
 // stream between the stages of gsr_forward / gsr_backward, so bench.py can price each kernel
 // group against its algorithmic bytes without a profiler attached.
 enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_OFFSET_SCAN, ST_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_BLEND_FWD,
-       ST_GRAD_MEMSET, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+       ST_GRAD_MEMSET, ST_BLEND_BWD, ST_REDUCE_PARTIALS, ST_PREPROCESS_BWD, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
                                                     "tile_sort", "tile_ranges", "blend_fwd", "grad_memset",
-                                                    "blend_bwd", "preprocess_bwd"};
+                                                    "blend_bwd", "reduce_partials", "preprocess_bwd"};
 struct Profiler {
 	bool on = false;
 	hipEvent_t fwd[8] = {};   // boundaries of the 7 forward stages
-	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
+	hipEvent_t bwd[5] = {};   // boundaries of the 4 backward stages
 	bool created = false, fwd_done = false, bwd_done = false;
 	int create()
 	{
@@ -270,9 +270,12 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.touched = bs.touched;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
+		PROF_BWD(2);
 		if ((st = launch_reduce_partials(P, g, bs.partials, bs.touched, g.grad_acc, W, H, stream)) != GSR_OK) return st;
+	} else {
+		PROF_BWD(2);
 	}
-	PROF_BWD(2);
+	PROF_BWD(3);
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;
@@ -288,7 +291,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
-	PROF_BWD(3);
+	PROF_BWD(4);
 	t_prof.bwd_done = t_prof.on;
 	return GSR_OK;
 }
@@ -314,8 +317,8 @@ int gsr_profile_read(float* ms, int count)
 		for (int i = 0; i < 7; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
 	}
 	if (t_prof.bwd_done) {
-		GSR_HIP(hipEventSynchronize(t_prof.bwd[3]));
-		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
+		GSR_HIP(hipEventSynchronize(t_prof.bwd[4]));
+		for (int i = 0; i < 4; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
 	}
 	return GSR_OK;
 }

@@ -29,7 +29,7 @@ constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per work
 
 // SH backward for aligned 48-float rows; DEG = active SH degree.
 template <int DEG>
-__global__ void __launch_bounds__(SHB_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs (3 dwords of scratch at degree 3)
+__global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(6, 8)   // 80 VGPRs (3 dwords of scratch at degree 3)
 sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];

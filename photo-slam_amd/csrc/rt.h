@@ -41,6 +41,13 @@ void set_last_hip_error(int err, const char* what);
 
 #define GSR_CHECK_LAUNCH() GSR_HIP(hipGetLastError())
 
+// Register-allocation target: at least `lo` waves per SIMD (the allocator spills rather than exceed 512/lo VGPRs).
+#ifdef GSR_EMU
+#define GSR_WAVES_PER_EU(lo, hi)
+#else
+#define GSR_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
 // Carve typed arrays out of one caller-owned byte chunk, 128-byte aligned (the role of
