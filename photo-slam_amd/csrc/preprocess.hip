@@ -30,12 +30,16 @@ __device__ __forceinline__ int f2i(float f)
 // auxiliary.h:41-44 (double because of the 1.0 / 0.5 literals)
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
-constexpr int PRE_THREADS = 128;   // 2 waves x 6.5 KiB of row staging per workgroup
+#ifndef GSR_FWD_STAGE_ROWS
+#define GSR_FWD_STAGE_ROWS STAGE_ROWS
+#endif
+constexpr int FWD_ROWS = GSR_FWD_STAGE_ROWS;   // SH rows staged per pass and wave
+constexpr int PRE_THREADS = 128;               // 2 waves per workgroup
 
 __global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 {
-	__shared__ float4 s_rows[PRE_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
+	__shared__ float4 s_rows[PRE_THREADS / 64][FWD_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[PRE_THREADS / 64][64];
 #ifdef GSR_EXP_LDS_PAD   // occupancy experiment
 	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
@@ -190,8 +194,8 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			if (vis) s_list[w][rank] = (uint32_t)lane_id();
 			wave_fence();
 			const int nf4 = (3 * ncoef + 3) >> 2;
-			for (int r0 = 0; r0 < nvis; r0 += STAGE_ROWS) {
-				const int count = (nvis - r0) < STAGE_ROWS ? (nvis - r0) : STAGE_ROWS;
+			for (int r0 = 0; r0 < nvis; r0 += FWD_ROWS) {
+				const int count = (nvis - r0) < FWD_ROWS ? (nvis - r0) : FWD_ROWS;
 				wave_load_listed_rows(reinterpret_cast<const float4*>(p.shs), wave_first, nf4, r0, count, s_rows[w], s_list[w]);
 				if (vis && rank >= r0 && rank < r0 + count) sh_row_to_rgb(s_rows[w][rank - r0], ncoef, d, rgb);
 				wave_fence();  // the next pass overwrites the slice
