@@ -46,7 +46,6 @@ def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2):
         "blend_fwd": 40 * R + 20 * Npix,
         "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
-        "reduce_partials": R + 48 * V,               # slot flags + one gradient record per visible Gaussian (implementation stage)
         "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V),
     }
 

@@ -65,7 +65,7 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		keys[slot] = (miny + yy) * (uint32_t)grid_x + (minx + xx);
 		vals[slot] = g;
 		// slot of the Gaussian's first instance = its emission offset (the backward blend writes its per-tile gradient
-		// partials there, reduce_partials sums the contiguous run)
+		// partials there, preprocess_bwd sums the contiguous run)
 		if (k == 0u) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = slot;
 	}
 }
@@ -87,97 +87,6 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 		}
 	}
 	if (i == R - 1) ranges[cur].y = (uint32_t)R;
-}
-
-// Sum every Gaussian's contiguous run of per-instance gradient slots (written by the backward
-// blend) into one 48-byte record per Gaussian, in a fixed order (no atomics: bit-reproducible).
-// Thread = Gaussian (id order, so the few screen-filling splats are spread over many waves).
-// Runs of up to 64 slots are summed by their owner lane; longer runs are summed by the whole wave
-// (strided 48-byte slots, then a DPP reduction) so that a 3000-tile splat costs 50 iterations,
-// not 3000.
-__global__ void __launch_bounds__(256)
-reduce_partials_kernel(int P, const float4* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
-                       const float* __restrict__ partials, const uint8_t* __restrict__ touched, float* __restrict__ grad_acc,
-                       float half_w, float half_h)
-{
-	const int l = lane_id();
-	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	const bool valid = idx < P;
-	const uint32_t cnt = valid ? tiles_touched[idx] : 0u;
-	if (wave_ballot(cnt != 0u) == 0ull) return;  // wave-uniform
-	const uint32_t first = cnt ? __float_as_uint(rec[3 * (size_t)idx + 2].w) : 0u;
-	const float4* part4 = reinterpret_cast<const float4*>(partials);
-	float a[9];
-#pragma unroll
-	for (int c = 0; c < 9; c++) a[c] = 0.f;
-	if (cnt != 0u && cnt <= 64u) {
-		// the run's flags, 16 bytes per load, squeezed to one bit per slot: the loop below then runs once per TOUCHED
-		// slot (~1 in 5) and its loads do not wait for one another (a byte-flag test per slot serialises on memory latency)
-		unsigned long long live = 0ull;
-#pragma unroll
-		for (int c = 0; c < 4; c++) {
-			if (16u * c < cnt) {
-				uint4 f;
-				__builtin_memcpy(&f, touched + first + 16 * c, 16);   // unaligned 16-byte load
-				const uint32_t bits = (((f.x * 0x01020408u) >> 24) & 0xFu) | ((((f.y * 0x01020408u) >> 24) & 0xFu) << 4) |
-				                      ((((f.z * 0x01020408u) >> 24) & 0xFu) << 8) | ((((f.w * 0x01020408u) >> 24) & 0xFu) << 12);
-				live |= (unsigned long long)bits << (16 * c);
-			}
-		}
-		if (cnt < 64u) live &= (1ull << cnt) - 1ull;
-		const float4* src = part4 + 3 * (size_t)first;
-		while (live) {
-			const int i = __ffsll((long long)live) - 1;
-			live &= live - 1ull;
-			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
-			const float z = src[3 * (size_t)i + 2].x;
-			a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
-			a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
-			a[8] += z;
-		}
-	}
-	unsigned long long big = wave_ballot(cnt > 64u);
-	while (big) {
-		const int b = __ffsll((long long)big) - 1;
-		big &= big - 1ull;
-		const uint32_t bfirst = wave_readlane_u32(first, b), bcnt = wave_readlane_u32(cnt, b);
-		float v[9];
-#pragma unroll
-		for (int c = 0; c < 9; c++) v[c] = 0.f;
-		const float4* src = part4 + 3 * (size_t)bfirst;
-		for (uint32_t i = (uint32_t)l; i < bcnt; i += 64u) {
-			if (!touched[bfirst + i]) continue;
-			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
-			const float z = src[3 * (size_t)i + 2].x;
-			v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-			v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
-			v[8] += z;
-		}
-		wave_reduce9_f32(v);  // totals in lane 63
-#pragma unroll
-		for (int c = 0; c < 9; c++) a[c] = wave_writelane_f32(a[c], wave_readlane_f32(v[c], 63), b);
-	}
-	if (cnt) {
-		// constant factors the blend left out: dL_dG = opacity * dL_dalpha; d(mean2D) carries -W/2, -H/2
-		// (backward.cu:460-461,539-546), the conic terms -1/2 (:549-551)
-		// a[3], a[4] = sum dL_dG*G*dx, sum dL_dG*G*dy: dG_ddelx = -G (dx A + dy B), dG_ddely = -G (dy C + dx B)
-		const float4 q0 = rec[3 * (size_t)idx];
-		const float4 q1 = rec[3 * (size_t)idx + 1];
-		const float A = q0.z, B = q0.w, C = q1.x, o = q1.y;
-		float4* dst = reinterpret_cast<float4*>(grad_acc) + 3 * (size_t)idx;
-		dst[0] = make_float4(a[0], a[1], a[2], -o * half_w * (a[3] * A + a[4] * B));
-		dst[1] = make_float4(-o * half_h * (a[4] * C + a[3] * B), -0.5f * o * a[5], -0.5f * o * a[6], -0.5f * o * a[7]);
-		dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
-	}
-}
-
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, const uint8_t* touched, float* grad_acc, int W, int H,
-                           hipStream_t stream)
-{
-	GSR_LAUNCH(reduce_partials_kernel, div_up(P, 256), 256, stream, P, (const float4*)g.rec, (const uint32_t*)g.tiles_touched,
-	           partials, touched, grad_acc, 0.5f * (float)W, 0.5f * (float)H);
-	GSR_CHECK_LAUNCH();
-	return GSR_OK;
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)

@@ -91,7 +91,7 @@ __device__ __forceinline__ bool quad_keep(const float4 q0, const float4 q1, floa
 //   [0..2] dL_dcolor  [3..4] sum w*dx, sum w*dy  [5..7] sum w*dx*dx, w*dx*dy, w*dy*dy  [8] sum w  [9..11] unused
 // with w = dL_dalpha * G per contributing pixel: components 3..7 are stored WITHOUT their per-Gaussian
 // constants (-opacity*W/2, -opacity*H/2 and the conic for the mean2D pair, -opacity/2 for the conic terms):
-// reduce_partials applies them once per Gaussian instead of once per pixel pair
+// preprocess_bwd (partials.h) applies them once per Gaussian instead of once per pixel pair
 // in `partials`, indexed by emission order: a Gaussian's instances were emitted contiguously
 // (row-major over its tile rectangle, binning.hip), so slot = first_slot + (ty-miny)*w + (tx-minx),
 // all of which ride in the spare words of the blend record.  The backward blend merges the four

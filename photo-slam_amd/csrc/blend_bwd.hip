@@ -18,7 +18,7 @@
 //     of a tile meet;
 //   * the two mean2D terms are reduced as sum(dL_dG*G*dx), sum(dL_dG*G*dy); their conic
 //     combination (backward.cu:539-546) is linear in them and applied once per Gaussian in
-//     reduce_partials;
+//     preprocess_bwd (partials.h);
 //   * at the end of a segment of 256 list entries the workgroup writes every touched entry's
 //     nine sums to that instance's private 48-byte slot with plain stores.
 #include "blend.h"
@@ -133,7 +133,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float dLm = ok ? dL_dalpha : 0.f;
 					const float dcol = am * Tn;
 					// the per-Gaussian constants (opacity, -1/2, W/2, H/2, the conic in the mean2D terms) are applied
-					// after the reduction (reduce_partials); pairs of products ride in v_pk_mul_f32
+					// after the reduction (preprocess_bwd, partials.h); pairs of products ride in v_pk_mul_f32
 					const float wG = dLm * G;
 					const v2f c01 = dprg * (v2f){dcol, dcol};
 					const v2f t = dxy * (v2f){wG, wG};          // sum w dx, sum w dy
@@ -169,7 +169,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 			float any = 0.f;
 #pragma unroll
 			for (int c = 0; c < 9; c++) any += fabsf(s_acc[c][i]);
-			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries stay unflagged: reduce_partials skips them
+			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries stay unflagged: the per-Gaussian sum skips them
 				p.touched[slot] = 1;
 				float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * 12);
 				dst[0] = make_float4(s_acc[0][i], s_acc[1][i], s_acc[2][i], s_acc[3][i]);

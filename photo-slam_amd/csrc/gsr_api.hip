@@ -43,14 +43,14 @@ static thread_local HostSync t_sync;
 // stream between the stages of gsr_forward / gsr_backward, so bench.py can price each kernel
 // group against its algorithmic bytes without a profiler attached.
 enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_OFFSET_SCAN, ST_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_BLEND_FWD,
-       ST_GRAD_MEMSET, ST_BLEND_BWD, ST_REDUCE_PARTIALS, ST_PREPROCESS_BWD, ST_COUNT };
+       ST_GRAD_MEMSET, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
 static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
                                                     "tile_sort", "tile_ranges", "blend_fwd", "grad_memset",
-                                                    "blend_bwd", "reduce_partials", "preprocess_bwd"};
+                                                    "blend_bwd", "preprocess_bwd"};
 struct Profiler {
 	bool on = false;
 	hipEvent_t fwd[8] = {};   // boundaries of the 7 forward stages
-	hipEvent_t bwd[5] = {};   // boundaries of the 4 backward stages
+	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
 	bool created = false, fwd_done = false, bwd_done = false;
 	int create()
 	{
@@ -270,12 +270,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.touched = bs.touched;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
-		PROF_BWD(2);
-		if ((st = launch_reduce_partials(P, g, bs.partials, bs.touched, g.grad_acc, W, H, stream)) != GSR_OK) return st;
-	} else {
-		PROF_BWD(2);
 	}
-	PROF_BWD(3);
+	PROF_BWD(2);
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;
@@ -286,12 +282,14 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_y = H / (2.0f * a->tan_fovy);
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
-	pb.grad_acc = g.grad_acc; pb.rec = g.rec; pb.raw_params = a->raw_params;
+	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
+	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
+	pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
-	PROF_BWD(4);
+	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on;
 	return GSR_OK;
 }
@@ -317,8 +315,8 @@ int gsr_profile_read(float* ms, int count)
 		for (int i = 0; i < 7; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
 	}
 	if (t_prof.bwd_done) {
-		GSR_HIP(hipEventSynchronize(t_prof.bwd[4]));
-		for (int i = 0; i < 4; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
+		GSR_HIP(hipEventSynchronize(t_prof.bwd[3]));
+		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
 	}
 	return GSR_OK;
 }

@@ -27,8 +27,6 @@ int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hip
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
-int launch_reduce_partials(int P, const GeometryState& g, const float* partials, const uint8_t* touched, float* grad_acc, int W, int H,
-                           hipStream_t stream);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
 
 struct BlendFwdParams {
@@ -71,7 +69,10 @@ struct PreprocessBwdParams {
 	const float* proj;      // [16] device
 	const float* campos;    // [3] device
 	float focal_x, focal_y, tan_fovx, tan_fovy;
-	const float* grad_acc;    // [P][12] per-Gaussian blend gradients (reduce_partials_kernel), valid where radii > 0
+	const uint32_t* tiles_touched;   // [P] length of each Gaussian's run of instance slots (0 = culled)
+	const float* partials;    // [R][12] per-instance gradient slots written by the backward blend (blend.h)
+	const uint8_t* touched;   // [R + 64] 1 where a slot was written
+	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)
 	float* dL_dconic;         // [P,4]  nullable

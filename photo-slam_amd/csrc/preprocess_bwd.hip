@@ -1,25 +1,26 @@
 // preprocess_bwd.hip -- per-Gaussian backward stage.
 //
 // Two kernels for the reference model's layout (48-float, 16-byte aligned SH rows):
-//   * sh_bwd_rows_kernel: the SH backward (cuda_rasterizer/backward.cu:20-139).  Rows move through LDS
-//     (shrows.h); it writes dL_dsh for EVERY Gaussian (zeros for culled ones) and parks the
-//     view-direction term of dL_dmean3D in that output array;
-//   * preprocess_bwd_kernel: computeCov2DCUDA (backward.cu:144-274) fused with the projection and
-//     cov3D backward of preprocessCUDA (backward.cu:346-396, :278-341), so dL_dcov3D and the partial
-//     dL_dmean3D never round-trip through HBM; it adds the parked SH term last (the reference's order)
-//     and writes every remaining output element, so the caller does not need the reference's
-//     torch::zeros pass (src/rasterize_points.cu:149-157, 300 B/Gaussian).
+//   * preprocess_bwd_kernel: sums the Gaussian's per-instance gradient slots (the per-Gaussian end of the atomic-free
+//     hand-off from the backward blend, partials.h) in registers, then computeCov2DCUDA (backward.cu:144-274) fused with
+//     the projection and cov3D backward of preprocessCUDA (backward.cu:346-396, :278-341): neither the blend-stage
+//     gradients nor dL_dcov3D nor the partial dL_dmean3D round-trip through HBM between launches.  It writes every output
+//     element but dL_dsh (zeros for culled Gaussians), so the caller does not need the reference's torch::zeros pass
+//     (src/rasterize_points.cu:149-157, 300 B/Gaussian);
+//   * sh_bwd_rows_kernel: the SH backward (cuda_rasterizer/backward.cu:20-139).  Rows move through LDS (shrows.h); it
+//     writes dL_dsh for EVERY Gaussian and adds the view-direction term to dL_dmean3D last (the reference's order).
 // They were one kernel until its 140+ VGPRs capped it at three waves per SIMD; both halves are
 // latency-bound (measured: time ~ 1/occupancy), and apart they run at 6-8 waves.  Other SH layouts take the
 // fused instantiation with per-lane row access.
 //
-// HBM per Gaussian: culled: 4 read (radius) + (55+3M)*4 written zeros; visible: reads mean 12 (x2),
-// cov3D 24, conic grad 16, mean2D grad 12, colour grad 12 (x2), SH 12K, scale 12, rot 16, clamp 1;
-// writes mean3D 12 (+12 parked and re-read), cov3D 24, SH 12M, scale 12, rot 16.
+// HBM per Gaussian: culled: 4 read (radius) + (55+3M)*4 written zeros; visible: reads mean 12 (x2), cov3D 24, record 32,
+// 36 per touched instance slot + 1 flag byte per slot, SH 12K, scale 12, rot 16, clamp 1; writes mean3D 12 (+12 re-read
+// and rewritten by the SH kernel), mean2D 12, colour 12 (re-read once), opacity 4, cov3D 24, SH 12M, scale 12, rot 16.
 #include "state.h"
 #include "wave64.h"
 #include "kernels.h"
 #include "shrows.h"
+#include "partials.h"
 
 namespace gsr {
 
@@ -51,11 +52,10 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		ox = p.means3D[3 * (size_t)idx] - p.campos[0];
 		oy = p.means3D[3 * (size_t)idx + 1] - p.campos[1];
 		oz = p.means3D[3 * (size_t)idx + 2] - p.campos[2];
-		const float4 ga0 = reinterpret_cast<const float4*>(p.grad_acc)[3 * (size_t)idx];   // colour gradient in x, y, z
-		const uint8_t cl = p.clamped[idx];
-		dRGB[0] = ga0.x * ((cl & 1) ? 0.f : 1.f);
-		dRGB[1] = ga0.y * ((cl & 2) ? 0.f : 1.f);
-		dRGB[2] = ga0.z * ((cl & 4) ? 0.f : 1.f);
+		const uint8_t cl = p.clamped[idx];   // dL_dcolor: written by preprocess_bwd_kernel, which runs first
+		dRGB[0] = p.dL_dcolor[3 * (size_t)idx + 0] * ((cl & 1) ? 0.f : 1.f);
+		dRGB[1] = p.dL_dcolor[3 * (size_t)idx + 1] * ((cl & 2) ? 0.f : 1.f);
+		dRGB[2] = p.dL_dcolor[3 * (size_t)idx + 2] * ((cl & 4) ? 0.f : 1.f);
 	}
 	// The wave handles its 64 rows in two halves of STAGE_ROWS: the SH rows of the half's visible lanes are fetched
 	// by the whole wave into LDS, each owner turns its row into the gradient row IN PLACE (zeros for culled
@@ -98,17 +98,18 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
 		const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
 		const float dLz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
-		// dnormvdv, auxiliary.h:107-117; parked in dL_dmean3D, preprocess_bwd_kernel adds the covariance and projection terms
+		// dnormvdv, auxiliary.h:107-117, added to the covariance + projection terms preprocess_bwd_kernel left in
+		// dL_dmean3D (the reference's order of the three contributions, backward.cu:271-273,384,137)
 		const float sum2 = ox * ox + oy * oy + oz * oz;
 		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-		p.dL_dmean3D[3 * (size_t)idx + 0] = ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
-		p.dL_dmean3D[3 * (size_t)idx + 1] = (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
-		p.dL_dmean3D[3 * (size_t)idx + 2] = (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+		p.dL_dmean3D[3 * (size_t)idx + 0] += ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
+		p.dL_dmean3D[3 * (size_t)idx + 1] += (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
+		p.dL_dmean3D[3 * (size_t)idx + 2] += (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
 	}
 }
 
-// ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel has
-// run and parked its dL_dmean3D term; otherwise the SH backward happens here with per-lane scalar row access.
+// ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel
+// follows and adds the SH term; otherwise the SH backward happens here with per-lane scalar row access.
 template <bool ROWS_OK>
 __global__ void __launch_bounds__(PRB_THREADS)
 preprocess_bwd_kernel(const PreprocessBwdParams p)
@@ -119,6 +120,16 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	const bool vis = in_range && (p.radii[idx] > 0);
 	const int M3 = 3 * p.M;
 	constexpr bool rows_ok = ROWS_OK;
+
+	// ------------------------------------------------------------------ gradients of the blend stage (partials.h)
+	// the per-instance slots of this Gaussian's tiles are summed here, in registers: colour 0..2, mean2D moments 3..4,
+	// conic moments 5..7, opacity 8 never round-trip through HBM
+	float a[9];
+	{
+		const uint32_t cnt = (vis && p.partials) ? p.tiles_touched[idx] : 0u;
+		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
+		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a);   // every lane of the wave takes part
+	}
 	float* out_sh = (p.dL_dsh && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
 	// Culled Gaussians take the same store instructions as visible ones, with zeros (the reference leaves the
@@ -132,7 +143,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	float mx = 0.f, my = 0.f, mz = 0.f;
 	float gmx = 0.f, gmy = 0.f, gmz = 0.f;
 	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-	// blend-stage gradients of this Gaussian (colour 0..2, mean2D 3..4, conic 5..7, opacity 8)
+	// dL_dcolor (x, y, z) + dL_dmean2D.x (w) ; dL_dmean2D.y (x) + dL_dconic (y, z, w)
 	float4 ga0 = make_float4(0.f, 0.f, 0.f, 0.f), ga1 = make_float4(0.f, 0.f, 0.f, 0.f);
 	float g_opacity = 0.f;
 
@@ -140,15 +151,16 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		mx = p.means3D[3 * (size_t)idx];
 		my = p.means3D[3 * (size_t)idx + 1];
 		mz = p.means3D[3 * (size_t)idx + 2];
-		const float4* ga = reinterpret_cast<const float4*>(p.grad_acc) + 3 * (size_t)idx;
-		ga0 = ga[0];
-		ga1 = ga[1];
-		g_opacity = ga[2].x;
+		// constant factors the blend left out: dL_dG = opacity * dL_dalpha; d(mean2D) carries -W/2, -H/2 and the conic
+		// (dG_ddelx = -G (dx A + dy B), dG_ddely = -G (dy C + dx B), backward.cu:460-461,539-546), the conic terms -1/2 (:549-551)
+		const float4 q0 = p.rec[3 * (size_t)idx];
+		const float4 q1 = p.rec[3 * (size_t)idx + 1];
+		const float A = q0.z, B = q0.w, C = q1.x, o = q1.y;
+		ga0 = make_float4(a[0], a[1], a[2], -o * p.half_w * (a[3] * A + a[4] * B));
+		ga1 = make_float4(-o * p.half_h * (a[4] * C + a[3] * B), -0.5f * o * a[5], -0.5f * o * a[6], -0.5f * o * a[7]);
+		g_opacity = a[8];
 		// raw logit: d sigmoid = o (1 - o), o = the activated opacity kept in the blend record
-		if (p.raw_params & GSR_RAW_OPACITY) {
-			const float o = p.rec[3 * (size_t)idx + 1].y;
-			g_opacity = g_opacity * o * (1.0f - o);
-		}
+		if (p.raw_params & GSR_RAW_OPACITY) g_opacity = g_opacity * o * (1.0f - o);
 	}
 	const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
 	if (in_range) {
@@ -165,13 +177,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 
 	// ------------------------------------------------------------------ SH backward, backward.cu:20-139
 	if (p.shs) {   // wave-uniform
-		if (rows_ok) {
-			if (vis) {   // computed and parked by sh_bwd_rows_kernel
-				shx = p.dL_dmean3D[3 * (size_t)idx + 0];
-				shy = p.dL_dmean3D[3 * (size_t)idx + 1];
-				shz = p.dL_dmean3D[3 * (size_t)idx + 2];
-			}
-		} else {
+		if (!rows_ok) {   // (aligned 48-float rows: sh_bwd_rows_kernel runs after this kernel and adds its term)
 			const int ncoef = (p.D + 1) * (p.D + 1);
 			float dRGB[3] = {0.f, 0.f, 0.f};
 			float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};  // dRGBdx/dy/dz
@@ -386,6 +392,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 	                     ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
 	const int grid = div_up(p.P, PRB_THREADS);
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
+		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
+		GSR_CHECK_LAUNCH();
 		const int g = div_up(p.P, SHB_THREADS);
 		if (p.D == 3)
 			GSR_LAUNCH(sh_bwd_rows_kernel<3>, g, SHB_THREADS, stream, p);
@@ -395,8 +403,6 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 			GSR_LAUNCH(sh_bwd_rows_kernel<1>, g, SHB_THREADS, stream, p);
 		else
 			GSR_LAUNCH(sh_bwd_rows_kernel<0>, g, SHB_THREADS, stream, p);
-		GSR_CHECK_LAUNCH();
-		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
 	} else {
 		GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
 	}

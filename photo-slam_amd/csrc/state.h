@@ -62,7 +62,6 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
-	float*    grad_acc;       // [12P] per-Gaussian blend gradients (backward only; written for visible Gaussians)
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -83,7 +82,6 @@ struct GeometryState {
 		g.sort_vals_b = c.take<uint32_t>(P);
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
-		g.grad_acc = c.take<float>(12 * P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
