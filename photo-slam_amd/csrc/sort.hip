@@ -169,6 +169,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 	__syncthreads();
 
 	uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
+	uint32_t place[SORT_ROUNDS];   // rank inside the lane's digit group of this round (low byte) | group size << 8
 	// Phase A: load (coalesced 256 B per wave instruction) and count digits per wave.
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
@@ -176,10 +177,17 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const bool valid = i < n;
 		key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
 		val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+	}
+#pragma unroll
+	for (int r = 0; r < SORT_ROUNDS; r++) {
+		const int i = wbase + r * 64 + l;
+		const bool valid = i < n;
 		const uint32_t d = (key[r] >> shift) & dmask;
 		const unsigned long long m = wave_match_digit(d, nbits, valid);
+		const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt()), size = (uint32_t)__popcll(m);
+		place[r] = rank | (size << 8);   // the ballots are not repeated in phase C
 		// the lowest lane of each digit group adds the group size; groups of one wave touch distinct bins
-		if (valid && (m & lanemask_lt()) == 0ull) s_whist[w][d] += (uint32_t)__popcll(m);
+		if (valid && rank == 0u) s_whist[w][d] += size;
 		wave_fence();
 	}
 	__syncthreads();
@@ -207,15 +215,14 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const int i = wbase + r * 64 + l;
 		const bool valid = i < n;
 		const uint32_t d = (key[r] >> shift) & dmask;
-		const unsigned long long m = wave_match_digit(d, nbits, valid);
-		const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+		const uint32_t rank = place[r] & 0xFFu, size = place[r] >> 8;
 		uint32_t cursor = 0;
 		if (valid) cursor = s_whist[w][d];
 		wave_fence();  // every lane has read the cursor before the group leader advances it
 		if (valid) {
 			s_keys[cursor + rank] = key[r];
 			s_vals[cursor + rank] = val[r];
-			if (rank == 0) s_whist[w][d] = cursor + (uint32_t)__popcll(m);
+			if (rank == 0) s_whist[w][d] = cursor + size;
 		}
 		wave_fence();
 	}
