@@ -118,10 +118,9 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const int i = wbase + r * 64 + lane_id();
-		const bool valid = i < n;
-		const uint32_t d = valid ? ((key[r] >> shift) & dmask) : 0u;
-		const unsigned long long m = wave_match_digit(d, nbits, valid);
-		if (valid && (m & lanemask_lt()) == 0ull) atomicAdd(&s_hist[d], (uint32_t)__popcll(m));
+		// one LDS atomic per key: even 64 lanes on one bin (64 serialised adds) cost less than the ~60 VALU of a ballot
+		// match; only the scatter kernel needs the match, for its stable ranks
+		if (i < n) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
 	}
 	__syncthreads();
 	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
