@@ -41,10 +41,6 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 {
 	__shared__ float4 s_rows[PRE_THREADS / 64][FWD_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[PRE_THREADS / 64][64];
-#ifdef GSR_EXP_LDS_PAD   // occupancy experiment
-	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
-	if (p.P < 0) s_pad[threadIdx.x] = 1, g.counters[0] = s_pad[threadIdx.x ^ 1];
-#endif
 
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id();

@@ -35,10 +35,6 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[SHB_THREADS / 64][STAGE_ROWS];
-#ifdef GSR_EXP_LDS_PAD   // occupancy experiment
-	__shared__ uint32_t s_pad[GSR_EXP_LDS_PAD / 4];
-	if (p.P < 0) s_pad[threadIdx.x] = 1, p.dL_dopacity[0] = (float)s_pad[threadIdx.x ^ 1];
-#endif
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
