@@ -14,10 +14,15 @@
 
 namespace gsr {
 
-constexpr int LT = 32;            // output tile
-constexpr int LH = 5;             // window half width (11 taps)
-constexpr int LR = LT + 2 * LH;   // 42: input tile with halo
-constexpr int LRP = LR + 1;       // padded pitch
+#ifndef GSR_LOSS_TILE_Y
+#define GSR_LOSS_TILE_Y 32
+#endif
+constexpr int LT = 32;                  // output tile width
+constexpr int LTY = GSR_LOSS_TILE_Y;    // output tile height (8 row groups per column: LTY / 8 outputs per thread)
+constexpr int LH = 5;                   // window half width (11 taps)
+constexpr int LR = LT + 2 * LH;         // 42: input tile width with halo
+constexpr int LRY = LTY + 2 * LH;       // input tile height with halo
+constexpr int LRP = LR + 1;             // padded pitch
 
 struct LossParams {
 	const float* rendered;  // [3,H,W]
@@ -60,24 +65,26 @@ __device__ __forceinline__ float block_sum_256(float v, float* s4)
 // FOUR consecutive outputs of a row (horizontal pass) or of a column (vertical pass) from 14 inputs held in
 // registers: 3.5 LDS reads per output and tap set instead of 11 (the first version, one output per thread, was
 // LDS-issue bound: 86 k ds_read_b32 per tile).
-constexpr int LG = 4;             // outputs per thread and pass
-constexpr int LW = LG + 2 * LH;   // 14 inputs feed them
+constexpr int LG = 4;              // outputs per thread in the horizontal pass
+constexpr int LW = LG + 2 * LH;    // 14 inputs feed them
+constexpr int LGV = LTY / 8;       // outputs per thread in the vertical pass (256 threads = 32 columns x 8 row groups)
+constexpr int LWV = LGV + 2 * LH;
 
 // Pass 1: window statistics -> SSIM map value + the three derivative maps, and L1 / SSIM partial sums.
 __global__ void __launch_bounds__(256)
 loss_fwd_kernel(const LossParams p)
 {
-	__shared__ float s_x[LR][LRP], s_y[LR][LRP];
-	__shared__ float s_h[5][LR][LT + 1];
+	__shared__ float s_x[LRY][LRP], s_y[LRY][LRP];
+	__shared__ float s_h[5][LRY][LT + 1];
 	__shared__ float s_red[4];
 	const int ch = (int)blockIdx.z;
-	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LT;
+	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
 	const size_t plane = (size_t)p.W * p.H;
 	const float* R = p.rendered + ch * plane;
 	const float* G = p.gt + ch * plane;
 	const float* Mk = p.mask ? p.mask + ch * plane : nullptr;
 	const int tid = (int)threadIdx.x;
-	for (int i = tid; i < LR * LR; i += 256) {
+	for (int i = tid; i < LRY * LR; i += 256) {
 		const int r = i / LR, c = i - r * LR;
 		const int gx = x0 - LH + c, gy = y0 - LH + r;
 		float xv = 0.f, yv = 0.f;
@@ -90,8 +97,8 @@ loss_fwd_kernel(const LossParams p)
 		s_y[r][c] = yv;
 	}
 	__syncthreads();
-	// horizontal pass: LR rows x (LT / LG) groups of LG columns
-	for (int u = tid; u < LR * (LT / LG); u += 256) {
+	// horizontal pass: LRY rows x (LT / LG) groups of LG columns
+	for (int u = tid; u < LRY * (LT / LG); u += 256) {
 		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
 		float xv[LW], yv[LW];
 #pragma unroll
@@ -120,15 +127,15 @@ loss_fwd_kernel(const LossParams p)
 	float l1_sum = 0.f, ssim_sum = 0.f;
 	{
 		// vertical pass: thread = (column c, group of LG rows)
-		const int c = tid & (LT - 1), r0 = (tid >> 5) * LG;
-		float st[5][LG];
+		const int c = tid & (LT - 1), r0 = (tid >> 5) * LGV;
+		float st[5][LGV];
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
-			float col[LW];
+			float col[LWV];
 #pragma unroll
-			for (int t = 0; t < LW; t++) col[t] = s_h[k][r0 + t][c];
+			for (int t = 0; t < LWV; t++) col[t] = s_h[k][r0 + t][c];
 #pragma unroll
-			for (int o = 0; o < LG; o++) {
+			for (int o = 0; o < LGV; o++) {
 				float a = 0.f;
 #pragma unroll
 				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
@@ -137,7 +144,7 @@ loss_fwd_kernel(const LossParams p)
 		}
 		const int gx = x0 + c;
 #pragma unroll
-		for (int o = 0; o < LG; o++) {
+		for (int o = 0; o < LGV; o++) {
 			const int gy = y0 + r0 + o;
 			if (gx < p.W && gy < p.H) {
 				const float mu1 = st[0][o], mu2 = st[1][o], e11 = st[2][o], e22 = st[3][o], e12 = st[4][o];
@@ -172,13 +179,13 @@ loss_fwd_kernel(const LossParams p)
 __global__ void __launch_bounds__(256)
 loss_bwd_kernel(const LossParams p)
 {
-	__shared__ float s_d[3][LR][LRP];
-	__shared__ float s_h[3][LR][LT + 1];
+	__shared__ float s_d[3][LRY][LRP];
+	__shared__ float s_h[3][LRY][LT + 1];
 	const int ch = (int)blockIdx.z;
-	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LT;
+	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
 	const size_t plane = (size_t)p.W * p.H;
 	const int tid = (int)threadIdx.x;
-	for (int i = tid; i < LR * LR; i += 256) {
+	for (int i = tid; i < LRY * LR; i += 256) {
 		const int r = i / LR, c = i - r * LR;
 		const int gx = x0 - LH + c, gy = y0 - LH + r;
 		const bool in = gx >= 0 && gx < p.W && gy >= 0 && gy < p.H;
@@ -187,7 +194,7 @@ loss_bwd_kernel(const LossParams p)
 		for (int k = 0; k < 3; k++) s_d[k][r][c] = in ? p.dmaps[(k * 3 + ch) * plane + o] : 0.f;
 	}
 	__syncthreads();
-	for (int u = tid; u < LR * (LT / LG); u += 256) {
+	for (int u = tid; u < LRY * (LT / LG); u += 256) {
 		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
 #pragma unroll
 		for (int k = 0; k < 3; k++) {
@@ -206,15 +213,15 @@ loss_bwd_kernel(const LossParams p)
 	__syncthreads();
 	const float inv_n = 1.0f / (3.0f * (float)plane);
 	{
-		const int c = tid & (LT - 1), r0 = (tid >> 5) * LG;
-		float cv[3][LG];
+		const int c = tid & (LT - 1), r0 = (tid >> 5) * LGV;
+		float cv[3][LGV];
 #pragma unroll
 		for (int k = 0; k < 3; k++) {
-			float col[LW];
+			float col[LWV];
 #pragma unroll
-			for (int t = 0; t < LW; t++) col[t] = s_h[k][r0 + t][c];
+			for (int t = 0; t < LWV; t++) col[t] = s_h[k][r0 + t][c];
 #pragma unroll
-			for (int o = 0; o < LG; o++) {
+			for (int o = 0; o < LGV; o++) {
 				float a = 0.f;
 #pragma unroll
 				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
@@ -223,7 +230,7 @@ loss_bwd_kernel(const LossParams p)
 		}
 		const int gx = x0 + c;
 #pragma unroll
-		for (int o = 0; o < LG; o++) {
+		for (int o = 0; o < LGV; o++) {
 			const int gy = y0 + r0 + o;
 			if (gx < p.W && gy < p.H) {
 				const size_t oo = ch * plane + (size_t)gy * p.W + gx;
@@ -339,7 +346,7 @@ size_t gsr_loss_scratch_bytes(int width, int height)
 {
 	if (width <= 0 || height <= 0) return 0;
 	const size_t plane = (size_t)width * height;
-	const size_t nb = (size_t)div_up(width, LT) * div_up(height, LT) * 3;
+	const size_t nb = (size_t)div_up(width, LT) * div_up(height, LTY) * 3;
 	return (9 * plane + 2 * nb + 64) * sizeof(float);
 }
 
@@ -359,7 +366,7 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 	}
 	for (int x = 0; x < 11; x++) p.g[x] /= sum;
 	const size_t plane = (size_t)width * height;
-	const int gx = div_up(width, LT), gy = div_up(height, LT);
+	const int gx = div_up(width, LT), gy = div_up(height, LTY);
 	p.nblocks = gx * gy * 3;
 	p.dmaps = reinterpret_cast<float*>(scratch);
 	p.partial = p.dmaps + 9 * plane;
