@@ -23,8 +23,6 @@ using ::hipemu::wave_uniform_u32;
 using ::hipemu::wave_readlane_f32;
 using ::hipemu::wave_readlane_u32;
 using ::hipemu::wave_writelane_f32;
-using ::hipemu::wave_reduce9_packed_f32;
-using ::hipemu::wave_packed9_total;
 using ::hipemu::wave_reduce9_swap_f32;
 using ::hipemu::wave_swap9_component;
 using ::hipemu::mask_select_f32;
@@ -168,61 +166,6 @@ __device__ __forceinline__ void wave_reduce9_f32(float (&v)[9])
 	for (int i = 0; i < 9; i++) v[i] += dpp_f32<DPP_ROW_BCAST31, 0xc>(0.f, v[i]);
 }
 
-// Nine full-wave sums with a packed butterfly: the first two levels (lane xor 1, xor 2) halve the
-// number of live values -- each lane keeps the half its low lane bits select and hands the other
-// half to its partner -- so the remaining four levels (rotate-adds inside a row of 16, then the
-// gfx950 v_permlane16_swap / v_permlane32_swap across rows) run on 3 registers instead of 9:
-// ~38 VALU instead of ~72.  On return v[0..2] hold the packed totals; the total of value c is in
-// register v[c >> 2] of every lane whose (lane & 3) == (c & 3)  ->  wave_packed9_total(v, c).
-__device__ __forceinline__ float dpp_xor16_add(float s)
-{
-	const unsigned u = __builtin_bit_cast(unsigned, s);
-	const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ float dpp_xor32_add(float s)
-{
-	const unsigned u = __builtin_bit_cast(unsigned, s);
-	const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ void wave_reduce9_packed_f32(float (&v)[9])
-{
-	const bool b0 = (threadIdx.x & 1u) != 0, b1 = (threadIdx.x & 2u) != 0;
-	float r[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const float keep = b0 ? v[2 * k + 1] : v[2 * k];
-		const float send = b0 ? v[2 * k] : v[2 * k + 1];
-		r[k] = keep + dpp_f32<DPP_QUAD_PERM_1032>(0.f, send);
-	}
-	float s2 = v[8] + dpp_f32<DPP_QUAD_PERM_1032>(0.f, v[8]);
-	float s0, s1;
-	{
-		const float keep = b1 ? r[1] : r[0], send = b1 ? r[0] : r[1];
-		s0 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
-	}
-	{
-		const float keep = b1 ? r[3] : r[2], send = b1 ? r[2] : r[3];
-		s1 = keep + dpp_f32<DPP_QUAD_PERM_2301>(0.f, send);
-	}
-	s2 += dpp_f32<DPP_QUAD_PERM_2301>(0.f, s2);
-	// lanes with equal (lane & 3) hold partial sums of the same value: rotate-add inside each row of 16 ...
-	constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
-	s0 += dpp_f32<DPP_ROW_ROR4>(0.f, s0);
-	s1 += dpp_f32<DPP_ROW_ROR4>(0.f, s1);
-	s2 += dpp_f32<DPP_ROW_ROR4>(0.f, s2);
-	s0 += dpp_f32<DPP_ROW_ROR8>(0.f, s0);
-	s1 += dpp_f32<DPP_ROW_ROR8>(0.f, s1);
-	s2 += dpp_f32<DPP_ROW_ROR8>(0.f, s2);
-	// ... then across the four rows (lane i <-> i+16, i <-> i+32 keep the residue class)
-	s0 = dpp_xor16_add(s0);
-	s1 = dpp_xor16_add(s1);
-	s2 = dpp_xor16_add(s2);
-	v[0] = dpp_xor32_add(s0);
-	v[1] = dpp_xor32_add(s1);
-	v[2] = dpp_xor32_add(s2);
-}
 // Nine full-wave sums, packed from the TOP of the butterfly.  gfx950's v_permlane32_swap / v_permlane16_swap
 // exchange half-waves / odd-even rows BETWEEN two registers, so one swap + one add folds two values
 // into one register (value a in the lower half / even rows, value b in the upper half / odd rows):
@@ -230,8 +173,8 @@ __device__ __forceinline__ void wave_reduce9_packed_f32(float (&v)[9])
 //   level 8 : 2 -> 1 with a DPP row_ror:8 whose bank_mask keeps one value per half row (3 ops),
 //   levels 4, 2, 1: half-mirror and quad_perm adds on ONE register (3 ops);
 // the ninth value is only summed inside each row of 16 (4 DPP adds; the caller merges the four row sums, e.g.
-// with the LDS atomic it issues anyway): 22 VALU for nine sums (72 unpacked, 38 for the bottom-packed
-// variant above).  Result: every lane of the 8-lane group g = lane >> 3 holds in `packed` the total of
+// with the LDS atomic it issues anyway): 22 VALU for nine sums (72 unpacked; 38 for a butterfly packed from the
+// bottom with quad_perm selects, the previous version).  Result: every lane of the 8-lane group g = lane >> 3 holds in `packed` the total of
 // value bitrev3(g) = {0,4,2,6,1,5,3,7}[g]; `ninth_row` holds the sum of v[8] over the lane's row of 16.
 __device__ __forceinline__ float swap32_add(float a, float b)
 {
@@ -273,11 +216,6 @@ __device__ __forceinline__ int wave_swap9_component(int lane)
 	const int g = lane >> 3;
 	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);
 }
-__device__ __forceinline__ float wave_packed9_total(const float (&v)[9], int c)
-{
-	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c >> 2]), c & 3));
-}
-
 // Inclusive prefix sum across the wave (Hillis-Steele on DPP row shifts + row broadcasts).
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {

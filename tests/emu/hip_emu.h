@@ -128,17 +128,6 @@ static inline void wave_reduce9_f32(float (&v)[9])
 		v[c] = acc;  // the real primitive only guarantees lane 63
 	}
 }
-// packed variant: same sums, delivered in the packed layout of csrc/wave64.h
-static inline void wave_reduce9_packed_f32(float (&v)[9])
-{
-	float t[9];
-	for (int c = 0; c < 9; c++) t[c] = v[c];
-	wave_reduce9_f32(t);
-	const int r = lane() & 3;
-	v[0] = t[r];
-	v[1] = t[4 + r];
-	v[2] = t[8];
-}
 static inline float mask_select_f32(unsigned long long mask, float if_set, float if_clear) { return ((mask >> lane()) & 1ull) ? if_set : if_clear; }
 static inline uint32_t mask_select_u32(unsigned long long mask, uint32_t if_set, uint32_t if_clear) { return ((mask >> lane()) & 1ull) ? if_set : if_clear; }
 static inline float mask_select0_f32(unsigned long long mask, float if_set) { return ((mask >> lane()) & 1ull) ? if_set : 0.f; }
@@ -217,7 +206,6 @@ static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 namespace hipemu {
-static inline float wave_packed9_total(const float (&v)[9], int c) { return wave_readlane_f32(v[c >> 2], c & 3); }
 }  // namespace hipemu
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
