@@ -74,7 +74,7 @@ def main():
     from photo_slam_amd import capi, scene
     from photo_slam_amd.gaussian_model import GaussianModel, GaussianOptimizationParams
     from photo_slam_amd.gaussian_renderer import GaussianKeyframe, GaussianPipelineParams, GaussianRenderer
-    from photo_slam_amd.trainer import TrainStep, allreduce_mean
+    from photo_slam_amd.trainer import TrainStep, GradientReduction
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,9 +132,18 @@ def main():
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
             if world > 1:
-                allreduce_mean(ops.trainer_grads(handle), world)
-            loss.item()                       # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
-            ops.trainer_finish(handle)
+                # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
+                # SH update overlaps the small reductions still on the links
+                red = GradientReduction(ops.trainer_grads(handle), world)
+                loss.item()                   # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
+                ops.trainer_finish_begin(handle)
+                for i in red.order():
+                    red.wait(i)
+                    ops.trainer_adam_group(handle, i)
+                ops.trainer_finish_end(handle)
+            else:
+                loss.item()
+                ops.trainer_finish(handle)
         elif args.raster_only:
             img, vsp, vis, radii = GaussianRenderer.render(kf, H, W, g, pipe, bg)
             img.backward(gt)

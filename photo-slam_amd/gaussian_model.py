@@ -25,23 +25,32 @@ class FusedAdam:
         self.step_count = 0
 
     def step(self):
-        lib = rp._lib()
+        self.begin_step()
+        for i in range(len(self.param_groups)):
+            self.step_group(i)
+
+    def begin_step(self):
         self.step_count += 1
+
+    def step_group(self, i):
+        """This step's update of parameter group i alone (after begin_step()): a data-parallel driver updates a tensor as
+        soon as ITS gradient reduction has landed, while the larger reductions are still in flight."""
+        lib = rp._lib()
+        grp = self.param_groups[i]
         with torch.no_grad():
-            for grp in self.param_groups:
-                for p in grp["params"]:
-                    if p.grad is None:
-                        continue
-                    st = self.state.get(id(p))
-                    if st is None:
-                        st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
-                    g = p.grad.contiguous()
-                    capi.check(lib, lib.gsr_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                      st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]),
-                                                      self.betas[0], self.betas[1], self.eps, self.step_count,
-                                                      int(grp.get("period", 0)), int(grp.get("split", 0)),
-                                                      float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
-                               "gsr_adam_step")
+            for p in grp["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state.get(id(p))
+                if st is None:
+                    st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                g = p.grad.contiguous()
+                capi.check(lib, lib.gsr_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                  st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]),
+                                                  self.betas[0], self.betas[1], self.eps, self.step_count,
+                                                  int(grp.get("period", 0)), int(grp.get("split", 0)),
+                                                  float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
+                           "gsr_adam_step")
 
     def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):
         """Swap a parameter tensor (densify / prune / opacity reset): the Adam moments are replaced by the given

@@ -51,6 +51,10 @@ public:
 	void trainingSetup(const GaussianOptimizationParams& opt);   // src/gaussian_model.cpp:477-510
 	float updateLearningRate(int step);                          // :1118-1131 (exponLrFunc)
 	void optimizerStep();                                        // torch::optim::Adam semantics, fused
+	// the same step one parameter group at a time (xyz, features, opacity, scaling, rotation), so that a data-parallel
+	// driver can update a tensor as soon as ITS gradient reduction has landed: beginOptimizerStep() once, then every group
+	void beginOptimizerStep() { adam_step_++; }
+	void optimizerStepGroup(int group);
 	void zeroGrad();
 	void addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter);  // :817-831
 	std::vector<torch::Tensor> params() { return {xyz_, features_, opacity_, scaling_, rotation_}; }
@@ -73,6 +77,11 @@ public:
 	// driver all-reduce before finishOneIteration()
 	torch::Tensor renderAndBackward(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask);
 	void finishOneIteration();
+	// finishOneIteration() in three pieces for the overlapped data-parallel step (bench.py): statistics, then Adam per
+	// group as the reductions complete, then the gradient reset
+	void finishBegin();
+	void finishAdamGroup(int group);
+	void finishEnd();
 	torch::Tensor trainForOneIteration(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
 	{
 		auto loss = renderAndBackward(kf, gt_image, mask);

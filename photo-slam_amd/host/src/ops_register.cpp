@@ -109,6 +109,9 @@ torch::Tensor trainer_render_and_backward(int64_t h, torch::Tensor view, torch::
 	return get(h)->renderAndBackward(make_kf(view, proj, campos, fovx, fovy, H, W), gt, mask).detach();
 }
 void trainer_finish(int64_t h) { get(h)->finishOneIteration(); }
+void trainer_finish_begin(int64_t h) { get(h)->finishBegin(); }
+void trainer_adam_group(int64_t h, int64_t group) { get(h)->finishAdamGroup(static_cast<int>(group)); }
+void trainer_finish_end(int64_t h) { get(h)->finishEnd(); }
 std::vector<torch::Tensor> trainer_params(int64_t h) { return get(h)->gaussians_->params(); }
 std::vector<torch::Tensor> trainer_grads(int64_t h)
 {
@@ -142,6 +145,9 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_create", &trainer_create);
 	m.def("trainer_render_and_backward", &trainer_render_and_backward);
 	m.def("trainer_finish", &trainer_finish);
+	m.def("trainer_finish_begin", &trainer_finish_begin);
+	m.def("trainer_adam_group", &trainer_adam_group);
+	m.def("trainer_finish_end", &trainer_finish_end);
 	m.def("trainer_params", &trainer_params);
 	m.def("trainer_grads", &trainer_grads);
 	m.def("trainer_stats", &trainer_stats);

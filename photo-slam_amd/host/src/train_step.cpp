@@ -112,19 +112,23 @@ float GaussianModel::updateLearningRate(int step)
 	return lr;
 }
 
-void GaussianModel::optimizerStep()
+void GaussianModel::optimizerStepGroup(int group)
 {
 	torch::NoGradGuard ng;
-	adam_step_++;
-	for (auto& g : groups_) {
-		auto grad = g.param.grad();
-		if (!grad.defined()) continue;
-		grad = grad.contiguous();
-		check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
-		                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, adam_step_,
-		                    g.period, g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
-		      "gsr_adam_step");
-	}
+	auto& g = groups_.at(static_cast<size_t>(group));
+	auto grad = g.param.grad();
+	if (!grad.defined()) return;
+	grad = grad.contiguous();
+	check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
+	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, adam_step_, g.period,
+	                    g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
+	      "gsr_adam_step");
+}
+
+void GaussianModel::optimizerStep()
+{
+	beginOptimizerStep();
+	for (int i = 0; i < static_cast<int>(groups_.size()); i++) optimizerStepGroup(i);
 }
 
 void GaussianModel::zeroGrad()
@@ -160,6 +164,24 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 
 void TrainStep::finishOneIteration()
 {
+	finishBegin();
+	if (iteration_ < gaussians_->opt_.iterations_)
+		for (int i = 0; i < static_cast<int>(gaussians_->groups_.size()); i++) gaussians_->optimizerStepGroup(i);
+	finishEnd();
+}
+
+void TrainStep::finishAdamGroup(int group)
+{
+	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->optimizerStepGroup(group);
+}
+
+void TrainStep::finishEnd()
+{
+	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->zeroGrad();
+}
+
+void TrainStep::finishBegin()
+{
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	if (iteration_ < g->opt_.densify_until_iter_) {
@@ -171,8 +193,5 @@ void TrainStep::finishOneIteration()
 		                        g->max_radii2D_.data_ptr<float>(), stream_of(grad)),
 		      "gsr_densify_stats");
 	}
-	if (iteration_ < g->opt_.iterations_) {
-		g->optimizerStep();
-		g->zeroGrad();
-	}
+	if (iteration_ < g->opt_.iterations_) g->beginOptimizerStep();
 }
