@@ -1062,11 +1062,11 @@ static uint32_t quad_keep_bits_ref(const float* m2, const float* co, float tile_
 
 void gsro_cull_stats(const gsro_state* st, double* out)
 {
-	for (int i = 0; i < 10; i++) out[i] = 0;
+	for (int i = 0; i < 12; i++) out[i] = 0;
 	const int W = st->W, H = st->H;
 	const int T = st->grid_x * st->grid_y;
-	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7, o8, o9)
+	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0, o10 = 0, o11 = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11)
 	for (int t = 0; t < T; t++) {
 		const int tx = t % st->grid_x, ty = t / st->grid_x;
 		const uint32_t rs = st->ranges[2 * t], re = st->ranges[2 * t + 1];
@@ -1114,10 +1114,19 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 				if ((used[k] >> q) & 1) o8 += 1;   /* (quad, entry) visits with at least one blending pixel */
 			}
 			if (used[k]) o9 += 1;                   /* (tile, entry) instances with at least one blending pixel */
+			/* what a 16x8 (two quads side by side) or 8x16 unit of execution would visit in the backward pass */
+			{
+				const uint32_t top = qmaxc[0] > qmaxc[1] ? qmaxc[0] : qmaxc[1], bot = qmaxc[2] > qmaxc[3] ? qmaxc[2] : qmaxc[3];
+				const uint32_t lef = qmaxc[0] > qmaxc[2] ? qmaxc[0] : qmaxc[2], rig = qmaxc[1] > qmaxc[3] ? qmaxc[1] : qmaxc[3];
+				if (k < top && (bits & 3u)) o10 += 1;
+				if (k < bot && (bits & 12u)) o10 += 1;
+				if (k < lef && (bits & 5u)) o11 += 1;
+				if (k < rig && (bits & 10u)) o11 += 1;
+			}
 		}
 		free(used);
 	}
-	out[8] = o8; out[9] = o9;
+	out[8] = o8; out[9] = o9; out[10] = o10; out[11] = o11;
 	out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
 }
 
