@@ -44,7 +44,8 @@ __device__ __forceinline__ void wave_load_listed_rows(const float4* __restrict__
 		const int j = j0 + slot;
 		if (col < nf4 && j < count) {
 			const uint32_t src = s_list[list_first + j];
-			s_rows[BY_SOURCE ? (int)src : j][col] = gbase[(first_row + src) * ROW_F4 + col];
+			// streaming load: a row is read once per pass over the model (the next reader comes after ~3 GB of other traffic)
+			s_rows[BY_SOURCE ? (int)src : j][col] = load_stream_f4(gbase + (first_row + src) * ROW_F4 + col);
 		}
 	}
 	wave_fence();

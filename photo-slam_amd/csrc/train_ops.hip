@@ -282,10 +282,12 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 	const uint32_t dr = per ? (uint32_t)(stride % (long long)per) : 0u;
 	for (long long i = i0; i < n; i += stride) {
 		if (i + 3 < n && aligned) {
-			float4 pv = *reinterpret_cast<float4*>(param + i);
+			// every access is streaming (non-temporal): nothing here is reused before 3 GB of other traffic has passed
+			// (measured 604 -> 531 us per step at C3 against default-cached accesses)
+			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(param + i));
 			const float4 gv = load_stream_f4(reinterpret_cast<const float4*>(grad + i));
-			float4 mv = *reinterpret_cast<float4*>(exp_avg + i);
-			float4 vv = *reinterpret_cast<float4*>(exp_avg_sq + i);
+			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(exp_avg + i));
+			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(exp_avg_sq + i));
 			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
@@ -296,9 +298,9 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 				vp[k] = b2 * vp[k] + (1.f - b2) * gp[k] * gp[k];
 				pp[k] -= ss * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
 			}
-			*reinterpret_cast<float4*>(param + i) = pv;
-			*reinterpret_cast<float4*>(exp_avg + i) = mv;
-			*reinterpret_cast<float4*>(exp_avg_sq + i) = vv;
+			store_stream_f4(reinterpret_cast<float4*>(param + i), pv);
+			store_stream_f4(reinterpret_cast<float4*>(exp_avg + i), mv);
+			store_stream_f4(reinterpret_cast<float4*>(exp_avg_sq + i), vv);
 		} else {
 			for (long long k = i; k < n && k < i + 4; k++) {
 				uint32_t rk = r + (uint32_t)(k - i);

@@ -30,6 +30,7 @@ using ::hipemu::mask_select_u32;
 using ::hipemu::mask_select0_f32;
 #define GSR_OPAQUE_F32(x) asm volatile("" : "+x"(x))
 static inline float4 load_stream_f4(const float4* p) { return *p; }
+static inline void store_stream_f4(float4* p, const float4 v) { *p = v; }
 #define GSR_SCHED_BARRIER() ((void)0)
 #else
 
@@ -87,6 +88,13 @@ __device__ __forceinline__ float4 load_stream_f4(const float4* p)
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
 	return make_float4(t.x, t.y, t.z, t.w);
+}
+
+__device__ __forceinline__ void store_stream_f4(float4* p, const float4 v)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	v4f t = {v.x, v.y, v.z, v.w};
+	__builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
 }
 
 // Make a value opaque to the optimiser (no instruction): stops loop-invariant hoisting of everything computed from it.
