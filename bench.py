@@ -127,6 +127,22 @@ def main():
         import math
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
 
+    # The reference reads the loss on the host every iteration (EMA for logging, gaussian_mapper.cpp:701-705).  So does this
+    # loop -- one step late: the value is copied to pinned memory behind the step's kernels and read while the NEXT step is
+    # already queued, so the stream never drains for a log value.
+    loss_pinned = [torch.zeros(1).pin_memory() for _ in range(2)]
+    loss_ready = [torch.cuda.Event() for _ in range(2)]
+    loss_state = {"n": 0, "ema": 0.0}
+
+    def read_loss_deferred(loss):
+        k = loss_state["n"] & 1
+        if loss_state["n"] >= 1:
+            loss_ready[k ^ 1].synchronize()                       # step n-1: finished long ago, or being finished now
+            loss_state["ema"] = 0.4 * float(loss_pinned[k ^ 1][0]) + 0.6 * loss_state["ema"]
+        loss_pinned[k].copy_(loss.detach().reshape(1), non_blocking=True)
+        loss_ready[k].record()
+        loss_state["n"] += 1
+
     def one_step():
         if ops is not None:
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
@@ -135,15 +151,14 @@ def main():
                 # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
                 # SH update overlaps the small reductions still on the links
                 red = GradientReduction(ops.trainer_grads(handle), world)
-                loss.item()                   # the reference's per-iteration host sync (gaussian_mapper.cpp:701-705)
                 ops.trainer_finish_begin(handle)
                 for i in red.order():
-                    red.wait(i)
+                    red.wait(i)               # stream-side wait: the host keeps queueing
                     ops.trainer_adam_group(handle, i)
                 ops.trainer_finish_end(handle)
             else:
-                loss.item()
-                ops.trainer_finish(handle)
+                ops.trainer_finish(handle)    # statistics + Adam
+            read_loss_deferred(loss)
         elif args.raster_only:
             img, vsp, vis, radii = GaussianRenderer.render(kf, H, W, g, pipe, bg)
             img.backward(gt)

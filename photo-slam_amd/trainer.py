@@ -70,8 +70,6 @@ class TrainStep:
             if self.world_size_ > 1:
                 # keyframe-batch data parallelism: mean of the per-view gradients over RCCL, in flight from here on
                 reduction = GradientReduction([p.grad for p in g.params()], self.world_size_)
-            if sync_loss:
-                self.ema_loss_for_log_ = 0.4 * loss.item() + 0.6 * self.ema_loss_for_log_   # :705 (host sync, as the reference)
             if it < opt.densify_until_iter_:
                 if self.world_size_ == 1:
                     g.addViewStats(viewspace_point_tensor, radii)                                   # :714-719, fused
@@ -114,4 +112,8 @@ class TrainStep:
                 g.optimizer_.zero_grad(set_to_none=True)
             elif reduction is not None:
                 reduction.wait_all()
+            if sync_loss:
+                # :705 (the reference's per-iteration host sync for the loss EMA) -- moved behind the optimizer launches, so
+                # that Adam is already queued behind backward while the host waits
+                self.ema_loss_for_log_ = 0.4 * loss.item() + 0.6 * self.ema_loss_for_log_
         return loss
