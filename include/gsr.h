@@ -196,7 +196,9 @@ size_t gsr_knn_scratch_bytes(int P);
  * meant for single-stream benchmarking).
  * After gsr_profile_enable(1), every gsr_forward / gsr_backward records events between its
  * stages; gsr_profile_read() waits for the last ones and returns milliseconds per stage
- * (-1 for stages that did not run), indexed 0..gsr_profile_stage_count()-1. */
+ * (-1 for stages that did not run or were not timed), indexed 0..gsr_profile_stage_count()-1.
+ * gsr_profile_enable(2) times only the backward blend (two event records per step instead of
+ * eleven: every record is a ~5 us bubble in the stream); gsr_profile_enable(0) switches off. */
 int gsr_profile_enable(int on);
 int gsr_profile_stage_count(void);
 const char* gsr_profile_stage_name(int stage);

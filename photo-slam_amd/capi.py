@@ -148,7 +148,8 @@ def check(lib, status, where):
 
 
 def profile_enable(lib, on=True):
-    check(lib, lib.gsr_profile_enable(1 if on else 0), "gsr_profile_enable")
+    """True / 1: every stage; 2: only the backward blend (cheap enough for a timed region); False / 0: off"""
+    check(lib, lib.gsr_profile_enable(int(on)), "gsr_profile_enable")
 
 
 def profile_read(lib):

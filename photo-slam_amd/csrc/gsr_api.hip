@@ -48,7 +48,8 @@ static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sor
                                                     "tile_sort", "tile_ranges", "blend_fwd", "grad_memset",
                                                     "blend_bwd", "preprocess_bwd"};
 struct Profiler {
-	bool on = false;
+	int on = 0;               // 0 off, 1 every stage, 2 only the backward blend (its two events: an event record costs a
+	                          // ~5 us pipeline bubble, eleven of them 2 % of a C3 train step)
 	hipEvent_t fwd[8] = {};   // boundaries of the 7 forward stages
 	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
 	bool created = false, fwd_done = false, bwd_done = false;
@@ -64,8 +65,8 @@ struct Profiler {
 // process-wide (not per thread): PyTorch runs backward on an autograd worker thread, and the
 // benchmark reads the timings from the main thread.  Intended for single-stream benchmarking.
 static Profiler t_prof;
-#define PROF_FWD(i) do { if (t_prof.on) GSR_HIP(hipEventRecord(t_prof.fwd[i], stream)); } while (0)
-#define PROF_BWD(i) do { if (t_prof.on) GSR_HIP(hipEventRecord(t_prof.bwd[i], stream)); } while (0)
+#define PROF_FWD(i) do { if (t_prof.on == 1) GSR_HIP(hipEventRecord(t_prof.fwd[i], stream)); } while (0)
+#define PROF_BWD(i) do { if (t_prof.on == 1 || (t_prof.on == 2 && ((i) == 1 || (i) == 2))) GSR_HIP(hipEventRecord(t_prof.bwd[i], stream)); } while (0)
 
 static inline size_t geometry_bytes(int P)
 {
@@ -227,7 +228,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(7);
-	t_prof.fwd_done = t_prof.on;
+	t_prof.fwd_done = t_prof.on == 1;
 	*num_rendered = R;
 	return GSR_OK;
 }
@@ -290,7 +291,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_drot = a->dL_drot;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	PROF_BWD(3);
-	t_prof.bwd_done = t_prof.on;
+	t_prof.bwd_done = t_prof.on != 0;
 	return GSR_OK;
 }
 
@@ -300,7 +301,7 @@ int gsr_profile_enable(int on)
 		int st = t_prof.create();
 		if (st != GSR_OK) return st;
 	}
-	t_prof.on = on != 0;
+	t_prof.on = on == 2 ? 2 : (on != 0 ? 1 : 0);
 	t_prof.fwd_done = t_prof.bwd_done = false;
 	return GSR_OK;
 }
@@ -314,7 +315,10 @@ int gsr_profile_read(float* ms, int count)
 		GSR_HIP(hipEventSynchronize(t_prof.fwd[7]));
 		for (int i = 0; i < 7; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
 	}
-	if (t_prof.bwd_done) {
+	if (t_prof.bwd_done && t_prof.on == 2) {
+		GSR_HIP(hipEventSynchronize(t_prof.bwd[2]));
+		GSR_HIP(hipEventElapsedTime(&ms[ST_BLEND_BWD], t_prof.bwd[1], t_prof.bwd[2]));
+	} else if (t_prof.bwd_done) {
 		GSR_HIP(hipEventSynchronize(t_prof.bwd[3]));
 		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
 	}
