@@ -1,0 +1,94 @@
+"""Builds oracle/_ref/libref_rasterizer.so: the REFERENCE's own rasterizer sources
+(/root/reference/cuda_rasterizer/{forward,backward,rasterizer_impl}.cu) and simple-knn
+(third_party/simple-knn/simple_knn.cu) and the __global__ kernels of src/operate_points.cu / src/stereo_vision.cu,
+compiled for the host with g++ against the
+CUDA / cooperative-groups / CUB / glm shims in oracle/ref_shim/ (our code: a fiber model of thread blocks and the
+published semantics of the two CUB calls and of the glm operators the sources use).
+
+TEST INFRASTRUCTURE ONLY.  It exists to PIN the CPU oracle (oracle/gsr_oracle.c) and, through committed fixtures
+(tests/golden/reference_small.npz, made by tests/golden/make_reference_golden.py), the HIP kernels against the
+reference's own code.  Nothing from /root/reference is copied into the repository: the sources are read where they lie;
+the only rewrite is the kernel-launch syntax `k<<<g, b>>>(args)` -> `CUDAEMU_LAUNCH((k), g, b, args)`, done on the fly
+into oracle/_ref/gen/ (git-ignored).  The reference tree is absent on the GPU boxes: there only the built .so or the
+fixtures are used.
+"""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("GSR_REFERENCE_ROOT", "/root/reference")
+SRC_DIR = os.path.join(REF, "cuda_rasterizer")
+OUT_DIR = os.path.join(HERE, "_ref")
+GEN = os.path.join(OUT_DIR, "gen")
+OUT = os.path.join(OUT_DIR, "libref_rasterizer.so")
+SOURCES = ["forward.cu", "backward.cu", "rasterizer_impl.cu"]
+KNN_DIR = os.path.join(REF, "third_party", "simple-knn")   # simple_knn.cu: the distance initialisation (distCUDA2)
+LAUNCH = re.compile(r"(\b\w+(?:<[^<>;(){}]*>)?)\s*<<\s*<\s*(.+?)\s*>>\s*>\s*\(")
+
+
+POINT_SRC = [os.path.join(REF, "src", "operate_points.cu"), os.path.join(REF, "src", "stereo_vision.cu")]
+
+
+def _global_functions(text):
+    """The `__global__` kernel definitions of a .cu file, verbatim (the files also hold LibTorch wrappers, which need torch)."""
+    out, i = [], 0
+    while True:
+        i = text.find("__global__", i)
+        if i < 0:
+            return out
+        j = text.index("{", i)
+        depth, k = 1, j + 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(text[k], 0)
+            k += 1
+        out.append(text[i:k])
+        i = k
+
+
+def available():
+    return all(os.path.exists(os.path.join(SRC_DIR, s)) for s in SOURCES) and os.path.exists(os.path.join(KNN_DIR, "simple_knn.cu")) \
+        and all(os.path.exists(f) for f in POINT_SRC)
+
+
+def build(force=False):
+    if not available():
+        return OUT if os.path.exists(OUT) else None
+    deps = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + POINT_SRC + [os.path.join(KNN_DIR, "simple_knn.cu"),
+                                                                     os.path.join(HERE, "ref_api.cpp"), __file__]
+    for root, _, files in os.walk(os.path.join(HERE, "ref_shim")):
+        deps += [os.path.join(root, f) for f in files]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+        return OUT
+    os.makedirs(GEN, exist_ok=True)
+    gen = []
+    for s in SOURCES + ["simple_knn.cu"]:
+        src_dir = KNN_DIR if s == "simple_knn.cu" else SRC_DIR
+        text = open(os.path.join(src_dir, s)).read()
+        text, n = LAUNCH.subn(lambda m: f"CUDAEMU_LAUNCH(({m.group(1)}), {m.group(2)}, ", text)
+        dst = os.path.join(GEN, s.replace(".cu", ".cpp"))
+        with open(dst, "w") as f:
+            f.write(f'#line 1 "{os.path.join(src_dir, s)}"\n' + text)
+        gen.append(dst)
+    # Photo-SLAM's point kernels: the __global__ functions of src/operate_points.cu and src/stereo_vision.cu (their device
+    # helpers live in cuda_rasterizer/operate_points.h and stereo_vision.h, included as they are)
+    kernels = []
+    for f in POINT_SRC:
+        kernels += _global_functions(open(f).read())
+    dst = os.path.join(GEN, "point_kernels.cpp")
+    with open(dst, "w") as f:
+        f.write('#include <cuda_runtime.h>\n#include <cooperative_groups.h>\nnamespace cg = cooperative_groups;\n'
+                '#include "operate_points.h"\n#include "stereo_vision.h"\n\n' + "\n\n".join(kernels) + "\n")
+    gen.append(dst)
+    shim = os.path.join(HERE, "ref_shim")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+           "-I", os.path.join(shim, "include"), "-I", SRC_DIR, "-I", KNN_DIR, "-I", shim,
+           "-o", OUT] + gen + [os.path.join(shim, "cudaemu.cpp"), os.path.join(HERE, "ref_api.cpp")]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    r = build(force="--force" in sys.argv)
+    print(r if r else "reference sources not available and no prebuilt library")

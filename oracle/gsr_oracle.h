@@ -6,12 +6,25 @@
  * only as the checker / the CPU baseline -- never as the thing shipped or measured
  * as the GPU path.
  *
- * PARITY UNPINNED: the reference (HuajianUP/Photo-SLAM) ships no tests, golden
- * vectors or fixtures for this path and cannot be compiled here (CUDA + glm + CUB
- * only).  This oracle is pinned by (i) line-by-line fidelity to the reference
- * sources cited on every function in gsr_oracle.c, (ii) analytic known-answer
- * tests, (iii) an independent float64 autograd renderer and (iv) brute-force kNN
- * (see tests/test_oracle_*.py).
+ * PINNING.  The reference (HuajianUP/Photo-SLAM) ships no tests, golden vectors or
+ * fixtures for this path, and it is CUDA-only.  Every function of this oracle is
+ * pinned against the reference's OWN sources compiled for the host with g++ against
+ * small shims of the CUDA block model, the CUB calls, thrust::device_vector and the
+ * glm operators they use (oracle/build_ref.py, oracle/ref_shim/ -> oracle/_ref/):
+ *   cuda_rasterizer/{forward,backward,rasterizer_impl}.cu   gsro_forward / _backward / _mark_visible
+ *   third_party/simple-knn/simple_knn.cu                     gsro_knn
+ *   the __global__ kernels of src/operate_points.cu, src/stereo_vision.cu (+ cuda_rasterizer/
+ *   operate_points.h, stereo_vision.h)                       the four point kernels
+ * tests/test_reference_pinning.py requires every forward quantity -- radii, tiles, sort
+ * keys, instance list, ranges, n_contrib, final T, image, kNN distances, points -- to
+ * agree BIT FOR BIT and the gradients to 1e-5, on random scenes and on the committed
+ * fixture tests/golden/reference_small.npz (which also checks the HIP kernels directly,
+ * on the GPU boxes where the reference tree does not exist).  What no host build
+ * reproduces: nvcc's FMA contraction and the GPU's float-atomic order; the shims restate
+ * the published semantics of CUB (stable LSD sort, inclusive sum, reduce) and of glm
+ * 0.9.9 (column-major mat3 product, dot, length), which the reference does not vendor.
+ * Further independent checks: analytic known-answer tests, a float64 autograd renderer
+ * and brute-force kNN (tests/test_oracle_pinning.py).
  */
 #ifndef GSR_ORACLE_H
 #define GSR_ORACLE_H

@@ -1,0 +1,3 @@
+/* shim: see oracle/ref_shim/cudaemu.h */
+#pragma once
+#include "../cudaemu.h"

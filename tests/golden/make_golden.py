@@ -1,8 +1,8 @@
 """Regenerates tests/golden/oracle_small.npz: outputs of the CPU oracle on a small seeded scene.
 
-The reference cannot be executed (CUDA only), so these vectors are NOT reference outputs; they freeze the
-oracle (which is pinned by tests/test_oracle_pinning.py) so that later edits to oracle/ or to the scene
-generator cannot silently change what the GPU path is compared against.
+These vectors are oracle outputs (reference outputs are in reference_small.npz, see make_reference_golden.py); they
+freeze the oracle together with the scene generator, so that later edits to either cannot silently change what the GPU
+path is compared against.
 
     python tests/golden/make_golden.py
 """

@@ -1,0 +1,201 @@
+"""Pins the CPU oracle -- and through it everything the HIP path is compared against -- to the REFERENCE's own rasterizer
+sources: /root/reference/cuda_rasterizer/{forward,backward,rasterizer_impl}.cu compiled for the host by oracle/build_ref.py
+against the CUDA / CUB / glm shims of oracle/ref_shim/.
+
+  * where the reference tree exists (this container): the oracle is compared with a fresh run of the reference sources on
+    random scenes, and the committed fixture tests/golden/reference_small.npz is checked to be current;
+  * everywhere (incl. the GPU boxes, where /root/reference does not exist): the oracle, and under `-m gpu` the HIP kernels,
+    are compared with the committed fixture.
+Forward quantities must agree BIT FOR BIT (both sides: IEEE fp32, no FMA contraction); gradients to 1e-5 relative L1 (the
+reference sums pixels with float atomics in thread order, the oracle in double)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import parity
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+FIXTURE = os.path.join(HERE, "golden", "reference_small.npz")
+GRADS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
+def _reference_available():
+    from oracle import ref
+    return ref.available()
+
+
+needs_reference = pytest.mark.skipif(not os.path.exists("/root/reference/cuda_rasterizer/forward.cu") and
+                                     not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_rasterizer.so")),
+                                     reason="reference sources (and a prebuilt oracle/_ref) are not available here")
+
+
+def _oracle_run(oracle, d):
+    W, H, deg = (int(v) for v in d["size"])
+    kw = dict(shs=d["features"], sh_degree=deg, scales=d["scaling"], rotations=d["rotation"])
+    if "colors" in d:
+        kw = dict(colors_precomp=d["colors"], sh_degree=deg, cov3D_precomp=d["cov3D_precomp"])
+    res, color, radii = oracle.forward(d["bg"], d["xyz"], d["opacity"], d["viewmatrix"], d["projmatrix"], d["campos"],
+                                       float(d["tanfov"][0]), float(d["tanfov"][1]), H, W, **kw)
+    return res, color, radii, oracle.backward(res, d["dpix"])
+
+
+def _check_oracle_against(want, res, color, radii, grads, precomp):
+    """want: dict of reference outputs (fixture entries or a RefResult's fields)"""
+    vis = want["radii"] > 0
+    assert np.array_equal(radii, want["radii"]) and np.array_equal(res.tiles_touched, want["tiles_touched"])
+    for k in ("depths", "means2D", "conic_opacity"):
+        assert np.array_equal(getattr(res, k)[vis], want[k][vis]), k            # bit for bit
+    if not precomp:
+        assert np.array_equal(res.rgb[vis], want["rgb"][vis]) and np.array_equal(res.cov3D[vis], want["cov3D"][vis])
+        assert np.array_equal(res.clamped.reshape(-1, 3)[vis].astype(bool), want["clamped"][vis].astype(bool))
+    assert res.R == want["point_list"].shape[0]
+    assert np.array_equal(res.point_list, want["point_list"]) and np.array_equal(res.keys_sorted, want["keys_sorted"])
+    assert np.array_equal(res.ranges.reshape(-1, 2), want["ranges"].reshape(-1, 2))
+    assert np.array_equal(res.n_contrib, want["n_contrib"])
+    assert np.array_equal(res.final_T, want["final_T"]) and np.array_equal(color, want["out_color"])
+    for k in GRADS:
+        if k in ("dL_dsh", "dL_dscales", "dL_drotations", "dL_dcov3D") and precomp and k != "dL_dcov3D":
+            continue
+        a, b = np.asarray(grads[k], np.float64).ravel(), np.asarray(want[k], np.float64).ravel()
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).sum() <= 1e-5 * (np.abs(b).sum() + 1e-30), (k, np.abs(a - b).sum() / (np.abs(b).sum() + 1e-30))
+
+
+@needs_reference
+@pytest.mark.parametrize("P,W,H,seed,deg", [(500, 64, 48, 11, 3), (900, 70, 50, 12, 2), (300, 33, 47, 13, 0), (1200, 96, 64, 14, 3)])
+def test_oracle_matches_the_reference_sources(oracle, P, W, H, seed, deg):
+    import make_reference_golden as mg
+    d = mg.inputs(("x", P, W, H, 0.9 * W, seed, 0.3, deg, False))
+    r = mg.run_reference(d)
+    want = {k: getattr(r, k) for k in mg.FIELDS}
+    want.update(r.grads)
+    _check_oracle_against(want, *_oracle_run(oracle, d), precomp=False)
+
+
+@needs_reference
+def test_reference_fixture_is_current():
+    import make_reference_golden as mg
+    want, got = np.load(FIXTURE), mg.compute()
+    assert sorted(want.files) == sorted(got.keys())
+    for k in want.files:
+        assert np.array_equal(want[k], got[k]), k      # the host build is deterministic: the fixture is reproduced exactly
+
+
+@needs_reference
+@pytest.mark.parametrize("P,seed", [(1, 0), (2, 1), (5, 2), (1000, 3), (1025, 4), (5000, 5)])
+def test_oracle_knn_matches_the_reference_sources(oracle, P, seed):
+    from oracle import ref
+    rng = np.random.default_rng(seed)
+    pts = (rng.standard_normal((P, 3)) * np.array([3.0, 1.0, 2.0])).astype(np.float32)
+    if P > 100:
+        pts[::7] = pts[1::7][: pts[::7].shape[0]]      # duplicates: zero distances
+    assert np.array_equal(oracle.knn(pts), ref.knn(pts))   # bit for bit
+
+
+@needs_reference
+def test_oracle_point_kernels_match_the_reference_sources(oracle):
+    from oracle import ref
+    rng = np.random.default_rng(7)
+    P = 3000
+    pts = rng.standard_normal((P, 3)).astype(np.float32) * 3
+    rots = rng.standard_normal((P, 4)).astype(np.float32)
+    rots /= np.linalg.norm(rots, axis=1, keepdims=True)
+    # a similarity transform, transposed like the reference's tensors (column-major 4x4)
+    A = np.linalg.qr(rng.standard_normal((3, 3)))[0].astype(np.float32)
+    m = np.eye(4, dtype=np.float32); m[:3, :3] = 1.7 * A; m[:3, 3] = [0.3, -1.2, 2.0]
+    m = np.ascontiguousarray(m.T)
+    mask = rng.random(P) < 0.6
+    assert np.array_equal(oracle.transform_points(pts, m), ref.transform_points(pts, m))
+    op, orot = oracle.scale_transform_points(1.7, pts, rots, m, mask, reference_rot_layout=True)
+    rp_, rrot = ref.scale_transform_points(1.7, pts, rots, m, mask)
+    assert np.array_equal(op, rp_) and np.array_equal(orot, rrot)
+    W, H = 64, 40
+    depth = (rng.random(W * H).astype(np.float32) * 5 + 0.1)
+    dmask = rng.random(W * H) < 0.7
+    intr = (50.0, 52.0, 31.5, 19.5)
+    assert np.array_equal(oracle.reproject_depth_pinhole(depth, dmask, intr, W), ref.reproject_depth_pinhole(depth, dmask, intr, W))
+    N = 400
+    pix = np.stack([rng.integers(0, W, N), rng.integers(0, H // 3, N)], 1).astype(np.float32)   # the colour index is v*width+u
+    has3D = rng.random(N) < 0.5
+    p3d = rng.standard_normal((N, 3)).astype(np.float32); p3d[:, 2] = np.abs(p3d[:, 2]) + 0.5
+    colors = rng.random((H * W,)).astype(np.float32)
+    a = oracle.neighborhood_depth_pinhole(pix, has3D, p3d, colors, 100.0, intr, W)
+    b = ref.neighborhood_depth_pinhole(pix, has3D, p3d, colors, 100.0, intr, W)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _fixture_case(name):
+    f = np.load(FIXTURE)
+    d = {k[len(name) + 4:]: f[k] for k in f.files if k.startswith(name + "_in_")}
+    want = {k[len(name) + 1:]: f[k] for k in f.files if k.startswith(name + "_") and not k.startswith(name + "_in_")}
+    return d, want
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_oracle_matches_the_reference_fixture(oracle, name):
+    d, want = _fixture_case(name)
+    _check_oracle_against(want, *_oracle_run(oracle, d), precomp="colors" in d)
+
+
+class _Cloud:
+    def __init__(self, d):
+        self.d, self.xyz = d, d["xyz"]
+    def get_opacity(self): return self.d["opacity"]
+    def get_features(self): return self.d["features"]
+    def get_scaling(self): return self.d["scaling"]
+    def get_rotation(self): return self.d["rotation"]
+
+
+class _Camera:
+    def __init__(self, d):
+        self.viewmatrix, self.projmatrix, self.campos = d["viewmatrix"], d["projmatrix"], d["campos"]
+        self.tanfovx, self.tanfovy = float(d["tanfov"][0]), float(d["tanfov"][1])
+        self.W, self.H = int(d["size"][0]), int(d["size"][1])
+
+
+def _check_backend_against_fixture(lib_path, dev, oracle, name):
+    """The HIP kernels (on the GPU, or compiled for the wave64 emulator) against outputs of the reference's own sources -- no
+    oracle in between, except for the flags of pixels whose skip / terminate decision lies within exp() rounding noise."""
+    d, want = _fixture_case(name)
+    precomp = "colors" in d
+    cl, cam, deg = _Cloud(d), _Camera(d), int(d["size"][2])
+    kw = dict(use_colors_precomp=True, use_cov3D_precomp=True, colors=d["colors"], cov3D=d["cov3D_precomp"]) if precomp else {}
+    r = parity.run_backend(lib_path, dev, cl, cam, d["bg"], sh_degree=deg, dL_dpix=d["dpix"], **kw)
+    vis = want["radii"] > 0
+    assert np.array_equal(r.radii, want["radii"]) and np.array_equal(r.tiles_touched, want["tiles_touched"])
+    assert np.array_equal(r.depth_key, np.where(vis, want["depths"].view(np.uint32), np.uint32(0xFFFFFFFF)))
+    rec = r.rec[vis]
+    assert np.array_equal(rec[:, 0:2], want["means2D"][vis])                                   # bit for bit
+    assert np.array_equal(np.stack([rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5]], 1), want["conic_opacity"][vis])
+    if not precomp:
+        assert np.array_equal(np.stack([rec[:, 6], rec[:, 7], rec[:, 8]], 1), want["rgb"][vis])
+        assert np.array_equal(r.cov3D[vis], want["cov3D"][vis])
+    assert r.R == want["point_list"].shape[0] and np.array_equal(r.point_list, want["point_list"])
+    assert np.array_equal(r.tile_keys, (want["keys_sorted"] >> np.uint64(32)).astype(np.uint32))
+    assert np.array_equal(r.ranges, want["ranges"].reshape(-1, 2))
+    # pixels whose decisions sit inside exp() rounding noise are flagged by the oracle and excluded from the exact count
+    ores, _, _, _ = _oracle_run(oracle, d)
+    solid = ores.fragile.reshape(cam.H, cam.W) == 0
+    assert np.array_equal(r.n_contrib[solid], want["n_contrib"][solid])
+    assert np.abs(r.out_color - want["out_color"]).mean() <= 1e-4 and np.abs(r.final_T - want["final_T"]).max() <= 1e-5
+    for k in GRADS:
+        if precomp and k in ("dL_dsh", "dL_dscales", "dL_drotations"):
+            continue
+        a, b = np.asarray(r.grads[k], np.float64).ravel(), np.asarray(want[k], np.float64).ravel()
+        assert np.abs(a - b).sum() <= 2e-4 * (np.abs(b).sum() + 1e-30), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_hip_matches_the_reference_fixture(oracle, name):
+    import torch
+    _check_backend_against_fixture(None, torch.device("cuda", 0), oracle, name)
+
+
+@pytest.mark.parametrize("name", ["a", "c"])
+def test_emulated_hip_kernels_match_the_reference_fixture(emu_lib_path, oracle, name):
+    import torch
+    _check_backend_against_fixture(emu_lib_path, torch.device("cpu"), oracle, name)
