@@ -86,6 +86,8 @@ def build(force=False):
            "-I", os.path.join(shim, "include"), "-I", SRC_DIR, "-I", KNN_DIR, "-I", shim,
            "-o", OUT] + gen + [os.path.join(shim, "cudaemu.cpp"), os.path.join(HERE, "ref_api.cpp")]
     subprocess.check_call(cmd)
+    import shutil
+    shutil.rmtree(GEN, ignore_errors=True)   # the rewritten copies of the reference sources do not outlive the compile
     return OUT
 
 
