@@ -91,6 +91,29 @@ def build(force=False):
     return OUT
 
 
+LOSS_OUT = os.path.join(OUT_DIR, "libref_loss.so")
+LOSS_HEADER = os.path.join(REF, "include", "loss_utils.h")
+
+
+def build_loss(force=False):
+    """oracle/_ref/libref_loss.so: torch ops (torch.ops.photoslam_reference.*) around the reference's include/loss_utils.h."""
+    if not os.path.exists(LOSS_HEADER):
+        return LOSS_OUT if os.path.exists(LOSS_OUT) else None
+    src = os.path.join(HERE, "ref_loss.cpp")
+    if not force and os.path.exists(LOSS_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(LOSS_OUT) for d in (src, LOSS_HEADER, __file__)):
+        return LOSS_OUT
+    import torch
+    base = os.path.dirname(torch.__file__)
+    inc = [os.path.join(base, "include"), os.path.join(base, "include", "torch", "csrc", "api", "include")]
+    libdir = os.path.join(base, "lib")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+                           "-w", "-I" + os.path.join(REF, "include")] + ["-I" + i for i in inc] +
+                          [src, "-o", LOSS_OUT, "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-Wl,-rpath," + libdir])
+    return LOSS_OUT
+
+
 if __name__ == "__main__":
     r = build(force="--force" in sys.argv)
     print(r if r else "reference sources not available and no prebuilt library")
+    print(build_loss(force="--force" in sys.argv))

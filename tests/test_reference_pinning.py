@@ -199,3 +199,30 @@ def test_hip_matches_the_reference_fixture(oracle, name):
 def test_emulated_hip_kernels_match_the_reference_fixture(emu_lib_path, oracle, name):
     import torch
     _check_backend_against_fixture(emu_lib_path, torch.device("cpu"), oracle, name)
+
+
+needs_reference_loss = pytest.mark.skipif(not os.path.exists("/root/reference/include/loss_utils.h") and
+                                          not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_loss.so")),
+                                          reason="the reference's loss_utils.h (and a prebuilt oracle/_ref/libref_loss.so) is not available here")
+
+
+@needs_reference_loss
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 53)])
+def test_loss_mirror_matches_the_reference_header(H, W):
+    """photo-slam_amd/loss_utils.py (the torch mirror the fused HIP loss is tested against) vs the reference's own
+    include/loss_utils.h compiled against LibTorch (oracle/ref_loss.cpp)."""
+    import torch
+    from oracle import build_ref
+    from photo_slam_amd import loss_utils
+    torch.ops.load_library(build_ref.build_loss())
+    ops = torch.ops.photoslam_reference
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    a, b = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    assert torch.equal(loss_utils.l1_loss(a, b), ops.l1_loss(a, b))
+    assert torch.allclose(loss_utils.ssim(a, b), ops.ssim(a, b), rtol=0, atol=1e-6)
+    assert torch.allclose(loss_utils.psnr(a, b), ops.psnr(a, b), rtol=1e-6, atol=1e-5)
+    # and the fused loss formula of the train step: (1 - lambda) L1 + lambda (1 - SSIM), gaussian_mapper.cpp:692-698
+    lam = 0.2
+    want = (1.0 - lam) * ops.l1_loss(a, b) + lam * (1.0 - ops.ssim(a, b))
+    got = (1.0 - lam) * loss_utils.l1_loss(a, b) + lam * (1.0 - loss_utils.ssim(a, b))
+    assert abs(float(want) - float(got)) <= 1e-6
