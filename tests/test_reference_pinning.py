@@ -226,3 +226,37 @@ def test_loss_mirror_matches_the_reference_header(H, W):
     want = (1.0 - lam) * ops.l1_loss(a, b) + lam * (1.0 - ops.ssim(a, b))
     got = (1.0 - lam) * loss_utils.l1_loss(a, b) + lam * (1.0 - loss_utils.ssim(a, b))
     assert abs(float(want) - float(got)) <= 1e-6
+
+
+@needs_reference
+@pytest.mark.parametrize("case", ["all_culled", "one_gaussian", "huge_splat_and_opaque_wall", "near_plane_band"])
+def test_oracle_matches_the_reference_sources_on_edge_cases(oracle, case):
+    """camera facing away (R == 0), P == 1, a splat covering every tile + an opaque stack (early termination, T < 1e-4),
+    and a cloud straddling the 0.2 near plane of Photo-SLAM's frustum test (auxiliary.h:154)."""
+    import make_reference_golden as mg
+    P = 1 if case == "one_gaussian" else 400
+    d = mg.inputs(("x", P, 64, 48, 50.0, 31, 0.35, 3, False))
+    view = d["viewmatrix"]                       # transposed 4x4: view[:3, 2] = forward axis in world coordinates
+    fwd, campos = view[:3, 2].copy(), d["campos"]
+    if case == "all_culled":
+        d["xyz"] = (campos - 5.0 * fwd)[None].repeat(P, 0).astype(np.float32)
+    elif case == "huge_splat_and_opaque_wall":
+        center = campos + 2.0 * fwd
+        d["xyz"][0] = center
+        d["scaling"][0] = 5.0
+        rng = np.random.default_rng(1)
+        d["xyz"][1:40] = center + 0.02 * rng.standard_normal((39, 3)).astype(np.float32) - 0.5 * fwd
+        d["scaling"][1:40] = 0.5
+        d["opacity"][:40] = 0.999
+    elif case == "near_plane_band":
+        rng = np.random.default_rng(2)
+        depth = 0.2 + 0.02 * rng.standard_normal(P).astype(np.float32)
+        d["xyz"] = (campos[None] + depth[:, None] * fwd[None] + 0.05 * rng.standard_normal((P, 3))).astype(np.float32)
+        d["scaling"][:] = 0.01
+    r = mg.run_reference(d)
+    want = {k: getattr(r, k) for k in mg.FIELDS}
+    want.update(r.grads)
+    res, color, radii, grads = _oracle_run(oracle, d)
+    if case == "all_culled":
+        assert r.R == 0 and res.R == 0 and not radii.any()
+    _check_oracle_against(want, res, color, radii, grads, precomp=False)
