@@ -26,7 +26,10 @@
 
 namespace gsr {
 
-constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB)
+#ifndef GSR_BWD_SEG
+#define GSR_BWD_SEG 256
+#endif
+constexpr int BWD_SEG = GSR_BWD_SEG;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB)
 
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
