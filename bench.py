@@ -74,7 +74,7 @@ def main():
     from photo_slam_amd import capi, scene
     from photo_slam_amd.gaussian_model import GaussianModel, GaussianOptimizationParams
     from photo_slam_amd.gaussian_renderer import GaussianKeyframe, GaussianPipelineParams, GaussianRenderer
-    from photo_slam_amd.trainer import TrainStep, GradientReduction
+    from photo_slam_amd.trainer import TrainStep, GradientReduction, ViewFactoredExchange, FEATURES_GROUP
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,10 +89,18 @@ def main():
     if os.environ.get("GSR_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    # GSR_BENCH_EXCHANGE=allreduce: the plain all-reduce of all five gradient tensors instead of the view-factored exchange
+    factored = os.environ.get("GSR_BENCH_EXCHANGE", "factored") != "allreduce"
+    # GSR_BENCH_FORCE_DP=1: the data-parallel code path (process group, exchange, per-group Adam) with a single rank -- a
+    # functional check of the RCCL calls on a 1-GPU box
+    dp = world > 1 or os.environ.get("GSR_BENCH_FORCE_DP") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -121,7 +129,8 @@ def main():
     mask = torch.ones(3, H, W, device=dev)
     if args.densify_interval:
         opt.densification_interval_, opt.densify_from_iter_ = args.densify_interval, 0
-    ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent, densify=bool(args.densify_interval))
+    ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent,
+                   densify=bool(args.densify_interval), factored_exchange=factored)
 
     ops = None
     if args.host == "cpp" and not args.raster_only:
@@ -133,6 +142,8 @@ def main():
                                     g.rotation_.detach(), 3, float(cl.extent), bg)
         import math
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+        if dp and factored:
+            ops.trainer_set_factored_exchange(handle, True)
 
     # The reference reads the loss on the host every iteration (EMA for logging, gaussian_mapper.cpp:701-705).  So does this
     # loop -- one step late: the value is copied to pinned memory behind the step's kernels and read while the NEXT step is
@@ -154,7 +165,21 @@ def main():
         if ops is not None:
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
-            if world > 1:
+            if dp and factored:
+                # view-factored exchange (trainer.ViewFactoredExchange): the colour gradients are gathered, the other four
+                # tensors reduced; the SH gradient is rebuilt from the views and applied while the reductions are on the links
+                grads = ops.trainer_grads(handle)
+                ex = ViewFactoredExchange(ops.trainer_sh_grad_view(handle), kf.camera_center_,
+                                          [(i, t) for i, t in enumerate(grads) if i != FEATURES_GROUP], world)
+                ops.trainer_finish_begin(handle)
+                centres, views = ex.gathered()
+                ops.trainer_features_grad_from_views(handle, centres, views)   # reads xyz: before ITS Adam
+                ops.trainer_adam_group(handle, FEATURES_GROUP)
+                for i in ex.order():
+                    ex.wait(i)                # stream-side wait: the host keeps queueing
+                    ops.trainer_adam_group(handle, i)
+                ops.trainer_finish_end(handle)
+            elif dp:
                 # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
                 # SH update overlaps the small reductions still on the links
                 red = GradientReduction(ops.trainer_grads(handle), world)
@@ -248,7 +273,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
-                       "parallelism": f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
+                       "parallelism": (f"dp{world} (one keyframe per GPU; all-gather of 3 + all-reduce of 11 floats/Gaussian, "
+                                       "SH gradient rebuilt per rank)") if factored else
+                                      f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else P,
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
@@ -292,9 +319,14 @@ def main():
                                    "sample": f"1 forward+backward of the same {args.config} view (initial parameters), "
                                              f"{cpu_s:.1f} s, OpenMP over Gaussians/tiles",
                                    "iters_per_s_raster_only": round(1.0 / cpu_s, 4)}
-        print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
+    # RCCL writes its version banner to C stdout, which is block-buffered on a pipe and would otherwise land AFTER the
+    # result at exit: drain it first, so that the JSON line is the last line of the output
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -116,6 +116,12 @@ typedef struct gsr_backward_args {
 	/* Same mask as gsr_forward_args.raw_params (must match the forward call): dL_dopacity / dL_dscale / dL_drot are
 	 * then gradients w.r.t. the RAW parameters (chain rule through sigmoid / exp / normalize applied in-kernel). */
 	int raw_params;
+	/* Extension for keyframe-batch data parallelism (NULL = the reference contract).  [P,3]: when set, dL_dsh is NOT
+	 * written (and may be NULL); instead the gradient w.r.t. the SH colour BEFORE the clamp -- dL_dcolor with the
+	 * clamped channels zeroed (backward.cu:41-48), zeros for culled Gaussians -- is written here.  dL_dsh of one view is
+	 * basis(dir) x this vector; gsr_sh_grad_from_views rebuilds it for all views after the exchange.  The SH term of
+	 * dL_dmean3D is computed as usual. */
+	float* dL_dcolor_view;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.
@@ -124,6 +130,15 @@ typedef struct gsr_backward_args {
  * which removes the reference's 300 B/Gaussian torch::zeros pass
  * (src/rasterize_points.cu:149-157).  No host synchronisation. */
 int gsr_backward(const gsr_backward_args* args, void* stream);
+
+/* The SH gradient of a keyframe batch from its per-view colour gradients (no counterpart in the reference, which trains
+ * on one view per step):   dL_dsh[i][k][ch] = scale * sum_v basis_k(normalize(means3D[i] - campos[v])) * views[v][i][ch]
+ * for k < (D+1)^2 and 0 for (D+1)^2 <= k < M; basis_k as computeColorFromSH (forward.cu:20-71).  views is
+ * [n_views,P,3] (the dL_dcolor_view outputs of gsr_backward, gathered), campos [n_views,3] on the device; scale is
+ * 1/n_views for the batch mean.  With one process per GPU this replaces the all-reduce of the [P,M,3] gradient
+ * (2 x 192 B sent per Gaussian on a ring) by an all-gather of 12 B per Gaussian and view. */
+int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                           const float* dL_dcolor_views, float scale, float* dL_dsh, void* stream);
 
 /* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
  * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */

@@ -244,7 +244,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dopacity || !a->dL_dcolor ||
 	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
 		return GSR_ERR_INVALID_ARG;
-	if (a->shs && !a->dL_dsh) return GSR_ERR_INVALID_ARG;
+	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view) return GSR_ERR_INVALID_ARG;
+	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
 	if (a->scales && (!a->dL_dscale || !a->dL_drot)) return GSR_ERR_INVALID_ARG;
 	if (a->R > 0 && !a->binning_buffer) return GSR_ERR_INVALID_ARG;
 	hipStream_t stream = (hipStream_t)stream_;
@@ -289,10 +290,20 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
+	pb.dL_dcolor_view = a->dL_dcolor_view;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on != 0;
 	return GSR_OK;
+}
+
+int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                           const float* dL_dcolor_views, float scale, float* dL_dsh, void* stream_)
+{
+	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1)) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!means3D || !campos || !dL_dcolor_views || !dL_dsh) return GSR_ERR_INVALID_ARG;
+	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, dL_dcolor_views, scale, dL_dsh, (hipStream_t)stream_);
 }
 
 int gsr_profile_enable(int on)

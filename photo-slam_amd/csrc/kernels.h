@@ -81,11 +81,15 @@ struct PreprocessBwdParams {
 	float* dL_dmean3D;        // [P,3]
 	float* dL_dcov3D;         // [P,6]
 	float* dL_dsh;            // [P,M,3] nullable
+	float* dL_dcolor_view;    // [P,3] nullable: view-factored mode (gsr.h) -- the clamp-masked colour gradient INSTEAD of dL_dsh
 	float* dL_dscale;         // [P,3] nullable
 	float* dL_drot;           // [P,4] nullable
 	int raw_params;           // GSR_RAW_* mask: outputs are gradients of the raw parameters
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
+// dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
+int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                              const float* dL_dcolor_views, float scale, float* dL_dsh, hipStream_t stream);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

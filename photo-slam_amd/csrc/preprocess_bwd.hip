@@ -28,8 +28,10 @@ namespace gsr {
 constexpr int PRB_THREADS = 128;
 constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per workgroup
 
-// SH backward for aligned 48-float rows; DEG = active SH degree.
-template <int DEG>
+// SH backward for aligned 48-float rows; DEG = active SH degree.  FACTORED (gsr_backward_args.dL_dcolor_view): the
+// gradient rows are not produced -- the clamp-masked colour gradient leaves instead (12 B instead of 192 B per Gaussian)
+// and gsr_sh_grad_from_views rebuilds dL_dsh for the whole keyframe batch after the exchange.
+template <int DEG, bool FACTORED>
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(6, 8)   // 80 VGPRs (3 dwords of scratch at degree 3)
 sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
@@ -52,6 +54,11 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		dRGB[0] = p.dL_dcolor[3 * (size_t)idx + 0] * ((cl & 1) ? 0.f : 1.f);
 		dRGB[1] = p.dL_dcolor[3 * (size_t)idx + 1] * ((cl & 2) ? 0.f : 1.f);
 		dRGB[2] = p.dL_dcolor[3 * (size_t)idx + 2] * ((cl & 4) ? 0.f : 1.f);
+	}
+	if (FACTORED && in_range) {
+		p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
+		p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
+		p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
 	}
 	// The wave handles its 64 rows in two halves of STAGE_ROWS: the SH rows of the half's visible lanes are fetched
 	// by the whole wave into LDS, each owner turns its row into the gradient row IN PLACE (zeros for culled
@@ -80,13 +87,16 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 						GSR_OPAQUE_F32(uz);
 						const float len = sqrtf(ux * ux + uy * uy + uz * uz);
 						const ShDir d = sh_dir(ux / len, uy / len, uz / len);
-						sh_row_backward(row, ncoef, d, dRGB, ddx, ddy, ddz);
-					} else {
+						sh_row_backward<!FACTORED>(row, ncoef, d, dRGB, ddx, ddy, ddz);
+					} else if (!FACTORED) {
 #pragma unroll
 						for (int i = 0; i < ROW_F4; i++) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 					}
 				}
-				wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+				if (!FACTORED)
+					wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+				else
+					wave_fence();   // the next pass refills the slice
 			}
 		}
 	}
@@ -126,7 +136,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
 		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a);   // every lane of the wave takes part
 	}
-	float* out_sh = (p.dL_dsh && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
+	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
 	// Culled Gaussians take the same store instructions as visible ones, with zeros (the reference leaves the
 	// torch::zeros content): every output leaves the wave as full contiguous lines.  Separate zero / value stores,
@@ -194,14 +204,15 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 #pragma unroll
 						for (int ch = 0; ch < 3; ch++) {
 							const float v = shrow[3 * k + ch];
-							out_sh[3 * k + ch] = sh_basis(k, d) * dRGB[ch];
+							if (out_sh) out_sh[3 * k + ch] = sh_basis(k, d) * dRGB[ch];
 							if (nz & 1) ddx[ch] += gx * v;
 							if (nz & 2) ddy[ch] += gy * v;
 							if (nz & 4) ddz[ch] += gz * v;
 						}
 					}
 				}
-				for (int i = 3 * (ncoef < p.M ? ncoef : p.M); i < M3; i++) out_sh[i] = 0.f;   // keep the row fully written
+				if (out_sh)
+					for (int i = 3 * (ncoef < p.M ? ncoef : p.M); i < M3; i++) out_sh[i] = 0.f;   // keep the row fully written
 				const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
 				const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
 				const float dLz = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
@@ -211,6 +222,11 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 				shx = ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
 				shy = (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
 				shz = (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+			}
+			if (p.dL_dcolor_view && in_range) {
+				p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
+				p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
+				p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
 			}
 		}
 	}
@@ -384,23 +400,159 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
-	const bool rows_ok = p.dL_dsh && p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0) &&
-	                     ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
+	const bool factored = p.dL_dcolor_view != nullptr;
+	const bool rows_ok = p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0) &&
+	                     (factored || (p.dL_dsh && (reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0));
 	const int grid = div_up(p.P, PRB_THREADS);
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
 		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
 		GSR_CHECK_LAUNCH();
 		const int g = div_up(p.P, SHB_THREADS);
+#define GSR_SHB(DEG)                                                                  \
+	do {                                                                              \
+		if (factored)                                                                 \
+			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, true>), g, SHB_THREADS, stream, p);   \
+		else                                                                          \
+			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, false>), g, SHB_THREADS, stream, p);  \
+	} while (0)
 		if (p.D == 3)
-			GSR_LAUNCH(sh_bwd_rows_kernel<3>, g, SHB_THREADS, stream, p);
+			GSR_SHB(3);
 		else if (p.D == 2)
-			GSR_LAUNCH(sh_bwd_rows_kernel<2>, g, SHB_THREADS, stream, p);
+			GSR_SHB(2);
 		else if (p.D == 1)
-			GSR_LAUNCH(sh_bwd_rows_kernel<1>, g, SHB_THREADS, stream, p);
+			GSR_SHB(1);
 		else
-			GSR_LAUNCH(sh_bwd_rows_kernel<0>, g, SHB_THREADS, stream, p);
+			GSR_SHB(0);
+#undef GSR_SHB
 	} else {
 		GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
+	}
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keyframe-batch data parallelism.  The SH gradient of ONE view is rank one per Gaussian:
+// dL_dsh[k][ch] = basis_k(dir) * dRGB[ch] (backward.cu:41-127), and dir = normalize(mean - campos) is known to every
+// rank.  So the ranks exchange the 3 floats dRGB per view (all-gather) instead of reducing the 48-float rows, and
+// each rebuilds   dL_dsh[i][k][ch] = scale * sum_v basis_k(dir_v(i)) * dRGB_v[i][ch]   here: 12 n_views B read and
+// 192 B written per Gaussian, against 2 * 192 B sent per Gaussian by a ring all-reduce of the rows.
+template <int DEG>
+__global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(4, 8)
+sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos,
+                          const float* __restrict__ views, float scale, float* __restrict__ dL_dsh)
+{
+	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int w = wave_id(), l = lane_id();
+	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
+	const bool in_range = idx < P;
+	constexpr int ncoef = (DEG + 1) * (DEG + 1);
+	float acc[3 * ncoef];
+#pragma unroll
+	for (int j = 0; j < 3 * ncoef; j++) acc[j] = 0.f;
+	float mx = 0.f, my = 0.f, mz = 0.f;
+	if (in_range) {
+		mx = means3D[3 * (size_t)idx];
+		my = means3D[3 * (size_t)idx + 1];
+		mz = means3D[3 * (size_t)idx + 2];
+	}
+#pragma unroll 1
+	for (int v = 0; v < n_views; v++) {
+		float r = 0.f, g = 0.f, b = 0.f;
+		if (in_range) {
+			const float* c = views + ((size_t)v * P + idx) * 3;
+			r = c[0]; g = c[1]; b = c[2];
+		}
+		// culled in this view (or every channel clamped): nothing to add, and most Gaussians are outside most views
+		if (r != 0.f || g != 0.f || b != 0.f) {
+			const float ox = mx - campos[3 * v], oy = my - campos[3 * v + 1], oz = mz - campos[3 * v + 2];
+			const float len = sqrtf(ox * ox + oy * oy + oz * oz);   // forward.cu:27-28
+			const ShDir d = sh_dir(ox / len, oy / len, oz / len);
+#pragma unroll
+			for (int k = 0; k < ncoef; k++) {
+				const float bk = sh_basis(k, d);
+				acc[3 * k + 0] += bk * r;
+				acc[3 * k + 1] += bk * g;
+				acc[3 * k + 2] += bk * b;
+			}
+		}
+	}
+	// rows leave through LDS as contiguous 6 KiB bursts, half a wave at a time (shrows.h)
+#pragma unroll 1
+	for (int h = 0; h < 64 / STAGE_ROWS; h++) {
+		const size_t half_first = wave_first + (size_t)(h * STAGE_ROWS);
+		const long long left = (long long)P - (long long)half_first;
+		if (left <= 0) break;   // wave-uniform
+		if ((l / STAGE_ROWS) == h) {
+			float4* row = s_rows[w][l % STAGE_ROWS];
+#pragma unroll
+			for (int i = 0; i < ROW_F4; i++) {
+				float o[4];
+#pragma unroll
+				for (int c = 0; c < 4; c++) o[c] = (4 * i + c < 3 * ncoef) ? acc[(4 * i + c < 3 * ncoef) ? 4 * i + c : 0] * scale : 0.f;
+				row[i] = make_float4(o[0], o[1], o[2], o[3]);
+			}
+		}
+		wave_store_rows(reinterpret_cast<float4*>(dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+	}
+}
+
+// any other row length / alignment: one thread per Gaussian, scalar stores
+__global__ void __launch_bounds__(128)
+sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float* __restrict__ means3D,
+                                  const float* __restrict__ campos, const float* __restrict__ views, float scale,
+                                  float* __restrict__ dL_dsh)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (idx >= P) return;
+	const int ncoef = (D + 1) * (D + 1);
+	float acc[48];
+#pragma unroll
+	for (int j = 0; j < 48; j++) acc[j] = 0.f;
+	const float mx = means3D[3 * (size_t)idx], my = means3D[3 * (size_t)idx + 1], mz = means3D[3 * (size_t)idx + 2];
+	for (int v = 0; v < n_views; v++) {
+		const float* c = views + ((size_t)v * P + idx) * 3;
+		const float r = c[0], g = c[1], b = c[2];
+		if (r == 0.f && g == 0.f && b == 0.f) continue;
+		const float ox = mx - campos[3 * v], oy = my - campos[3 * v + 1], oz = mz - campos[3 * v + 2];
+		const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+		const ShDir d = sh_dir(ox / len, oy / len, oz / len);
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (k < ncoef) {
+				const float bk = sh_basis(k, d);
+				acc[3 * k + 0] += bk * r;
+				acc[3 * k + 1] += bk * g;
+				acc[3 * k + 2] += bk * b;
+			}
+		}
+	}
+	float* out = dL_dsh + (size_t)idx * 3 * M;
+#pragma unroll
+	for (int j = 0; j < 48; j++)
+		if (j < 3 * ncoef) out[j] = acc[j] * scale;
+	for (int j = 3 * ncoef; j < 3 * M; j++) out[j] = 0.f;
+}
+
+int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                              const float* views, float scale, float* dL_dsh, hipStream_t stream)
+{
+	if (P == 0) return GSR_OK;
+	const bool rows_ok = (3 * M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0);
+	if (rows_ok) {
+		const int g = div_up(P, SHB_THREADS);
+		if (D == 3)
+			GSR_LAUNCH(sh_grad_from_views_kernel<3>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+		else if (D == 2)
+			GSR_LAUNCH(sh_grad_from_views_kernel<2>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+		else if (D == 1)
+			GSR_LAUNCH(sh_grad_from_views_kernel<1>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+		else
+			GSR_LAUNCH(sh_grad_from_views_kernel<0>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+	} else {
+		GSR_LAUNCH(sh_grad_from_views_generic_kernel, div_up(P, 128), 128, stream, P, D, M, n_views, means3D, campos, views,
+		           scale, dL_dsh);
 	}
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;

@@ -162,8 +162,9 @@ __device__ __forceinline__ void sh_row_to_rgb(const float4* row, int ncoef, cons
 	}
 }
 
-// SH backward in place: the row holds sh on entry and dL_dsh = basis * dRGB on exit (zeros beyond ncoef);
+// SH backward in place: the row holds sh on entry and (WRITE) dL_dsh = basis * dRGB on exit (zeros beyond ncoef);
 // dd{x,y,z}[ch] accumulate dRGB/d(direction).
+template <bool WRITE = true>
 __device__ __forceinline__ void sh_row_backward(float4* row, int ncoef, const ShDir& d, const float (&dRGB)[3], float (&ddx)[3],
                                                 float (&ddy)[3], float (&ddz)[3])
 {
@@ -186,7 +187,7 @@ __device__ __forceinline__ void sh_row_backward(float4* row, int ncoef, const Sh
 				}
 			}
 		}
-		row[i] = make_float4(out[0], out[1], out[2], out[3]);
+		if (WRITE) row[i] = make_float4(out[0], out[1], out[2], out[3]);
 	}
 }
 

@@ -25,6 +25,9 @@ class GaussianRasterizationSettings:
     campos_: torch.Tensor
     prefiltered_: bool
     raw_params_: int = 0   # extension: GSR_RAW_* mask, activations fused into the rasterizer (include/gsr.h)
+    # extension: a [P,3] tensor that receives the clamp-masked colour gradient in backward; the SH gradient is then left
+    # to the view-factored exchange (trainer.ViewFactoredExchange) and autograd gets None for sh
+    sh_grad_view_: torch.Tensor = None
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -53,10 +56,10 @@ class GaussianRasterizerFunction(torch.autograd.Function):
          dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_)
+            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_)
         # order of src/gaussian_rasterizer.cpp:159-179
         def g(t, like):
-            return t if like.numel() else None
+            return t if like.numel() and t is not None else None
         return (dL_dmeans3D, dL_dmeans2D, g(dL_dsh, sh), g(dL_dcolors, colors_precomp), dL_dopacity,
                 g(dL_dscales, scales), g(dL_drotations, rotations), g(dL_dcov3D, cov3Ds_precomp), None)
 

@@ -88,6 +88,13 @@ public:
 		finishOneIteration();
 		return loss;
 	}
+	// Data-parallel keyframe batches with the view-factored exchange (include/gsr.h, gsr_sh_grad_from_views): backward
+	// then leaves the clamp-masked colour gradient of this view in sh_grad_view_ and no gradient on features_; after the
+	// driver has gathered the views of all ranks, setFeaturesGradFromViews() installs the batch-mean SH gradient.  It reads
+	// xyz_, so it must run before finishAdamGroup(0).
+	bool factored_exchange_ = false;
+	torch::Tensor sh_grad_view_;
+	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	std::shared_ptr<GaussianModel> gaussians_;
 	torch::Tensor background_;
 	int iteration_ = 0;

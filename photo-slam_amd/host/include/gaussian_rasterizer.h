@@ -30,6 +30,9 @@ struct GaussianRasterizationSettings {
 	torch::Tensor campos_;
 	bool prefiltered_;
 	int raw_params_ = 0;   // extension: GSR_RAW_* mask (activations fused into the rasterizer), see include/gsr.h
+	// extension: a [P,3] tensor that receives the clamp-masked colour gradient in backward; sh then gets no gradient from
+	// autograd -- the view-factored exchange of the data-parallel step rebuilds it (shGradFromViews)
+	torch::Tensor sh_grad_view_;
 };
 
 class GaussianRasterizerFunction : public torch::autograd::Function<GaussianRasterizerFunction> {

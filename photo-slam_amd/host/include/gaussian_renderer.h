@@ -34,7 +34,8 @@ public:
 	static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> render(
 	    std::shared_ptr<Keyframe> viewpoint_camera, int image_height, int image_width, std::shared_ptr<Model> pc,
 	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
-	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false)
+	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false,
+	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationSettings::sh_grad_view_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -49,6 +50,7 @@ public:
 		                                              viewpoint_camera->full_proj_transform_, pc->active_sh_degree_,
 		                                              viewpoint_camera->camera_center_, false);
 		raster_settings.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
+		if (!use_override_color) raster_settings.sh_grad_view_ = sh_grad_view;
 		GaussianRasterizer rasterizer(raster_settings);
 
 		auto means3D = pc->getXYZ();

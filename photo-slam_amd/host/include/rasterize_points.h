@@ -27,6 +27,14 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
                                const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                               const int raw_params = 0);
+                               const int raw_params = 0,
+                               /* extension: a [P,3] float tensor that receives the clamp-masked colour gradient; dL_dsh is
+                                  then NOT computed and comes back undefined (gsr_backward_args.dL_dcolor_view) */
+                               const torch::Tensor& dL_dcolor_view = torch::Tensor());
+
+// gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
+// [n_views,P,3] dL_dcolor_view tensors and the [n_views,3] camera centres; scale = 1/n_views for the batch mean
+torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views,
+                              const torch::Tensor& dL_dcolor_views, const int degree, const int M, const float scale);
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);

@@ -24,6 +24,7 @@ torch::autograd::tensor_list GaussianRasterizerFunction::forward(
 	ctx->saved_data["tanfovy"] = static_cast<double>(s.tanfovy_);
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
 	ctx->saved_data["raw_params"] = s.raw_params_;
+	if (s.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = s.sh_grad_view_;
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
 	// same 14 tensors, same order as the reference (src/gaussian_rasterizer.cpp:87-100)
@@ -42,14 +43,17 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 	const float tanfovy = static_cast<float>(ctx->saved_data["tanfovy"].toDouble());
 	const int sh_degree = static_cast<int>(ctx->saved_data["sh_degree"].toInt());
 	const int raw_params = static_cast<int>(ctx->saved_data["raw_params"].toInt());
+	torch::Tensor sh_grad_view;
+	if (ctx->saved_data.count("sh_grad_view")) sh_grad_view = ctx->saved_data["sh_grad_view"].toTensor();
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
 	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
-	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params);
+	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params,
+	                                        sh_grad_view);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
-		return (input.defined() && input.numel() != 0) ? grad : torch::Tensor();
+		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();
 	};
 	return {std::get<3>(g) /*means3D*/,
 	        std::get<0>(g) /*means2D*/,

@@ -116,8 +116,21 @@ std::vector<torch::Tensor> trainer_params(int64_t h) { return get(h)->gaussians_
 std::vector<torch::Tensor> trainer_grads(int64_t h)
 {
 	std::vector<torch::Tensor> g;
-	for (auto& p : get(h)->gaussians_->params()) g.push_back(p.grad());
+	// (features_ has no gradient yet in the factored mode: an empty tensor keeps the positions)
+	for (auto& p : get(h)->gaussians_->params()) g.push_back(p.grad().defined() ? p.grad() : torch::empty({0}, p.options()));
 	return g;
+}
+// view-factored exchange of the data-parallel step (bench.py --gpus N, trainer.ViewFactoredExchange)
+void trainer_set_factored_exchange(int64_t h, bool on) { get(h)->factored_exchange_ = on; }
+torch::Tensor trainer_sh_grad_view(int64_t h) { return get(h)->sh_grad_view_; }
+void trainer_features_grad_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views)
+{
+	get(h)->setFeaturesGradFromViews(campos_views, views);
+}
+torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
+                                 int64_t M, double scale)
+{
+	return shGradFromViews(means3D, campos_views, views, (int)degree, (int)M, (float)scale);
 }
 std::vector<torch::Tensor> trainer_stats(int64_t h)
 {
@@ -151,5 +164,9 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_params", &trainer_params);
 	m.def("trainer_grads", &trainer_grads);
 	m.def("trainer_stats", &trainer_stats);
+	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
+	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
+	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
+	m.def("sh_grad_from_views", &sh_grad_from_views);
 	m.def("trainer_destroy", &trainer_destroy);
 }

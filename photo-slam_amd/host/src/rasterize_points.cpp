@@ -120,7 +120,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
                                const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                               const int raw_params)
+                               const int raw_params, const torch::Tensor& dL_dcolor_view)
 {
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = static_cast<int>(dL_dout_color.size(1));
@@ -135,7 +135,13 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
 	torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
 	torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
-	torch::Tensor dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
+	const bool factored = dL_dcolor_view.defined();
+	if (factored && (!has_sh || dL_dcolor_view.dim() != 2 || dL_dcolor_view.size(0) != P || dL_dcolor_view.size(1) != 3 ||
+	                 dL_dcolor_view.scalar_type() != torch::kFloat32 || !dL_dcolor_view.is_contiguous() ||
+	                 dL_dcolor_view.device() != means3D.device()))
+		throw std::runtime_error("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D, with SHs");
+	torch::Tensor dL_dsh;
+	if (!factored) dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
 	torch::Tensor dL_dscales = has_scales ? torch::empty({P, 3}, o) : torch::zeros({P, 3}, o);
 	torch::Tensor dL_drotations = has_scales ? torch::empty({P, 4}, o) : torch::zeros({P, 4}, o);
 
@@ -175,7 +181,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		a.dL_dcolor = dL_dcolors.data_ptr<float>();
 		a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
 		a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
-		a.dL_dsh = has_sh ? dL_dsh.data_ptr<float>() : nullptr;
+		a.dL_dsh = (has_sh && !factored) ? dL_dsh.data_ptr<float>() : nullptr;
+		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
 		a.dL_dscale = has_scales ? dL_dscales.data_ptr<float>() : nullptr;
 		a.dL_drot = has_scales ? dL_drotations.data_ptr<float>() : nullptr;
 		a.raw_params = raw_params;
@@ -183,6 +190,23 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	}
 	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
 	                       dL_drotations);
+}
+
+torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views,
+                              const torch::Tensor& dL_dcolor_views, const int degree, const int M, const float scale)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	if (dL_dcolor_views.dim() != 3 || dL_dcolor_views.size(1) != P || dL_dcolor_views.size(2) != 3 || campos_views.dim() != 2 ||
+	    campos_views.size(0) != dL_dcolor_views.size(0) || campos_views.size(1) != 3)
+		throw std::runtime_error("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)");
+	torch::Tensor out = torch::empty({P, M, 3}, means3D.options().dtype(torch::kFloat32));
+	if (P != 0) {
+		F32 m3(means3D), cam(campos_views), views(dL_dcolor_views);
+		check(gsr_sh_grad_from_views(P, degree, M, static_cast<int>(dL_dcolor_views.size(0)), m3.ptr, cam.ptr, views.ptr,
+		                             scale, out.data_ptr<float>(), current_stream(means3D)),
+		      "shGradFromViews");
+	}
+	return out;
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)

@@ -151,8 +151,12 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	g->updateLearningRate(iteration_);
 	GaussianPipelineParams pipe;
 	torch::Tensor override_color;
+	if (factored_exchange_)
+		sh_grad_view_ = torch::empty({g->xyz_.size(0), 3}, g->xyz_.options().requires_grad(false));
+	else
+		sh_grad_view_ = torch::Tensor();
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
-	                                    1.0f, false, /*fuse_activations=*/true);
+	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_);
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);
@@ -168,6 +172,15 @@ void TrainStep::finishOneIteration()
 	if (iteration_ < gaussians_->opt_.iterations_)
 		for (int i = 0; i < static_cast<int>(gaussians_->groups_.size()); i++) gaussians_->optimizerStepGroup(i);
 	finishEnd();
+}
+
+void TrainStep::setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views)
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	g->features_.mutable_grad() =
+	    shGradFromViews(g->xyz_.detach(), campos_views, dL_dcolor_views, g->active_sh_degree_,
+	                    static_cast<int>(g->features_.size(1)), 1.0f / static_cast<float>(dL_dcolor_views.size(0)));
 }
 
 void TrainStep::finishAdamGroup(int group)

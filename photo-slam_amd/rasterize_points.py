@@ -109,7 +109,10 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0):
+                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None):
+    """dL_dcolor_view (extension, default None = reference contract): a [P,3] float tensor that receives the clamp-masked
+    colour gradient; dL_dsh is then NOT computed and None is returned in its place (view-factored gradient exchange,
+    shGradFromViews below)."""
     lib = _lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -123,7 +126,11 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     dL_dconic = torch.empty((P, 2, 2), **opts)
     dL_dopacity = torch.empty((P, 1), **opts)
     dL_dcov3D = torch.empty((P, 6), **opts)
-    dL_dsh = torch.empty((P, M, 3), **opts)
+    factored = dL_dcolor_view is not None
+    if factored and (dL_dcolor_view.shape != (P, 3) or dL_dcolor_view.dtype != torch.float32 or
+                     not dL_dcolor_view.is_contiguous() or dL_dcolor_view.device != dev):
+        raise RuntimeError("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D")
+    dL_dsh = None if factored else torch.empty((P, M, 3), **opts)
     dL_dscales = torch.empty((P, 3), **opts)
     dL_drotations = torch.empty((P, 4), **opts)
     if P != 0:
@@ -144,17 +151,40 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         has_scales = a.scales is not None
         a.dL_dmean2D, a.dL_dconic, a.dL_dopacity = dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr()
         a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
-        a.dL_dsh = dL_dsh.data_ptr() if has_sh and M else None
+        if factored and not (has_sh and M):
+            raise RuntimeError("dL_dcolor_view needs spherical harmonics")
+        a.dL_dsh = dL_dsh.data_ptr() if has_sh and M and not factored else None
+        a.dL_dcolor_view = dL_dcolor_view.data_ptr() if factored else None
         a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
         a.dL_drot = dL_drotations.data_ptr() if has_scales else None
         st = lib.gsr_backward(C.byref(a), _stream_ptr(means3D))
         capi.check(lib, st, "RasterizeGaussiansBackwardCUDA")
-        if not has_sh:
+        if not has_sh and not factored:
             dL_dsh.zero_()
         if not has_scales:
             dL_dscales.zero_()
             dL_drotations.zero_()
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def shGradFromViews(means3D, campos_views, dL_dcolor_views, degree, M, scale, out=None):
+    """gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
+    [n_views,P,3] dL_dcolor_view outputs and the [n_views,3] camera centres; scale = 1/n_views for the batch mean."""
+    lib = _lib()
+    P, n_views = means3D.size(0), dL_dcolor_views.size(0)
+    if dL_dcolor_views.shape != (n_views, P, 3) or campos_views.shape != (n_views, 3):
+        raise RuntimeError("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)")
+    _check_device(lib, means3D, campos_views, dL_dcolor_views)
+    if out is None:
+        out = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
+    if P != 0:
+        k1, p1 = _ptr(means3D)
+        k2, p2 = _ptr(campos_views.float())
+        k3, p3 = _ptr(dL_dcolor_views)
+        st = lib.gsr_sh_grad_from_views(P, int(degree), int(M), n_views, p1, p2, p3, float(scale),
+                                        C.c_void_p(out.data_ptr()), _stream_ptr(means3D))
+        capi.check(lib, st, "shGradFromViews")
+    return out
 
 
 def markVisible(means3D, viewmatrix, projmatrix):

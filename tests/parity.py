@@ -46,8 +46,9 @@ def _features(cl, sh_coeffs):
 
 
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True, sh_coeffs=None):
-    """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library."""
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False):
+    """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  factored: backward in the
+    view-factored mode (dL_dcolor_view instead of dL_dsh, include/gsr.h)."""
     rp._LIB_OVERRIDE = lib_path
     try:
         lib = capi.load(lib_path)
@@ -89,12 +90,16 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                 r.tile_keys = np.zeros(0, np.uint32)
         if do_backward:
             dpix = _t(dL_dpix if dL_dpix is not None else np.ones((3, cam.H, cam.W), np.float32), dev)
+            view = torch.full((P, 3), float("nan"), device=dev) if factored else None
             g = rp.RasterizeGaussiansBackwardCUDA(a["background"], a["means3D"], radii, a["colors"], a["scales"],
                                                   a["rotations"], 1.0, a["cov3D_precomp"], a["viewmatrix"],
                                                   a["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, a["sh"], sh_degree,
-                                                  a["campos"], geom, R, binning, img)
+                                                  a["campos"], geom, R, binning, img,
+                                                  dL_dcolor_view=view)
             names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
-            r.grads = {n: t.cpu().numpy() for n, t in zip(names, g)}
+            r.grads = {n: t.cpu().numpy() for n, t in zip(names, g) if t is not None}
+            if factored:
+                r.grads["dL_dcolor_view"] = view.cpu().numpy()
         return r
     finally:
         rp._LIB_OVERRIDE = None
@@ -181,3 +186,47 @@ def compare(r, ores, ocolor, oradii, ograds, cam, use_colors_precomp=False, use_
             # culled Gaussians: exact zeros
             assert not np.any(g.reshape(g.shape[0], -1)[~vis]), f"{name} non-zero on culled Gaussians"
     return rep
+
+
+def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed=0):
+    """The view-factored gradient exchange of the keyframe batch (include/gsr.h: dL_dcolor_view +
+    gsr_sh_grad_from_views) against the plain path: for every camera of `cl` the factored backward must leave every other
+    gradient bit-identical, and the SH gradient rebuilt from the stacked per-view colour gradients must equal the mean
+    of the per-view dL_dsh (rtol 1e-5: same products, another summation order)."""
+    rng = np.random.default_rng(seed)
+    full, views = [], []
+    for cam in cl.cameras:
+        dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
+        a = run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix, sh_coeffs=sh_coeffs)
+        b = run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix, sh_coeffs=sh_coeffs, factored=True)
+        assert "dL_dsh" not in b.grads
+        exact = dev.type == "cpu"   # the emulator is deterministic; on the GPU the blend's LDS float atomics are not ordered
+        for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+            if exact:
+                assert np.array_equal(a.grads[n], b.grads[n]), f"{n} differs in the factored mode"
+            else:
+                assert rel_l1(b.grads[n], a.grads[n]) < 2e-5, (n, rel_l1(b.grads[n], a.grads[n]))
+        v = b.grads["dL_dcolor_view"]
+        assert np.isfinite(v).all() and not v[b.radii <= 0].any()
+        masked = b.grads["dL_dcolors"] * (1 - ((b.clamped[:, None] >> np.arange(3)[None, :]) & 1)) * (b.radii > 0)[:, None]
+        assert np.array_equal(v, masked.astype(np.float32)), "dL_dcolor_view is not the clamp-masked dL_dcolor"
+        # the plain rows of THIS backward's colour gradient: basis x v, compared through the rebuilt batch below
+        full.append(a.grads["dL_dsh"])
+        views.append(v)
+    n = len(cl.cameras)
+    M = full[0].shape[1]
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        out = rp.shGradFromViews(_t(cl.xyz, dev), _t(np.stack([c.campos for c in cl.cameras]).astype(np.float32), dev),
+                                 _t(np.stack(views), dev), sh_degree, M, 1.0 / n).cpu().numpy()
+    finally:
+        rp._LIB_OVERRIDE = None
+    want = np.sum(np.stack(full).astype(np.float64), axis=0) / n
+    assert out.shape == want.shape
+    k = (sh_degree + 1) ** 2
+    assert not out[:, k:].any()
+    assert np.abs(want).sum() > 0
+    if dev.type == "cpu":
+        assert np.allclose(out, want, rtol=1e-5, atol=1e-6 * np.abs(want).max()), float(np.abs(out - want).max())
+    assert rel_l1(out, want) < 2e-5, rel_l1(out, want)   # GPU: the two backward runs differ by the atomics' order
+    return rel_l1(out, want)

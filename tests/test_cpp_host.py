@@ -93,6 +93,27 @@ def run_trainer_checks(ops, dev, lib_path):
         losses_cpp.append(float(ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx,
                                                                 fovy, cam.H, cam.W, gt, mask)))
         ops.trainer_finish(h)
+    # the same three steps through the pieces of the data-parallel step with the view-factored exchange (a batch of one
+    # view: the rebuilt SH gradient is this view's own), per-group Adam in the order bench.py uses
+    h2 = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                            g.rotation_.detach(), 3, float(cl.extent), bg)
+    ops.trainer_set_factored_exchange(h2, True)
+    for it in range(3):
+        l2 = float(ops.trainer_render_and_backward(h2, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy,
+                                                   cam.H, cam.W, gt, mask))
+        assert np.isclose(l2, losses_cpp[it], rtol=1e-6)
+        grads = ops.trainer_grads(h2)
+        assert grads[1].numel() == 0 and all(grads[i].numel() for i in (0, 2, 3, 4))
+        view = ops.trainer_sh_grad_view(h2)
+        assert view.shape == (300, 3)
+        ops.trainer_finish_begin(h2)
+        ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
+        for i in (1, 4, 0, 3, 2):
+            ops.trainer_adam_group(h2, i)
+        ops.trainer_finish_end(h2)
+    for a, b in zip(ops.trainer_params(h2), ops.trainer_params(h)):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    ops.trainer_destroy(h2)
     rp._LIB_OVERRIDE = lib_path
     try:
         g.trainingSetup(GaussianOptimizationParams())

@@ -121,6 +121,13 @@ def test_compact_sh_layouts(emu_lib_path, oracle, degree, coeffs):
     assert not r.grads["dL_dsh"][:, k:, :].any()
 
 
+@pytest.mark.parametrize("degree,coeffs,n_views", [(3, None, 3), (1, None, 2), (1, 4, 2)])
+def test_view_factored_sh_gradient(emu_lib_path, degree, coeffs, n_views):
+    cl = _scene(P=300, seed=21, n_views=n_views)
+    parity.check_view_factored(emu_lib_path, CPU, cl, np.array([0.1, 0.2, 0.3], np.float32), sh_degree=degree,
+                               sh_coeffs=coeffs)
+
+
 def test_empty_and_tiny_inputs(emu_lib_path, oracle):
     rp._LIB_OVERRIDE = emu_lib_path
     try:

@@ -63,6 +63,15 @@ def test_compact_sh_layouts(oracle, dev, degree, coeffs):
     _check(oracle, dev, cl, cl.cameras[0], np.array([0.2, 0.4, 0.6], np.float32), sh_degree=degree, sh_coeffs=coeffs)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree,coeffs,n_views", [(3, None, 4), (2, None, 2), (0, None, 2), (1, 4, 3)])
+def test_view_factored_sh_gradient(dev, degree, coeffs, n_views):
+    # keyframe-batch data parallelism: dL_dcolor_view + gsr_sh_grad_from_views == mean of the per-view dL_dsh, and the
+    # factored backward leaves every other gradient bit-identical (parity.check_view_factored)
+    cl = scene.make_cloud(40000, 320, 240, 250.0, 250.0, seed=12, scale_k=0.15, n_views=n_views)
+    parity.check_view_factored(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32), sh_degree=degree, sh_coeffs=coeffs)
+
+
 def test_precomputed_colors_and_cov3D(oracle, dev):
     cl = scene.make_cloud(30000, 256, 192, 200.0, 200.0, seed=9, scale_k=0.15)
     cam = cl.cameras[0]

@@ -86,7 +86,8 @@ cl = scene.make_cloud(300, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=ws)
 g = GaussianModel.from_cloud(cl, device="cpu"); g.trainingSetup(GaussianOptimizationParams())
 kf = GaussianKeyframe.from_camera(cl.cameras[rank], "cpu")
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
-ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), world_size=ws)
+ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), world_size=ws,
+               factored_exchange=sys.argv[4] == "factored")
 for _ in range(2): ts.trainForOneIteration(kf, gt, torch.ones(3, 32, 48))
 out = {n: p.detach().numpy() for n, p in zip(["xyz","features","opacity","scaling","rotation"], g.params())}
 out["accum"] = g.xyz_gradient_accum_.numpy(); out["denom"] = g.denom_.numpy(); out["maxr"] = g.max_radii2D_.numpy()
@@ -95,13 +96,16 @@ dist.barrier()
 '''
 
 
-def test_keyframe_batch_data_parallel_gloo(emu, tmp_path):
-    """2 ranks x 1 keyframe each == 1 process accumulating both keyframes' gradients (mean)."""
+@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
+    """2 ranks x 1 keyframe each == 1 process accumulating both keyframes' gradients (mean), with the view-factored
+    exchange (all-gather of the colour gradients + local SH rebuild, the default) and with the plain all-reduce."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29511", str(script), ROOT, emu, str(tmp_path)],
+                           "--master-addr", "127.0.0.1", "--master-port", "29511" if exchange == "factored" else "29513", str(script), ROOT, emu,
+                           str(tmp_path), exchange],
                           env=env, timeout=600)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in r0.files:
