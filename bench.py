@@ -67,6 +67,7 @@ def main():
     if args.densify_interval:
         args.host = "py"
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
