@@ -62,9 +62,10 @@ def main():
     ap.add_argument("--host", default="cpp", choices=["cpp", "py"],
                     help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
     ap.add_argument("--densify-interval", type=int, default=0,
-                    help="run densifyAndPrune every N steps inside the timed region (Python host only; 0 = off; reference: 100)")
+                    help="run densifyAndPrune every N steps inside the timed region (0 = off; reference: 100); with several "
+                         "ranks the Python host drives it (it reduces the per-view statistics over the ranks)")
     args = ap.parse_args()
-    if args.densify_interval:
+    if args.densify_interval and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.host = "py"
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
@@ -145,6 +146,9 @@ def main():
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
         if dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
+        if args.densify_interval:
+            ops.trainer_set_options(handle, {"densify": 1.0, "cameras_extent": float(cl.extent), "seed": 0.0,
+                                             "densify_from_iter": 0.0, "densification_interval": float(args.densify_interval)})
 
     # The reference reads the loss on the host every iteration (EMA for logging, gaussian_mapper.cpp:701-705).  So does this
     # loop -- one step late: the value is copied to pinned memory behind the step's kernels and read while the NEXT step is

@@ -21,8 +21,7 @@ class FusedAdam:
     def __init__(self, groups, betas=(0.9, 0.999), eps=1e-15):
         self.param_groups = groups
         self.betas, self.eps = betas, eps
-        self.state = {}
-        self.step_count = 0
+        self.state = {}   # id(param) -> exp_avg, exp_avg_sq, step (per parameter, as torch::optim::AdamParamState)
 
     def step(self):
         self.begin_step()
@@ -30,11 +29,12 @@ class FusedAdam:
             self.step_group(i)
 
     def begin_step(self):
-        self.step_count += 1
+        """(kept for the per-group drivers: the step counters are per parameter and advance in step_group)"""
 
     def step_group(self, i):
-        """This step's update of parameter group i alone (after begin_step()): a data-parallel driver updates a tensor as
-        soon as ITS gradient reduction has landed, while the larger reductions are still in flight."""
+        """This step's update of parameter group i alone: a data-parallel driver updates a tensor as soon as ITS gradient
+        reduction has landed, while the larger reductions are still in flight.  A parameter without a gradient (the
+        iteration that densified) is skipped and its step counter does not advance -- torch::optim::Adam semantics."""
         lib = rp._lib()
         grp = self.param_groups[i]
         with torch.no_grad():
@@ -43,23 +43,25 @@ class FusedAdam:
                     continue
                 st = self.state.get(id(p))
                 if st is None:
-                    st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                    st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
+                st["step"] += 1
                 g = p.grad.contiguous()
                 capi.check(lib, lib.gsr_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                   st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]),
-                                                  self.betas[0], self.betas[1], self.eps, self.step_count,
+                                                  self.betas[0], self.betas[1], self.eps, st["step"],
                                                   int(grp.get("period", 0)), int(grp.get("split", 0)),
                                                   float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
                            "gsr_adam_step")
 
     def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):
         """Swap a parameter tensor (densify / prune / opacity reset): the Adam moments are replaced by the given
-        tensors, or by zeros (replaceTensorToOptimizer, src/gaussian_model.cpp:567-586)."""
+        tensors, or by zeros; the step counter carries over (replaceTensorToOptimizer, src/gaussian_model.cpp:567-586)."""
         for grp in self.param_groups:
             grp["params"] = [new if p is old else p for p in grp["params"]]
-        self.state.pop(id(old), None)
+        prev = self.state.pop(id(old), None)
         self.state[id(new)] = dict(exp_avg=torch.zeros_like(new) if exp_avg is None else exp_avg,
-                                   exp_avg_sq=torch.zeros_like(new) if exp_avg_sq is None else exp_avg_sq)
+                                   exp_avg_sq=torch.zeros_like(new) if exp_avg_sq is None else exp_avg_sq,
+                                   step=prev["step"] if prev else 0)
 
     def moments(self, p):
         st = self.state.get(id(p))

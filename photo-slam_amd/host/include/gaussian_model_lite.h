@@ -32,12 +32,26 @@ struct AdamGroup {
 	torch::Tensor param, exp_avg, exp_avg_sq;
 	float lr = 0.f, lr_tail = 0.f;
 	int period = 0, split = 0;
+	int step = 0;   // per parameter, as torch::optim::AdamParamState: advances only when the parameter has a gradient
 };
 
 class GaussianModel {
 public:
 	GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity, torch::Tensor scaling,
 	              torch::Tensor rotation, float spatial_lr_scale);
+	explicit GaussianModel(int sh_degree);   // empty model: createFromPcd() next
+
+	// map maintenance (src/gaussian_model_densify.cpp; include/gaussian_model.h:72-137 of the reference)
+	void createFromPcd(torch::Tensor points, torch::Tensor colors, float spatial_lr_scale);
+	void oneUpShDegree();
+	void resetOpacity();
+	void prunePoints(torch::Tensor& mask);
+	struct DensifyResult {
+		int64_t cloned = 0, split = 0, pruned = 0, points = 0;
+	};
+	// generator: the sampler of the split children's positions (every data-parallel rank seeds it identically)
+	DensifyResult densifyAndPrune(float max_grad, float min_opacity, float extent, int max_screen_size,
+	                              c10::optional<at::Generator> generator = c10::nullopt);
 
 	// activations, src/gaussian_model.cpp:48-71
 	torch::Tensor getXYZ() { return xyz_; }
@@ -52,8 +66,8 @@ public:
 	float updateLearningRate(int step);                          // :1118-1131 (exponLrFunc)
 	void optimizerStep();                                        // torch::optim::Adam semantics, fused
 	// the same step one parameter group at a time (xyz, features, opacity, scaling, rotation), so that a data-parallel
-	// driver can update a tensor as soon as ITS gradient reduction has landed: beginOptimizerStep() once, then every group
-	void beginOptimizerStep() { adam_step_++; }
+	// driver can update a tensor as soon as ITS gradient reduction has landed
+	void beginOptimizerStep() {}   // (the step counters are per group and advance in optimizerStepGroup)
 	void optimizerStepGroup(int group);
 	void zeroGrad();
 	void addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter);  // :817-831
@@ -65,7 +79,12 @@ public:
 	torch::Tensor max_radii2D_, xyz_gradient_accum_, denom_;
 	GaussianOptimizationParams opt_;
 	std::vector<AdamGroup> groups_;
-	int adam_step_ = 0;
+
+private:
+	torch::Tensor& paramByIndex(int i);
+	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq);
+	void rebuildWithSources(const torch::Tensor& gather_index, const torch::Tensor& child_pos, const torch::Tensor& child_xyz,
+	                        const torch::Tensor& child_scaling);
 };
 
 // GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774) without the SLAM keyframe
@@ -92,6 +111,15 @@ public:
 	// then leaves the clamp-masked colour gradient of this view in sh_grad_view_ and no gradient on features_; after the
 	// driver has gathered the views of all ranks, setFeaturesGradFromViews() installs the batch-mean SH gradient.  It reads
 	// xyz_, so it must run before finishAdamGroup(0).
+	// Densification schedule of GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:711-735), off by default:
+	// every densification_interval_ iterations after densify_from_iter_, and the opacity reset.  Runs inside
+	// finishBegin(); an iteration that rebuilt the tensors skips its optimizer step exactly as the reference does (the
+	// fresh leaves have no gradient).
+	bool densify_ = false;
+	float cameras_extent_ = 1.0f, densify_min_opacity_ = 0.005f;
+	int prune_big_point_after_iter_ = 0;
+	c10::optional<at::Generator> generator_;
+	GaussianModel::DensifyResult last_densify_;
 	bool factored_exchange_ = false;
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);

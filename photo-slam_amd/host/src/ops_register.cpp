@@ -82,6 +82,23 @@ int64_t trainer_create(torch::Tensor xyz, torch::Tensor features, torch::Tensor 
 	g_trainers[g_next] = std::make_shared<TrainStep>(model, background);
 	return g_next++;
 }
+int64_t trainer_create_from_pcd(torch::Tensor points, torch::Tensor colors, int64_t sh_degree, double spatial_lr_scale,
+                                torch::Tensor background)
+{
+	auto model = std::make_shared<GaussianModel>((int)sh_degree);
+	model->createFromPcd(points, colors, (float)spatial_lr_scale);
+	model->trainingSetup(GaussianOptimizationParams());
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_trainers[g_next] = std::make_shared<TrainStep>(model, background);
+	return g_next++;
+}
+// a generator of the tensors' device seeded like torch.Generator(device).manual_seed(seed)
+at::Generator make_generator(const torch::Device& device, int64_t seed)
+{
+	auto gen = at::globalContext().defaultGenerator(device).clone();
+	gen.set_current_seed(static_cast<uint64_t>(seed));
+	return gen;
+}
 std::shared_ptr<TrainStep> get(int64_t h)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -120,6 +137,54 @@ std::vector<torch::Tensor> trainer_grads(int64_t h)
 	for (auto& p : get(h)->gaussians_->params()) g.push_back(p.grad().defined() ? p.grad() : torch::empty({0}, p.options()));
 	return g;
 }
+// densification: options of the schedule (names of GaussianOptimizationParams / GaussianMapper without the trailing
+// underscore; unknown keys are refused), and the single operations for the parity tests
+void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
+{
+	auto t = get(h);
+	auto& p = t->gaussians_->opt_;
+	for (const auto& kv : o) {
+		const std::string& k = kv.key();
+		const double v = kv.value();
+		if (k == "densify") t->densify_ = v != 0.0;
+		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
+		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
+		else if (k == "prune_big_point_after_iter") t->prune_big_point_after_iter_ = (int)v;
+		else if (k == "seed") t->generator_ = make_generator(t->gaussians_->xyz_.device(), (int64_t)v);
+		else if (k == "iterations") p.iterations_ = (int)v;
+		else if (k == "densify_from_iter") p.densify_from_iter_ = (int)v;
+		else if (k == "densify_until_iter") p.densify_until_iter_ = (int)v;
+		else if (k == "densification_interval") p.densification_interval_ = (int)v;
+		else if (k == "opacity_reset_interval") p.opacity_reset_interval_ = (int)v;
+		else if (k == "densify_grad_threshold") p.densify_grad_threshold_ = (float)v;
+		else if (k == "percent_dense") p.percent_dense_ = (float)v;
+		else TORCH_CHECK(false, "unknown trainer option: ", k);
+	}
+}
+std::vector<int64_t> trainer_densify_and_prune(int64_t h, double max_grad, double min_opacity, double extent,
+                                               int64_t max_screen_size, int64_t seed)
+{
+	auto g = get(h)->gaussians_;
+	auto r = g->densifyAndPrune((float)max_grad, (float)min_opacity, (float)extent, (int)max_screen_size,
+	                            make_generator(g->xyz_.device(), seed));
+	return {r.cloned, r.split, r.pruned, r.points};
+}
+std::vector<int64_t> trainer_last_densify(int64_t h)
+{
+	auto r = get(h)->last_densify_;
+	return {r.cloned, r.split, r.pruned, r.points};
+}
+void trainer_reset_opacity(int64_t h) { get(h)->gaussians_->resetOpacity(); }
+void trainer_prune_points(int64_t h, torch::Tensor mask) { get(h)->gaussians_->prunePoints(mask); }
+void trainer_one_up_sh_degree(int64_t h) { get(h)->gaussians_->oneUpShDegree(); }
+std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five groups, then exp_avg_sq
+{
+	std::vector<torch::Tensor> out;
+	for (auto& g : get(h)->gaussians_->groups_) out.push_back(g.exp_avg);
+	for (auto& g : get(h)->gaussians_->groups_) out.push_back(g.exp_avg_sq);
+	return out;
+}
+
 // view-factored exchange of the data-parallel step (bench.py --gpus N, trainer.ViewFactoredExchange)
 void trainer_set_factored_exchange(int64_t h, bool on) { get(h)->factored_exchange_ = on; }
 torch::Tensor trainer_sh_grad_view(int64_t h) { return get(h)->sh_grad_view_; }
@@ -164,6 +229,14 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_params", &trainer_params);
 	m.def("trainer_grads", &trainer_grads);
 	m.def("trainer_stats", &trainer_stats);
+	m.def("trainer_create_from_pcd", &trainer_create_from_pcd);
+	m.def("trainer_set_options", &trainer_set_options);
+	m.def("trainer_densify_and_prune", &trainer_densify_and_prune);
+	m.def("trainer_last_densify", &trainer_last_densify);
+	m.def("trainer_reset_opacity", &trainer_reset_opacity);
+	m.def("trainer_prune_points", &trainer_prune_points);
+	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
+	m.def("trainer_moments", &trainer_moments);
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);

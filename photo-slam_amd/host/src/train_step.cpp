@@ -96,7 +96,6 @@ void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)
 	add(opacity_, opt.opacity_lr_);
 	add(scaling_, opt.scaling_lr_);
 	add(rotation_, opt.rotation_lr_);
-	adam_step_ = 0;
 }
 
 float GaussianModel::updateLearningRate(int step)
@@ -119,8 +118,9 @@ void GaussianModel::optimizerStepGroup(int group)
 	auto grad = g.param.grad();
 	if (!grad.defined()) return;
 	grad = grad.contiguous();
+	g.step++;
 	check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
-	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, adam_step_, g.period,
+	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, g.step, g.period,
 	                    g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
 	      "gsr_adam_step");
 }
@@ -205,6 +205,16 @@ void TrainStep::finishBegin()
 		                        g->xyz_gradient_accum_.data_ptr<float>(), g->denom_.data_ptr<float>(),
 		                        g->max_radii2D_.data_ptr<float>(), stream_of(grad)),
 		      "gsr_densify_stats");
+	}
+	if (iteration_ < g->opt_.densify_until_iter_ && densify_) {
+		const auto& o = g->opt_;
+		if (iteration_ > o.densify_from_iter_ && o.densification_interval_ && iteration_ % o.densification_interval_ == 0) {
+			const int size_threshold = (prune_big_point_after_iter_ > 0 && iteration_ > prune_big_point_after_iter_) ? 20 : 0;
+			g->zeroGrad();   // shapes change; this step's update is skipped
+			last_densify_ = g->densifyAndPrune(o.densify_grad_threshold_, densify_min_opacity_, cameras_extent_, size_threshold,
+			                                   generator_);
+		}
+		if (o.opacity_reset_interval_ && iteration_ % o.opacity_reset_interval_ == 0) g->resetOpacity();
 	}
 	if (iteration_ < g->opt_.iterations_) g->beginOptimizerStep();
 }

@@ -131,6 +131,148 @@ def run_trainer_checks(ops, dev, lib_path):
     ops.trainer_destroy(h)
 
 
+def run_map_maintenance_checks(ops, dev, lib_path):
+    """C++ GaussianModel::densifyAndPrune / resetOpacity / prunePoints / createFromPcd (host/src/gaussian_model_densify.cpp)
+    == the Python mirror (gaussian_model.py), from identical states and identically seeded generators: same selection,
+    same order, same children, same Adam moments."""
+    cl, t = _scene(dev, P=400)
+    cam = cl.cameras[0]
+    torch.manual_seed(0)
+    gt = torch.rand(3, cam.H, cam.W).to(dev)
+    mask = torch.ones(3, cam.H, cam.W, device=dev)
+    bg = torch.zeros(3, device=dev)
+    names = ("xyz_", "features_", "opacity_", "scaling_", "rotation_")
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        g = GaussianModel.from_cloud(cl, device=dev)
+        g.trainingSetup(GaussianOptimizationParams())
+        ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), bg)
+        kf = GaussianKeyframe.from_camera(cam, dev)
+        for _ in range(3):
+            ts.trainForOneIteration(kf, gt, mask)
+        # a C++ model in exactly this state: parameters through the constructor, statistics and moments copied in place
+        h = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                               g.rotation_.detach(), 3, float(cl.extent), bg)
+        for dst, src in zip(ops.trainer_stats(h), (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_)):
+            dst.copy_(src)
+        mom = ops.trainer_moments(h)
+        for i, n in enumerate(names):
+            m, v = g.optimizer_.moments(getattr(g, n))
+            mom[i].copy_(m)
+            mom[5 + i].copy_(v)
+        grads = (g.xyz_gradient_accum_ / g.denom_).nan_to_num(0.0).squeeze(-1)
+        thr = float(grads[grads > 0].median())
+        gen = torch.Generator(device=dev).manual_seed(5)
+        extent = float(torch.exp(g.scaling_.detach()).max(dim=1).values.median()) / 0.01   # half clone, half split
+        info = g.densifyAndPrune(thr, 0.005, extent, 20, generator=gen)
+        got = ops.trainer_densify_and_prune(h, thr, 0.005, extent, 20, 5)
+        assert list(got) == [info["cloned"], info["split"], info["pruned"], info["points"]] and info["split"] > 0 and info["cloned"] > 0
+
+        def same_state():
+            for a, n in zip(ops.trainer_params(h), names):
+                assert torch.equal(a, getattr(g, n).detach()), n
+            mom = ops.trainer_moments(h)
+            for i, n in enumerate(names):
+                m, v = g.optimizer_.moments(getattr(g, n))
+                assert torch.equal(mom[i], m) and torch.equal(mom[5 + i], v), n
+            for a, b in zip(ops.trainer_stats(h), (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_)):
+                assert torch.equal(a, b)
+        same_state()
+        # the rebuilt leaves train on: one more iteration on both sides
+        l_py = float(ts.trainForOneIteration(kf, gt, mask))
+        import math
+        l_cpp = float(ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos),
+                                                      2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy), cam.H, cam.W,
+                                                      gt, mask))
+        ops.trainer_finish(h)
+        assert np.isclose(l_py, l_cpp, rtol=1e-5)
+        # (the C++ trainer is three iterations younger: its Adam step counters and learning-rate schedule differ, so the
+        # updated values are compared by the schedule test below, not here)
+        for a, n in zip(ops.trainer_params(h), names):
+            assert a.shape == getattr(g, n).shape and torch.isfinite(a).all(), n
+            a.detach().copy_(getattr(g, n).detach())
+        # resetOpacity / prunePoints
+        g.resetOpacity()
+        ops.trainer_reset_opacity(h)
+        assert torch.allclose(ops.trainer_params(h)[2], g.opacity_.detach(), rtol=1e-4, atol=1e-6)
+        assert not ops.trainer_moments(h)[2].any() and (torch.sigmoid(ops.trainer_params(h)[2]) <= 0.0100001).all()
+        pm = torch.zeros(g.xyz_.shape[0], dtype=torch.bool, device=dev)
+        pm[::3] = True
+        g.prunePoints(pm)
+        ops.trainer_prune_points(h, pm)
+        for a, n in zip(ops.trainer_params(h), names):
+            assert a.shape == getattr(g, n).shape and torch.allclose(a, getattr(g, n).detach(), rtol=1e-4, atol=1e-6), n
+        assert ops.trainer_stats(h)[0].shape == g.xyz_gradient_accum_.shape
+        ops.trainer_destroy(h)
+        # createFromPcd (kNN scales)
+        pts = torch.from_numpy(cl.xyz).to(dev)
+        cols = torch.rand(pts.shape[0], 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        g2 = GaussianModel(3, device=dev)
+        g2.createFromPcd(pts, cols, 2.5)
+        h2 = ops.trainer_create_from_pcd(pts, cols, 3, 2.5, bg)
+        for a, n in zip(ops.trainer_params(h2), names):
+            assert torch.equal(a, getattr(g2, n).detach()), n
+        ops.trainer_destroy(h2)
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def run_densify_schedule_checks(ops, dev, lib_path):
+    """TrainStep's densification schedule (gaussian_mapper.cpp:711-735) in C++ == the Python trainer over 7 iterations
+    with densification every 2nd and an opacity reset at the 6th."""
+    cl, t = _scene(dev, P=400)
+    cam = cl.cameras[0]
+    torch.manual_seed(0)
+    gt = torch.rand(3, cam.H, cam.W).to(dev)
+    mask = torch.ones(3, cam.H, cam.W, device=dev)
+    bg = torch.zeros(3, device=dev)
+    g = GaussianModel.from_cloud(cl, device=dev)
+    h = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                           g.rotation_.detach(), 3, float(cl.extent), bg)
+    ops.trainer_set_options(h, {"densify": 1.0, "cameras_extent": float(cl.extent), "seed": 7.0, "densify_from_iter": 1.0,
+                                "densification_interval": 2.0, "opacity_reset_interval": 6.0, "densify_grad_threshold": 2e-5,
+                                "prune_big_point_after_iter": 3.0})
+    with pytest.raises(RuntimeError, match="unknown trainer option"):
+        ops.trainer_set_options(h, {"no_such_option": 1.0})
+    import math
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        opt = GaussianOptimizationParams()
+        opt.densify_from_iter_, opt.densification_interval_, opt.opacity_reset_interval_ = 1, 2, 6
+        opt.densify_grad_threshold_ = 2e-5
+        g.trainingSetup(opt)
+        ts = TrainStep(g, opt, GaussianPipelineParams(), bg, cameras_extent=float(cl.extent), densify=True,
+                       prune_big_point_after_iter=3, seed=7)
+        kf = GaussianKeyframe.from_camera(cam, dev)
+        sizes = []
+        for it in range(1, 8):
+            l_py = float(ts.trainForOneIteration(kf, gt, mask))
+            l_cpp = float(ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy,
+                                                          cam.H, cam.W, gt, mask))
+            ops.trainer_finish(h)
+            assert np.isclose(l_py, l_cpp, rtol=2e-4), (it, l_py, l_cpp)
+            assert ops.trainer_params(h)[0].shape == g.xyz_.shape, it
+            sizes.append(g.xyz_.shape[0])
+            if it % 2 == 0:
+                d = ts.last_densify_
+                assert list(ops.trainer_last_densify(h)) == [d["cloned"], d["split"], d["pruned"], d["points"]], it
+        assert len(set(sizes)) > 2, sizes   # the model did change size
+        for a, b in zip(ops.trainer_params(h), g.params()):
+            assert torch.allclose(a, b.detach(), rtol=1e-3, atol=1e-5)
+    finally:
+        rp._LIB_OVERRIDE = None
+    ops.trainer_destroy(h)
+
+
+def test_cpp_map_maintenance_matches_python(emu_lib_path):
+    run_map_maintenance_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
+
+
+def test_cpp_densify_schedule_matches_python(emu_lib_path):
+    run_densify_schedule_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
+
+
 def test_cpp_rasterizer_matches_python_mirror(emu_lib_path):
     run_rasterize_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
 
@@ -146,6 +288,7 @@ def test_cpp_host_layer_on_gpu():
     ops = load_host("hip")
     run_rasterize_checks(ops, torch.device("cuda:0"), None)
     run_trainer_checks(ops, torch.device("cuda:0"), None)
+    run_map_maintenance_checks(ops, torch.device("cuda:0"), None)
 
 
 def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
