@@ -193,11 +193,36 @@ void TrainStep::finishEnd()
 	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->zeroGrad();
 }
 
+std::vector<torch::Tensor> TrainStep::viewStats()
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	const auto P = g->xyz_.size(0);
+	auto o = g->xyz_.options().requires_grad(false);
+	auto sum = torch::zeros({2, P}, o), max = torch::zeros({P}, o);
+	auto grad = last_viewspace_.grad().contiguous();
+	auto radii = last_radii_.contiguous();
+	check(gsr_densify_stats(static_cast<int>(P), grad.data_ptr<float>(), radii.data_ptr<int>(), sum.data_ptr<float>(),
+	                        sum.data_ptr<float>() + P, max.data_ptr<float>(), stream_of(grad)),
+	      "gsr_densify_stats");
+	return {sum, max};
+}
+
+void TrainStep::applyViewStats(torch::Tensor sum, torch::Tensor max)
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	if (iteration_ >= g->opt_.densify_until_iter_) return;
+	g->xyz_gradient_accum_.add_(sum.select(0, 0).unsqueeze(1));
+	g->denom_.add_(sum.select(0, 1).unsqueeze(1));
+	g->max_radii2D_ = torch::max(g->max_radii2D_, max);
+}
+
 void TrainStep::finishBegin()
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
-	if (iteration_ < g->opt_.densify_until_iter_) {
+	if (iteration_ < g->opt_.densify_until_iter_ && !external_stats_) {
 		// :714-719 in one pass (gsr_densify_stats) instead of boolean-mask gathers/scatters + a host sync
 		auto grad = last_viewspace_.grad().contiguous();
 		auto radii = last_radii_.contiguous();

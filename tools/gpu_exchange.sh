@@ -14,3 +14,4 @@ GSR_BENCH_SHARE_GPU=1 GSR_BENCH_BACKEND=gloo timeout 600 python -m torch.distrib
   --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --config C2 --no-cpu-baseline \
   > gpurun_out/dist_smoke.log 2>&1
 tail -1 gpurun_out/dist_smoke.log | cut -c1-400
+timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --densify-interval 10 > gpurun_out/bench_densify_cpp.log 2>&1; tail -1 gpurun_out/bench_densify_cpp.log | cut -c1-200
