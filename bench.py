@@ -296,7 +296,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
-                       "parallelism": (f"dp{world} (one keyframe per GPU; all-gather of 3 + all-reduce of 11 floats/Gaussian, "
+                       "parallelism": "single GPU" if not dp else
+                                      (f"dp{world} (one keyframe per GPU; all-gather of 3 + all-reduce of 11 floats/Gaussian, "
                                        "SH gradient rebuilt per rank; + 3 floats of densification statistics)") if factored else
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 + 3 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
