@@ -1062,17 +1062,18 @@ static uint32_t quad_keep_bits_ref(const float* m2, const float* co, float tile_
 
 void gsro_cull_stats(const gsro_state* st, double* out)
 {
-	for (int i = 0; i < 12; i++) out[i] = 0;
+	for (int i = 0; i < 16; i++) out[i] = 0;
 	const int W = st->W, H = st->H;
 	const int T = st->grid_x * st->grid_y;
-	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0, o10 = 0, o11 = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11)
+	double o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0, o10 = 0, o11 = 0, o12 = 0, o13 = 0, o14 = 0, o15 = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(NT()) reduction(+ : o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11, o12, o13, o14, o15)
 	for (int t = 0; t < T; t++) {
 		const int tx = t % st->grid_x, ty = t / st->grid_x;
 		const uint32_t rs = st->ranges[2 * t], re = st->ranges[2 * t + 1];
 		const uint32_t n = re - rs;
 		o0 += n;
 		uint8_t* used = (uint8_t*)calloc((size_t)n + 1, 1); /* bit q: some pixel of quad q blends entry k */
+		uint16_t* used16 = (uint16_t*)calloc((size_t)n + 1, 2); /* bit 4q+s: some pixel of the 4x4 block s of quad q blends entry k */
 		uint32_t qmaxc[4] = {0, 0, 0, 0}; /* deepest n_contrib per quad */
 		uint32_t qdone_at[4] = {0, 0, 0, 0}; /* entries the fwd quad walks before all its pixels are done */
 		for (int q = 0; q < 4; q++)
@@ -1097,6 +1098,7 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 					T_ = test_T;
 					o4 += 1;
 					used[k] |= (uint8_t)(1u << q);
+					used16[k] |= (uint16_t)(1u << (4 * q + ((l >> 5) << 1) + ((l & 7) >> 2)));
 					uint32_t bits = quad_keep_bits_ref(st->means2D + 2 * g, co, (float)(tx * 16), (float)(ty * 16));
 					if (!((bits >> q) & 1)) o6 += 1;
 				}
@@ -1124,8 +1126,26 @@ void gsro_cull_stats(const gsro_state* st, double* out)
 				if (k < rig && (bits & 10u)) o11 += 1;
 			}
 		}
+		/* finer units of execution inside a quad: four 4x4 blocks (16 lanes each, every block walking its own entries) or
+		 * two 8x4 halves: entries with a blending pixel per unit, and the longest unit of each quad (= its walk length) */
+		for (int q = 0; q < 4; q++) {
+			uint32_t c4[4] = {0, 0, 0, 0}, c2[2] = {0, 0}, cq = 0;
+			for (uint32_t k = 0; k < n; k++) {
+				const uint32_t b = (used16[k] >> (4 * q)) & 15u;
+				for (int s_ = 0; s_ < 4; s_++) c4[s_] += (b >> s_) & 1u;
+				c2[0] += (b & 3u) != 0; c2[1] += (b & 12u) != 0;
+				cq += b != 0;
+			}
+			o12 += c4[0] + c4[1] + c4[2] + c4[3];
+			uint32_t m4 = c4[0]; for (int s_ = 1; s_ < 4; s_++) if (c4[s_] > m4) m4 = c4[s_];
+			o13 += m4;
+			o14 += c2[0] > c2[1] ? c2[0] : c2[1];
+			o15 += c2[0] + c2[1];
+		}
 		free(used);
+		free(used16);
 	}
+	out[12] = o12; out[13] = o13; out[14] = o14; out[15] = o15;
 	out[8] = o8; out[9] = o9; out[10] = o10; out[11] = o11;
 	out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
 }

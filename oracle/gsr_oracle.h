@@ -125,7 +125,7 @@ void gsro_neighborhood_depth_pinhole(int N, int width, float fx, float fy, float
                                      float* out_p, float* out_c);
 
 /* Analysis helper (not in the reference): work statistics of the per-quad rejection of the HIP
- * blend kernels, and the count of blended pairs it would wrongly reject (must be 0).  out[12]. */
+ * blend kernels, and the count of blended pairs it would wrongly reject (must be 0).  out[16]. */
 void gsro_cull_stats(const gsro_state* st, double* out);
 
 /* getHigherMsb, rasterizer_impl.cu:35-50. */

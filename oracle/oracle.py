@@ -217,12 +217,13 @@ def higher_msb(n):
 
 
 def cull_stats(res):
-    out = (C.c_double * 12)()
+    out = (C.c_double * 16)()
     lib().gsro_cull_stats(res._st, out)
     names = ("list_entries", "bwd_staged_entries", "fwd_quad_visits", "bwd_quad_visits", "blended_pairs",
              "reference_fwd_pair_evals", "wrongly_rejected_pairs", "fwd_quad_visits_without_rejection",
              "quad_visits_with_a_blending_pixel", "tile_instances_with_a_blending_pixel",
-             "bwd_visits_16x8_units", "bwd_visits_8x16_units")
+             "bwd_visits_16x8_units", "bwd_visits_8x16_units", "block4x4_visits_with_a_blending_pixel",
+             "longest_4x4_block_walk_per_quad", "longest_8x4_half_walk_per_quad", "half8x4_visits_with_a_blending_pixel")
     return dict(zip(names, [float(v) for v in out]))
 
 
