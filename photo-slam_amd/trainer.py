@@ -1,7 +1,8 @@
 """The measured train step: GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774)
 without the SLAM keyframe scheduling -- render -> mask -> L1 + lambda*(1-SSIM) -> backward ->
 densification statistics -> Adam -- plus the keyframe-batch data parallelism of SURVEY.md 8(e):
-one keyframe per rank, all-reduce (mean) of the six leaf gradients, SUM/MAX of the statistics."""
+one keyframe per rank, mean of the five leaf gradients over the ranks (ViewFactoredExchange, or the plain
+all-reduce of GradientReduction), SUM/MAX of the statistics."""
 import torch
 import torch.distributed as dist
 
@@ -40,8 +41,8 @@ class GradientReduction:
 
 
 class ViewFactoredExchange:
-    """The same batch mean with 2.6x (8 ranks) to 4.2x (2 ranks) fewer bytes on the links.  81 % of the gradient is the [P,16,3]
-    SH tensor, and one view's SH gradient is rank one per Gaussian: basis(dir) x dL_dcolor, with dir known to every rank.
+    """The same batch mean with 2.6x (8 ranks) to 4.2x (2 ranks) fewer bytes on the links.  81 % of
+    the gradient is the [P,16,3] SH tensor, and one view's SH gradient is rank one per Gaussian: basis(dir) x dL_dcolor, with dir known to every rank.
     So the ranks ALL-GATHER the 3-float colour gradients (rasterizer backward with sh_grad_view_) and the camera centres,
     each rebuilds the mean SH gradient locally (gsr_sh_grad_from_views), and only the other four tensors (11 floats per
     Gaussian) are all-reduced.  Per Gaussian a rank sends (N-1) * 12 + 2 (N-1)/N * 44 B instead of 2 (N-1)/N * 236 B.

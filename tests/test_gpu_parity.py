@@ -72,6 +72,14 @@ def test_view_factored_sh_gradient(dev, degree, coeffs, n_views):
     parity.check_view_factored(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32), sh_degree=degree, sh_coeffs=coeffs)
 
 
+@pytest.mark.gpu
+def test_full_size_view_factored_exchange(dev):
+    # the same property at BASELINE.json's size: 2 M Gaussians @1080p, a batch of two keyframes
+    cl = scene.make_config("C3", seed=0, n_views=2)
+    rel = parity.check_view_factored(None, dev, cl, np.zeros(3, np.float32))
+    assert rel < 1e-6, rel
+
+
 def test_precomputed_colors_and_cov3D(oracle, dev):
     cl = scene.make_cloud(30000, 256, 192, 200.0, 200.0, seed=9, scale_k=0.15)
     cam = cl.cameras[0]
