@@ -33,9 +33,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2):
+def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, fused_sh_adam=False):
     """Compulsory HBM bytes per stage (each array read/written once per stage that
-    needs it), restated for this implementation's stage split."""
+    needs it), restated for this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the
+    Adam step of the SH tensor (no gradient rows written; both moments read, parameter + moments written for every
+    Gaussian, the parameter row read for the culled ones too)."""
+    adam = 12 * M * (4 * P + (P - V)) if fused_sh_adam else 0
     return {
         "preprocess_fwd": 52 * P + (12 * K + 67) * V,
         "depth_sort": 4 * 16 * P,                    # 4 passes x (8 B read + 8 B write) over P pairs
@@ -46,7 +49,7 @@ def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2):
         "blend_fwd": 40 * R + 20 * Npix,
         "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
-        "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V),
+        "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V) + adam,
     }
 
 
@@ -146,6 +149,7 @@ def main():
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
         if dp:
             ops.trainer_set_external_stats(handle, True)   # the per-view statistics are reduced over the ranks below
+            ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
         if args.densify_interval:
@@ -241,7 +245,11 @@ def main():
             dom_ms.append(v)
     barrier()
     elapsed = time.perf_counter() - t0
-    # Stage table: the same step with events between all stages, outside the timed region.
+    # Stage table: the same step with events between all stages, outside the timed region -- and with the separate Adam pass
+    # on the SH tensor, so that the rasterizer stages (and the Mpix/s derived from them) contain no optimizer work.
+    if ops is not None:
+        ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})
+    ts.fused_sh_adam_ = False
     capi.profile_enable(lib, 1)
     stage_ms = {}
     for _ in range(min(args.steps, 10)):
@@ -267,7 +275,8 @@ def main():
                                   kf.tanfovx_, kf.tanfovy_, H, W, g.getFeatures().detach(), 3, kf.camera_center_, False)[0]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
-    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8)
+    fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank (timed region)
+    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8)   # the stage table ran unfused (above)
     stages = {}
     for k, ms in stage_ms.items():
         ms = [m for m in ms if m >= 0]
@@ -301,6 +310,7 @@ def main():
                                        "SH gradient rebuilt per rank; + 3 floats of densification statistics)") if factored else
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 + 3 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
+                       "sh_adam_fused_into_backward": fused_sh_adam,
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else P,
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,

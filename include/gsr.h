@@ -82,6 +82,16 @@ int gsr_forward(const gsr_forward_args* args,
                 gsr_alloc_fn imageBuffer, void* image_ctx,
                 void* stream, int* num_rendered);
 
+/* Extension: Adam state of the [P,16,3] SH tensor for the fused update inside gsr_backward (see
+ * gsr_backward_args.sh_adam).  torch::optim::Adam semantics as gsr_adam_step; the first 3 floats of a row
+ * (features_dc) use lr, the other 45 (features_rest) lr_tail. */
+typedef struct gsr_sh_adam {
+	float* exp_avg;              /* [P,16,3] */
+	float* exp_avg_sq;           /* [P,16,3] */
+	float lr, lr_tail, beta1, beta2, eps;
+	int step;                    /* >= 1: the step being taken (bias correction) */
+} gsr_sh_adam;
+
 /* Rasterizer::backward parameter list, cuda_rasterizer/rasterizer.h:61-91. */
 typedef struct gsr_backward_args {
 	int P, D, M, R;
@@ -122,6 +132,12 @@ typedef struct gsr_backward_args {
 	 * basis(dir) x this vector; gsr_sh_grad_from_views rebuilds it for all views after the exchange.  The SH term of
 	 * dL_dmean3D is computed as usual. */
 	float* dL_dcolor_view;
+	/* Extension, optimizer-in-backward for the SH tensor (NULL = the reference contract).  When set, dL_dsh is NOT written
+	 * (and may be NULL): the kernel that produces the gradient rows applies this step's Adam update to `shs` IN PLACE
+	 * (shs is written despite its const type) and to the two moment tensors, for every Gaussian (culled ones with a zero
+	 * gradient, as a dense optimizer does) -- the 192 B/Gaussian gradient row never round-trips through HBM.  Only for
+	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise); mutually exclusive with dL_dcolor_view. */
+	const gsr_sh_adam* sh_adam;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.

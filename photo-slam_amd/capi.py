@@ -34,6 +34,11 @@ class ForwardArgs(C.Structure):
                 ("out_color", C.c_void_p), ("radii", C.c_void_p), ("raw_params", C.c_int)]
 
 
+class ShAdam(C.Structure):
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_float), ("lr_tail", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int)]
+
+
 class BackwardArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("R", C.c_int), ("background", C.c_void_p),
                 ("width", C.c_int), ("height", C.c_int), ("means3D", C.c_void_p), ("shs", C.c_void_p),
@@ -45,7 +50,7 @@ class BackwardArgs(C.Structure):
                 ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int),
-                ("dL_dcolor_view", C.c_void_p)]
+                ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam))]
 
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 

@@ -8,6 +8,7 @@
 //   -> depth sort of the P Gaussians (4 x 8-bit passes) -> exclusive scan in depth order
 //   -> host waits for the event only now, sizes the binning buffer
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
+#include <cmath>
 #include "kernels.h"
 #include "../../include/gsr_stages.h"
 
@@ -244,7 +245,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dopacity || !a->dL_dcolor ||
 	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
 		return GSR_ERR_INVALID_ARG;
-	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view) return GSR_ERR_INVALID_ARG;
+	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view && !a->sh_adam) return GSR_ERR_INVALID_ARG;
+	if (a->sh_adam && (!a->shs || a->dL_dcolor_view || !a->sh_adam->exp_avg || !a->sh_adam->exp_avg_sq || a->sh_adam->step < 1))
+		return GSR_ERR_INVALID_ARG;
 	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
 	if (a->scales && (!a->dL_dscale || !a->dL_drot)) return GSR_ERR_INVALID_ARG;
 	if (a->R > 0 && !a->binning_buffer) return GSR_ERR_INVALID_ARG;
@@ -291,6 +294,17 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	pb.dL_dcolor_view = a->dL_dcolor_view;
+	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
+	pb.adam_step_size = pb.adam_step_size_tail = pb.adam_b1 = pb.adam_b2 = pb.adam_eps = pb.adam_inv_sqrt_bc2 = 0.f;
+	if (a->sh_adam) {
+		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (train_ops.hip)
+		const double bc1 = 1.0 - pow((double)o.beta1, o.step), bc2 = 1.0 - pow((double)o.beta2, o.step);
+		pb.adam_param = const_cast<float*>(a->shs);
+		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
+		pb.adam_step_size = (float)(o.lr / bc1); pb.adam_step_size_tail = (float)(o.lr_tail / bc1);
+		pb.adam_b1 = o.beta1; pb.adam_b2 = o.beta2; pb.adam_eps = o.eps;
+		pb.adam_inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+	}
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on != 0;

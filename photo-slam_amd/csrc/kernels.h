@@ -85,6 +85,11 @@ struct PreprocessBwdParams {
 	float* dL_dscale;         // [P,3] nullable
 	float* dL_drot;           // [P,4] nullable
 	int raw_params;           // GSR_RAW_* mask: outputs are gradients of the raw parameters
+	// fused Adam step of the SH tensor (gsr_backward_args.sh_adam): dL_dsh never leaves the LDS rows; null exp_avg = off
+	float* adam_param;        // == shs, written
+	float* adam_exp_avg;
+	float* adam_exp_avg_sq;
+	float adam_step_size, adam_step_size_tail, adam_b1, adam_b2, adam_eps, adam_inv_sqrt_bc2;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)

@@ -31,7 +31,7 @@ constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per work
 // SH backward for aligned 48-float rows; DEG = active SH degree.  FACTORED (gsr_backward_args.dL_dcolor_view): the
 // gradient rows are not produced -- the clamp-masked colour gradient leaves instead (12 B instead of 192 B per Gaussian)
 // and gsr_sh_grad_from_views rebuilds dL_dsh for the whole keyframe batch after the exchange.
-template <int DEG, bool FACTORED>
+template <int DEG, int MODE>   // MODE: 0 = gradient rows out, 1 = factored (colour gradient out), 2 = fused Adam step
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(6, 8)   // 80 VGPRs (3 dwords of scratch at degree 3)
 sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
@@ -43,6 +43,7 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 	const bool in_range = idx < p.P;
 	const bool vis = in_range && (p.radii[idx] > 0);
 	constexpr int ncoef = (DEG + 1) * (DEG + 1);
+	constexpr bool FACTORED = MODE == 1;
 	float dRGB[3] = {0.f, 0.f, 0.f};
 	float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};  // dRGBdx/dy/dz
 	float ox = 0.f, oy = 0.f, oz = 1.f;
@@ -93,10 +94,15 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 						for (int i = 0; i < ROW_F4; i++) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 					}
 				}
-				if (!FACTORED)
+				if (MODE == 0) {
 					wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
-				else
+				} else if (MODE == 2) {
+					const RowAdam ra = {p.adam_param, p.adam_exp_avg, p.adam_exp_avg_sq, p.adam_step_size, p.adam_step_size_tail,
+					                    p.adam_b1, p.adam_b2, p.adam_eps, p.adam_inv_sqrt_bc2};
+					wave_adam_rows(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+				} else {
 					wave_fence();   // the next pass refills the slice
+				}
 			}
 		}
 	}
@@ -136,7 +142,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
 		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a);   // every lane of the wave takes part
 	}
-	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
+	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && !p.adam_exp_avg && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
 	// Culled Gaussians take the same store instructions as visible ones, with zeros (the reference leaves the
 	// torch::zeros content): every output leaves the wave as full contiguous lines.  Separate zero / value stores,
@@ -401,8 +407,11 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
 	const bool factored = p.dL_dcolor_view != nullptr;
+	const bool adam = p.adam_exp_avg != nullptr;
 	const bool rows_ok = p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0) &&
-	                     (factored || (p.dL_dsh && (reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0));
+	                     (factored || adam || (p.dL_dsh && (reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0));
+	if (adam && (!rows_ok || factored || ((reinterpret_cast<uintptr_t>(p.adam_exp_avg) | reinterpret_cast<uintptr_t>(p.adam_exp_avg_sq)) & 15)))
+		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
 	const int grid = div_up(p.P, PRB_THREADS);
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
 		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
@@ -411,9 +420,11 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 #define GSR_SHB(DEG)                                                                  \
 	do {                                                                              \
 		if (factored)                                                                 \
-			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, true>), g, SHB_THREADS, stream, p);   \
+			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, 1>), g, SHB_THREADS, stream, p);      \
+		else if (adam)                                                                \
+			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, 2>), g, SHB_THREADS, stream, p);      \
 		else                                                                          \
-			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, false>), g, SHB_THREADS, stream, p);  \
+			GSR_LAUNCH((sh_bwd_rows_kernel<DEG, 0>), g, SHB_THREADS, stream, p);      \
 	} while (0)
 		if (p.D == 3)
 			GSR_SHB(3);

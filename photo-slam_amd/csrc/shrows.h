@@ -68,6 +68,47 @@ __device__ __forceinline__ void wave_store_rows(float4* __restrict__ gbase, size
 	wave_fence();
 }
 
+// One Adam step (train_ops.hip: adam_kernel, same arithmetic) on rows [first_row, first_row + nrows) whose GRADIENT sits in
+// s_rows: the movers read parameter and moments from global (four whole rows = 768 contiguous bytes per instruction and
+// array), update them and write them back; the gradient never reaches HBM.  The first 3 floats of a row (features_dc) use
+// step_size, the other 45 (features_rest) step_size_tail.
+struct RowAdam {
+	float* param;
+	float* exp_avg;
+	float* exp_avg_sq;
+	float step_size, step_size_tail, b1, b2, eps, inv_sqrt_bc2;
+};
+__device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD])
+{
+	const int l = lane_id();
+	const int slot = l >> 4, col = l & 15;
+	wave_fence();
+	const size_t base = (first_row + slot) * ROW_F4 + col;
+	const float ss_first = col == 0 ? a.step_size : a.step_size_tail;   // .x .y .z of vector 0 are features_dc
+#pragma unroll 2
+	for (int k = 0; k < STAGE_ROWS / 4; k++) {
+		if (col < ROW_F4 && 4 * k + slot < nrows) {
+			const size_t i = base + (size_t)(4 * k * ROW_F4);
+			const float4 gv = s_rows[4 * k + slot][col];
+			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
+			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
+			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const float ss = e < 3 ? ss_first : a.step_size_tail;
+				mp[e] = a.b1 * mp[e] + (1.f - a.b1) * gp[e];
+				vp[e] = a.b2 * vp[e] + (1.f - a.b2) * gp[e] * gp[e];
+				pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.inv_sqrt_bc2 + a.eps);
+			}
+			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+		}
+	}
+	wave_fence();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // SH basis, cuda_rasterizer/auxiliary.h:22-39 + forward.cu:20-71 / backward.cu:20-139.
 __device__ static const float SHB_C0 = 0.28209479177387814f;

@@ -53,6 +53,20 @@ class FusedAdam:
                                                   float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
                            "gsr_adam_step")
 
+    def begin_fused_step(self, i):
+        """Arguments of the fused update of single-tensor group i (GaussianRasterizationSettings.sh_adam_): advances the
+        parameter's step counter -- the update itself happens inside the rasterizer's backward, and step_group(i) then finds
+        no gradient and does nothing."""
+        grp = self.param_groups[i]
+        (p,) = grp["params"]
+        st = self.state.get(id(p))
+        if st is None:
+            st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
+        st["step"] += 1
+        return dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=float(grp["lr"]),
+                    lr_tail=float(grp.get("lr_tail", grp["lr"])), beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                    step=st["step"])
+
     def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):
         """Swap a parameter tensor (densify / prune / opacity reset): the Adam moments are replaced by the given
         tensors, or by zeros; the step counter carries over (replaceTensorToOptimizer, src/gaussian_model.cpp:567-586)."""

@@ -28,6 +28,9 @@ class GaussianRasterizationSettings:
     # extension: a [P,3] tensor that receives the clamp-masked colour gradient in backward; the SH gradient is then left
     # to the view-factored exchange (trainer.ViewFactoredExchange) and autograd gets None for sh
     sh_grad_view_: torch.Tensor = None
+    # extension, optimizer-in-backward for the SH tensor: dict(exp_avg, exp_avg_sq, lr, lr_tail, beta1, beta2, eps, step) --
+    # backward applies this Adam step to sh in place instead of returning its gradient (gsr_backward_args.sh_adam)
+    sh_adam_: dict = None
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -56,7 +59,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
          dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_)
+            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_, s.sh_adam_)
         # order of src/gaussian_rasterizer.cpp:159-179
         def g(t, like):
             return t if like.numel() and t is not None else None

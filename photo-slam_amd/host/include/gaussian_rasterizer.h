@@ -33,6 +33,8 @@ struct GaussianRasterizationSettings {
 	// extension: a [P,3] tensor that receives the clamp-masked colour gradient in backward; sh then gets no gradient from
 	// autograd -- the view-factored exchange of the data-parallel step rebuilds it (shGradFromViews)
 	torch::Tensor sh_grad_view_;
+	// extension, optimizer-in-backward for the SH tensor (rasterize_points.h): set exp_avg to enable
+	ShAdamStep sh_adam_;
 };
 
 class GaussianRasterizerFunction : public torch::autograd::Function<GaussianRasterizerFunction> {

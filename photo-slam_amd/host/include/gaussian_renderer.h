@@ -35,7 +35,8 @@ public:
 	    std::shared_ptr<Keyframe> viewpoint_camera, int image_height, int image_width, std::shared_ptr<Model> pc,
 	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
 	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false,
-	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationSettings::sh_grad_view_ */)
+	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationSettings::sh_grad_view_ */,
+	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationSettings::sh_adam_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -51,6 +52,7 @@ public:
 		                                              viewpoint_camera->camera_center_, false);
 		raster_settings.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
 		if (!use_override_color) raster_settings.sh_grad_view_ = sh_grad_view;
+		if (!use_override_color) raster_settings.sh_adam_ = sh_adam;
 		GaussianRasterizer rasterizer(raster_settings);
 
 		auto means3D = pc->getXYZ();

@@ -17,6 +17,14 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
     const bool prefiltered, const int raw_params = 0 /* extension: GSR_RAW_* mask, see include/gsr.h */);
 
+// Extension, optimizer-in-backward for the SH tensor (gsr_sh_adam of include/gsr.h): when exp_avg is defined, backward applies
+// this Adam step to `sh` IN PLACE instead of computing dL_dsh (which then comes back undefined).
+struct ShAdamStep {
+	torch::Tensor exp_avg, exp_avg_sq;   // [P,16,3], contiguous
+	float lr = 0.f, lr_tail = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f;
+	int step = 0;
+};
+
 // (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
@@ -30,7 +38,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const int raw_params = 0,
                                /* extension: a [P,3] float tensor that receives the clamp-masked colour gradient; dL_dsh is
                                   then NOT computed and comes back undefined (gsr_backward_args.dL_dcolor_view) */
-                               const torch::Tensor& dL_dcolor_view = torch::Tensor());
+                               const torch::Tensor& dL_dcolor_view = torch::Tensor(),
+                               const ShAdamStep& sh_adam = ShAdamStep());
 
 // gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
 // [n_views,P,3] dL_dcolor_view tensors and the [n_views,3] camera centres; scale = 1/n_views for the batch mean

@@ -25,6 +25,12 @@ torch::autograd::tensor_list GaussianRasterizerFunction::forward(
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
 	ctx->saved_data["raw_params"] = s.raw_params_;
 	if (s.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = s.sh_grad_view_;
+	if (s.sh_adam_.exp_avg.defined()) {
+		ctx->saved_data["sh_adam_m"] = s.sh_adam_.exp_avg;
+		ctx->saved_data["sh_adam_v"] = s.sh_adam_.exp_avg_sq;
+		ctx->saved_data["sh_adam_h"] = std::vector<double>{s.sh_adam_.lr, s.sh_adam_.lr_tail, s.sh_adam_.beta1, s.sh_adam_.beta2,
+		                                                   s.sh_adam_.eps, static_cast<double>(s.sh_adam_.step)};
+	}
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
 	// same 14 tensors, same order as the reference (src/gaussian_rasterizer.cpp:87-100)
@@ -45,12 +51,21 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 	const int raw_params = static_cast<int>(ctx->saved_data["raw_params"].toInt());
 	torch::Tensor sh_grad_view;
 	if (ctx->saved_data.count("sh_grad_view")) sh_grad_view = ctx->saved_data["sh_grad_view"].toTensor();
+	ShAdamStep sh_adam;
+	if (ctx->saved_data.count("sh_adam_m")) {
+		sh_adam.exp_avg = ctx->saved_data["sh_adam_m"].toTensor();
+		sh_adam.exp_avg_sq = ctx->saved_data["sh_adam_v"].toTensor();
+		const auto h = ctx->saved_data["sh_adam_h"].toDoubleVector();
+		sh_adam.lr = static_cast<float>(h[0]); sh_adam.lr_tail = static_cast<float>(h[1]);
+		sh_adam.beta1 = static_cast<float>(h[2]); sh_adam.beta2 = static_cast<float>(h[3]);
+		sh_adam.eps = static_cast<float>(h[4]); sh_adam.step = static_cast<int>(h[5]);
+	}
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
 	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
 	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params,
-	                                        sh_grad_view);
+	                                        sh_grad_view, sh_adam);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();

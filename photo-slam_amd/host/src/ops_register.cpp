@@ -147,6 +147,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		const std::string& k = kv.key();
 		const double v = kv.value();
 		if (k == "densify") t->densify_ = v != 0.0;
+		else if (k == "fused_sh_adam") t->fused_sh_adam_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
 		else if (k == "prune_big_point_after_iter") t->prune_big_point_after_iter_ = (int)v;

@@ -120,7 +120,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
                                const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                               const int raw_params, const torch::Tensor& dL_dcolor_view)
+                               const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam)
 {
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = static_cast<int>(dL_dout_color.size(1));
@@ -140,8 +140,13 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	                 dL_dcolor_view.scalar_type() != torch::kFloat32 || !dL_dcolor_view.is_contiguous() ||
 	                 dL_dcolor_view.device() != means3D.device()))
 		throw std::runtime_error("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D, with SHs");
+	const bool fused_adam = sh_adam.exp_avg.defined();
+	if (fused_adam && (factored || !has_sh || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 ||
+	                   !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() ||
+	                   sh_adam.exp_avg.sizes() != sh.sizes() || sh_adam.exp_avg_sq.sizes() != sh.sizes() || sh_adam.step < 1))
+		throw std::runtime_error("sh_adam needs contiguous float32 sh and moments of one shape, step >= 1, and no dL_dcolor_view");
 	torch::Tensor dL_dsh;
-	if (!factored) dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
+	if (!factored && !fused_adam) dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
 	torch::Tensor dL_dscales = has_scales ? torch::empty({P, 3}, o) : torch::zeros({P, 3}, o);
 	torch::Tensor dL_drotations = has_scales ? torch::empty({P, 4}, o) : torch::zeros({P, 4}, o);
 
@@ -181,7 +186,16 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		a.dL_dcolor = dL_dcolors.data_ptr<float>();
 		a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
 		a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
-		a.dL_dsh = (has_sh && !factored) ? dL_dsh.data_ptr<float>() : nullptr;
+		a.dL_dsh = (has_sh && dL_dsh.defined()) ? dL_dsh.data_ptr<float>() : nullptr;
+		gsr_sh_adam adam{};
+		if (fused_adam) {
+			adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
+			adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
+			adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
+			adam.beta1 = sh_adam.beta1; adam.beta2 = sh_adam.beta2; adam.eps = sh_adam.eps;
+			adam.step = sh_adam.step;
+			a.sh_adam = &adam;
+		}
 		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
 		a.dL_dscale = has_scales ? dL_dscales.data_ptr<float>() : nullptr;
 		a.dL_drot = has_scales ? dL_drotations.data_ptr<float>() : nullptr;

@@ -155,8 +155,22 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_grad_view_ = torch::empty({g->xyz_.size(0), 3}, g->xyz_.options().requires_grad(false));
 	else
 		sh_grad_view_ = torch::Tensor();
+	ShAdamStep sh_adam;
+	const auto& o = g->opt_;
+	const bool rebuilds = densify_ && iteration_ < o.densify_until_iter_ && iteration_ > o.densify_from_iter_ &&
+	                      o.densification_interval_ && iteration_ % o.densification_interval_ == 0;
+	if (fused_sh_adam_ && !factored_exchange_ && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
+	    g->features_.size(1) == 16) {
+		auto& grp = g->groups_[1];
+		grp.step++;   // the step happens inside backward; optimizerStepGroup(1) then finds no gradient
+		sh_adam.exp_avg = grp.exp_avg;
+		sh_adam.exp_avg_sq = grp.exp_avg_sq;
+		sh_adam.lr = grp.lr;
+		sh_adam.lr_tail = grp.lr_tail;
+		sh_adam.step = grp.step;
+	}
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
-	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_);
+	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam);
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);

@@ -109,10 +109,13 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None):
+                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None, sh_adam=None):
     """dL_dcolor_view (extension, default None = reference contract): a [P,3] float tensor that receives the clamp-masked
     colour gradient; dL_dsh is then NOT computed and None is returned in its place (view-factored gradient exchange,
-    shGradFromViews below)."""
+    shGradFromViews below).
+    sh_adam (extension, default None): dict(exp_avg, exp_avg_sq, lr, lr_tail, beta1, beta2, eps, step) -- this step's Adam
+    update of `sh` is applied IN PLACE by the kernel that produces its gradient (gsr_backward_args.sh_adam); dL_dsh is then
+    not computed and None is returned in its place."""
     lib = _lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -127,10 +130,18 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     dL_dopacity = torch.empty((P, 1), **opts)
     dL_dcov3D = torch.empty((P, 6), **opts)
     factored = dL_dcolor_view is not None
+    if sh_adam is not None:
+        if factored:
+            raise RuntimeError("sh_adam and dL_dcolor_view are mutually exclusive")
+        for t in (sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
+            if t.shape != sh.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise RuntimeError("sh_adam moments must be contiguous float32 tensors shaped like sh")
+        if not sh.is_contiguous():
+            raise RuntimeError("sh_adam needs a contiguous sh tensor (it is updated in place)")
     if factored and (dL_dcolor_view.shape != (P, 3) or dL_dcolor_view.dtype != torch.float32 or
                      not dL_dcolor_view.is_contiguous() or dL_dcolor_view.device != dev):
         raise RuntimeError("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D")
-    dL_dsh = None if factored else torch.empty((P, M, 3), **opts)
+    dL_dsh = None if factored or sh_adam is not None else torch.empty((P, M, 3), **opts)
     dL_dscales = torch.empty((P, 3), **opts)
     dL_drotations = torch.empty((P, 4), **opts)
     if P != 0:
@@ -153,13 +164,18 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
         if factored and not (has_sh and M):
             raise RuntimeError("dL_dcolor_view needs spherical harmonics")
-        a.dL_dsh = dL_dsh.data_ptr() if has_sh and M and not factored else None
+        a.dL_dsh = dL_dsh.data_ptr() if has_sh and M and dL_dsh is not None else None
+        if sh_adam is not None:
+            adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
+                               float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]),
+                               float(sh_adam["eps"]), int(sh_adam["step"]))
+            a.sh_adam = C.pointer(adam)
         a.dL_dcolor_view = dL_dcolor_view.data_ptr() if factored else None
         a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
         a.dL_drot = dL_drotations.data_ptr() if has_scales else None
         st = lib.gsr_backward(C.byref(a), _stream_ptr(means3D))
         capi.check(lib, st, "RasterizeGaussiansBackwardCUDA")
-        if not has_sh and not factored:
+        if not has_sh and dL_dsh is not None:
             dL_dsh.zero_()
         if not has_scales:
             dL_dscales.zero_()

@@ -104,7 +104,7 @@ def allreduce_mean(tensors, world_size):
 
 class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
-                 densify_min_opacity=0.005, prune_big_point_after_iter=0, seed=0, factored_exchange=True):
+                 densify_min_opacity=0.005, prune_big_point_after_iter=0, seed=0, factored_exchange=True, fused_sh_adam=True):
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
         self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
         self.densify_, self.densify_min_opacity_ = densify, densify_min_opacity
@@ -116,6 +116,9 @@ class TrainStep:
         self.world_size_ = world_size
         # world_size > 1: ViewFactoredExchange (default) or the plain all-reduce of all five gradients
         self.factored_exchange_ = factored_exchange
+        # world_size == 1: the Adam step of the SH tensor runs inside the rasterizer's backward (its 192 B/Gaussian gradient
+        # row never reaches HBM); same arithmetic, same result as the separate pass
+        self.fused_sh_adam_ = fused_sh_adam
         self.ema_loss_for_log_ = 0.0
 
     def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
@@ -123,12 +126,17 @@ class TrainStep:
         self.iteration_ += 1
         it = self.iteration_
         g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
-        sh_view = None
+        sh_view = sh_adam = None
         if self.world_size_ > 1 and self.factored_exchange_:
             sh_view = torch.empty((g.xyz_.size(0), 3), dtype=torch.float32, device=g.xyz_.device)
+        rebuilds = self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and \
+            it % opt.densification_interval_ == 0    # this iteration densifies: the reference skips its optimizer step
+        if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
+                g.features_.size(1) == 16 and g.optimizer_ is not None:
+            sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP)
         rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
             viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-            sh_grad_view=sh_view)
+            sh_grad_view=sh_view, sh_adam=sh_adam)
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
         loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_)
         loss.backward()                                                  # :699

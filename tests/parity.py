@@ -46,7 +46,7 @@ def _features(cl, sh_coeffs):
 
 
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False):
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None):
     """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  factored: backward in the
     view-factored mode (dL_dcolor_view instead of dL_dsh, include/gsr.h)."""
     rp._LIB_OVERRIDE = lib_path
@@ -95,7 +95,9 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                                                   a["rotations"], 1.0, a["cov3D_precomp"], a["viewmatrix"],
                                                   a["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, a["sh"], sh_degree,
                                                   a["campos"], geom, R, binning, img,
-                                                  dL_dcolor_view=view)
+                                                  dL_dcolor_view=view, sh_adam=sh_adam)
+            if sh_adam is not None:
+                r.sh_after = a["sh"].cpu().numpy()
             names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
             r.grads = {n: t.cpu().numpy() for n, t in zip(names, g) if t is not None}
             if factored:
@@ -230,3 +232,43 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
         assert np.allclose(out, want, rtol=1e-5, atol=1e-6 * np.abs(want).max()), float(np.abs(out - want).max())
     assert rel_l1(out, want) < 2e-5, rel_l1(out, want)   # GPU: the two backward runs differ by the atomics' order
     return rel_l1(out, want)
+
+
+def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0):
+    """Optimizer-in-backward for the SH tensor (gsr_backward_args.sh_adam) against backward + gsr_adam_step: same
+    parameter and moments after the step (same arithmetic; rtol 1e-6 for the two translation units' contraction), every
+    other gradient unchanged."""
+    rng = np.random.default_rng(seed)
+    cam = cl.cameras[0]
+    dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
+    a = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix)
+    P, M = a.grads["dL_dsh"].shape[:2]
+    m0 = (0.01 * rng.standard_normal((P, M, 3))).astype(np.float32)
+    v0 = (1e-4 * rng.random((P, M, 3))).astype(np.float32)
+    hyper = dict(lr=0.0025, lr_tail=0.0025 / 20, beta1=0.9, beta2=0.999, eps=1e-15, step=step)
+    # reference: the separate Adam pass on the plain gradient
+    lib = capi.load(lib_path)
+    p_ref, m_ref, v_ref = _t(cl.get_features(), dev).clone(), _t(m0, dev).clone(), _t(v0, dev).clone()
+    g = _t(a.grads["dL_dsh"], dev)
+    capi.check(lib, lib.gsr_adam_step(p_ref.data_ptr(), g.data_ptr(), m_ref.data_ptr(), v_ref.data_ptr(), p_ref.numel(),
+                                      hyper["lr"], hyper["beta1"], hyper["beta2"], hyper["eps"], step, 3 * M, 3,
+                                      hyper["lr_tail"], None), "gsr_adam_step")
+    if dev.type != "cpu":
+        torch.cuda.synchronize()
+    m1, v1 = _t(m0, dev).clone(), _t(v0, dev).clone()   # (on the host _t aliases the numpy array)
+    b = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix, sh_adam=dict(exp_avg=m1, exp_avg_sq=v1, **hyper))
+    assert "dL_dsh" not in b.grads
+    for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        if dev.type == "cpu":
+            assert np.array_equal(a.grads[n], b.grads[n]), n
+        else:
+            assert rel_l1(b.grads[n], a.grads[n]) < 2e-5, n
+    tol = dict(rtol=1e-6, atol=1e-9) if dev.type == "cpu" else dict(rtol=2e-4, atol=1e-7)   # GPU: two backward runs
+    assert np.allclose(b.sh_after, p_ref.cpu().numpy(), **tol)
+    assert np.allclose(m1.cpu().numpy(), m_ref.cpu().numpy(), **tol)
+    assert np.allclose(v1.cpu().numpy(), v_ref.cpu().numpy(), **tol)
+    moved = np.abs(b.sh_after - cl.get_features()).max()
+    assert moved > 1e-5, moved   # the step did happen, for culled Gaussians too (their moments decay)
+    culled = a.radii <= 0
+    if culled.any():
+        assert np.allclose(m1.cpu().numpy()[culled], 0.9 * m0[culled], rtol=1e-6, atol=1e-12)

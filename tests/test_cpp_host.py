@@ -93,6 +93,20 @@ def run_trainer_checks(ops, dev, lib_path):
         losses_cpp.append(float(ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx,
                                                                 fovy, cam.H, cam.W, gt, mask)))
         ops.trainer_finish(h)
+    # ... and with the separate Adam pass on the SH tensor instead of the step fused into backward (the default)
+    h3 = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                            g.rotation_.detach(), 3, float(cl.extent), bg)
+    ops.trainer_set_options(h3, {"fused_sh_adam": 0.0})
+    for it in range(3):
+        ops.trainer_render_and_backward(h3, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy, cam.H, cam.W, gt,
+                                        mask)
+        assert ops.trainer_grads(h3)[1].numel() == 300 * 48 and ops.trainer_grads(h)[1].numel() == 0
+        ops.trainer_finish(h3)
+    for a, b in zip(ops.trainer_params(h3), ops.trainer_params(h)):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    for a, b in zip(ops.trainer_moments(h3), ops.trainer_moments(h)):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-12)
+    ops.trainer_destroy(h3)
     # the same three steps through the pieces of the data-parallel step with the view-factored exchange (a batch of one
     # view: the rebuilt SH gradient is this view's own), per-group Adam in the order bench.py uses
     h2 = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),

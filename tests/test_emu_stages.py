@@ -128,6 +128,10 @@ def test_view_factored_sh_gradient(emu_lib_path, degree, coeffs, n_views):
                                sh_coeffs=coeffs)
 
 
+def test_fused_sh_adam(emu_lib_path):
+    parity.check_fused_sh_adam(emu_lib_path, CPU, _scene(P=330, seed=23), np.array([0.1, 0.2, 0.3], np.float32))
+
+
 def test_empty_and_tiny_inputs(emu_lib_path, oracle):
     rp._LIB_OVERRIDE = emu_lib_path
     try:

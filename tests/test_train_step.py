@@ -70,6 +70,26 @@ def test_train_step_reduces_loss(emu):
     assert g.denom_.sum() > 0 and g.max_radii2D_.max() > 0
 
 
+def test_fused_sh_adam_step_equals_separate_pass(emu):
+    """The Adam step of the SH tensor inside the rasterizer's backward (default) == the separate gsr_adam_step pass."""
+    out = []
+    for fused in (True, False):
+        cl, g, kfs = _setup()
+        torch.manual_seed(0)
+        gt = torch.rand(3, 32, 48)
+        ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), fused_sh_adam=fused)
+        losses = [float(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))) for _ in range(4)]
+        out.append((losses, [p.detach().clone() for p in g.params()], g.optimizer_.moments(g.features_),
+                    g.optimizer_.state[id(g.features_)]["step"]))
+    (l1, p1, m1, s1), (l2, p2, m2, s2) = out
+    assert s1 == s2 == 4
+    assert np.allclose(l1, l2, rtol=1e-6)
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
+    for a, b in zip(m1, m2):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-12) and a.abs().sum() > 0
+
+
 WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
