@@ -197,8 +197,7 @@ def main():
                 stats = reduce_view_stats()
                 ops.trainer_finish_begin(handle)
                 centres, views = ex.gathered()
-                ops.trainer_features_grad_from_views(handle, centres, views)   # reads xyz: before ITS Adam
-                ops.trainer_adam_group(handle, FEATURES_GROUP)
+                ops.trainer_features_step_from_views(handle, centres, views)   # rebuild + Adam in one pass; reads xyz: before ITS Adam
                 for i in ex.order():
                     ex.wait(i)                # stream-side wait: the host keeps queueing
                     ops.trainer_adam_group(handle, i)

@@ -156,6 +156,12 @@ int gsr_backward(const gsr_backward_args* args, void* stream);
 int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                            const float* dL_dcolor_views, float scale, float* dL_dsh, void* stream);
 
+/* The same with the optimizer fused in (as gsr_backward_args.sh_adam): instead of writing dL_dsh, this step's Adam update with
+ * that batch-mean gradient is applied to shs [P,16,3] IN PLACE and to the two moment tensors.  16-byte aligned [P,16,3]
+ * tensors only (GSR_ERR_UNSUPPORTED otherwise).  Reads means3D: call it before the positions' own update. */
+int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                           const float* dL_dcolor_views, float scale, float* shs, const gsr_sh_adam* sh_adam, void* stream);
+
 /* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
  * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

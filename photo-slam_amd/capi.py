@@ -71,7 +71,7 @@ class ImageView(C.Structure):
 # every symbol include/gsr.h and include/gsr_stages.h declare
 EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
-    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
+    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
     "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
     "gsr_neighborhood_depth_pinhole", "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
@@ -98,6 +98,8 @@ def load(path=None):
     L.gsr_backward.argtypes = [C.POINTER(BackwardArgs), vp]
     L.gsr_sh_grad_from_views.restype = i32
     L.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, f32, vp, vp]
+    L.gsr_sh_adam_from_views.restype = i32
+    L.gsr_sh_adam_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, f32, vp, C.POINTER(ShAdam), vp]
     L.gsr_mark_visible.restype = i32
     L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.gsr_knn_mean_dist2.restype = i32

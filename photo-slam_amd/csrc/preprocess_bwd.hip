@@ -448,10 +448,12 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 // rank.  So the ranks exchange the 3 floats dRGB per view (all-gather) instead of reducing the 48-float rows, and
 // each rebuilds   dL_dsh[i][k][ch] = scale * sum_v basis_k(dir_v(i)) * dRGB_v[i][ch]   here: 12 n_views B read and
 // 192 B written per Gaussian, against 2 * 192 B sent per Gaussian by a ring all-reduce of the rows.
-template <int DEG>
+// ADAM: the rows do not leave as a gradient -- this step's Adam update of the SH tensor is applied from LDS
+// (gsr_sh_adam_from_views; wave_adam_rows, shrows.h).
+template <int DEG, bool ADAM>
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(4, 8)
 sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos,
-                          const float* __restrict__ views, float scale, float* __restrict__ dL_dsh)
+                          const float* __restrict__ views, float scale, float* __restrict__ dL_dsh, const RowAdam adam)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -505,7 +507,10 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 				row[i] = make_float4(o[0], o[1], o[2], o[3]);
 			}
 		}
-		wave_store_rows(reinterpret_cast<float4*>(dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+		if (ADAM)
+			wave_adam_rows(adam, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+		else
+			wave_store_rows(reinterpret_cast<float4*>(dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 	}
 }
 
@@ -547,20 +552,34 @@ sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float*
 }
 
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                              const float* views, float scale, float* dL_dsh, hipStream_t stream)
+                              const float* views, float scale, float* dL_dsh, const RowAdam* adam, hipStream_t stream)
 {
 	if (P == 0) return GSR_OK;
-	const bool rows_ok = (3 * M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0);
+	float* rows = adam ? adam->param : dL_dsh;
+	const bool rows_ok = (3 * M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+	if (adam && (!rows_ok || ((reinterpret_cast<uintptr_t>(adam->exp_avg) | reinterpret_cast<uintptr_t>(adam->exp_avg_sq)) & 15)))
+		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
 	if (rows_ok) {
 		const int g = div_up(P, SHB_THREADS);
+		const RowAdam ra = adam ? *adam : RowAdam{};
+#define GSR_SHV(DEG)                                                                                                          \
+	do {                                                                                                                      \
+		if (adam)                                                                                                             \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos, views,   \
+			           scale, dL_dsh, ra);                                                                                    \
+		else                                                                                                                  \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos, views,  \
+			           scale, dL_dsh, ra);                                                                                    \
+	} while (0)
 		if (D == 3)
-			GSR_LAUNCH(sh_grad_from_views_kernel<3>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+			GSR_SHV(3);
 		else if (D == 2)
-			GSR_LAUNCH(sh_grad_from_views_kernel<2>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+			GSR_SHV(2);
 		else if (D == 1)
-			GSR_LAUNCH(sh_grad_from_views_kernel<1>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+			GSR_SHV(1);
 		else
-			GSR_LAUNCH(sh_grad_from_views_kernel<0>, g, SHB_THREADS, stream, P, n_views, means3D, campos, views, scale, dL_dsh);
+			GSR_SHV(0);
+#undef GSR_SHV
 	} else {
 		GSR_LAUNCH(sh_grad_from_views_generic_kernel, div_up(P, 128), 128, stream, P, D, M, n_views, means3D, campos, views,
 		           scale, dL_dsh);

@@ -134,6 +134,9 @@ public:
 	bool factored_exchange_ = false;
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
+	// ... or rebuilds it and takes the Adam step of features_ in the same pass (gsr_sh_adam_from_views): the mean gradient
+	// never reaches HBM.  Replaces setFeaturesGradFromViews() + finishAdamGroup(1); same ordering constraint.
+	void stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	std::shared_ptr<GaussianModel> gaussians_;
 	torch::Tensor background_;
 	int iteration_ = 0;

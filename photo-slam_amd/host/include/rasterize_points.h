@@ -46,4 +46,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views,
                               const torch::Tensor& dL_dcolor_views, const int degree, const int M, const float scale);
 
+// gsr_sh_adam_from_views: the same rebuild with this step's Adam update of `sh` [P,16,3] applied in place (no gradient tensor)
+void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views, const torch::Tensor& dL_dcolor_views,
+                     const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam);
+
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);

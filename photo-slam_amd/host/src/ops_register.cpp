@@ -197,6 +197,10 @@ void trainer_features_grad_from_views(int64_t h, torch::Tensor campos_views, tor
 {
 	get(h)->setFeaturesGradFromViews(campos_views, views);
 }
+void trainer_features_step_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views)
+{
+	get(h)->stepFeaturesFromViews(campos_views, views);
+}
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
                                  int64_t M, double scale)
 {
@@ -248,6 +252,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
+	m.def("trainer_features_step_from_views", &trainer_features_step_from_views);
 	m.def("sh_grad_from_views", &sh_grad_from_views);
 	m.def("trainer_destroy", &trainer_destroy);
 }

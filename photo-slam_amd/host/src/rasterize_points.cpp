@@ -223,6 +223,30 @@ torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor&
 	return out;
 }
 
+void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views, const torch::Tensor& dL_dcolor_views,
+                     const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	if (dL_dcolor_views.dim() != 3 || dL_dcolor_views.size(1) != P || dL_dcolor_views.size(2) != 3 || campos_views.dim() != 2 ||
+	    campos_views.size(0) != dL_dcolor_views.size(0) || campos_views.size(1) != 3)
+		throw std::runtime_error("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)");
+	if (sh.dim() != 3 || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 || !sh_adam.exp_avg.defined() ||
+	    !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() || sh_adam.exp_avg.sizes() != sh.sizes() ||
+	    sh_adam.exp_avg_sq.sizes() != sh.sizes())
+		throw std::runtime_error("sh and its moments must be contiguous float32 (num_points, M, 3) tensors");
+	if (P == 0) return;
+	F32 m3(means3D), cam(campos_views), views(dL_dcolor_views);
+	gsr_sh_adam adam{};
+	adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
+	adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
+	adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
+	adam.beta1 = sh_adam.beta1; adam.beta2 = sh_adam.beta2; adam.eps = sh_adam.eps;
+	adam.step = sh_adam.step;
+	check(gsr_sh_adam_from_views(P, degree, static_cast<int>(sh.size(1)), static_cast<int>(dL_dcolor_views.size(0)), m3.ptr,
+	                             cam.ptr, views.ptr, scale, sh.data_ptr<float>(), &adam, current_stream(means3D)),
+	      "shAdamFromViews");
+}
+
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)
 {
 	const int P = static_cast<int>(means3D.size(0));

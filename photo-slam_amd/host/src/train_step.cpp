@@ -197,6 +197,29 @@ void TrainStep::setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tens
 	                    static_cast<int>(g->features_.size(1)), 1.0f / static_cast<float>(dL_dcolor_views.size(0)));
 }
 
+void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views)
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	if (iteration_ >= g->opt_.iterations_) return;
+	if (g->features_.size(1) != 16 || g->groups_.size() < 2) {   // other layouts: gradient tensor + separate pass
+		setFeaturesGradFromViews(campos_views, dL_dcolor_views);
+		finishAdamGroup(1);
+		return;
+	}
+	auto& grp = g->groups_[1];
+	grp.step++;
+	ShAdamStep a;
+	a.exp_avg = grp.exp_avg;
+	a.exp_avg_sq = grp.exp_avg_sq;
+	a.lr = grp.lr;
+	a.lr_tail = grp.lr_tail;
+	a.step = grp.step;
+	auto sh = g->features_.detach();
+	shAdamFromViews(g->xyz_.detach(), campos_views, dL_dcolor_views, g->active_sh_degree_,
+	                1.0f / static_cast<float>(dL_dcolor_views.size(0)), sh, a);
+}
+
 void TrainStep::finishAdamGroup(int group)
 {
 	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->optimizerStepGroup(group);

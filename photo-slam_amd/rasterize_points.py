@@ -203,6 +203,29 @@ def shGradFromViews(means3D, campos_views, dL_dcolor_views, degree, M, scale, ou
     return out
 
 
+def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, sh_adam):
+    """gsr_sh_adam_from_views (include/gsr.h): this step's Adam update of the [P,16,3] tensor `sh` IN PLACE with the batch-mean
+    gradient rebuilt from the gathered views; sh_adam as in RasterizeGaussiansBackwardCUDA."""
+    lib = _lib()
+    P, n_views = means3D.size(0), dL_dcolor_views.size(0)
+    if dL_dcolor_views.shape != (n_views, P, 3) or campos_views.shape != (n_views, 3):
+        raise RuntimeError("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)")
+    _check_device(lib, means3D, campos_views, dL_dcolor_views, sh)
+    for t in (sh, sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
+        if t.dim() != 3 or t.shape != sh.shape or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("sh and its moments must be contiguous float32 (num_points, M, 3) tensors")
+    if P != 0:
+        k1, p1 = _ptr(means3D)
+        k2, p2 = _ptr(campos_views.float())
+        k3, p3 = _ptr(dL_dcolor_views)
+        adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
+                           float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]), float(sh_adam["eps"]),
+                           int(sh_adam["step"]))
+        st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, p2, p3, float(scale),
+                                        C.c_void_p(sh.data_ptr()), C.byref(adam), _stream_ptr(means3D))
+        capi.check(lib, st, "shAdamFromViews")
+
+
 def markVisible(means3D, viewmatrix, projmatrix):
     lib = _lib()
     P = means3D.size(0)

@@ -85,6 +85,13 @@ class ViewFactoredExchange:
         centres, views = self.gathered()
         return rp.shGradFromViews(means3D.detach(), centres, views, degree, M, 1.0 / self.world_size_, out)
 
+    def sh_adam_step(self, means3D, degree, sh, sh_adam):
+        """The rebuild and the Adam step of the SH tensor in one pass (gsr_sh_adam_from_views): the mean gradient never
+        reaches HBM.  sh_adam: FusedAdam.begin_fused_step(FEATURES_GROUP)."""
+        from . import rasterize_points as rp
+        centres, views = self.gathered()
+        rp.shAdamFromViews(means3D.detach(), centres, views, degree, 1.0 / self.world_size_, sh.detach(), sh_adam)
+
     def order(self):
         """parameter indices of the all-reduced tensors in completion order"""
         return [self.indices_[j] for j in self.reduction_.order()]
@@ -189,8 +196,12 @@ class TrainStep:
                     if sh_view is not None:
                         # the SH gradient is rebuilt from the gathered views (reads xyz_: before ITS update) and applied
                         # while the all-reduces of the other four tensors are on the links
-                        g.features_.grad = reduction.sh_gradient(g.xyz_, g.active_sh_degree_, g.features_.size(1))
-                        g.optimizer_.step_group(FEATURES_GROUP)
+                        if g.features_.size(1) == 16:   # rebuild + Adam in one pass
+                            reduction.sh_adam_step(g.xyz_, g.active_sh_degree_, g.features_,
+                                                   g.optimizer_.begin_fused_step(FEATURES_GROUP))
+                        else:
+                            g.features_.grad = reduction.sh_gradient(g.xyz_, g.active_sh_degree_, g.features_.size(1))
+                            g.optimizer_.step_group(FEATURES_GROUP)
                     for i in reduction.order():
                         reduction.wait(i)
                         g.optimizer_.step_group(i)

@@ -231,6 +231,28 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
     if dev.type == "cpu":
         assert np.allclose(out, want, rtol=1e-5, atol=1e-6 * np.abs(want).max()), float(np.abs(out - want).max())
     assert rel_l1(out, want) < 2e-5, rel_l1(out, want)   # GPU: the two backward runs differ by the atomics' order
+    if M == 16:
+        # gsr_sh_adam_from_views: rebuild + Adam in one pass == gsr_adam_step on the rebuilt gradient (same views, same order)
+        lib = capi.load(lib_path)
+        P = cl.xyz.shape[0]
+        m0 = (0.01 * rng.standard_normal((P, M, 3))).astype(np.float32)
+        v0 = (1e-4 * rng.random((P, M, 3))).astype(np.float32)
+        hyper = dict(lr=0.0025, lr_tail=0.0025 / 20, beta1=0.9, beta2=0.999, eps=1e-15, step=2)
+        p_ref, m_ref, v_ref = _t(cl.get_features(), dev).clone(), _t(m0, dev).clone(), _t(v0, dev).clone()
+        g = _t(out, dev)
+        capi.check(lib, lib.gsr_adam_step(p_ref.data_ptr(), g.data_ptr(), m_ref.data_ptr(), v_ref.data_ptr(), p_ref.numel(),
+                                          hyper["lr"], hyper["beta1"], hyper["beta2"], hyper["eps"], hyper["step"], 3 * M, 3,
+                                          hyper["lr_tail"], None), "gsr_adam_step")
+        sh, m1, v1 = _t(cl.get_features(), dev).clone(), _t(m0, dev).clone(), _t(v0, dev).clone()
+        rp._LIB_OVERRIDE = lib_path
+        try:
+            rp.shAdamFromViews(_t(cl.xyz, dev), _t(np.stack([c.campos for c in cl.cameras]).astype(np.float32), dev),
+                               _t(np.stack(views), dev), sh_degree, 1.0 / n, sh, dict(exp_avg=m1, exp_avg_sq=v1, **hyper))
+        finally:
+            rp._LIB_OVERRIDE = None
+        for a_, b_ in ((sh, p_ref), (m1, m_ref), (v1, v_ref)):
+            assert np.allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-6, atol=1e-9)
+        assert np.abs(sh.cpu().numpy() - cl.get_features()).max() > 1e-5
     return rel_l1(out, want)
 
 

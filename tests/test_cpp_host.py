@@ -127,8 +127,12 @@ def run_trainer_checks(ops, dev, lib_path):
         assert vsum.shape == (2, 300) and vmax.shape == (300,)
         ops.trainer_apply_view_stats(h2, vsum, vmax)
         ops.trainer_finish_begin(h2)
-        ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
-        for i in (1, 4, 0, 3, 2):
+        if it == 1:   # the gradient tensor + the separate pass
+            ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
+            ops.trainer_adam_group(h2, 1)
+        else:         # rebuild + Adam in one pass (what bench.py does)
+            ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
+        for i in (4, 0, 3, 2):
             ops.trainer_adam_group(h2, i)
         ops.trainer_finish_end(h2)
     for a, b in zip(ops.trainer_params(h2), ops.trainer_params(h)):
