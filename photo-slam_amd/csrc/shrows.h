@@ -85,7 +85,10 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 	wave_fence();
 	const size_t base = (first_row + slot) * ROW_F4 + col;
 	const float ss_first = col == 0 ? a.step_size : a.step_size_tail;   // .x .y .z of vector 0 are features_dc
-#pragma unroll 2
+#ifndef GSR_ADAM_UNROLL
+#define GSR_ADAM_UNROLL 2
+#endif
+#pragma unroll GSR_ADAM_UNROLL
 	for (int k = 0; k < STAGE_ROWS / 4; k++) {
 		if (col < ROW_F4 && 4 * k + slot < nrows) {
 			const size_t i = base + (size_t)(4 * k * ROW_F4);

@@ -18,6 +18,10 @@ for k, d in out.items():
         d["valu_active_per_busy"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_BUSY_CYCLES"]
     if d.get("SQ_INSTS_VALU"):
         d["valu_cycles_per_inst"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_INSTS_VALU"]
+    if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU"):
+        d["kernel_cycles"] = d["GRBM_GUI_ACTIVE"] / 8.0     # the counter sums the 8 XCDs
+        # wave64 VALU instructions x 4 issue cycles / (1024 SIMDs x kernel cycles)
+        d["valu_issue_utilisation"] = d["SQ_INSTS_VALU"] * 4.0 / (1024 * d["kernel_cycles"])
 json.dump(out, open("gpurun_out/sq_counters.json", "w"), indent=1)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:8]:
     print(k, {c: f"{v:.3g}" for c, v in d.items()})
