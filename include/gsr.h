@@ -138,6 +138,12 @@ typedef struct gsr_backward_args {
 	 * gradient, as a dense optimizer does) -- the 192 B/Gaussian gradient row never round-trips through HBM.  Only for
 	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise); mutually exclusive with dL_dcolor_view. */
 	const gsr_sh_adam* sh_adam;
+	/* Extension (all three or none; NULL = the reference contract): the densification statistics of this view, updated by
+	 * the kernel that holds dL_dmean2D in registers instead of a separate pass (gsr_densify_stats, same arithmetic): for
+	 * radii > 0: stat_grad_accum += |dL_dmean2D.xy|, stat_denom += 1, stat_max_radii = max(., radii).  [P] floats each. */
+	float* stat_grad_accum;
+	float* stat_denom;
+	float* stat_max_radii;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.

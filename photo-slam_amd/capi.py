@@ -50,7 +50,8 @@ class BackwardArgs(C.Structure):
                 ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int),
-                ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam))]
+                ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam)),
+                ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p)]
 
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 

@@ -247,6 +247,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
 		return GSR_ERR_INVALID_ARG;
 	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view && !a->sh_adam) return GSR_ERR_INVALID_ARG;
+	if ((a->stat_grad_accum != nullptr) != (a->stat_denom != nullptr) || (a->stat_denom != nullptr) != (a->stat_max_radii != nullptr))
+		return GSR_ERR_INVALID_ARG;
 	if (a->sh_adam && (!a->shs || a->dL_dcolor_view || !a->sh_adam->exp_avg || !a->sh_adam->exp_avg_sq || a->sh_adam->step < 1))
 		return GSR_ERR_INVALID_ARG;
 	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
@@ -295,6 +297,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	pb.dL_dcolor_view = a->dL_dcolor_view;
+	pb.stat_accum = a->stat_grad_accum; pb.stat_denom = a->stat_denom; pb.stat_max_radii = a->stat_max_radii;
 	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
 	pb.adam_step_size = pb.adam_step_size_tail = pb.adam_b1 = pb.adam_b2 = pb.adam_eps = pb.adam_inv_sqrt_bc2 = 0.f;
 	if (a->sh_adam) {

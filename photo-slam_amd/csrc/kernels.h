@@ -85,6 +85,10 @@ struct PreprocessBwdParams {
 	float* dL_dscale;         // [P,3] nullable
 	float* dL_drot;           // [P,4] nullable
 	int raw_params;           // GSR_RAW_* mask: outputs are gradients of the raw parameters
+	// densification statistics of this view fused in (gsr_backward_args.stat_*): null = off
+	float* stat_accum;
+	float* stat_denom;
+	float* stat_max_radii;
 	// fused Adam step of the SH tensor (gsr_backward_args.sh_adam): dL_dsh never leaves the LDS rows; null exp_avg = off
 	float* adam_param;        // == shs, written
 	float* adam_exp_avg;

@@ -185,6 +185,12 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		p.dL_dopacity[idx] = g_opacity;
 		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
 	}
+	if (p.stat_accum && vis) {
+		// densify_stats_kernel (train_ops.hip; gaussian_mapper.cpp:714-719, gaussian_model.cpp:817-831) on the values at hand
+		p.stat_accum[idx] += sqrtf(ga0.w * ga0.w + ga1.x * ga1.x);
+		p.stat_denom[idx] += 1.0f;
+		p.stat_max_radii[idx] = fmaxf(p.stat_max_radii[idx], (float)p.radii[idx]);
+	}
 	float shx = 0.f, shy = 0.f, shz = 0.f;   // d(loss)/d(mean) through the view direction of the SH colour
 
 	// ------------------------------------------------------------------ SH backward, backward.cu:20-139

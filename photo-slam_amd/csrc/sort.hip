@@ -33,14 +33,20 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* to
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ block_sums,
-                   int n, int items_per_block)
+scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ staged,
+                   uint32_t* __restrict__ block_sums, int n, int items_per_block)
 {
 	__shared__ uint32_t s_wave[4];
 	const int base = blockIdx.x * items_per_block;
 	const int end = min(n, base + items_per_block);
 	uint32_t acc = 0;
-	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) acc += gather ? in[gather[i]] : in[i];
+	// a gathered input (in[gather[i]]: one 64-byte line per element, measured 10x the linear traffic) is staged in the output
+	// array here, so that the apply pass reads it linearly instead of gathering a second time
+	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) {
+		const uint32_t v = gather ? in[gather[i]] : in[i];
+		if (staged) staged[i] = v;
+		acc += v;
+	}
 	uint32_t tot;
 	block_excl_scan_256(acc, &tot, s_wave);
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
@@ -63,7 +69,7 @@ scan_spine_kernel(uint32_t* __restrict__ block_sums, int nblocks)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ out,
+scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint32_t* out,   // in may alias out (staged input)
                   const uint32_t* __restrict__ block_sums, int n, int items_per_block, int inclusive)
 {
 	__shared__ uint32_t s_wave[4];
@@ -86,10 +92,11 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 	if (n <= 0) return GSR_OK;
 	const int ipb = scan_items_per_block(n);
 	const int nb = div_up(n, ipb);
-	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, scratch, n, ipb);
+	uint32_t* staged = gather ? out : nullptr;
+	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, staged, scratch, n, ipb);
 	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
-	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, in, gather, out, (const uint32_t*)scratch, n, ipb,
-	           inclusive ? 1 : 0);
+	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, gather ? (const uint32_t*)out : in, (const uint32_t*)nullptr, out,
+	           (const uint32_t*)scratch, n, ipb, inclusive ? 1 : 0);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -31,6 +31,8 @@ class GaussianRasterizationSettings:
     # extension, optimizer-in-backward for the SH tensor: dict(exp_avg, exp_avg_sq, lr, lr_tail, beta1, beta2, eps, step) --
     # backward applies this Adam step to sh in place instead of returning its gradient (gsr_backward_args.sh_adam)
     sh_adam_: dict = None
+    # extension: (xyz_gradient_accum, denom, max_radii2D) -- backward adds this view's densification statistics itself
+    view_stats_: tuple = None
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -59,7 +61,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
          dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_, s.sh_adam_)
+            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_, s.sh_adam_, s.view_stats_)
         # order of src/gaussian_rasterizer.cpp:159-179
         def g(t, like):
             return t if like.numel() and t is not None else None

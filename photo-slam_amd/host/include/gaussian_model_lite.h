@@ -141,7 +141,11 @@ public:
 	torch::Tensor background_;
 	int iteration_ = 0;
 	torch::Tensor last_viewspace_, last_visibility_, last_radii_;
+	bool stats_in_backward_ = false;   // this iteration's statistics were added by the rasterizer's backward (view_stats)
 };
 
 // loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)
-torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim);
+// is_root: the caller promises to call backward() on this very value (upstream gradient exactly 1, as TrainStep does):
+// backward then hands the stored gradient on without the [3,H,W] multiply by one
+torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim,
+                              bool is_root = false);

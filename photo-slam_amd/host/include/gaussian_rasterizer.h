@@ -35,6 +35,8 @@ struct GaussianRasterizationSettings {
 	torch::Tensor sh_grad_view_;
 	// extension, optimizer-in-backward for the SH tensor (rasterize_points.h): set exp_avg to enable
 	ShAdamStep sh_adam_;
+	// extension: {xyz_gradient_accum, denom, max_radii2D} -- backward adds this view's densification statistics itself
+	std::vector<torch::Tensor> view_stats_;
 };
 
 class GaussianRasterizerFunction : public torch::autograd::Function<GaussianRasterizerFunction> {

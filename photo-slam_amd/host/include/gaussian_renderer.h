@@ -36,7 +36,8 @@ public:
 	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
 	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false,
 	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationSettings::sh_grad_view_ */,
-	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationSettings::sh_adam_ */)
+	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationSettings::sh_adam_ */,
+	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationSettings::view_stats_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -53,6 +54,7 @@ public:
 		raster_settings.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
 		if (!use_override_color) raster_settings.sh_grad_view_ = sh_grad_view;
 		if (!use_override_color) raster_settings.sh_adam_ = sh_adam;
+		raster_settings.view_stats_ = view_stats;
 		GaussianRasterizer rasterizer(raster_settings);
 
 		auto means3D = pc->getXYZ();

@@ -7,6 +7,7 @@
 #include <torch/torch.h>
 
 #include <tuple>
+#include <vector>
 
 // (num_rendered, out_color[3,H,W], radii[P] i32, geomBuffer u8, binningBuffer u8, imgBuffer u8)
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
@@ -39,7 +40,10 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                /* extension: a [P,3] float tensor that receives the clamp-masked colour gradient; dL_dsh is
                                   then NOT computed and comes back undefined (gsr_backward_args.dL_dcolor_view) */
                                const torch::Tensor& dL_dcolor_view = torch::Tensor(),
-                               const ShAdamStep& sh_adam = ShAdamStep());
+                               const ShAdamStep& sh_adam = ShAdamStep(),
+                               /* extension: {xyz_gradient_accum, denom, max_radii2D} (P floats each), updated in place with
+                                  this view's densification statistics (gsr_backward_args.stat_*); empty = off */
+                               const std::vector<torch::Tensor>& view_stats = {});
 
 // gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
 // [n_views,P,3] dL_dcolor_view tensors and the [n_views,3] camera centres; scale = 1/n_views for the batch mean

@@ -25,6 +25,7 @@ torch::autograd::tensor_list GaussianRasterizerFunction::forward(
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
 	ctx->saved_data["raw_params"] = s.raw_params_;
 	if (s.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = s.sh_grad_view_;
+	if (!s.view_stats_.empty()) ctx->saved_data["view_stats"] = s.view_stats_;
 	if (s.sh_adam_.exp_avg.defined()) {
 		ctx->saved_data["sh_adam_m"] = s.sh_adam_.exp_avg;
 		ctx->saved_data["sh_adam_v"] = s.sh_adam_.exp_avg_sq;
@@ -60,12 +61,14 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 		sh_adam.beta1 = static_cast<float>(h[2]); sh_adam.beta2 = static_cast<float>(h[3]);
 		sh_adam.eps = static_cast<float>(h[4]); sh_adam.step = static_cast<int>(h[5]);
 	}
+	std::vector<torch::Tensor> view_stats;
+	if (ctx->saved_data.count("view_stats")) view_stats = ctx->saved_data["view_stats"].toTensorVector();
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
 	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
 	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params,
-	                                        sh_grad_view, sh_adam);
+	                                        sh_grad_view, sh_adam, view_stats);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();

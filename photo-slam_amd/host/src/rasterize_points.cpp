@@ -120,7 +120,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
                                const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                               const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam)
+                               const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam,
+                               const std::vector<torch::Tensor>& view_stats)
 {
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = static_cast<int>(dL_dout_color.size(1));
@@ -187,6 +188,15 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
 		a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
 		a.dL_dsh = (has_sh && dL_dsh.defined()) ? dL_dsh.data_ptr<float>() : nullptr;
+		if (!view_stats.empty()) {
+			if (view_stats.size() != 3) throw std::runtime_error("view_stats: {xyz_gradient_accum, denom, max_radii2D}");
+			for (const auto& t : view_stats)
+				if (t.numel() != P || t.scalar_type() != torch::kFloat32 || !t.is_contiguous() || t.device() != means3D.device())
+					throw std::runtime_error("view_stats tensors must be contiguous float32 with num_points elements");
+			a.stat_grad_accum = view_stats[0].data_ptr<float>();
+			a.stat_denom = view_stats[1].data_ptr<float>();
+			a.stat_max_radii = view_stats[2].data_ptr<float>();
+		}
 		gsr_sh_adam adam{};
 		if (fused_adam) {
 			adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();

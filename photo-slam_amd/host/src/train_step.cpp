@@ -26,8 +26,9 @@ void check(int status, const char* where)
 class FusedL1SSIMFunction : public torch::autograd::Function<FusedL1SSIMFunction> {
 public:
 	static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor rendered, torch::Tensor gt,
-	                             torch::Tensor mask, double lambda_dssim)
+	                             torch::Tensor mask, double lambda_dssim, bool is_root)
 	{
+		ctx->saved_data["is_root"] = is_root;
 		auto r = rendered.contiguous(), g = gt.contiguous();
 		torch::Tensor m = mask.defined() && mask.numel() ? mask.contiguous() : torch::Tensor();
 		const int H = static_cast<int>(r.size(1)), W = static_cast<int>(r.size(2));
@@ -44,14 +45,15 @@ public:
 	static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list go)
 	{
 		auto grad = ctx->get_saved_variables()[0];
-		return {grad * go[0], torch::Tensor(), torch::Tensor(), torch::Tensor()};
+		if (ctx->saved_data["is_root"].toBool()) return {grad, torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+		return {grad * go[0], torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
 	}
 };
 }  // namespace
 
-torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim)
+torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim, bool is_root)
 {
-	return FusedL1SSIMFunction::apply(rendered, gt, mask, static_cast<double>(lambda_dssim));
+	return FusedL1SSIMFunction::apply(rendered, gt, mask, static_cast<double>(lambda_dssim), is_root);
 }
 
 GaussianModel::GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity,
@@ -169,13 +171,18 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_adam.lr_tail = grp.lr_tail;
 		sh_adam.step = grp.step;
 	}
+	// one rank: the densification statistics of this view (:714-719) are added by the backward kernel that holds
+	// dL_dmean2D in registers; with external_stats_ the driver reduces per-view increments instead (viewStats)
+	std::vector<torch::Tensor> view_stats;
+	stats_in_backward_ = !external_stats_ && iteration_ < o.densify_until_iter_;
+	if (stats_in_backward_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
-	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam);
+	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats);
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);
 	last_radii_ = std::get<3>(pkg);
-	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_);
+	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_, /*is_root=*/true);
 	loss.backward();
 	return loss;
 }
@@ -259,7 +266,7 @@ void TrainStep::finishBegin()
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
-	if (iteration_ < g->opt_.densify_until_iter_ && !external_stats_) {
+	if (iteration_ < g->opt_.densify_until_iter_ && !external_stats_ && !stats_in_backward_) {
 		// :714-719 in one pass (gsr_densify_stats) instead of boolean-mask gathers/scatters + a host sync
 		auto grad = last_viewspace_.grad().contiguous();
 		auto radii = last_radii_.contiguous();

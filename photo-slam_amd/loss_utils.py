@@ -62,7 +62,8 @@ from . import rasterize_points as _rp
 
 class _FusedL1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rendered, gt, mask, lambda_dssim):
+    def forward(ctx, rendered, gt, mask, lambda_dssim, is_root=False):
+        ctx.is_root = bool(is_root)
         lib = _rp._lib()
         _rp._check_device(lib, rendered, gt)
         r = rendered.contiguous().float()
@@ -83,8 +84,12 @@ class _FusedL1SSIM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
-        return grad * grad_out, None, None, None
+        if ctx.is_root:
+            return grad, None, None, None, None
+        return grad * grad_out, None, None, None, None
 
 
-def fused_l1_ssim_loss(rendered, gt, mask, lambda_dssim):
-    return _FusedL1SSIM.apply(rendered, gt, mask, lambda_dssim)
+def fused_l1_ssim_loss(rendered, gt, mask, lambda_dssim, is_root=False):
+    """is_root: the caller promises to call .backward() on this very value (upstream gradient exactly 1, as the train step
+    does): backward then hands the stored gradient on without the [3,H,W] multiply by one."""
+    return _FusedL1SSIM.apply(rendered, gt, mask, lambda_dssim, is_root)

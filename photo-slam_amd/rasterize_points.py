@@ -109,13 +109,16 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None, sh_adam=None):
+                                   geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None, sh_adam=None,
+                                   view_stats=None):
     """dL_dcolor_view (extension, default None = reference contract): a [P,3] float tensor that receives the clamp-masked
     colour gradient; dL_dsh is then NOT computed and None is returned in its place (view-factored gradient exchange,
     shGradFromViews below).
     sh_adam (extension, default None): dict(exp_avg, exp_avg_sq, lr, lr_tail, beta1, beta2, eps, step) -- this step's Adam
     update of `sh` is applied IN PLACE by the kernel that produces its gradient (gsr_backward_args.sh_adam); dL_dsh is then
-    not computed and None is returned in its place."""
+    not computed and None is returned in its place.
+    view_stats (extension, default None): (xyz_gradient_accum, denom, max_radii2D) float tensors with P elements, updated in
+    place with this view's densification statistics (gsr_backward_args.stat_*)."""
     lib = _lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -165,6 +168,11 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         if factored and not (has_sh and M):
             raise RuntimeError("dL_dcolor_view needs spherical harmonics")
         a.dL_dsh = dL_dsh.data_ptr() if has_sh and M and dL_dsh is not None else None
+        if view_stats is not None:
+            for t in view_stats:
+                if t.numel() != P or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                    raise RuntimeError("view_stats tensors must be contiguous float32 with num_points elements")
+            a.stat_grad_accum, a.stat_denom, a.stat_max_radii = (t.data_ptr() for t in view_stats)
         if sh_adam is not None:
             adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
                                float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]),

@@ -141,11 +141,14 @@ class TrainStep:
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
                 g.features_.size(1) == 16 and g.optimizer_ is not None:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP)
+        # one rank: this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D
+        view_stats = (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_) \
+            if self.world_size_ == 1 and it < opt.densify_until_iter_ else None
         rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
             viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-            sh_grad_view=sh_view, sh_adam=sh_adam)
+            sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats)
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
-        loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_)
+        loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_, is_root=True)
         loss.backward()                                                  # :699
         with torch.no_grad():
             reduction = None
@@ -159,7 +162,7 @@ class TrainStep:
                     reduction = GradientReduction([p.grad for p in g.params()], self.world_size_)
             if it < opt.densify_until_iter_:
                 if self.world_size_ == 1:
-                    g.addViewStats(viewspace_point_tensor, radii)                                   # :714-719, fused
+                    pass                                                         # :714-719 happened inside backward (view_stats)
                 else:
                     # per-view increments (norm BEFORE the sum over views, gaussian_model.cpp:821-826), then SUM / MAX
                     vis = visibility_filter

@@ -46,7 +46,7 @@ def _features(cl, sh_coeffs):
 
 
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None):
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None, view_stats=None):
     """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  factored: backward in the
     view-factored mode (dL_dcolor_view instead of dL_dsh, include/gsr.h)."""
     rp._LIB_OVERRIDE = lib_path
@@ -95,7 +95,7 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                                                   a["rotations"], 1.0, a["cov3D_precomp"], a["viewmatrix"],
                                                   a["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, a["sh"], sh_degree,
                                                   a["campos"], geom, R, binning, img,
-                                                  dL_dcolor_view=view, sh_adam=sh_adam)
+                                                  dL_dcolor_view=view, sh_adam=sh_adam, view_stats=view_stats)
             if sh_adam is not None:
                 r.sh_after = a["sh"].cpu().numpy()
             names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
@@ -294,3 +294,28 @@ def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0):
     culled = a.radii <= 0
     if culled.any():
         assert np.allclose(m1.cpu().numpy()[culled], 0.9 * m0[culled], rtol=1e-6, atol=1e-12)
+
+
+def check_fused_view_stats(lib_path, dev, cl, bg, seed=0):
+    """gsr_backward_args.stat_* (the densification statistics of the view added inside backward) == gsr_densify_stats on
+    the returned dL_dmean2D, starting from non-trivial accumulators."""
+    rng = np.random.default_rng(seed)
+    cam = cl.cameras[0]
+    P = cl.xyz.shape[0]
+    dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
+    acc0, den0 = rng.random(P).astype(np.float32), rng.integers(0, 5, P).astype(np.float32)
+    max0 = rng.integers(0, 12, P).astype(np.float32)
+    stats = [_t(a, dev).clone() for a in (acc0, den0, max0)]
+    r = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix, view_stats=stats)
+    lib = capi.load(lib_path)
+    ref = [_t(a, dev).clone() for a in (acc0, den0, max0)]
+    g2d, radii = _t(r.grads["dL_dmeans2D"], dev), _t(r.radii.astype(np.int32), dev)
+    capi.check(lib, lib.gsr_densify_stats(P, g2d.data_ptr(), radii.data_ptr(), ref[0].data_ptr(), ref[1].data_ptr(),
+                                          ref[2].data_ptr(), None), "gsr_densify_stats")
+    if dev.type != "cpu":
+        torch.cuda.synchronize()
+    vis = r.radii > 0
+    assert vis.any() and (~vis).any()
+    assert np.allclose(stats[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=1e-6, atol=0)
+    assert np.array_equal(stats[1].cpu().numpy(), ref[1].cpu().numpy()) and np.array_equal(stats[2].cpu().numpy(), ref[2].cpu().numpy())
+    assert np.array_equal(stats[1].cpu().numpy(), den0 + vis) and np.array_equal(stats[0].cpu().numpy()[~vis], acc0[~vis])

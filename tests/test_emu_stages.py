@@ -132,6 +132,10 @@ def test_fused_sh_adam(emu_lib_path):
     parity.check_fused_sh_adam(emu_lib_path, CPU, _scene(P=330, seed=23), np.array([0.1, 0.2, 0.3], np.float32))
 
 
+def test_fused_view_stats(emu_lib_path):
+    parity.check_fused_view_stats(emu_lib_path, CPU, _scene(P=330, seed=24), np.array([0.1, 0.2, 0.3], np.float32))
+
+
 def test_empty_and_tiny_inputs(emu_lib_path, oracle):
     rp._LIB_OVERRIDE = emu_lib_path
     try:

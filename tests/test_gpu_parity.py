@@ -80,6 +80,12 @@ def test_fused_sh_adam(dev):
 
 
 @pytest.mark.gpu
+def test_fused_view_stats(dev):
+    cl = scene.make_cloud(50000, 320, 240, 250.0, 250.0, seed=15, scale_k=0.15)
+    parity.check_fused_view_stats(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
+
+
+@pytest.mark.gpu
 def test_full_size_view_factored_exchange(dev):
     # the same property at BASELINE.json's size: 2 M Gaussians @1080p, a batch of two keyframes
     cl = scene.make_config("C3", seed=0, n_views=2)
