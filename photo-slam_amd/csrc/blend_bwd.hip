@@ -141,14 +141,18 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const v2f c01 = dprg * (v2f){dcol, dcol};
 					const v2f t = dxy * (v2f){wG, wG};          // sum w dx, sum w dy
 					const v2f m56 = dxy * (v2f){t[0], t[0]};    // sum w dx dx, sum w dx dy
+					// order of the nine sums in the LDS accumulators: 0 colour r, 1 w dx, 2 w dx dx, 3 colour b, 4 colour g, 5 w dy,
+					// 6 w dx dy, 7 w dy dy, 8 w -- chosen so that the halves of each packed product sit four apart: the
+					// butterfly's first level then adds (v0, v4) + (v1, v5) and (v2, v6) + (v3, v7) as register pairs
+					// without a move (wave_reduce9_swap_f32); the segment write-out below restores the slot order
 					float v[9];
 					v[0] = c01[0];
-					v[1] = c01[1];
-					v[2] = dcol * dpb;
-					v[3] = t[0];
-					v[4] = t[1];
-					v[5] = m56[0];
+					v[4] = c01[1];
+					v[1] = t[0];
+					v[5] = t[1];
+					v[2] = m56[0];
 					v[6] = m56[1];
+					v[3] = dcol * dpb;
 					v[7] = t[1] * dy;
 					v[8] = wG;
 					T = ok ? Tn : T;
@@ -175,8 +179,9 @@ blend_bwd_kernel(const BlendBwdParams p)
 			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries stay unflagged: the per-Gaussian sum skips them
 				p.touched[slot] = 1;
 				float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * 12);
-				dst[0] = make_float4(s_acc[0][i], s_acc[1][i], s_acc[2][i], s_acc[3][i]);
-				dst[1] = make_float4(s_acc[4][i], s_acc[5][i], s_acc[6][i], s_acc[7][i]);
+				// slot order (partials.h): colour r g b, w dx, w dy, w dx dx, w dx dy, w dy dy, w
+				dst[0] = make_float4(s_acc[0][i], s_acc[4][i], s_acc[3][i], s_acc[1][i]);
+				dst[1] = make_float4(s_acc[5][i], s_acc[2][i], s_acc[6][i], s_acc[7][i]);
 				reinterpret_cast<float*>(dst + 2)[0] = s_acc[8][i];
 			}
 		}

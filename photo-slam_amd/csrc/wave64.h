@@ -197,12 +197,41 @@ __device__ __forceinline__ float swap16_add(float a, float b)
 __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	constexpr int DPP_ROW_ROR8 = 0x128;
+	typedef float v2f __attribute__((vector_size(8)));
+#ifdef GSR_REDUCE_SCALAR_ADDS
 	const float p01 = swap32_add(v[0], v[1]);   // rows 0,1: v0 (row r + row r+2), rows 2,3: v1
 	const float p23 = swap32_add(v[2], v[3]);
 	const float p45 = swap32_add(v[4], v[5]);
 	const float p67 = swap32_add(v[6], v[7]);
 	const float q0 = swap16_add(p01, p23);      // rows: v0 v2 v1 v3 (each lane: its column over all four rows)
 	const float q1 = swap16_add(p45, p67);      // rows: v4 v6 v5 v7
+#else
+	// The adds of two swaps ride in one v_pk_add_f32, and the operands are paired so that no move is needed between the
+	// levels: (p01, p45) = (a0, c0) + (a1, c1), (p23, p67) likewise, then the 16-lane swaps act on (p01, p23) and (p45, p67)
+	// in place and one packed add finishes (q0, q1): 9 instructions instead of 12.  Every swap result passes an empty asm:
+	// building the vectors straight from the builtins' results makes this compiler drop two of the four swaps.
+	float a0 = v[0], a1 = v[1], b0 = v[2], b1 = v[3], c0 = v[4], c1 = v[5], d0 = v[6], d1 = v[7];
+#define GSR_SWAP(builtin, x, y)                                                                                          \
+	do {                                                                                                                 \
+		const auto r_ = builtin(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);         \
+		x = __builtin_bit_cast(float, (unsigned)r_[0]);                                                                  \
+		y = __builtin_bit_cast(float, (unsigned)r_[1]);                                                                  \
+		GSR_OPAQUE_F32(x);                                                                                               \
+		GSR_OPAQUE_F32(y);                                                                                               \
+	} while (0)
+	GSR_SWAP(__builtin_amdgcn_permlane32_swap, a0, a1);
+	GSR_SWAP(__builtin_amdgcn_permlane32_swap, c0, c1);
+	GSR_SWAP(__builtin_amdgcn_permlane32_swap, b0, b1);
+	GSR_SWAP(__builtin_amdgcn_permlane32_swap, d0, d1);
+	const v2f pa = (v2f){a0, c0} + (v2f){a1, c1};   // (p01, p45): rows 0,1: v0 (row r + row r+2), rows 2,3: v1
+	const v2f pb = (v2f){b0, d0} + (v2f){b1, d1};   // (p23, p67)
+	float p01 = pa[0], p45 = pa[1], p23 = pb[0], p67 = pb[1];
+	GSR_SWAP(__builtin_amdgcn_permlane16_swap, p01, p23);   // rows: v0 v2 v1 v3 (each lane: its column over all four rows)
+	GSR_SWAP(__builtin_amdgcn_permlane16_swap, p45, p67);   // rows: v4 v6 v5 v7
+#undef GSR_SWAP
+	const v2f qq = (v2f){p01, p45} + (v2f){p23, p67};
+	const float q0 = qq[0], q1 = qq[1];
+#endif
 	float r = q0 + dpp_f32<DPP_ROW_ROR8>(0.f, q0);
 	// lanes 8..15 of every row <- q1 + q1 rotated by 8 (one v_add_f32_dpp whose bank_mask leaves lanes 0..7 alone;
 	// the builtin form costs five instructions).  s_nop: a DPP source needs two wait states after its VALU write.
