@@ -316,7 +316,7 @@ def main():
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic_C3_raster_only.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic_C3_raster_only.json")
         # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, tools/gpu_pmc.sh), corrected as
         # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only.
         kernel_of = {"blend_bwd": "gsr::blend_bwd_kernel", "blend_fwd": "gsr::blend_fwd_kernel",
@@ -327,7 +327,7 @@ def main():
                 traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
         # the blend kernels are VALU-bound: their VALU issue utilisation from the SQ counters (tools/gpu_sq.sh, C3 only) rides along
         valu = None
-        sq_file = os.path.join(ROOT, "profiles", "r01_i_sq_counters_C3_raster_only.json")
+        sq_file = os.path.join(ROOT, "profiles", "r01_j_sq_counters_C3_raster_only.json")
         if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(sq_file):
             sq = json.load(open(sq_file)).get(kernel_of[dom])
             if sq and "valu_issue_utilisation" in sq:
