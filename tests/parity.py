@@ -256,14 +256,14 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
     return rel_l1(out, want)
 
 
-def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0):
+def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0, sh_degree=3):
     """Optimizer-in-backward for the SH tensor (gsr_backward_args.sh_adam) against backward + gsr_adam_step: same
     parameter and moments after the step (same arithmetic; rtol 1e-6 for the two translation units' contraction), every
     other gradient unchanged."""
     rng = np.random.default_rng(seed)
     cam = cl.cameras[0]
     dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
-    a = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix)
+    a = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix, sh_degree=sh_degree)
     P, M = a.grads["dL_dsh"].shape[:2]
     m0 = (0.01 * rng.standard_normal((P, M, 3))).astype(np.float32)
     v0 = (1e-4 * rng.random((P, M, 3))).astype(np.float32)
@@ -278,7 +278,8 @@ def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0):
     if dev.type != "cpu":
         torch.cuda.synchronize()
     m1, v1 = _t(m0, dev).clone(), _t(v0, dev).clone()   # (on the host _t aliases the numpy array)
-    b = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix, sh_adam=dict(exp_avg=m1, exp_avg_sq=v1, **hyper))
+    b = run_backend(lib_path, dev, cl, cam, bg, dL_dpix=dpix, sh_degree=sh_degree,
+                    sh_adam=dict(exp_avg=m1, exp_avg_sq=v1, **hyper))
     assert "dL_dsh" not in b.grads
     for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
         if dev.type == "cpu":

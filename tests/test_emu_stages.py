@@ -128,8 +128,10 @@ def test_view_factored_sh_gradient(emu_lib_path, degree, coeffs, n_views):
                                sh_coeffs=coeffs)
 
 
-def test_fused_sh_adam(emu_lib_path):
-    parity.check_fused_sh_adam(emu_lib_path, CPU, _scene(P=330, seed=23), np.array([0.1, 0.2, 0.3], np.float32))
+@pytest.mark.parametrize("degree", [3, 1])
+def test_fused_sh_adam(emu_lib_path, degree):
+    parity.check_fused_sh_adam(emu_lib_path, CPU, _scene(P=330, seed=23), np.array([0.1, 0.2, 0.3], np.float32),
+                               sh_degree=degree)
 
 
 def test_fused_view_stats(emu_lib_path):
