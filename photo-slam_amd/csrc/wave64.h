@@ -177,35 +177,17 @@ __device__ __forceinline__ void wave_reduce9_f32(float (&v)[9])
 // Nine full-wave sums, packed from the TOP of the butterfly.  gfx950's v_permlane32_swap / v_permlane16_swap
 // exchange half-waves / odd-even rows BETWEEN two registers, so one swap + one add folds two values
 // into one register (value a in the lower half / even rows, value b in the upper half / odd rows):
-//   level 32: 8 values -> 4 registers (8 ops), level 16: 4 -> 2 (4 ops),
+//   level 32: 8 values -> 4 registers (4 swaps + 2 packed adds), level 16: 4 -> 2 (2 swaps + 1 packed add),
 //   level 8 : 2 -> 1 with a DPP row_ror:8 whose bank_mask keeps one value per half row (3 ops),
 //   levels 4, 2, 1: half-mirror and quad_perm adds on ONE register (3 ops);
 // the ninth value is only summed inside each row of 16 (4 DPP adds; the caller merges the four row sums, e.g.
-// with the LDS atomic it issues anyway): 22 VALU for nine sums (72 unpacked; 38 for a butterfly packed from the
-// bottom with quad_perm selects, the previous version).  Result: every lane of the 8-lane group g = lane >> 3 holds in `packed` the total of
+// with the LDS atomic it issues anyway): 19 VALU for nine sums (72 unpacked; 38 for a butterfly packed from the
+// bottom with quad_perm selects, an earlier version).  Result: every lane of the 8-lane group g = lane >> 3 holds in `packed` the total of
 // value bitrev3(g) = {0,4,2,6,1,5,3,7}[g]; `ninth_row` holds the sum of v[8] over the lane's row of 16.
-__device__ __forceinline__ float swap32_add(float a, float b)
-{
-	const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ float swap16_add(float a, float b)
-{
-	const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-	return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
 __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float& packed, float& ninth_row)
 {
 	constexpr int DPP_ROW_ROR8 = 0x128;
 	typedef float v2f __attribute__((vector_size(8)));
-#ifdef GSR_REDUCE_SCALAR_ADDS
-	const float p01 = swap32_add(v[0], v[1]);   // rows 0,1: v0 (row r + row r+2), rows 2,3: v1
-	const float p23 = swap32_add(v[2], v[3]);
-	const float p45 = swap32_add(v[4], v[5]);
-	const float p67 = swap32_add(v[6], v[7]);
-	const float q0 = swap16_add(p01, p23);      // rows: v0 v2 v1 v3 (each lane: its column over all four rows)
-	const float q1 = swap16_add(p45, p67);      // rows: v4 v6 v5 v7
-#else
 	// The adds of two swaps ride in one v_pk_add_f32, and the operands are paired so that no move is needed between the
 	// levels: (p01, p45) = (a0, c0) + (a1, c1), (p23, p67) likewise, then the 16-lane swaps act on (p01, p23) and (p45, p67)
 	// in place and one packed add finishes (q0, q1): 9 instructions instead of 12.  Every swap result passes an empty asm:
@@ -231,7 +213,6 @@ __device__ __forceinline__ void wave_reduce9_swap_f32(const float (&v)[9], float
 #undef GSR_SWAP
 	const v2f qq = (v2f){p01, p45} + (v2f){p23, p67};
 	const float q0 = qq[0], q1 = qq[1];
-#endif
 	float r = q0 + dpp_f32<DPP_ROW_ROR8>(0.f, q0);
 	// lanes 8..15 of every row <- q1 + q1 rotated by 8 (one v_add_f32_dpp whose bank_mask leaves lanes 0..7 alone;
 	// the builtin form costs five instructions).  s_nop: a DPP source needs two wait states after its VALU write.
