@@ -246,7 +246,7 @@ def run_map_maintenance_checks(ops, dev, lib_path):
 def run_densify_schedule_checks(ops, dev, lib_path):
     """TrainStep's densification schedule (gaussian_mapper.cpp:711-735) in C++ == the Python trainer over 7 iterations
     with densification every 2nd and an opacity reset at the 6th."""
-    cl, t = _scene(dev, P=400)
+    cl, t = _scene(dev, P=250)
     cam = cl.cameras[0]
     torch.manual_seed(0)
     gt = torch.rand(3, cam.H, cam.W).to(dev)
