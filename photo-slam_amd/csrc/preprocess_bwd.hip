@@ -32,7 +32,10 @@ constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per work
 // gradient rows are not produced -- the clamp-masked colour gradient leaves instead (12 B instead of 192 B per Gaussian)
 // and gsr_sh_grad_from_views rebuilds dL_dsh for the whole keyframe batch after the exchange.
 template <int DEG, int MODE>   // MODE: 0 = gradient rows out, 1 = factored (colour gradient out), 2 = fused Adam step
-__global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(6, 8)   // 80 VGPRs (3 dwords of scratch at degree 3)
+#ifndef GSR_SHB_WAVES_LO
+#define GSR_SHB_WAVES_LO 6
+#endif
+__global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(GSR_SHB_WAVES_LO, 8)   // 80 VGPRs (3 dwords of scratch at degree 3)
 sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
