@@ -148,7 +148,6 @@ def main():
         import math
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
         if dp:
-            ops.trainer_set_external_stats(handle, True)   # the per-view statistics are reduced over the ranks below
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
@@ -172,18 +171,6 @@ def main():
         loss_ready[k].record()
         loss_state["n"] += 1
 
-    def reduce_view_stats():
-        # densification statistics of the batch (gaussian_model.cpp:817-831 per view): SUM of the gradient norms and the
-        # visibility counts, MAX of the radii -- queued behind the gradient collectives, needed only at the end of the step
-        s, m = ops.trainer_view_stats(handle)
-        return s, m, dist.all_reduce(s, op=dist.ReduceOp.SUM, async_op=True), dist.all_reduce(m, op=dist.ReduceOp.MAX, async_op=True)
-
-    def apply_view_stats(stats):
-        s, m, ws, wm = stats
-        ws.wait()
-        wm.wait()
-        ops.trainer_apply_view_stats(handle, s, m)
-
     def one_step():
         if ops is not None:
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
@@ -194,25 +181,21 @@ def main():
                 grads = ops.trainer_grads(handle)
                 ex = ViewFactoredExchange(ops.trainer_sh_grad_view(handle), kf.camera_center_,
                                           [(i, t) for i, t in enumerate(grads) if i != FEATURES_GROUP], world)
-                stats = reduce_view_stats()
                 ops.trainer_finish_begin(handle)
                 centres, views = ex.gathered()
                 ops.trainer_features_step_from_views(handle, centres, views)   # rebuild + Adam in one pass; reads xyz: before ITS Adam
                 for i in ex.order():
                     ex.wait(i)                # stream-side wait: the host keeps queueing
                     ops.trainer_adam_group(handle, i)
-                apply_view_stats(stats)
                 ops.trainer_finish_end(handle)
             elif dp:
                 # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
                 # SH update overlaps the small reductions still on the links
                 red = GradientReduction(ops.trainer_grads(handle), world)
-                stats = reduce_view_stats()
                 ops.trainer_finish_begin(handle)
                 for i in red.order():
                     red.wait(i)               # stream-side wait: the host keeps queueing
                     ops.trainer_adam_group(handle, i)
-                apply_view_stats(stats)
                 ops.trainer_finish_end(handle)
             else:
                 ops.trainer_finish(handle)    # statistics + Adam
@@ -306,8 +289,8 @@ def main():
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": "single GPU" if not dp else
                                       (f"dp{world} (one keyframe per GPU; all-gather of 3 + all-reduce of 11 floats/Gaussian, "
-                                       "SH gradient rebuilt per rank; + 3 floats of densification statistics)") if factored else
-                                      f"dp{world} (one keyframe per GPU, all-reduce of 59 + 3 floats/Gaussian)",
+                                       "SH gradient rebuilt per rank; densification statistics accumulate per rank)") if factored else
+                                      f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "sh_adam_fused_into_backward": fused_sh_adam,
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else P,

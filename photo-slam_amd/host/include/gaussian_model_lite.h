@@ -101,13 +101,10 @@ public:
 	void finishBegin();
 	void finishAdamGroup(int group);
 	void finishEnd();
-	// Densification statistics of a keyframe batch: with external_stats_ set, finishBegin() leaves the statistics alone and
-	// the driver reduces the per-view increments over the ranks -- viewStats() = {[2,P]: |dL_dmean2D.xy| and 1 for the
-	// Gaussians visible in this view (to be SUMmed), [P]: their radii (to be MAXed)}, zeros elsewhere (the norm is taken
-	// BEFORE the sum over views, gaussian_model.cpp:821-826) -- and hands the totals to applyViewStats() before finishBegin().
-	bool external_stats_ = false;
-	std::vector<torch::Tensor> viewStats();
-	void applyViewStats(torch::Tensor sum, torch::Tensor max);
+	// Keyframe batches over several ranks: every rank accumulates the statistics of ITS views (they are added inside
+	// backward); SUM / MAX commute with that accumulation, so the driver reduces xyz_gradient_accum_ and denom_ (SUM) and
+	// max_radii2D_ (MAX) over the ranks only before a finishBegin() that will densify -- densifyDue() says when.
+	bool densifyDue() const;
 	torch::Tensor trainForOneIteration(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
 	{
 		auto loss = renderAndBackward(kf, gt_image, mask);

@@ -186,9 +186,7 @@ std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five g
 	return out;
 }
 
-void trainer_set_external_stats(int64_t h, bool on) { get(h)->external_stats_ = on; }
-std::vector<torch::Tensor> trainer_view_stats(int64_t h) { return get(h)->viewStats(); }
-void trainer_apply_view_stats(int64_t h, torch::Tensor sum, torch::Tensor max) { get(h)->applyViewStats(sum, max); }
+bool trainer_densify_due(int64_t h) { return get(h)->densifyDue(); }
 
 // view-factored exchange of the data-parallel step (bench.py --gpus N, trainer.ViewFactoredExchange)
 void trainer_set_factored_exchange(int64_t h, bool on) { get(h)->factored_exchange_ = on; }
@@ -246,9 +244,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_prune_points", &trainer_prune_points);
 	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
 	m.def("trainer_moments", &trainer_moments);
-	m.def("trainer_set_external_stats", &trainer_set_external_stats);
-	m.def("trainer_view_stats", &trainer_view_stats);
-	m.def("trainer_apply_view_stats", &trainer_apply_view_stats);
+	m.def("trainer_densify_due", &trainer_densify_due);
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);

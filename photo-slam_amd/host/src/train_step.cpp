@@ -159,8 +159,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_grad_view_ = torch::Tensor();
 	ShAdamStep sh_adam;
 	const auto& o = g->opt_;
-	const bool rebuilds = densify_ && iteration_ < o.densify_until_iter_ && iteration_ > o.densify_from_iter_ &&
-	                      o.densification_interval_ && iteration_ % o.densification_interval_ == 0;
+	const bool rebuilds = densifyDue();
 	if (fused_sh_adam_ && !factored_exchange_ && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
 	    g->features_.size(1) == 16) {
 		auto& grp = g->groups_[1];
@@ -171,10 +170,10 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_adam.lr_tail = grp.lr_tail;
 		sh_adam.step = grp.step;
 	}
-	// one rank: the densification statistics of this view (:714-719) are added by the backward kernel that holds
-	// dL_dmean2D in registers; with external_stats_ the driver reduces per-view increments instead (viewStats)
+	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
+	// registers
 	std::vector<torch::Tensor> view_stats;
-	stats_in_backward_ = !external_stats_ && iteration_ < o.densify_until_iter_;
+	stats_in_backward_ = iteration_ < o.densify_until_iter_;
 	if (stats_in_backward_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
 	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats);
@@ -237,36 +236,18 @@ void TrainStep::finishEnd()
 	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->zeroGrad();
 }
 
-std::vector<torch::Tensor> TrainStep::viewStats()
+bool TrainStep::densifyDue() const
 {
-	torch::NoGradGuard ng;
-	auto& g = gaussians_;
-	const auto P = g->xyz_.size(0);
-	auto o = g->xyz_.options().requires_grad(false);
-	auto sum = torch::zeros({2, P}, o), max = torch::zeros({P}, o);
-	auto grad = last_viewspace_.grad().contiguous();
-	auto radii = last_radii_.contiguous();
-	check(gsr_densify_stats(static_cast<int>(P), grad.data_ptr<float>(), radii.data_ptr<int>(), sum.data_ptr<float>(),
-	                        sum.data_ptr<float>() + P, max.data_ptr<float>(), stream_of(grad)),
-	      "gsr_densify_stats");
-	return {sum, max};
-}
-
-void TrainStep::applyViewStats(torch::Tensor sum, torch::Tensor max)
-{
-	torch::NoGradGuard ng;
-	auto& g = gaussians_;
-	if (iteration_ >= g->opt_.densify_until_iter_) return;
-	g->xyz_gradient_accum_.add_(sum.select(0, 0).unsqueeze(1));
-	g->denom_.add_(sum.select(0, 1).unsqueeze(1));
-	g->max_radii2D_ = torch::max(g->max_radii2D_, max);
+	const auto& o = gaussians_->opt_;
+	return densify_ && iteration_ < o.densify_until_iter_ && iteration_ > o.densify_from_iter_ && o.densification_interval_ &&
+	       iteration_ % o.densification_interval_ == 0;
 }
 
 void TrainStep::finishBegin()
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
-	if (iteration_ < g->opt_.densify_until_iter_ && !external_stats_ && !stats_in_backward_) {
+	if (iteration_ < g->opt_.densify_until_iter_ && !stats_in_backward_) {
 		// :714-719 in one pass (gsr_densify_stats) instead of boolean-mask gathers/scatters + a host sync
 		auto grad = last_viewspace_.grad().contiguous();
 		auto radii = last_radii_.contiguous();
@@ -277,7 +258,7 @@ void TrainStep::finishBegin()
 	}
 	if (iteration_ < g->opt_.densify_until_iter_ && densify_) {
 		const auto& o = g->opt_;
-		if (iteration_ > o.densify_from_iter_ && o.densification_interval_ && iteration_ % o.densification_interval_ == 0) {
+		if (densifyDue()) {
 			const int size_threshold = (prune_big_point_after_iter_ > 0 && iteration_ > prune_big_point_after_iter_) ? 20 : 0;
 			g->zeroGrad();   // shapes change; this step's update is skipped
 			last_densify_ = g->densifyAndPrune(o.densify_grad_threshold_, densify_min_opacity_, cameras_extent_, size_threshold,

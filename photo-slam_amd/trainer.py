@@ -141,9 +141,10 @@ class TrainStep:
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
                 g.features_.size(1) == 16 and g.optimizer_ is not None:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP)
-        # one rank: this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D
-        view_stats = (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_) \
-            if self.world_size_ == 1 and it < opt.densify_until_iter_ else None
+        # this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D.  With
+        # several ranks they accumulate PER RANK and are reduced only when densification consumes them (below): SUM and MAX
+        # commute with the accumulation over iterations, so nothing crosses the links for them on the other 99 of 100 steps
+        view_stats = (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_) if it < opt.densify_until_iter_ else None
         rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
             viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
             sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats)
@@ -161,27 +162,17 @@ class TrainStep:
                 else:
                     reduction = GradientReduction([p.grad for p in g.params()], self.world_size_)
             if it < opt.densify_until_iter_:
-                if self.world_size_ == 1:
-                    pass                                                         # :714-719 happened inside backward (view_stats)
-                else:
-                    # per-view increments (norm BEFORE the sum over views, gaussian_model.cpp:821-826), then SUM / MAX
-                    vis = visibility_filter
-                    gn = torch.zeros_like(g.xyz_gradient_accum_)
-                    gn[vis] = torch.norm(viewspace_point_tensor.grad[vis][:, :2], dim=-1, keepdim=True)
-                    cnt = vis.float().unsqueeze(1)
-                    rad = torch.where(vis, radii.float(), torch.zeros_like(g.max_radii2D_))
-                    dist.all_reduce(gn, op=dist.ReduceOp.SUM)
-                    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-                    dist.all_reduce(rad, op=dist.ReduceOp.MAX)
-                    g.xyz_gradient_accum_ += gn
-                    g.denom_ += cnt
-                    g.max_radii2D_ = torch.max(g.max_radii2D_, rad)
                 if self.densify_:
                     if reduction is not None and (it % opt.densification_interval_ == 0 or
                                                   (opt.opacity_reset_interval_ and it % opt.opacity_reset_interval_ == 0)):
                         reduction.wait_all()   # the tensors are about to be rebuilt
                         reduction = None
                     if it > opt.densify_from_iter_ and it % opt.densification_interval_ == 0:       # :721-730
+                        if self.world_size_ > 1:
+                            # the batch's statistics since the last densification: norm sums and counts SUM, radii MAX
+                            dist.all_reduce(g.xyz_gradient_accum_, op=dist.ReduceOp.SUM)
+                            dist.all_reduce(g.denom_, op=dist.ReduceOp.SUM)
+                            dist.all_reduce(g.max_radii2D_, op=dist.ReduceOp.MAX)
                         size_threshold = 20 if it > self.prune_big_point_after_iter_ > 0 else 0
                         g.optimizer_.zero_grad(set_to_none=True)   # shapes change; this step's update is skipped
                         self.last_densify_ = g.densifyAndPrune(opt.densify_grad_threshold_, self.densify_min_opacity_,

@@ -114,7 +114,6 @@ def run_trainer_checks(ops, dev, lib_path):
     h2 = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
                             g.rotation_.detach(), 3, float(cl.extent), bg)
     ops.trainer_set_factored_exchange(h2, True)
-    ops.trainer_set_external_stats(h2, True)   # statistics through the per-view increments a driver reduces over the ranks
     for it in range(3):
         l2 = float(ops.trainer_render_and_backward(h2, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy,
                                                    cam.H, cam.W, gt, mask))
@@ -123,9 +122,7 @@ def run_trainer_checks(ops, dev, lib_path):
         assert grads[1].numel() == 0 and all(grads[i].numel() for i in (0, 2, 3, 4))
         view = ops.trainer_sh_grad_view(h2)
         assert view.shape == (300, 3)
-        vsum, vmax = ops.trainer_view_stats(h2)
-        assert vsum.shape == (2, 300) and vmax.shape == (300,)
-        ops.trainer_apply_view_stats(h2, vsum, vmax)
+        assert not ops.trainer_densify_due(h2)
         ops.trainer_finish_begin(h2)
         if it == 1:   # the gradient tensor + the separate pass
             ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))

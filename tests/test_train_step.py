@@ -103,12 +103,16 @@ rp._LIB_OVERRIDE = sys.argv[2]
 dist.init_process_group("gloo")
 rank, ws = dist.get_rank(), dist.get_world_size()
 cl = scene.make_cloud(300, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=ws)
-g = GaussianModel.from_cloud(cl, device="cpu"); g.trainingSetup(GaussianOptimizationParams())
+opt = GaussianOptimizationParams()
+densify = len(sys.argv) > 5 and sys.argv[5] == "densify"
+if densify:
+    opt.densify_from_iter_, opt.densification_interval_, opt.densify_grad_threshold_ = 1, 2, 2e-5
+g = GaussianModel.from_cloud(cl, device="cpu"); g.trainingSetup(opt)
 kf = GaussianKeyframe.from_camera(cl.cameras[rank], "cpu")
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
-ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3), world_size=ws,
-               factored_exchange=sys.argv[4] == "factored")
-for _ in range(2): ts.trainForOneIteration(kf, gt, torch.ones(3, 32, 48))
+ts = TrainStep(g, opt, GaussianPipelineParams(), torch.zeros(3), world_size=ws,
+               factored_exchange=sys.argv[4] == "factored", densify=densify, cameras_extent=float(cl.extent), seed=7)
+for _ in range(3 if densify else 2): ts.trainForOneIteration(kf, gt, torch.ones(3, 32, 48))
 out = {n: p.detach().numpy() for n, p in zip(["xyz","features","opacity","scaling","rotation"], g.params())}
 out["accum"] = g.xyz_gradient_accum_.numpy(); out["denom"] = g.denom_.numpy(); out["maxr"] = g.max_radii2D_.numpy()
 np.savez(os.path.join(sys.argv[3], f"rank{rank}.npz"), **out)
@@ -128,7 +132,7 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
                            str(tmp_path), exchange],
                           env=env, timeout=600)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in r0.files:
+    for k in ("xyz", "features", "opacity", "scaling", "rotation"):
         assert np.array_equal(r0[k], r1[k]), f"replicas diverged on {k}"
     # single-process reference: mean gradient of the two views, same Adam
     cl, g, kfs = _setup(n_views=2)
@@ -165,8 +169,62 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
     names = ["xyz", "features", "opacity", "scaling", "rotation"]
     for n, p in zip(names, g.params()):
         assert np.allclose(r0[n], p.detach().numpy(), rtol=1e-5, atol=1e-7), n
-    assert np.allclose(r0["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
-    assert np.array_equal(r0["denom"], g.denom_.numpy()) and np.array_equal(r0["maxr"], g.max_radii2D_.numpy())
+    # the statistics accumulate per rank (reduced only when densification consumes them): their SUM / MAX is the batch's
+    assert np.allclose(r0["accum"] + r1["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
+    assert np.array_equal(r0["denom"] + r1["denom"], g.denom_.numpy())
+    assert np.array_equal(np.maximum(r0["maxr"], r1["maxr"]), g.max_radii2D_.numpy())
+    assert not np.array_equal(r0["denom"], r1["denom"])
+
+
+def test_keyframe_batch_densification_gloo(emu, tmp_path):
+    """Two ranks that densify at the second iteration: the per-rank statistics are reduced right before, every rank takes the
+    same decisions with the same samples, and the replicas (new size, Adam moments carried) stay bit-identical; the cloned /
+    split / pruned counts equal a single process that saw both views."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER + """
+np.savez(os.path.join(sys.argv[3], f"densify{rank}.npz"), info=np.array([ts.last_densify_[k] for k in ("cloned", "split", "pruned", "points")]))
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29515", str(script), ROOT, emu, str(tmp_path),
+                           "factored", "densify"], env=env, timeout=600)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("xyz", "features", "opacity", "scaling", "rotation"):
+        assert r0[k].shape == r1[k].shape and np.array_equal(r0[k], r1[k]), f"replicas diverged on {k}"
+    d0, d1 = np.load(tmp_path / "densify0.npz")["info"], np.load(tmp_path / "densify1.npz")["info"]
+    assert np.array_equal(d0, d1) and d0[0] + d0[1] > 0 and d0[3] == r0["xyz"].shape[0] != 300
+    # a single process with both views: same statistics at the second iteration, same densification decisions
+    cl, g, kfs = _setup(n_views=2)
+    opt = GaussianOptimizationParams()
+    opt.densify_from_iter_, opt.densification_interval_, opt.densify_grad_threshold_ = 1, 2, 2e-5
+    g.trainingSetup(opt)
+    mask = torch.ones(3, 32, 48)
+    gts = []
+    for rank in range(2):
+        torch.manual_seed(100 + rank)
+        gts.append(torch.rand(3, 32, 48))
+    from photo_slam_amd import loss_utils
+    gen = torch.Generator().manual_seed(7)
+    for it in range(1, 3):
+        g.updateLearningRate(it)
+        grads = None
+        for kf, gt in zip(kfs, gts):
+            img, vsp, vis, radii = GaussianRenderer.render(kf, 32, 48, g, GaussianPipelineParams(), torch.zeros(3),
+                                                           view_stats=(g.xyz_gradient_accum_, g.denom_, g.max_radii2D_))
+            loss_utils.fused_l1_ssim_loss(img, gt, mask, 0.2).backward()
+            cur = [p.grad.clone() for p in g.params()]
+            for p in g.params():
+                p.grad = None
+            grads = cur if grads is None else [a + b for a, b in zip(grads, cur)]
+        with torch.no_grad():
+            if it == 2:
+                info = g.densifyAndPrune(opt.densify_grad_threshold_, 0.005, float(cl.extent), 0, generator=gen)
+                assert [info[k] for k in ("cloned", "split", "pruned", "points")] == list(d0)
+            else:
+                for p, gr in zip(g.params(), grads):
+                    p.grad = gr * 0.5
+                g.optimizer_.step()
+                g.optimizer_.zero_grad(set_to_none=True)
 
 
 def test_densify_and_prune_keeps_model_consistent(emu):
