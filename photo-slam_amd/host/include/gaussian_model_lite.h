@@ -138,7 +138,6 @@ public:
 	torch::Tensor background_;
 	int iteration_ = 0;
 	torch::Tensor last_viewspace_, last_visibility_, last_radii_;
-	bool stats_in_backward_ = false;   // this iteration's statistics were added by the rasterizer's backward (view_stats)
 };
 
 // loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)

@@ -173,8 +173,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
 	// registers
 	std::vector<torch::Tensor> view_stats;
-	stats_in_backward_ = iteration_ < o.densify_until_iter_;
-	if (stats_in_backward_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
+	if (iteration_ < o.densify_until_iter_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
 	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats);
 	auto rendered = std::get<0>(pkg);
@@ -247,15 +246,7 @@ void TrainStep::finishBegin()
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
-	if (iteration_ < g->opt_.densify_until_iter_ && !stats_in_backward_) {
-		// :714-719 in one pass (gsr_densify_stats) instead of boolean-mask gathers/scatters + a host sync
-		auto grad = last_viewspace_.grad().contiguous();
-		auto radii = last_radii_.contiguous();
-		check(gsr_densify_stats(static_cast<int>(g->xyz_.size(0)), grad.data_ptr<float>(), radii.data_ptr<int>(),
-		                        g->xyz_gradient_accum_.data_ptr<float>(), g->denom_.data_ptr<float>(),
-		                        g->max_radii2D_.data_ptr<float>(), stream_of(grad)),
-		      "gsr_densify_stats");
-	}
+	// (the statistics of :714-719 were added inside backward: view_stats)
 	if (iteration_ < g->opt_.densify_until_iter_ && densify_) {
 		const auto& o = g->opt_;
 		if (densifyDue()) {
