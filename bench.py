@@ -179,7 +179,7 @@ def main():
                 # view-factored exchange (trainer.ViewFactoredExchange): the colour gradients are gathered, the other four
                 # tensors reduced; the SH gradient is rebuilt from the views and applied while the reductions are on the links
                 grads = ops.trainer_grads(handle)
-                ex = ViewFactoredExchange(ops.trainer_sh_grad_view(handle), kf.camera_center_,
+                ex = ViewFactoredExchange(ops.trainer_sh_send_buffer(handle), kf.camera_center_,
                                           [(i, t) for i, t in enumerate(grads) if i != FEATURES_GROUP], world)
                 ops.trainer_finish_begin(handle)
                 centres, views = ex.gathered()
@@ -288,7 +288,7 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
                        "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": "single GPU" if not dp else
-                                      (f"dp{world} (one keyframe per GPU; all-gather of 3 + all-reduce of 11 floats/Gaussian, "
+                                      (f"dp{world} (one keyframe per GPU; one all-gather of 3 + one all-reduce of 11 floats/Gaussian, "
                                        "SH gradient rebuilt per rank; densification statistics accumulate per rank)") if factored else
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,

@@ -156,17 +156,21 @@ int gsr_backward(const gsr_backward_args* args, void* stream);
 /* The SH gradient of a keyframe batch from its per-view colour gradients (no counterpart in the reference, which trains
  * on one view per step):   dL_dsh[i][k][ch] = scale * sum_v basis_k(normalize(means3D[i] - campos[v])) * views[v][i][ch]
  * for k < (D+1)^2 and 0 for (D+1)^2 <= k < M; basis_k as computeColorFromSH (forward.cu:20-71).  views is
- * [n_views,P,3] (the dL_dcolor_view outputs of gsr_backward, gathered), campos [n_views,3] on the device; scale is
- * 1/n_views for the batch mean.  With one process per GPU this replaces the all-reduce of the [P,M,3] gradient
+ * [n_views,P,3] (the dL_dcolor_view outputs of gsr_backward, gathered), campos [n_views,3] on the device; view_stride /
+ * campos_stride = floats between consecutive views / centres (0 = dense: 3 P and 3), so that both may live in ONE gathered
+ * buffer of [n_views, P + 1, 3] whose last row per view is the camera centre (a single all-gather); scale is 1/n_views
+ * for the batch mean.  With one process per GPU this replaces the all-reduce of the [P,M,3] gradient
  * (2 x 192 B sent per Gaussian on a ring) by an all-gather of 12 B per Gaussian and view. */
 int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                           const float* dL_dcolor_views, float scale, float* dL_dsh, void* stream);
+                           long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
+                           float* dL_dsh, void* stream);
 
 /* The same with the optimizer fused in (as gsr_backward_args.sh_adam): instead of writing dL_dsh, this step's Adam update with
  * that batch-mean gradient is applied to shs [P,16,3] IN PLACE and to the two moment tensors.  16-byte aligned [P,16,3]
  * tensors only (GSR_ERR_UNSUPPORTED otherwise).  Reads means3D: call it before the positions' own update. */
 int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                           const float* dL_dcolor_views, float scale, float* shs, const gsr_sh_adam* sh_adam, void* stream);
+                           long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
+                           float* shs, const gsr_sh_adam* sh_adam, void* stream);
 
 /* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
  * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */

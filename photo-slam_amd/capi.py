@@ -98,9 +98,9 @@ def load(path=None):
     L.gsr_backward.restype = i32
     L.gsr_backward.argtypes = [C.POINTER(BackwardArgs), vp]
     L.gsr_sh_grad_from_views.restype = i32
-    L.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, f32, vp, vp]
+    L.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.c_longlong, f32, vp, vp]
     L.gsr_sh_adam_from_views.restype = i32
-    L.gsr_sh_adam_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, f32, vp, C.POINTER(ShAdam), vp]
+    L.gsr_sh_adam_from_views.argtypes = [i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.c_longlong, f32, vp, C.POINTER(ShAdam), vp]
     L.gsr_mark_visible.restype = i32
     L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.gsr_knn_mean_dist2.restype = i32

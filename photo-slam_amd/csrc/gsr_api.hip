@@ -316,26 +316,31 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 }
 
 int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                           const float* dL_dcolor_views, float scale, float* dL_dsh, void* stream_)
+                           long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
+                           float* dL_dsh, void* stream_)
 {
-	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1)) return GSR_ERR_INVALID_ARG;
+	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || campos_stride < 0 || view_stride < 0)
+		return GSR_ERR_INVALID_ARG;
 	if (P == 0) return GSR_OK;
 	if (!means3D || !campos || !dL_dcolor_views || !dL_dsh) return GSR_ERR_INVALID_ARG;
-	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, dL_dcolor_views, scale, dL_dsh, nullptr,
-	                                 (hipStream_t)stream_);
+	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
+	                                 dL_dsh, nullptr, (hipStream_t)stream_);
 }
 
 int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                           const float* dL_dcolor_views, float scale, float* shs, const gsr_sh_adam* o, void* stream_)
+                           long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
+                           float* shs, const gsr_sh_adam* o, void* stream_)
 {
-	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1)) return GSR_ERR_INVALID_ARG;
+	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || campos_stride < 0 || view_stride < 0)
+		return GSR_ERR_INVALID_ARG;
 	if (P == 0) return GSR_OK;
 	if (!means3D || !campos || !dL_dcolor_views || !shs || !o || !o->exp_avg || !o->exp_avg_sq || o->step < 1)
 		return GSR_ERR_INVALID_ARG;
 	const double bc1 = 1.0 - pow((double)o->beta1, o->step), bc2 = 1.0 - pow((double)o->beta2, o->step);
 	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, (float)(o->lr / bc1), (float)(o->lr_tail / bc1), o->beta1, o->beta2,
 	                    o->eps, (float)(1.0 / sqrt(bc2))};
-	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, dL_dcolor_views, scale, nullptr, &ra, (hipStream_t)stream_);
+	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
+	                                 nullptr, &ra, (hipStream_t)stream_);
 }
 
 int gsr_profile_enable(int on)

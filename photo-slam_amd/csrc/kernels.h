@@ -99,7 +99,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
 struct RowAdam;   // shrows.h: Adam state + scalars of the fused row update (null = write the gradient rows)
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                              const float* dL_dcolor_views, float scale, float* dL_dsh, const RowAdam* adam, hipStream_t stream);
+                              long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
+                              float* dL_dsh, const RowAdam* adam, hipStream_t stream);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

@@ -462,7 +462,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 template <int DEG, bool ADAM>
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(4, 8)
 sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos,
-                          const float* __restrict__ views, float scale, float* __restrict__ dL_dsh, const RowAdam adam)
+                          long long campos_stride, const float* __restrict__ views, long long view_stride, float scale,
+                          float* __restrict__ dL_dsh, const RowAdam adam)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -483,12 +484,13 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 	for (int v = 0; v < n_views; v++) {
 		float r = 0.f, g = 0.f, b = 0.f;
 		if (in_range) {
-			const float* c = views + ((size_t)v * P + idx) * 3;
+			const float* c = views + (size_t)v * (size_t)view_stride + (size_t)idx * 3;
 			r = c[0]; g = c[1]; b = c[2];
 		}
 		// culled in this view (or every channel clamped): nothing to add, and most Gaussians are outside most views
 		if (r != 0.f || g != 0.f || b != 0.f) {
-			const float ox = mx - campos[3 * v], oy = my - campos[3 * v + 1], oz = mz - campos[3 * v + 2];
+			const float* cp = campos + (size_t)v * (size_t)campos_stride;
+			const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
 			const float len = sqrtf(ox * ox + oy * oy + oz * oz);   // forward.cu:27-28
 			const ShDir d = sh_dir(ox / len, oy / len, oz / len);
 #pragma unroll
@@ -526,7 +528,8 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 // any other row length / alignment: one thread per Gaussian, scalar stores
 __global__ void __launch_bounds__(128)
 sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float* __restrict__ means3D,
-                                  const float* __restrict__ campos, const float* __restrict__ views, float scale,
+                                  const float* __restrict__ campos, long long campos_stride,
+                                  const float* __restrict__ views, long long view_stride, float scale,
                                   float* __restrict__ dL_dsh)
 {
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -537,10 +540,11 @@ sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float*
 	for (int j = 0; j < 48; j++) acc[j] = 0.f;
 	const float mx = means3D[3 * (size_t)idx], my = means3D[3 * (size_t)idx + 1], mz = means3D[3 * (size_t)idx + 2];
 	for (int v = 0; v < n_views; v++) {
-		const float* c = views + ((size_t)v * P + idx) * 3;
+		const float* c = views + (size_t)v * (size_t)view_stride + (size_t)idx * 3;
 		const float r = c[0], g = c[1], b = c[2];
 		if (r == 0.f && g == 0.f && b == 0.f) continue;
-		const float ox = mx - campos[3 * v], oy = my - campos[3 * v + 1], oz = mz - campos[3 * v + 2];
+		const float* cp = campos + (size_t)v * (size_t)campos_stride;
+			const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
 		const float len = sqrtf(ox * ox + oy * oy + oz * oz);
 		const ShDir d = sh_dir(ox / len, oy / len, oz / len);
 #pragma unroll
@@ -561,9 +565,12 @@ sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float*
 }
 
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
-                              const float* views, float scale, float* dL_dsh, const RowAdam* adam, hipStream_t stream)
+                              long long campos_stride, const float* views, long long view_stride, float scale, float* dL_dsh,
+                              const RowAdam* adam, hipStream_t stream)
 {
 	if (P == 0) return GSR_OK;
+	if (campos_stride == 0) campos_stride = 3;
+	if (view_stride == 0) view_stride = 3ll * P;
 	float* rows = adam ? adam->param : dL_dsh;
 	const bool rows_ok = (3 * M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
 	if (adam && (!rows_ok || ((reinterpret_cast<uintptr_t>(adam->exp_avg) | reinterpret_cast<uintptr_t>(adam->exp_avg_sq)) & 15)))
@@ -574,11 +581,11 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 #define GSR_SHV(DEG)                                                                                                          \
 	do {                                                                                                                      \
 		if (adam)                                                                                                             \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos, views,   \
-			           scale, dL_dsh, ra);                                                                                    \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos,          \
+			           campos_stride, views, view_stride, scale, dL_dsh, ra);                                                                                    \
 		else                                                                                                                  \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos, views,  \
-			           scale, dL_dsh, ra);                                                                                    \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,         \
+			           campos_stride, views, view_stride, scale, dL_dsh, ra);                                                                                    \
 	} while (0)
 		if (D == 3)
 			GSR_SHV(3);
@@ -590,8 +597,8 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 			GSR_SHV(0);
 #undef GSR_SHV
 	} else {
-		GSR_LAUNCH(sh_grad_from_views_generic_kernel, div_up(P, 128), 128, stream, P, D, M, n_views, means3D, campos, views,
-		           scale, dL_dsh);
+		GSR_LAUNCH(sh_grad_from_views_generic_kernel, div_up(P, 128), 128, stream, P, D, M, n_views, means3D, campos,
+		           campos_stride, views, view_stride, scale, dL_dsh);
 	}
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;

@@ -129,6 +129,7 @@ public:
 	// densifies (the reference skips that optimizer step) nor with the factored exchange.
 	bool fused_sh_adam_ = true;
 	bool factored_exchange_ = false;
+	torch::Tensor sh_send_;        // [P + 1, 3]: rows 0 .. P-1 = sh_grad_view_, row P = this view's camera centre (one all-gather)
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	// ... or rebuilds it and takes the Adam step of features_ in the same pass (gsr_sh_adam_from_views): the mean gradient

@@ -191,6 +191,7 @@ bool trainer_densify_due(int64_t h) { return get(h)->densifyDue(); }
 // view-factored exchange of the data-parallel step (bench.py --gpus N, trainer.ViewFactoredExchange)
 void trainer_set_factored_exchange(int64_t h, bool on) { get(h)->factored_exchange_ = on; }
 torch::Tensor trainer_sh_grad_view(int64_t h) { return get(h)->sh_grad_view_; }
+torch::Tensor trainer_sh_send_buffer(int64_t h) { return get(h)->sh_send_; }
 void trainer_features_grad_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views)
 {
 	get(h)->setFeaturesGradFromViews(campos_views, views);
@@ -247,6 +248,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_densify_due", &trainer_densify_due);
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
+	m.def("trainer_sh_send_buffer", &trainer_sh_send_buffer);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
 	m.def("trainer_features_step_from_views", &trainer_features_step_from_views);
 	m.def("sh_grad_from_views", &sh_grad_from_views);

@@ -131,10 +131,20 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	const bool has_sh = M != 0, has_scales = scales.defined() && scales.numel() != 0;
 	// the reference zero-fills all nine (src/rasterize_points.cu:149-157); gsr_backward writes every
 	// element of every output it is given, so only the outputs it is NOT given need zeros
-	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o);
+	// the gradients of the four small parameter tensors are slices of ONE buffer (rotation first: its float4 stores need
+	// the 16-byte alignment), so that a data-parallel driver reduces them over the ranks with a single collective; the
+	// buffer itself is not kept: autograd adopts a gradient only if nothing else references it
+	torch::Tensor dL_drotations, dL_dmeans3D, dL_dscales, dL_dopacity;
+	{
+		const int64_t n = P;
+		torch::Tensor flat = torch::empty({11 * n}, o);
+		dL_drotations = flat.narrow(0, 0, 4 * n).view({n, 4});
+		dL_dmeans3D = flat.narrow(0, 4 * n, 3 * n).view({n, 3});
+		dL_dscales = flat.narrow(0, 7 * n, 3 * n).view({n, 3});
+		dL_dopacity = flat.narrow(0, 10 * n, n).view({n, 1});
+	}
 	torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
-	torch::Tensor dL_dopacity = torch::empty({P, 1}, o);
 	torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
 	const bool factored = dL_dcolor_view.defined();
 	if (factored && (!has_sh || dL_dcolor_view.dim() != 2 || dL_dcolor_view.size(0) != P || dL_dcolor_view.size(1) != 3 ||
@@ -148,8 +158,10 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		throw std::runtime_error("sh_adam needs contiguous float32 sh and moments of one shape, step >= 1, and no dL_dcolor_view");
 	torch::Tensor dL_dsh;
 	if (!factored && !fused_adam) dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
-	torch::Tensor dL_dscales = has_scales ? torch::empty({P, 3}, o) : torch::zeros({P, 3}, o);
-	torch::Tensor dL_drotations = has_scales ? torch::empty({P, 4}, o) : torch::zeros({P, 4}, o);
+	if (!has_scales) {
+		dL_dscales.zero_();
+		dL_drotations.zero_();
+	}
 
 	if (P != 0) {
 		F32 bg(background), m3(means3D), col(colors), sc(scales), rot(rotations), cov(cov3D_precomp), view(viewmatrix),
@@ -216,17 +228,45 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	                       dL_drotations);
 }
 
+namespace {
+// the gathered views / centres: dim 0 may be strided (both may be slices of one gathered [n_views, P + 1, 3] buffer -- no
+// copy is made of them), the inner dimensions must be dense
+struct ViewsArgs {
+	const float* campos;
+	const float* views;
+	long long campos_stride, view_stride;
+	int n_views;
+};
+ViewsArgs views_args(const torch::Tensor& means3D, const torch::Tensor& campos_views, const torch::Tensor& dL_dcolor_views)
+{
+	const int64_t P = means3D.size(0);
+	if (dL_dcolor_views.dim() != 3 || dL_dcolor_views.size(1) != P || dL_dcolor_views.size(2) != 3 || campos_views.dim() != 2 ||
+	    campos_views.size(0) != dL_dcolor_views.size(0) || campos_views.size(1) != 3)
+		throw std::runtime_error("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)");
+	if (dL_dcolor_views.scalar_type() != torch::kFloat32 || campos_views.scalar_type() != torch::kFloat32 ||
+	    dL_dcolor_views.device() != means3D.device() || campos_views.device() != means3D.device())
+		throw std::runtime_error("dL_dcolor_views and campos_views must be float32 tensors on the device of means3D");
+	if ((P && (dL_dcolor_views.stride(1) != 3 || dL_dcolor_views.stride(2) != 1)) || campos_views.stride(1) != 1)
+		throw std::runtime_error("dL_dcolor_views / campos_views: only the view dimension may be strided");
+	ViewsArgs a;
+	a.n_views = static_cast<int>(dL_dcolor_views.size(0));
+	a.campos = campos_views.data_ptr<float>();
+	a.views = dL_dcolor_views.data_ptr<float>();
+	a.campos_stride = a.n_views > 1 ? campos_views.stride(0) : 3;
+	a.view_stride = a.n_views > 1 ? dL_dcolor_views.stride(0) : 3 * P;
+	return a;
+}
+}  // namespace
+
 torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views,
                               const torch::Tensor& dL_dcolor_views, const int degree, const int M, const float scale)
 {
 	const int P = static_cast<int>(means3D.size(0));
-	if (dL_dcolor_views.dim() != 3 || dL_dcolor_views.size(1) != P || dL_dcolor_views.size(2) != 3 || campos_views.dim() != 2 ||
-	    campos_views.size(0) != dL_dcolor_views.size(0) || campos_views.size(1) != 3)
-		throw std::runtime_error("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)");
+	const ViewsArgs va = views_args(means3D, campos_views, dL_dcolor_views);
 	torch::Tensor out = torch::empty({P, M, 3}, means3D.options().dtype(torch::kFloat32));
 	if (P != 0) {
-		F32 m3(means3D), cam(campos_views), views(dL_dcolor_views);
-		check(gsr_sh_grad_from_views(P, degree, M, static_cast<int>(dL_dcolor_views.size(0)), m3.ptr, cam.ptr, views.ptr,
+		F32 m3(means3D);
+		check(gsr_sh_grad_from_views(P, degree, M, va.n_views, m3.ptr, va.campos, va.campos_stride, va.views, va.view_stride,
 		                             scale, out.data_ptr<float>(), current_stream(means3D)),
 		      "shGradFromViews");
 	}
@@ -237,23 +277,21 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
                      const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam)
 {
 	const int P = static_cast<int>(means3D.size(0));
-	if (dL_dcolor_views.dim() != 3 || dL_dcolor_views.size(1) != P || dL_dcolor_views.size(2) != 3 || campos_views.dim() != 2 ||
-	    campos_views.size(0) != dL_dcolor_views.size(0) || campos_views.size(1) != 3)
-		throw std::runtime_error("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)");
+	const ViewsArgs va = views_args(means3D, campos_views, dL_dcolor_views);
 	if (sh.dim() != 3 || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 || !sh_adam.exp_avg.defined() ||
 	    !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() || sh_adam.exp_avg.sizes() != sh.sizes() ||
 	    sh_adam.exp_avg_sq.sizes() != sh.sizes())
 		throw std::runtime_error("sh and its moments must be contiguous float32 (num_points, M, 3) tensors");
 	if (P == 0) return;
-	F32 m3(means3D), cam(campos_views), views(dL_dcolor_views);
+	F32 m3(means3D);
 	gsr_sh_adam adam{};
 	adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
 	adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
 	adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
 	adam.beta1 = sh_adam.beta1; adam.beta2 = sh_adam.beta2; adam.eps = sh_adam.eps;
 	adam.step = sh_adam.step;
-	check(gsr_sh_adam_from_views(P, degree, static_cast<int>(sh.size(1)), static_cast<int>(dL_dcolor_views.size(0)), m3.ptr,
-	                             cam.ptr, views.ptr, scale, sh.data_ptr<float>(), &adam, current_stream(means3D)),
+	check(gsr_sh_adam_from_views(P, degree, static_cast<int>(sh.size(1)), va.n_views, m3.ptr, va.campos, va.campos_stride,
+	                             va.views, va.view_stride, scale, sh.data_ptr<float>(), &adam, current_stream(means3D)),
 	      "shAdamFromViews");
 }
 

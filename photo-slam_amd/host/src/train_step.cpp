@@ -153,10 +153,15 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	g->updateLearningRate(iteration_);
 	GaussianPipelineParams pipe;
 	torch::Tensor override_color;
-	if (factored_exchange_)
-		sh_grad_view_ = torch::empty({g->xyz_.size(0), 3}, g->xyz_.options().requires_grad(false));
-	else
+	if (factored_exchange_) {
+		const auto P = g->xyz_.size(0);
+		sh_send_ = torch::empty({P + 1, 3}, g->xyz_.options().requires_grad(false));
+		sh_grad_view_ = sh_send_.narrow(0, 0, P);
+		sh_send_.select(0, P).copy_(kf->camera_center_.detach().reshape({3}));
+	} else {
+		sh_send_ = torch::Tensor();
 		sh_grad_view_ = torch::Tensor();
+	}
 	ShAdamStep sh_adam;
 	const auto& o = g->opt_;
 	const bool rebuilds = densifyDue();

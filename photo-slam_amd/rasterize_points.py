@@ -126,11 +126,17 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     dev = means3D.device
     opts = dict(dtype=torch.float32, device=dev)
     # torch::zeros in the reference (rasterize_points.cu:149-157); gsr_backward writes every element itself
-    dL_dmeans3D = torch.empty((P, 3), **opts)
+    # the gradients of the four small parameter tensors are slices of ONE buffer (rotation first: its float4 stores need the
+    # 16-byte alignment): a data-parallel trainer reduces them over the ranks with a single collective (trainer.py)
+    flat = torch.empty((11 * P,), **opts)
+    dL_drotations = flat[0:4 * P].view(P, 4)
+    dL_dmeans3D = flat[4 * P:7 * P].view(P, 3)
+    dL_dscales = flat[7 * P:10 * P].view(P, 3)
+    dL_dopacity = flat[10 * P:11 * P].view(P, 1)
+    del flat   # (autograd adopts a gradient only if nothing else references it)
     dL_dmeans2D = torch.empty((P, 3), **opts)
     dL_dcolors = torch.empty((P, 3), **opts)
     dL_dconic = torch.empty((P, 2, 2), **opts)
-    dL_dopacity = torch.empty((P, 1), **opts)
     dL_dcov3D = torch.empty((P, 6), **opts)
     factored = dL_dcolor_view is not None
     if sh_adam is not None:
@@ -145,8 +151,6 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
                      not dL_dcolor_view.is_contiguous() or dL_dcolor_view.device != dev):
         raise RuntimeError("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D")
     dL_dsh = None if factored or sh_adam is not None else torch.empty((P, M, 3), **opts)
-    dL_dscales = torch.empty((P, 3), **opts)
-    dL_drotations = torch.empty((P, 4), **opts)
     if P != 0:
         keep = []
         a = capi.BackwardArgs()
@@ -191,21 +195,32 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
+def _views_args(means3D, campos_views, dL_dcolor_views):
+    """pointers + strides (in floats) of the gathered views / centres: dim 0 may be strided (both may be slices of one
+    gathered [n_views, P + 1, 3] buffer), the inner dimensions must be dense"""
+    P, n_views = means3D.size(0), dL_dcolor_views.size(0)
+    if dL_dcolor_views.shape != (n_views, P, 3) or campos_views.shape != (n_views, 3):
+        raise RuntimeError("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)")
+    if dL_dcolor_views.dtype != torch.float32 or campos_views.dtype != torch.float32:
+        raise RuntimeError("dL_dcolor_views and campos_views must be float32")
+    if (P and dL_dcolor_views.stride()[1:] != (3, 1)) or campos_views.stride(1) != 1:
+        raise RuntimeError("dL_dcolor_views / campos_views: only the view dimension may be strided")
+    return (C.c_void_p(campos_views.data_ptr()), int(campos_views.stride(0)) if n_views > 1 else 3,
+            C.c_void_p(dL_dcolor_views.data_ptr()), int(dL_dcolor_views.stride(0)) if n_views > 1 else 3 * P)
+
+
 def shGradFromViews(means3D, campos_views, dL_dcolor_views, degree, M, scale, out=None):
     """gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
     [n_views,P,3] dL_dcolor_view outputs and the [n_views,3] camera centres; scale = 1/n_views for the batch mean."""
     lib = _lib()
     P, n_views = means3D.size(0), dL_dcolor_views.size(0)
-    if dL_dcolor_views.shape != (n_views, P, 3) or campos_views.shape != (n_views, 3):
-        raise RuntimeError("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)")
+    pc, sc, pv, sv = _views_args(means3D, campos_views, dL_dcolor_views)
     _check_device(lib, means3D, campos_views, dL_dcolor_views)
     if out is None:
         out = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
     if P != 0:
         k1, p1 = _ptr(means3D)
-        k2, p2 = _ptr(campos_views.float())
-        k3, p3 = _ptr(dL_dcolor_views)
-        st = lib.gsr_sh_grad_from_views(P, int(degree), int(M), n_views, p1, p2, p3, float(scale),
+        st = lib.gsr_sh_grad_from_views(P, int(degree), int(M), n_views, p1, pc, sc, pv, sv, float(scale),
                                         C.c_void_p(out.data_ptr()), _stream_ptr(means3D))
         capi.check(lib, st, "shGradFromViews")
     return out
@@ -216,20 +231,17 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
     gradient rebuilt from the gathered views; sh_adam as in RasterizeGaussiansBackwardCUDA."""
     lib = _lib()
     P, n_views = means3D.size(0), dL_dcolor_views.size(0)
-    if dL_dcolor_views.shape != (n_views, P, 3) or campos_views.shape != (n_views, 3):
-        raise RuntimeError("dL_dcolor_views must be (n_views, num_points, 3) and campos_views (n_views, 3)")
+    pc, sc, pv, sv = _views_args(means3D, campos_views, dL_dcolor_views)
     _check_device(lib, means3D, campos_views, dL_dcolor_views, sh)
     for t in (sh, sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
         if t.dim() != 3 or t.shape != sh.shape or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("sh and its moments must be contiguous float32 (num_points, M, 3) tensors")
     if P != 0:
         k1, p1 = _ptr(means3D)
-        k2, p2 = _ptr(campos_views.float())
-        k3, p3 = _ptr(dL_dcolor_views)
         adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
                            float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]), float(sh_adam["eps"]),
                            int(sh_adam["step"]))
-        st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, p2, p3, float(scale),
+        st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, pc, sc, pv, sv, float(scale),
                                         C.c_void_p(sh.data_ptr()), C.byref(adam), _stream_ptr(means3D))
         capi.check(lib, st, "shAdamFromViews")
 

@@ -13,27 +13,72 @@ from .gaussian_renderer import GaussianRenderer
 FEATURES_GROUP = 1   # position of features_ in GaussianModel.params() and in the optimizer's groups
 
 
+def _one_buffer(tensors):
+    """A flat view over the storage the given contiguous tensors tile exactly and without gaps (the rasterizer's backward
+    hands the gradients of the four small parameter tensors out as slices of one buffer), or None."""
+    if len(tensors) < 2 or any(t is None or not t.is_contiguous() or t.dtype != torch.float32 for t in tensors):
+        return None
+    base = tensors[0].untyped_storage()
+    if any(t.untyped_storage().data_ptr() != base.data_ptr() for t in tensors):
+        return None
+    spans = sorted((t.storage_offset(), t.numel()) for t in tensors)
+    end = spans[0][0]
+    for off, n in spans:
+        if off != end:
+            return None
+        end = off + n
+    if spans[0][0] != 0 or end * 4 != base.nbytes():
+        return None
+    return torch.empty(0, dtype=torch.float32, device=tensors[0].device).set_(base, 0, (end,))
+
+
 class GradientReduction:
     """Mean of the per-view gradients over the ranks, overlapped with the optimizer: every tensor's all-reduce is issued
     asynchronously right after backward, largest first (the [P,16,3] SH gradient is 81 % of the 472 MB), and wait(i) blocks
-    only the compute stream, only for tensor i -- so Adam on the SH tensor runs while the four small reductions are still
-    on the links, and their Adam follows.  RCCL averages inside the collective (ncclAvg); gloo (the CPU test path) has no
-    AVG: it sums, and wait() scales."""
+    only the compute stream, only for tensor i -- so Adam on the SH tensor runs while the small reductions are still on the
+    links, and their Adam follows.  Tensors that tile one buffer (the four small gradients, see _one_buffer) travel as ONE
+    collective.  RCCL averages inside the collective (ncclAvg); gloo (the CPU test path) has no AVG: it sums, and wait()
+    scales."""
 
     def __init__(self, tensors, world_size):
         self.tensors_, self.world_size_ = tensors, world_size
         self.avg_ = dist.get_backend() == "nccl"
         op = dist.ReduceOp.AVG if self.avg_ else dist.ReduceOp.SUM
         self.order_ = sorted(range(len(tensors)), key=lambda i: -tensors[i].numel())
-        self.works_ = {i: dist.all_reduce(tensors[i], op=op, async_op=True) for i in self.order_}
+        # members of one buffer share a single collective: group -> [tensor to reduce, work, scaled?]
+        self.group_of_, self.groups_ = {}, []
+        by_storage = {}
+        for i in self.order_:
+            by_storage.setdefault(tensors[i].untyped_storage().data_ptr(), []).append(i)
+        for members in by_storage.values():
+            flat = _one_buffer([tensors[i] for i in members])
+            if flat is not None:
+                for i in members:
+                    self.group_of_[i] = len(self.groups_)
+                self.groups_.append([flat, None, False])
+        for i in self.order_:
+            if i not in self.group_of_:
+                self.group_of_[i] = len(self.groups_)
+                self.groups_.append([tensors[i], None, False])
+        issued = set()
+        for i in self.order_:   # issue in size order; a shared buffer goes out when its first member comes up
+            k = self.group_of_[i]
+            if k not in issued:
+                issued.add(k)
+                self.groups_[k][1] = dist.all_reduce(self.groups_[k][0], op=op, async_op=True)
+
+    def collectives(self):
+        return len(self.groups_)
 
     def order(self):
         return self.order_
 
     def wait(self, i):
-        self.works_[i].wait()
-        if not self.avg_:
-            self.tensors_[i].mul_(1.0 / self.world_size_)
+        grp = self.groups_[self.group_of_[i]]
+        grp[1].wait()
+        if not self.avg_ and not grp[2]:
+            grp[0].mul_(1.0 / self.world_size_)
+            grp[2] = True
 
     def wait_all(self):
         for i in self.order_:
@@ -47,29 +92,32 @@ class ViewFactoredExchange:
     each rebuilds the mean SH gradient locally (gsr_sh_grad_from_views), and only the other four tensors (11 floats per
     Gaussian) are all-reduced.  Per Gaussian a rank sends (N-1) * 12 + 2 (N-1)/N * 44 B instead of 2 (N-1)/N * 236 B.
 
-    Usage: color_view = the [P,3] tensor handed to the backward; others = [(index, grad), ...] of the remaining
-    parameters; after construction everything is in flight.  sh_gradient() waits for the gather and returns the
-    [P,M,3] mean gradient -- it reads means3D, so call it BEFORE Adam moves the positions."""
+    Usage: send, color_view = ViewFactoredExchange.send_buffer(P, device) before the render; color_view ([P,3], rows 0..P-1 of
+    send) is handed to the backward, the camera centre travels as row P of the same buffer -- ONE all-gather; others =
+    [(index, grad), ...] of the remaining parameters (one all-reduce when they share a buffer, GradientReduction); after
+    construction everything is in flight.  sh_gradient() / sh_adam_step() wait for the gather; they read means3D, so call
+    them BEFORE Adam moves the positions."""
 
-    def __init__(self, color_view, camera_center, others, world_size):
+    @staticmethod
+    def send_buffer(P, device):
+        send = torch.empty((P + 1, 3), dtype=torch.float32, device=device)
+        return send, send[:P]
+
+    def __init__(self, send, camera_center, others, world_size):
         self.world_size_ = world_size
-        P = color_view.size(0)
-        self.views_ = torch.empty((world_size, P, 3), dtype=torch.float32, device=color_view.device)
-        self.centres_ = torch.empty((world_size, 3), dtype=torch.float32, device=color_view.device)
-        centre = camera_center.detach().reshape(1, 3).float().contiguous()
-        color_view = color_view.unsqueeze(0)   # [1,P,3] -> rows of the [N,P,3] gather
+        P = send.size(0) - 1
+        send[P].copy_(camera_center.detach().reshape(3))
+        self.all_ = torch.empty((world_size, P + 1, 3), dtype=torch.float32, device=send.device)
         self.nccl_ = dist.get_backend() == "nccl"
         if self.nccl_:
-            self.gathers_ = [dist.all_gather_into_tensor(self.centres_, centre, async_op=True),
-                             dist.all_gather_into_tensor(self.views_, color_view, async_op=True)]
+            self.gathers_ = [dist.all_gather_into_tensor(self.all_, send.unsqueeze(0), async_op=True)]
         else:
             # gloo (the CPU test path) gathers host tensors
-            hv, hc = self.views_.cpu(), self.centres_.cpu()
-            dist.all_gather_into_tensor(hc, centre.cpu())
-            dist.all_gather_into_tensor(hv, color_view.cpu())
-            self.views_.copy_(hv)
-            self.centres_.copy_(hc)
+            host = self.all_.cpu()
+            dist.all_gather_into_tensor(host, send.unsqueeze(0).cpu())
+            self.all_.copy_(host)
             self.gathers_ = []
+        self.centres_, self.views_ = self.all_[:, P, :], self.all_[:, :P, :]   # strided views of the gathered buffer
         self.indices_ = [i for i, _ in others]
         self.reduction_ = GradientReduction([t for _, t in others], world_size)
 
@@ -133,9 +181,9 @@ class TrainStep:
         self.iteration_ += 1
         it = self.iteration_
         g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
-        sh_view = sh_adam = None
+        sh_send = sh_view = sh_adam = None
         if self.world_size_ > 1 and self.factored_exchange_:
-            sh_view = torch.empty((g.xyz_.size(0), 3), dtype=torch.float32, device=g.xyz_.device)
+            sh_send, sh_view = ViewFactoredExchange.send_buffer(g.xyz_.size(0), g.xyz_.device)
         rebuilds = self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and \
             it % opt.densification_interval_ == 0    # this iteration densifies: the reference skips its optimizer step
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
@@ -156,7 +204,7 @@ class TrainStep:
             if self.world_size_ > 1:
                 # keyframe-batch data parallelism: mean of the per-view gradients over RCCL, in flight from here on
                 if sh_view is not None:
-                    reduction = ViewFactoredExchange(sh_view, viewpoint_cam.camera_center_,
+                    reduction = ViewFactoredExchange(sh_send, viewpoint_cam.camera_center_,
                                                      [(i, p.grad) for i, p in enumerate(g.params()) if i != FEATURES_GROUP],
                                                      self.world_size_)
                 else:

@@ -219,8 +219,13 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
     M = full[0].shape[1]
     rp._LIB_OVERRIDE = lib_path
     try:
-        out = rp.shGradFromViews(_t(cl.xyz, dev), _t(np.stack([c.campos for c in cl.cameras]).astype(np.float32), dev),
-                                 _t(np.stack(views), dev), sh_degree, M, 1.0 / n).cpu().numpy()
+        # views and camera centres as they arrive from ONE all-gather: slices of a [n_views, P + 1, 3] buffer (strided)
+        P_ = cl.xyz.shape[0]
+        packed = np.zeros((n, P_ + 1, 3), np.float32)
+        packed[:, :P_] = np.stack(views)
+        packed[:, P_] = np.stack([c.campos for c in cl.cameras])
+        packed = _t(packed, dev)
+        out = rp.shGradFromViews(_t(cl.xyz, dev), packed[:, P_, :], packed[:, :P_, :], sh_degree, M, 1.0 / n).cpu().numpy()
     finally:
         rp._LIB_OVERRIDE = None
     want = np.sum(np.stack(full).astype(np.float64), axis=0) / n

@@ -120,6 +120,9 @@ def run_trainer_checks(ops, dev, lib_path):
         assert np.isclose(l2, losses_cpp[it], rtol=1e-6)
         grads = ops.trainer_grads(h2)
         assert grads[1].numel() == 0 and all(grads[i].numel() for i in (0, 2, 3, 4))
+        from photo_slam_amd.trainer import _one_buffer
+        flat = _one_buffer([grads[i] for i in (0, 2, 3, 4)])   # one collective for the four in a data-parallel step
+        assert flat is not None and flat.numel() == 11 * 300
         view = ops.trainer_sh_grad_view(h2)
         assert view.shape == (300, 3)
         assert not ops.trainer_densify_due(h2)

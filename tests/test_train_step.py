@@ -90,6 +90,21 @@ def test_fused_sh_adam_step_equals_separate_pass(emu):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-12) and a.abs().sum() > 0
 
 
+def test_small_gradients_share_one_buffer(emu):
+    """The rasterizer's backward hands the gradients of rotation, position, scaling and opacity out as slices of one buffer
+    and autograd adopts them as the leaves' .grad: a data-parallel trainer reduces the four with one collective."""
+    from photo_slam_amd.trainer import _one_buffer
+    cl, g, kfs = _setup()
+    img, _, _, _ = GaussianRenderer.render(kfs[0], 32, 48, g, GaussianPipelineParams(), torch.zeros(3))
+    img.sum().backward()
+    small = [g.rotation_.grad, g.xyz_.grad, g.scaling_.grad, g.opacity_.grad]
+    flat = _one_buffer(small)
+    assert flat is not None and flat.numel() == 11 * 300
+    assert flat.data_ptr() == g.rotation_.grad.data_ptr() and torch.equal(flat[4 * 300:7 * 300].view(300, 3), g.xyz_.grad)
+    assert _one_buffer(small + [g.features_.grad]) is None and _one_buffer(small[:3]) is None
+    assert _one_buffer([torch.zeros(4), torch.zeros(4)]) is None
+
+
 WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
