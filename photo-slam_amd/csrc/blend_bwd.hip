@@ -12,7 +12,7 @@
 //   * the per-pair arithmetic is branch-free; 1/(1-alpha) is one v_rcp_f32 shared by the two
 //     divisions of the reference;
 //   * the nine terms are summed across the 64 pixels of a quad with a butterfly packed from the
-//     top through v_permlane32_swap / v_permlane16_swap (wave64.h, 24 VALU) that leaves eight
+//     top through v_permlane32_swap / v_permlane16_swap (wave64.h, 19 VALU) that leaves eight
 //     totals in one register (one per 8-lane group) and the ninth in lane 63; ONE ds_add_f32
 //     with nine active lanes adds them to the tile's LDS accumulators, where the four quads
 //     of a tile meet;
