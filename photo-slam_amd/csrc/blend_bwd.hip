@@ -13,8 +13,8 @@
 //     divisions of the reference;
 //   * the nine terms are summed across the 64 pixels of a quad with a butterfly packed from the
 //     top through v_permlane32_swap / v_permlane16_swap (wave64.h, 19 VALU) that leaves eight
-//     totals in one register (one per 8-lane group) and the ninth in lane 63; ONE ds_add_f32
-//     with nine active lanes adds them to the tile's LDS accumulators, where the four quads
+//     totals in one register (one per 8-lane group) and the ninth as four row sums; ONE ds_add_f32
+//     with twelve active lanes adds them to the tile's LDS accumulators, where the four quads
 //     of a tile meet;
 //   * the two mean2D terms are reduced as sum(dL_dG*G*dx), sum(dL_dG*G*dy); their conic
 //     combination (backward.cu:539-546) is linear in them and applied once per Gaussian in
