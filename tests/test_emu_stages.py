@@ -206,3 +206,34 @@ def test_invalid_argument_combinations(emu_lib_path):
     a.colors_precomp = p; a.cov3D_precomp = p; a.means3D = p; a.opacities = p; a.background = p
     a.viewmatrix = p; a.projmatrix = p; a.cam_pos = p; a.out_color = p
     assert lib.gsr_forward(C.byref(a), cb, None, cb, None, cb, None, None, C.byref(n)) == -2
+
+
+def test_backward_extension_errors(emu_lib_path):
+    """Error behaviour of the gsr_backward extensions: the fused SH Adam step needs [P,16,3] rows, excludes the factored
+    mode, and the three statistics pointers come together."""
+    cl = _scene(P=120, seed=31)
+    cam = cl.cameras[0]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    hyper = dict(lr=0.0025, lr_tail=0.0025 / 20, beta1=0.9, beta2=0.999, eps=1e-15, step=1)
+    # compact SH layout (4 coefficients): the fused step is refused by the library
+    moments = dict(exp_avg=torch.zeros(120, 4, 3), exp_avg_sq=torch.zeros(120, 4, 3))
+    with pytest.raises(capi.GsrError, match="unsupported"):
+        parity.run_backend(emu_lib_path, CPU, cl, cam, bg, sh_degree=1, sh_coeffs=4, sh_adam=dict(**moments, **hyper))
+    # moments of another shape, step 0, both SH extensions at once: refused by the wrapper / the library
+    with pytest.raises(RuntimeError, match="shaped like sh"):
+        parity.run_backend(emu_lib_path, CPU, cl, cam, bg, sh_adam=dict(**moments, **hyper))
+    full = dict(exp_avg=torch.zeros(120, 16, 3), exp_avg_sq=torch.zeros(120, 16, 3))
+    with pytest.raises(capi.GsrError, match="invalid argument"):
+        parity.run_backend(emu_lib_path, CPU, cl, cam, bg, sh_adam=dict(**full, **dict(hyper, step=0)))
+    with pytest.raises(RuntimeError, match="mutually exclusive"):
+        parity.run_backend(emu_lib_path, CPU, cl, cam, bg, factored=True, sh_adam=dict(**full, **hyper))
+    with pytest.raises(RuntimeError, match="num_points elements"):
+        parity.run_backend(emu_lib_path, CPU, cl, cam, bg, view_stats=[torch.zeros(120), torch.zeros(120), torch.zeros(7)])
+    # strided views are fine, strided inner dimensions are not
+    views = torch.zeros(2, 121, 3)
+    with pytest.raises(RuntimeError, match="only the view dimension may be strided"):
+        rp._LIB_OVERRIDE = emu_lib_path
+        try:
+            rp.shGradFromViews(torch.zeros(120, 3), views[:, 120, :], torch.zeros(2, 120, 6)[:, :, ::2], 3, 16, 0.5)
+        finally:
+            rp._LIB_OVERRIDE = None
