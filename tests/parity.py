@@ -5,8 +5,8 @@ Bars (BASELINE.md section 3 / north_star):
   * integer / index work -- radii, tile rectangles, tiles_touched, sort order (point_list),
     tile ranges, n_contrib -- bit-exact (n_contrib outside oracle-flagged fragile pixels,
     where a skip/terminate decision sits inside exp() rounding noise);
-  * rendered RGB: mean |diff| <= 1e-4; gradients: relative L1 <= 1e-4 * (a small factor for the
-    undefined fp32 atomic order), tolerance written at each assert.
+  * rendered RGB: mean |diff| <= 1e-4; gradients: relative L1 <= 1e-4, tolerance written at each assert;
+  * the pixels excluded from the exact n_contrib comparison are bounded: <= 1 % of the image.
 """
 import ctypes as C
 
@@ -17,7 +17,8 @@ from photo_slam_amd import capi
 from photo_slam_amd import rasterize_points as rp
 
 RGB_L1_TOL = 1e-4
-GRAD_REL_L1_TOL = 2e-4
+GRAD_REL_L1_TOL = 1e-4      # north_star: "within 1e-4 L1 on rendered RGB / gradients" (measured: 3e-7 ... 6e-7)
+FRAGILE_PX_MAX_FRAC = 0.01   # the oracle-flagged pixels excluded from the exact n_contrib check must stay a sliver
 
 
 def _t(a, dev):
@@ -171,6 +172,7 @@ def compare(r, ores, ocolor, oradii, ograds, cam, use_colors_precomp=False, use_
     assert rep["rgb_L1"] <= RGB_L1_TOL, rep
     solid = ores.fragile == 0
     rep["fragile_px"] = int((~solid).sum())
+    assert rep["fragile_px"] <= FRAGILE_PX_MAX_FRAC * solid.size, rep
     mism = (r.n_contrib != ores.n_contrib) & solid
     rep["n_contrib_mismatch_nonfragile"] = int(mism.sum())
     assert rep["n_contrib_mismatch_nonfragile"] == 0, rep

@@ -49,6 +49,52 @@ def test_config_C2_full_size(oracle, dev):
     assert ores.R > 1_000_000
 
 
+def test_config_C3_full_size(oracle, dev):
+    """The headline config (BASELINE.json configs[2], the one bench.py times): 2 M Gaussians at 1920x1080, every stage
+    against the oracle at full size (the oracle needs a few seconds on the GPU box's host cores)."""
+    cl = scene.make_config("C3", seed=0)
+    r, ores = _check(oracle, dev, cl, cl.cameras[0], np.zeros(3, np.float32))
+    assert ores.R > 4_000_000 and ores.T == 120 * 68
+
+
+def test_config_C4_view_full_size(oracle, dev):
+    """One keyframe of BASELINE config C4 (2 M Gaussians at 640x480, TUM intrinsics): the per-rank work of the 8-GPU batch."""
+    cl = scene.make_config("C4", seed=0, n_views=8)
+    for v in (0, 7):
+        r, ores = _check(oracle, dev, cl, cl.cameras[v], np.zeros(3, np.float32), seed=v)
+        assert ores.T == 40 * 30
+
+
+def test_config_C5_view_full_size(oracle, dev):
+    """One keyframe of BASELINE config C5 (4 M Gaussians at 752x480, EuRoC intrinsics, SH degree 3)."""
+    cl = scene.make_config("C5", seed=0)
+    r, ores = _check(oracle, dev, cl, cl.cameras[0], np.array([0.1, 0.1, 0.1], np.float32))
+    assert ores.P == 4_000_000 and ores.T == 47 * 30
+
+
+def test_no_gaussians(dev):
+    """P == 0 (src/rasterize_points.cu:68,81): a valid no-op -- the image is all ZERO (not the background: out_color is
+    created as zeros and the launch is skipped), zero instances, empty radii and empty gradients."""
+    from photo_slam_amd import rasterize_points as rp
+    e = torch.empty(0, device=dev)
+    z3 = torch.empty((0, 3), device=dev)
+    bg = torch.tensor([0.3, 0.6, 0.9], device=dev)
+    cam = scene.make_cloud(1, 96, 64, 80.0, 80.0, seed=0).cameras[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(
+        bg, z3, e, torch.empty((0, 1), device=dev), z3, torch.empty((0, 4), device=dev), 1.0, e, t(cam.viewmatrix),
+        t(cam.projmatrix), cam.tanfovx, cam.tanfovy, cam.H, cam.W, torch.empty((0, 16, 3), device=dev), 3, t(cam.campos), False)
+    assert R == 0 and radii.numel() == 0 and tuple(color.shape) == (3, cam.H, cam.W)
+    assert not color.any()
+    g = rp.RasterizeGaussiansBackwardCUDA(bg, z3, radii, e, z3, torch.empty((0, 4), device=dev), 1.0, e, t(cam.viewmatrix),
+                                          t(cam.projmatrix), cam.tanfovx, cam.tanfovy, torch.ones_like(color),
+                                          torch.empty((0, 16, 3), device=dev), 3, t(cam.campos), geom, R, binning, img)
+    assert all(x is None or x.numel() == 0 for x in g)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        rp.RasterizeGaussiansCUDA(bg, torch.empty((4,), device=dev), e, e, e, e, 1.0, e, t(cam.viewmatrix), t(cam.projmatrix),
+                                  cam.tanfovx, cam.tanfovy, cam.H, cam.W, e, 3, t(cam.campos), False)
+
+
 @pytest.mark.parametrize("degree", [0, 1, 2])
 def test_lower_sh_degrees(oracle, dev, degree):
     cl = scene.make_cloud(30000, 256, 192, 200.0, 200.0, seed=8, scale_k=0.15)
@@ -141,8 +187,8 @@ def test_forward_is_deterministic_and_backward_is_stable(dev):
 
 
 def test_full_size_C3_properties(dev):
-    """BASELINE headline size (2M Gaussians, 1920x1080): size-independent properties instead of the
-    (slow) full oracle: sortedness of the instance list, ranges partition it, the instance count
+    """BASELINE headline size (2M Gaussians, 1920x1080): size-independent properties next to the full oracle comparison
+    of test_config_C3_full_size: sortedness of the instance list, ranges partition it, the instance count
     equals sum(tiles_touched), rectangles are consistent, blend weights are a sub-convex
     combination, and background linearity C(bg) = C(0) + T*bg."""
     cl = scene.make_config("C3", seed=0)
