@@ -88,7 +88,8 @@ int gsr_forward(const gsr_forward_args* args,
 typedef struct gsr_sh_adam {
 	float* exp_avg;              /* [P,16,3] */
 	float* exp_avg_sq;           /* [P,16,3] */
-	float lr, lr_tail, beta1, beta2, eps;
+	double lr, lr_tail, beta1, beta2, eps;   /* double like torch::optim::AdamOptions: the bias corrections 1 - beta^step are
+	                                            formed in double as torch does (0.999f instead of 0.999 is 1e-5 of the step) */
 	int step;                    /* >= 1: the step being taken (bias correction) */
 } gsr_sh_adam;
 
@@ -197,11 +198,14 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 
 /* One torch::optim::Adam step (no amsgrad / weight decay; src/gaussian_model.cpp:477-510 uses eps 1e-15)
  * on a flat fp32 tensor: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
- * p -= (lr / (1-b1^step)) * m / (sqrt(v) / sqrt(1-b2^step) + eps).
+ * p -= (lr / (1-b1^step)) * m / (sqrt(v) / sqrt(1-b2^step) + eps).  The hyper-parameters are double as in
+ * torch::optim::AdamOptions; the scalars derived from them (step size, 1-beta, 1/sqrt(bias correction 2)) are formed in
+ * double and rounded once, the element arithmetic is fp32 (pinned to the reference's own trainingSetup +
+ * torch::optim::Adam::step, tests/test_densify_reference.py).
  * period/split/lr_tail: if period > 0, elements [split, period) of every period-element row use lr_tail
  * (features_dc and features_rest live in one [P,16,3] buffer with learning rates lr and lr/20). */
-int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                  float beta1, float beta2, float eps, int step, int period, int split, float lr_tail, void* stream);
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
+                  double beta1, double beta2, double eps, int step, int period, int split, double lr_tail, void* stream);
 
 /* Per-view densification statistics (src/gaussian_mapper.cpp:714-719, src/gaussian_model.cpp:817-831) for
  * vis = radii > 0:  max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmean2D.xy|; denom += 1.

@@ -113,7 +113,65 @@ def build_loss(force=False):
     return LOSS_OUT
 
 
+MODEL_SRC = os.path.join(REF, "src", "gaussian_model.cpp")
+MODEL_OUT = {"cpu": os.path.join(OUT_DIR, "libref_densify.so"), "cuda": os.path.join(OUT_DIR, "libref_densify_cuda.so")}
+# the member functions of GaussianModel that oracle/ref_densify.cpp compiles, extracted verbatim by name
+MODEL_FUNCTIONS = ["getScalingActivation", "getXYZ", "getOpacityActivation", "trainingSetup", "resetOpacity",
+                   "replaceTensorToOptimizer", "prunePoints", "densificationPostfix", "densifyAndSplit", "densifyAndClone",
+                   "densifyAndPrune", "addDensificationStats", "percentDense", "setPercentDense"]
+ADAM_KEY = "c10::guts::to_string(param.unsafeGetTensorImpl())"   # LibTorch <= 2.1 state key (src/gaussian_model.cpp:571,598,670)
+
+
+def _member_function(text, name):
+    """`<return type> GaussianModel::name(...) {...}` of a .cpp file, verbatim."""
+    m = re.search(r"^[\w:<>&\* ]+\bGaussianModel::" + name + r"\s*\(", text, re.M)
+    if not m:
+        raise RuntimeError(f"GaussianModel::{name} not found in {MODEL_SRC}")
+    j = text.index("{", m.end())
+    depth, k = 1, j + 1
+    while depth:
+        depth += {"{": 1, "}": -1}.get(text[k], 0)
+        k += 1
+    return text[m.start():k]
+
+
+def build_densify(force=False):
+    """oracle/_ref/libref_densify.so (host) and libref_densify_cuda.so (GPU boxes): torch ops around the reference's own
+    densification / Adam-state code, see oracle/ref_densify.cpp.  Returns {"cpu": path, "cuda": path} (None where absent)."""
+    src = os.path.join(HERE, "ref_densify.cpp")
+    have = {k: (v if os.path.exists(v) else None) for k, v in MODEL_OUT.items()}
+    if not os.path.exists(MODEL_SRC):
+        return have
+    deps = (src, MODEL_SRC, os.path.join(REF, "include", "general_utils.h"), os.path.join(REF, "include", "gaussian_parameters.h"),
+            os.path.join(REF, "src", "gaussian_parameters.cpp"), __file__)
+    if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in MODEL_OUT.values()):
+        return have
+    import shutil
+    import torch
+    text = open(MODEL_SRC).read()
+    body = "\n\n".join(_member_function(text, n) for n in MODEL_FUNCTIONS)
+    assert body.count(ADAM_KEY) == 6, "the Adam state key idiom changed in the reference"
+    body = body.replace(ADAM_KEY, "param.unsafeGetTensorImpl()")
+    os.makedirs(GEN, exist_ok=True)
+    with open(os.path.join(GEN, "ref_gaussian_model_functions.inc"), "w") as f:
+        f.write(f'#line 1 "{MODEL_SRC} (extract)"\n' + body + "\n")
+    base = os.path.dirname(torch.__file__)
+    inc = [os.path.join(base, "include"), os.path.join(base, "include", "torch", "csrc", "api", "include")]
+    libdir = os.path.join(base, "lib")
+    try:
+        for kind, out in MODEL_OUT.items():
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+                                   "-w", "-I" + GEN, "-I" + os.path.join(REF, "include"), "-I" + REF] + ["-I" + i for i in inc] +
+                                  (["-DREF_DENSIFY_DEVICE_CPU"] if kind == "cpu" else []) +
+                                  [src, os.path.join(REF, "src", "gaussian_parameters.cpp"), "-o", out, "-L" + libdir, "-ltorch",
+                                   "-ltorch_cpu", "-lc10", "-Wl,-rpath," + libdir])
+    finally:
+        shutil.rmtree(GEN, ignore_errors=True)   # the extracted reference text does not outlive the compile
+    return dict(MODEL_OUT)
+
+
 if __name__ == "__main__":
     r = build(force="--force" in sys.argv)
     print(r if r else "reference sources not available and no prebuilt library")
     print(build_loss(force="--force" in sys.argv))
+    print(build_densify(force="--force" in sys.argv))

@@ -1,0 +1,59 @@
+"""Python access to oracle/_ref/libref_densify{,_cuda}.so: the reference's own GaussianModel map-maintenance and optimizer
+code (src/gaussian_model.cpp:477-510, 553-831) behind torch ops -- see oracle/ref_densify.cpp.  TEST INFRASTRUCTURE ONLY."""
+import torch
+
+from . import build_ref
+
+PARAMS = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")   # the reference's param-group order
+_ops = {}
+
+
+def load(kind="cpu"):
+    """kind: "cpu" (this container and any host) or "cuda" (a GPU box: tensors on the HIP device).  None if the library
+    was never built (the reference tree is absent and no prebuilt .so travelled)."""
+    if kind not in _ops:
+        path = build_ref.build_densify().get(kind)
+        if path is None:
+            _ops[kind] = None
+        else:
+            torch.ops.load_library(path)
+            _ops[kind] = torch.ops.photoslam_reference_model if kind == "cpu" else torch.ops.photoslam_reference_model_cuda
+    return _ops[kind]
+
+
+class State:
+    """A GaussianModel + Adam state as plain tensors: params / exp_avg / exp_avg_sq (six each, the reference's group order),
+    steps (six ints), xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P], exist_since_iter [P] int32."""
+
+    def __init__(self, params, exp_avg, exp_avg_sq, steps, accum, denom, max_radii2D, exist_since_iter):
+        self.params, self.exp_avg, self.exp_avg_sq, self.steps = list(params), list(exp_avg), list(exp_avg_sq), list(steps)
+        self.accum, self.denom, self.max_radii2D, self.exist_since_iter = accum, denom, max_radii2D, exist_since_iter
+
+    def args(self):
+        return (self.params, self.exp_avg, self.exp_avg_sq, self.steps, self.accum, self.denom, self.max_radii2D,
+                self.exist_since_iter)
+
+    @staticmethod
+    def from_dump(out):
+        return State(out[0:6], out[6:12], out[12:18], [int(s) for s in out[22].tolist()], out[18], out[19], out[20], out[21])
+
+    @property
+    def features(self):
+        """[P,16,3]: cat(features_dc, features_rest), the single SH leaf of this repository's hosts"""
+        return torch.cat([self.params[1], self.params[2]], 1)
+
+
+def densify_and_prune(ops, st, percent_dense, max_grad, min_opacity, extent, max_screen_size):
+    return State.from_dump(ops.densify_and_prune(*st.args(), percent_dense, max_grad, min_opacity, extent, max_screen_size))
+
+
+def reset_opacity(ops, st):
+    return State.from_dump(ops.reset_opacity(*st.args()))
+
+
+def prune_points(ops, st, mask):
+    return State.from_dump(ops.prune_points(*st.args(), mask))
+
+
+def adam_step(ops, st, grads, spatial_lr_scale=1.0, xyz_lr=-1.0):
+    return State.from_dump(ops.adam_step(st.params, list(grads), st.exp_avg, st.exp_avg_sq, st.steps, spatial_lr_scale, xyz_lr))

@@ -35,8 +35,8 @@ class ForwardArgs(C.Structure):
 
 
 class ShAdam(C.Structure):
-    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_float), ("lr_tail", C.c_float),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int)]
+    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("lr_tail", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int)]
 
 
 class BackwardArgs(C.Structure):
@@ -128,7 +128,8 @@ def load(path=None):
     L.gsr_l1_ssim_loss.restype = i32
     L.gsr_l1_ssim_loss.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.gsr_adam_step.restype = i32
-    L.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_longlong, f32, f32, f32, f32, i32, i32, i32, f32, vp]
+    f64 = C.c_double
+    L.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_longlong, f64, f64, f64, f64, i32, i32, i32, f64, vp]
     L.gsr_densify_stats.restype = i32
     L.gsr_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.gsr_transform_points.restype = i32

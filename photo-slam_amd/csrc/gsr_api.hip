@@ -299,15 +299,12 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dcolor_view = a->dL_dcolor_view;
 	pb.stat_accum = a->stat_grad_accum; pb.stat_denom = a->stat_denom; pb.stat_max_radii = a->stat_max_radii;
 	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
-	pb.adam_step_size = pb.adam_step_size_tail = pb.adam_b1 = pb.adam_b2 = pb.adam_eps = pb.adam_inv_sqrt_bc2 = 0.f;
+	pb.adam = AdamScalars{};
 	if (a->sh_adam) {
-		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (train_ops.hip)
-		const double bc1 = 1.0 - pow((double)o.beta1, o.step), bc2 = 1.0 - pow((double)o.beta2, o.step);
+		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
 		pb.adam_param = const_cast<float*>(a->shs);
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
-		pb.adam_step_size = (float)(o.lr / bc1); pb.adam_step_size_tail = (float)(o.lr_tail / bc1);
-		pb.adam_b1 = o.beta1; pb.adam_b2 = o.beta2; pb.adam_eps = o.eps;
-		pb.adam_inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+		pb.adam = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
 	}
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	PROF_BWD(3);
@@ -336,9 +333,7 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 	if (P == 0) return GSR_OK;
 	if (!means3D || !campos || !dL_dcolor_views || !shs || !o || !o->exp_avg || !o->exp_avg_sq || o->step < 1)
 		return GSR_ERR_INVALID_ARG;
-	const double bc1 = 1.0 - pow((double)o->beta1, o->step), bc2 = 1.0 - pow((double)o->beta2, o->step);
-	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, (float)(o->lr / bc1), (float)(o->lr_tail / bc1), o->beta1, o->beta2,
-	                    o->eps, (float)(1.0 / sqrt(bc2))};
+	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, adam_scalars(o->lr, o->lr_tail, o->beta1, o->beta2, o->eps, o->step)};
 	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
 	                                 nullptr, &ra, (hipStream_t)stream_);
 }

@@ -2,7 +2,30 @@
 #pragma once
 #include "state.h"
 
+#include <math.h>
+
 namespace gsr {
+
+// The scalars one Adam step needs, derived ONCE on the host from torch::optim::AdamOptions-style double hyper-parameters
+// (torch forms bias_correction = 1 - beta^step, 1 - beta and lr / bias_correction1 in double and hands fp32 tensors the
+// rounded results): m = b1 m + omb1 g; v = b2 v + omb2 g g; p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps).
+struct AdamScalars {
+	float step_size, step_size_tail, b1, b2, omb1, omb2, eps, inv_sqrt_bc2;
+};
+static inline AdamScalars adam_scalars(double lr, double lr_tail, double beta1, double beta2, double eps, int step)
+{
+	const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+	AdamScalars a;
+	a.step_size = (float)(lr / bc1);
+	a.step_size_tail = (float)(lr_tail / bc1);
+	a.b1 = (float)beta1;
+	a.b2 = (float)beta2;
+	a.omb1 = (float)(1.0 - beta1);
+	a.omb2 = (float)(1.0 - beta2);
+	a.eps = (float)eps;
+	a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+	return a;
+}
 
 struct PreprocessParams {
 	int P, D, M;
@@ -93,7 +116,7 @@ struct PreprocessBwdParams {
 	float* adam_param;        // == shs, written
 	float* adam_exp_avg;
 	float* adam_exp_avg_sq;
-	float adam_step_size, adam_step_size_tail, adam_b1, adam_b2, adam_eps, adam_inv_sqrt_bc2;
+	AdamScalars adam;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)

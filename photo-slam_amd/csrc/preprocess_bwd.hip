@@ -100,8 +100,7 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 				if (MODE == 0) {
 					wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 				} else if (MODE == 2) {
-					const RowAdam ra = {p.adam_param, p.adam_exp_avg, p.adam_exp_avg_sq, p.adam_step_size, p.adam_step_size_tail,
-					                    p.adam_b1, p.adam_b2, p.adam_eps, p.adam_inv_sqrt_bc2};
+					const RowAdam ra = {p.adam_param, p.adam_exp_avg, p.adam_exp_avg_sq, p.adam};
 					wave_adam_rows(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 				} else {
 					wave_fence();   // the next pass refills the slice

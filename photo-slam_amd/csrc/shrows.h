@@ -76,7 +76,7 @@ struct RowAdam {
 	float* param;
 	float* exp_avg;
 	float* exp_avg_sq;
-	float step_size, step_size_tail, b1, b2, eps, inv_sqrt_bc2;
+	AdamScalars s;
 };
 __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD])
 {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 	const int slot = l >> 4, col = l & 15;
 	wave_fence();
 	const size_t base = (first_row + slot) * ROW_F4 + col;
-	const float ss_first = col == 0 ? a.step_size : a.step_size_tail;   // .x .y .z of vector 0 are features_dc
+	const float ss_first = col == 0 ? a.s.step_size : a.s.step_size_tail;   // .x .y .z of vector 0 are features_dc
 #ifndef GSR_ADAM_UNROLL
 #define GSR_ADAM_UNROLL 2
 #endif
@@ -99,10 +99,10 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
 			for (int e = 0; e < 4; e++) {
-				const float ss = e < 3 ? ss_first : a.step_size_tail;
-				mp[e] = a.b1 * mp[e] + (1.f - a.b1) * gp[e];
-				vp[e] = a.b2 * vp[e] + (1.f - a.b2) * gp[e] * gp[e];
-				pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.inv_sqrt_bc2 + a.eps);
+				const float ss = e < 3 ? ss_first : a.s.step_size_tail;
+				mp[e] = a.s.b1 * mp[e] + a.s.omb1 * gp[e];
+				vp[e] = a.s.b2 * vp[e] + a.s.omb2 * gp[e] * gp[e];
+				pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.s.inv_sqrt_bc2 + a.s.eps);
 			}
 			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
 			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);

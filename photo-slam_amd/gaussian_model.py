@@ -229,26 +229,30 @@ class GaussianModel:
     def trainingSetup(self, opt):
         self.percent_dense_ = opt.percent_dense_
         self.opt_ = opt
+        # GaussianOptimizationParams holds C++ floats and set_lr() widens them to double (:489-502): the same values here
+        import numpy as _np
+        f32 = lambda x: float(_np.float32(x))
         groups = [
-            dict(params=[self.xyz_], lr=opt.position_lr_init_ * self.spatial_lr_scale_, name="xyz"),
-            dict(params=[self.features_], lr=opt.feature_lr_, name="f_dc+f_rest", period=3 * (self.max_sh_degree_ + 1) ** 2,
-                 split=3, lr_tail=opt.feature_lr_ / 20.0),
-            dict(params=[self.opacity_], lr=opt.opacity_lr_, name="opacity"),
-            dict(params=[self.scaling_], lr=opt.scaling_lr_, name="scaling"),
-            dict(params=[self.rotation_], lr=opt.rotation_lr_, name="rotation"),
+            dict(params=[self.xyz_], lr=float(_np.float32(opt.position_lr_init_) * _np.float32(self.spatial_lr_scale_)), name="xyz"),
+            dict(params=[self.features_], lr=f32(opt.feature_lr_), name="f_dc+f_rest", period=3 * (self.max_sh_degree_ + 1) ** 2,
+                 split=3, lr_tail=f32(opt.feature_lr_) / 20.0),
+            dict(params=[self.opacity_], lr=f32(opt.opacity_lr_), name="opacity"),
+            dict(params=[self.scaling_], lr=f32(opt.scaling_lr_), name="scaling"),
+            dict(params=[self.rotation_], lr=f32(opt.rotation_lr_), name="rotation"),
         ]
         self.optimizer_ = FusedAdam(groups, eps=1e-15)
 
     def exponLrFunc(self, step):
         """src/gaussian_model.cpp:1118-1131"""
+        import numpy as _np
+        f32 = _np.float32
         o = self.opt_
-        lr_init, lr_final = o.position_lr_init_ * self.spatial_lr_scale_, o.position_lr_final_ * self.spatial_lr_scale_
+        lr_init = f32(o.position_lr_init_) * f32(self.spatial_lr_scale_)       # float arithmetic throughout, as the reference
+        lr_final = f32(o.position_lr_final_) * f32(self.spatial_lr_scale_)
         if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
             return 0.0
-        delay_rate = 1.0
-        t = min(max(step / o.position_lr_max_steps_, 0.0), 1.0)
-        log_lerp = math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
-        return delay_rate * log_lerp
+        t = min(max(f32(step) / f32(o.position_lr_max_steps_), f32(0.0)), f32(1.0))   # lr_delay_steps_ == 0: delay_rate 1
+        return float(_np.exp(_np.log(lr_init) * (f32(1) - t) + _np.log(lr_final) * t))
 
     def updateLearningRate(self, step):
         lr = self.exponLrFunc(step)
@@ -320,7 +324,12 @@ class GaussianModel:
             g = grads.squeeze(-1)
             scal = self.getScalingActivation()
             smax = scal.max(dim=1).values
-            big = smax > self.percent_dense_ * extent
+            # the reference's thresholds are C++ float products / float arguments: evaluate them in fp32 too, or a Gaussian
+            # sitting exactly on a threshold is classified differently
+            import numpy as _np
+            f32 = _np.float32
+            max_grad, min_opacity = float(f32(max_grad)), float(f32(min_opacity))
+            big = smax > float(f32(self.percent_dense_) * f32(extent))
             clone_mask = (g.abs() >= max_grad) & ~big          # frobenius_norm over the last dim of [P,1]
             split_mask = (g >= max_grad) & big
             P = self.xyz_.shape[0]
@@ -348,7 +357,7 @@ class GaussianModel:
             if max_screen_size:
                 # max_radii2D is reset by densificationPostfix before the prune, so big_points_vs is always false
                 new_smax = torch.cat([smax[keep_idx], smax[clone_idx], torch.exp(child_scaling).max(dim=1).values])
-                prune = prune | (new_smax > 0.1 * extent)
+                prune = prune | (new_smax > float(f32(0.1) * f32(extent)))   # 0.1f * extent
             sel = ~prune
             child_pos_all = torch.arange(keep_idx.shape[0] + clone_idx.shape[0], index.shape[0], device=index.device)
             new_pos = torch.cumsum(sel.to(torch.int64), 0) - 1
@@ -364,7 +373,8 @@ class GaussianModel:
         self.xyz_gradient_accum_ = torch.zeros((n, 1), device=dev)
         self.denom_ = torch.zeros((n, 1), device=dev)
         self.max_radii2D_ = torch.zeros(n, device=dev)
-        return dict(cloned=int(clone_idx.shape[0]), split=int(split_idx.shape[0]), pruned=int(prune.sum()), points=n)
+        return dict(cloned=int(clone_idx.shape[0]), split=int(split_idx.shape[0]), pruned=int(prune.sum()), points=n,
+                    children_kept=int(child_sel.sum()))
 
     def _rebuild_with_sources(self, gather_index, overrides):
         """gather_index >= 0: existing row (keeps its Adam moments); < 0: copy of row (-1 - value) with zero moments."""
@@ -387,10 +397,16 @@ class GaussianModel:
             if self.optimizer_ is not None:
                 self.optimizer_.replace_param(old, new, m2, v2)
 
-    def resetOpacity(self):
-        """src/gaussian_model.cpp:553-565: opacity <- inverse_sigmoid(min(opacity, 0.01)), zero Adam moments."""
+    def resetOpacity(self, clamp_to=None):
+        """src/gaussian_model.cpp:556-565 exactly as shipped: opacities_new = inverse_sigmoid(min(sigmoid(o), ones_like(sigmoid(o)
+        * 0.01))) -- the 0.01 sits INSIDE ones_like, so the clamp is against 1 and never binds: the values survive (up to the
+        sigmoid / logit round trip, which sends logits above ~17 to +inf exactly as the reference does) and only the Adam
+        moments of the opacity group are zeroed (replaceTensorToOptimizer :567-586).  clamp_to=0.01 gives the reset 3DGS
+        intended (opacity <- min(opacity, 0.01)), a deliberate deviation a caller has to ask for."""
         with torch.no_grad():
-            new = inverse_sigmoid(torch.min(self.getOpacityActivation(), torch.ones_like(self.opacity_) * 0.01))
+            act = self.getOpacityActivation()
+            bound = torch.ones_like(act * 0.01) if clamp_to is None else torch.ones_like(act) * clamp_to
+            new = inverse_sigmoid(torch.min(act, bound))
         new = new.clone().requires_grad_(True)
         old = self.opacity_
         self.opacity_ = new

@@ -30,7 +30,7 @@ struct GaussianKeyframe {
 // One Adam parameter group of the fused optimizer (gsr_adam_step)
 struct AdamGroup {
 	torch::Tensor param, exp_avg, exp_avg_sq;
-	float lr = 0.f, lr_tail = 0.f;
+	double lr = 0.0, lr_tail = 0.0;   // torch::optim::AdamOptions::lr is double (set_lr(float) widens: src/gaussian_model.cpp:489-502)
 	int period = 0, split = 0;
 	int step = 0;   // per parameter, as torch::optim::AdamParamState: advances only when the parameter has a gradient
 };
@@ -45,6 +45,7 @@ public:
 	void createFromPcd(torch::Tensor points, torch::Tensor colors, float spatial_lr_scale);
 	void oneUpShDegree();
 	void resetOpacity();
+	bool intended_opacity_reset_ = false;   // see resetOpacity(): false = the reference as shipped
 	void prunePoints(torch::Tensor& mask);
 	struct DensifyResult {
 		int64_t cloned = 0, split = 0, pruned = 0, points = 0;
@@ -121,7 +122,7 @@ public:
 	// fresh leaves have no gradient).
 	bool densify_ = false;
 	float cameras_extent_ = 1.0f, densify_min_opacity_ = 0.005f;
-	int prune_big_point_after_iter_ = 0;
+	int prune_big_point_after_iter_ = 30000;   // Optimization.prune_big_point_after_iter of the shipped Replica / EuRoC configs (no in-code default in the reference)
 	c10::optional<at::Generator> generator_;
 	GaussianModel::DensifyResult last_densify_;
 	// The Adam step of the SH tensor inside the rasterizer's backward (gsr_backward_args.sh_adam: its gradient rows never

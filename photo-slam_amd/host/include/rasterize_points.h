@@ -22,7 +22,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 // this Adam step to `sh` IN PLACE instead of computing dL_dsh (which then comes back undefined).
 struct ShAdamStep {
 	torch::Tensor exp_avg, exp_avg_sq;   // [P,16,3], contiguous
-	float lr = 0.f, lr_tail = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-15f;
+	double lr = 0.0, lr_tail = 0.0, beta1 = 0.9, beta2 = 0.999, eps = 1e-15;   // double, as torch::optim::AdamOptions
 	int step = 0;
 };
 

@@ -77,11 +77,16 @@ void GaussianModel::replaceParam(int group, torch::Tensor fresh, torch::Tensor e
 	}
 }
 
-// src/gaussian_model.cpp:553-565: opacity <- inverse_sigmoid(min(opacity, 0.01)), Adam moments zeroed
+// src/gaussian_model.cpp:556-565 exactly as shipped: inverse_sigmoid(min(sigmoid(o), ones_like(sigmoid(o) * 0.01))) -- the
+// 0.01 sits INSIDE ones_like, so the clamp is against 1 and never binds: the values survive (up to the sigmoid / logit round
+// trip) and only the Adam moments of the opacity group are zeroed.  intended_opacity_reset_ (default off) selects the reset
+// 3DGS intended, opacity <- min(opacity, 0.01): a deliberate deviation a caller has to ask for.
 void GaussianModel::resetOpacity()
 {
 	torch::NoGradGuard ng;
-	auto fresh = inverse_sigmoid(torch::min(getOpacityActivation(), torch::ones_like(opacity_) * 0.01)).detach().clone();
+	auto act = getOpacityActivation();
+	auto bound = intended_opacity_reset_ ? torch::ones_like(act) * 0.01 : torch::ones_like(act * 0.01);
+	auto fresh = inverse_sigmoid(torch::min(act, bound)).detach().clone();
 	replaceParam(2, fresh, torch::Tensor(), torch::Tensor());
 }
 
@@ -162,7 +167,7 @@ GaussianModel::DensifyResult GaussianModel::densifyAndPrune(float max_grad, floa
 		// max_radii2D is reset by densificationPostfix before the prune, so big_points_vs is always false there
 		auto new_smax = torch::cat({smax.index_select(0, keep_idx), smax.index_select(0, clone_idx),
 		                            std::get<0>(torch::exp(child_scaling).max(1))});
-		prune = prune | (new_smax > 0.1 * extent);
+		prune = prune | (new_smax > 0.1f * extent);   // float product, as the reference
 	}
 	auto sel = ~prune;
 	const auto n_old = keep_idx.size(0) + clone_idx.size(0);

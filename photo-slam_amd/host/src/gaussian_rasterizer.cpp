@@ -57,9 +57,9 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 		sh_adam.exp_avg = ctx->saved_data["sh_adam_m"].toTensor();
 		sh_adam.exp_avg_sq = ctx->saved_data["sh_adam_v"].toTensor();
 		const auto h = ctx->saved_data["sh_adam_h"].toDoubleVector();
-		sh_adam.lr = static_cast<float>(h[0]); sh_adam.lr_tail = static_cast<float>(h[1]);
-		sh_adam.beta1 = static_cast<float>(h[2]); sh_adam.beta2 = static_cast<float>(h[3]);
-		sh_adam.eps = static_cast<float>(h[4]); sh_adam.step = static_cast<int>(h[5]);
+		sh_adam.lr = h[0]; sh_adam.lr_tail = h[1];
+		sh_adam.beta1 = h[2]; sh_adam.beta2 = h[3];
+		sh_adam.eps = h[4]; sh_adam.step = static_cast<int>(h[5]);
 	}
 	std::vector<torch::Tensor> view_stats;
 	if (ctx->saved_data.count("view_stats")) view_stats = ctx->saved_data["view_stats"].toTensorVector();

@@ -186,6 +186,21 @@ std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five g
 	return out;
 }
 
+// Adam step counters of the five groups (torch::optim::AdamParamState::step of the reference's six: features_dc and
+// features_rest share one counter here, as they always carry a gradient together)
+std::vector<int64_t> trainer_steps(int64_t h)
+{
+	std::vector<int64_t> out;
+	for (auto& g : get(h)->gaussians_->groups_) out.push_back(g.step);
+	return out;
+}
+void trainer_set_steps(int64_t h, std::vector<int64_t> steps)
+{
+	auto& groups = get(h)->gaussians_->groups_;
+	TORCH_CHECK(steps.size() == groups.size(), "one step counter per parameter group");
+	for (size_t i = 0; i < groups.size(); i++) groups[i].step = (int)steps[i];
+}
+
 bool trainer_densify_due(int64_t h) { return get(h)->densifyDue(); }
 
 // view-factored exchange of the data-parallel step (bench.py --gpus N, trainer.ViewFactoredExchange)
@@ -245,6 +260,8 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_prune_points", &trainer_prune_points);
 	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
 	m.def("trainer_moments", &trainer_moments);
+	m.def("trainer_steps", &trainer_steps);
+	m.def("trainer_set_steps", &trainer_set_steps);
 	m.def("trainer_densify_due", &trainer_densify_due);
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);

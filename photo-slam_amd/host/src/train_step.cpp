@@ -81,7 +81,7 @@ void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)
 {
 	opt_ = opt;
 	groups_.clear();
-	auto add = [&](torch::Tensor& p, float lr, int period = 0, int split = 0, float lr_tail = 0.f) {
+	auto add = [&](torch::Tensor& p, double lr, int period = 0, int split = 0, double lr_tail = 0.0) {
 		AdamGroup g;
 		g.param = p;
 		g.exp_avg = torch::zeros_like(p);
@@ -94,7 +94,7 @@ void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)
 	};
 	add(xyz_, opt.position_lr_init_ * spatial_lr_scale_);
 	// features_dc (lr) | features_rest (lr / 20) share the [P,16,3] buffer
-	add(features_, opt.feature_lr_, 3 * (max_sh_degree_ + 1) * (max_sh_degree_ + 1), 3, opt.feature_lr_ / 20.0f);
+	add(features_, opt.feature_lr_, 3 * (max_sh_degree_ + 1) * (max_sh_degree_ + 1), 3, opt.feature_lr_ / 20.0);   // double division, :495
 	add(opacity_, opt.opacity_lr_);
 	add(scaling_, opt.scaling_lr_);
 	add(rotation_, opt.rotation_lr_);
@@ -122,7 +122,7 @@ void GaussianModel::optimizerStepGroup(int group)
 	grad = grad.contiguous();
 	g.step++;
 	check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
-	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9f, 0.999f, 1e-15f, g.step, g.period,
+	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9, 0.999, 1e-15, g.step, g.period,
 	                    g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
 	      "gsr_adam_step");
 }
@@ -255,7 +255,7 @@ void TrainStep::finishBegin()
 	if (iteration_ < g->opt_.densify_until_iter_ && densify_) {
 		const auto& o = g->opt_;
 		if (densifyDue()) {
-			const int size_threshold = (prune_big_point_after_iter_ > 0 && iteration_ > prune_big_point_after_iter_) ? 20 : 0;
+			const int size_threshold = iteration_ > prune_big_point_after_iter_ ? 20 : 0;   // src/gaussian_mapper.cpp:723
 			g->zeroGrad();   // shapes change; this step's update is skipped
 			last_densify_ = g->densifyAndPrune(o.densify_grad_threshold_, densify_min_opacity_, cameras_extent_, size_threshold,
 			                                   generator_);

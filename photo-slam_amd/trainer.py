@@ -159,7 +159,7 @@ def allreduce_mean(tensors, world_size):
 
 class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
-                 densify_min_opacity=0.005, prune_big_point_after_iter=0, seed=0, factored_exchange=True, fused_sh_adam=True):
+                 densify_min_opacity=0.005, prune_big_point_after_iter=30000, seed=0, factored_exchange=True, fused_sh_adam=True):
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
         self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
         self.densify_, self.densify_min_opacity_ = densify, densify_min_opacity
@@ -184,8 +184,10 @@ class TrainStep:
         sh_send = sh_view = sh_adam = None
         if self.world_size_ > 1 and self.factored_exchange_:
             sh_send, sh_view = ViewFactoredExchange.send_buffer(g.xyz_.size(0), g.xyz_.device)
-        rebuilds = self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and \
-            it % opt.densification_interval_ == 0    # this iteration densifies: the reference skips its optimizer step
+        # this iteration densifies (src/gaussian_mapper.cpp:720-721; the fresh leaves have no gradient, so the reference's
+        # optimizer step skips every group)
+        rebuilds = bool(self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and
+                        opt.densification_interval_ and it % opt.densification_interval_ == 0)
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
                 g.features_.size(1) == 16 and g.optimizer_ is not None:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP)
@@ -211,17 +213,19 @@ class TrainStep:
                     reduction = GradientReduction([p.grad for p in g.params()], self.world_size_)
             if it < opt.densify_until_iter_:
                 if self.densify_:
-                    if reduction is not None and (it % opt.densification_interval_ == 0 or
-                                                  (opt.opacity_reset_interval_ and it % opt.opacity_reset_interval_ == 0)):
-                        reduction.wait_all()   # the tensors are about to be rebuilt
+                    if reduction is not None and rebuilds:
+                        # every tensor is about to be rebuilt and this step's update is skipped: the exchange only has to
+                        # finish.  (An opacity reset alone replaces ONE leaf: the other groups keep their gradients and
+                        # step below through the reduction, the reset opacity has no gradient and is skipped -- :732-735.)
+                        reduction.wait_all()
                         reduction = None
-                    if it > opt.densify_from_iter_ and it % opt.densification_interval_ == 0:       # :721-730
+                    if rebuilds:                                                                    # :721-730
                         if self.world_size_ > 1:
                             # the batch's statistics since the last densification: norm sums and counts SUM, radii MAX
                             dist.all_reduce(g.xyz_gradient_accum_, op=dist.ReduceOp.SUM)
                             dist.all_reduce(g.denom_, op=dist.ReduceOp.SUM)
                             dist.all_reduce(g.max_radii2D_, op=dist.ReduceOp.MAX)
-                        size_threshold = 20 if it > self.prune_big_point_after_iter_ > 0 else 0
+                        size_threshold = 20 if it > self.prune_big_point_after_iter_ else 0   # :723
                         g.optimizer_.zero_grad(set_to_none=True)   # shapes change; this step's update is skipped
                         self.last_densify_ = g.densifyAndPrune(opt.densify_grad_threshold_, self.densify_min_opacity_,
                                                                self.cameras_extent_, size_threshold,
