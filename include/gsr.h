@@ -213,6 +213,58 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int gsr_densify_stats(int P, const float* dL_dmean2D, const int* radii, float* xyz_gradient_accum, float* denom,
                       float* max_radii2D, void* stream);
 
+/* ---- densification / pruning as stream compaction ----
+ * GaussianModel::densifyAndPrune = densifyAndClone + densifyAndSplit (N = 2) + the final prunePoints
+ * (src/gaussian_model.cpp:716-815) rebuild every tensor and Adam moment 4-6 times through boolean-mask indexing and cat.
+ * Here: gsr_densify_select turns the per-Gaussian decisions into a gather plan with deterministic ballot/prefix ranks (no
+ * atomics, no host round trip inside), the caller reads the six counts ONCE to size the new tensors, and
+ * gsr_densify_gather rebuilds all five parameter tensors, their ten moment tensors and the statistics in one launch.
+ * Order of the new set, as the reference's: [originals neither split nor pruned | surviving clones | surviving first
+ * children | surviving second children], each block in source order.
+ *
+ * Decisions (all fp32, thresholds formed as the reference forms them):
+ *   g = accum / denom, nan -> 0;  smax = max(exp(scaling));  big = smax > percent_dense * extent
+ *   clone: sqrt(g*g) >= max_grad && !big          split: g >= max_grad && big
+ *   pruned row: sigmoid(opacity) < min_opacity || (max_screen_size != 0 && its activated scale > 0.1f * extent)
+ *   (clones inherit the source's decision; both children carry scale / 1.6; max_radii2D is zero at that point -- it was
+ *   reset by densificationPostfix -- so the reference's screen-size term never fires)
+ * prune_mask != NULL selects GaussianModel::prunePoints(mask) (:588-642) instead: keep = !mask, no clones, no children. */
+typedef struct gsr_densify_select_args {
+	int P;
+	const float* xyz_gradient_accum;  /* [P] ([P,1]) */
+	const float* denom;               /* [P] */
+	const float* scaling;             /* [P,3] log-scales (the raw parameter) */
+	const float* opacity;             /* [P] logits (the raw parameter) */
+	float percent_dense, max_grad, min_opacity, extent;
+	int max_screen_size;
+	const uint8_t* prune_mask;        /* [P] bytes (bool) or NULL */
+} gsr_densify_select_args;
+size_t gsr_densify_scratch_bytes(int P);
+/* counts: DEVICE int[8], written on the stream: [0] kept originals, [1] surviving clones, [2] surviving parents of
+ * children (2 rows each), [3] split-selected parents k (the reference draws 2k x 3 normal samples, parent-major per copy),
+ * [4] clone-selected, [5] rows of the new set = [0] + [1] + 2 [2].  scratch: gsr_densify_scratch_bytes(P) device bytes; it
+ * holds the plan and must reach gsr_densify_gather unchanged. */
+int gsr_densify_select(const gsr_densify_select_args* args, char* scratch, int* counts, void* stream);
+
+typedef struct gsr_densify_gather_args {
+	int P;                            /* rows of the source arrays (as passed to gsr_densify_select) */
+	int n_new, n_keep, n_clone, n_child, n_split;   /* counts[5], [0], [1], [2], [3] read back by the caller */
+	int features_row_floats;          /* 3 * M of the [P,M,3] SH tensor */
+	/* index 0..4 = xyz [.,3], features [.,M,3], opacity [.,1], scaling [.,3], rotation [.,4]; moments may be NULL (in and
+	 * out together) when no optimizer state exists.  In and out must not overlap. */
+	const float* param_in[5];
+	const float* exp_avg_in[5];
+	const float* exp_avg_sq_in[5];
+	float* param_out[5];
+	float* exp_avg_out[5];
+	float* exp_avg_sq_out[5];
+	/* [2 n_split, 3] STANDARD normal draws: a child's offset is R(q_parent) * (z * exp(scaling_parent)), i.e.
+	 * at::normal(0, std) of the reference (:731-736) is randn * std.  NULL allowed when n_child == 0. */
+	const float* samples;
+	float* stats_out[3];              /* xyz_gradient_accum, denom, max_radii2D of the new set ([n_new] each): zero-filled; NULL = skip */
+} gsr_densify_gather_args;
+int gsr_densify_gather(const gsr_densify_gather_args* args, const char* scratch, void* stream);
+
 /* ---- Photo-SLAM's point-cloud kernels ----
  * transformPoints (src/operate_points.cu:73-93): out = M[:3,:4] * (p, 1), M = transformmatrix[16] with
  * element (r,c) at [4c+r] (transformPoint4x3). */

@@ -23,6 +23,7 @@ SOURCES = [
     ("preprocess_bwd.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("knn.hip", ["-ffp-contract=off"]),
     ("points.hip", ["-ffp-contract=off"]),
+    ("densify.hip", ["-ffp-contract=off"]),
     ("sort.hip", []),
     ("binning.hip", []),
     ("blend_fwd.hip", []),

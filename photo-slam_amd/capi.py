@@ -53,6 +53,20 @@ class BackwardArgs(C.Structure):
                 ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam)),
                 ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p)]
 
+class DensifySelectArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("scaling", C.c_void_p),
+                ("opacity", C.c_void_p), ("percent_dense", C.c_float), ("max_grad", C.c_float), ("min_opacity", C.c_float),
+                ("extent", C.c_float), ("max_screen_size", C.c_int), ("prune_mask", C.c_void_p)]
+
+
+class DensifyGatherArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("n_new", C.c_int), ("n_keep", C.c_int), ("n_clone", C.c_int), ("n_child", C.c_int),
+                ("n_split", C.c_int), ("features_row_floats", C.c_int),
+                ("param_in", C.c_void_p * 5), ("exp_avg_in", C.c_void_p * 5), ("exp_avg_sq_in", C.c_void_p * 5),
+                ("param_out", C.c_void_p * 5), ("exp_avg_out", C.c_void_p * 5), ("exp_avg_sq_out", C.c_void_p * 5),
+                ("samples", C.c_void_p), ("stats_out", C.c_void_p * 3)]
+
+
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 
 
@@ -74,7 +88,8 @@ EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
     "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
-    "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
+    "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_densify_scratch_bytes",
+    "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
     "gsr_neighborhood_depth_pinhole", "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
     "gsr_stage_scan_u32", "gsr_sort_scratch_bytes", "gsr_stage_radix_sort_pairs",
 ]
@@ -132,6 +147,12 @@ def load(path=None):
     L.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_longlong, f64, f64, f64, f64, i32, i32, i32, f64, vp]
     L.gsr_densify_stats.restype = i32
     L.gsr_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.gsr_densify_scratch_bytes.restype = sz
+    L.gsr_densify_scratch_bytes.argtypes = [i32]
+    L.gsr_densify_select.restype = i32
+    L.gsr_densify_select.argtypes = [C.POINTER(DensifySelectArgs), vp, vp, vp]
+    L.gsr_densify_gather.restype = i32
+    L.gsr_densify_gather.argtypes = [C.POINTER(DensifyGatherArgs), vp, vp]
     L.gsr_transform_points.restype = i32
     L.gsr_transform_points.argtypes = [i32, vp, vp, vp, vp]
     L.gsr_scale_transform_points.restype = i32

@@ -3,6 +3,7 @@ densification statistics -- the parts of src/gaussian_model.cpp the measured tra
 (activations :48-101, trainingSetup :477-510, addDensificationStats :817-831,
 exponLrFunc :1118-1131).  ATen ops on the HIP device; fused HIP versions are a "next" row
 (SURVEY.md 8f)."""
+import ctypes as C
 import math
 from dataclasses import dataclass
 
@@ -277,125 +278,118 @@ class GaussianModel:
 
 
     # ------------------------------------------------------------------ densification (amortised 1/interval)
-    # src/gaussian_model.cpp:588-815.  Same selection rules, same resulting order
-    # [originals that were not split | clones | split children] and the same Adam-state surgery, but each
-    # tensor is rebuilt ONCE (the reference copies every tensor 4-6 times through clone -> cat -> split -> cat
-    # -> prune -> prune and then drops the allocator cache).
+    # src/gaussian_model.cpp:588-815 as stream compaction (csrc/densify.hip, include/gsr.h): gsr_densify_select turns the
+    # per-Gaussian decisions into a gather plan on the device, the host reads the counts ONCE (it has to size the new
+    # tensors), gsr_densify_gather rebuilds the five parameter tensors, their ten Adam moments and the statistics in one
+    # launch.  Same selection rules, same resulting order [originals that were not split | clones | first children | second
+    # children] and the same Adam-state surgery as the reference, which copies every tensor 4-6 times through clone -> cat ->
+    # split -> cat -> prune -> prune and then drops the allocator cache (:814).  Pinned to the reference's own functions by
+    # tests/test_densify_reference.py.
     _PARAM_NAMES = ("xyz_", "features_", "opacity_", "scaling_", "rotation_")
 
-    def _rebuild(self, index, overrides=None):
-        """Gather all parameters / Adam moments with `index` (long tensor into the current arrays; -1 = new
-        entry whose moments are zero); overrides: {name: (positions, values)} applied after the gather."""
-        new_rows = index < 0
-        safe = index.clamp_min(0)
-        for name in self._PARAM_NAMES:
-            old = getattr(self, name)
-            m, v = self.optimizer_.moments(old) if self.optimizer_ is not None else (None, None)
-            with torch.no_grad():
-                new = old.detach()[safe].clone()
-                if overrides and name in overrides:
-                    pos, val = overrides[name]
-                    new[pos] = val
-                new.requires_grad_(True)
+    def reserve(self, capacity):
+        """Arena for the rebuilds: two sets of [capacity, row] buffers for the five parameters, their moments and the three
+        statistics arrays.  densifyAndPrune / prunePoints gather from the live tensors into the idle set and swap, so a
+        growing map allocates nothing until it outgrows the capacity (then the arena grows by 1.5x).  Without this call the
+        arena is created on the first rebuild with 25 % headroom."""
+        rows = dict(xyz_=(3,), features_=tuple(self.features_.shape[1:]), opacity_=(1,), scaling_=(3,), rotation_=(4,))
+        dev = self.xyz_.device
+        mk = lambda shape: torch.empty((capacity,) + shape, device=dev, dtype=torch.float32)
+        self._arena = dict(capacity=capacity, cur=0,
+                           sets=[dict(params={n: [mk(r), mk(r), mk(r)] for n, r in rows.items()},
+                                      stats=[mk((1,)), mk((1,)), mk(())]) for _ in range(2)])
+
+    def _compact(self, select, generator=None):
+        """select: fills a capi.DensifySelectArgs.  Returns the counts [kept, clones, child parents, split, clone-selected,
+        rows of the new set]."""
+        lib = rp._lib()
+        P = self.xyz_.shape[0]
+        dev = self.xyz_.device
+        stream = rp._stream_ptr(self.xyz_)
+        with torch.no_grad():
+            a = capi.DensifySelectArgs()
+            a.P = P
+            keep = select(a)
+            nbytes = lib.gsr_densify_scratch_bytes(P)
+            scratch = getattr(self, "_densify_scratch", None)
+            if scratch is None or scratch.numel() < nbytes or scratch.device != dev:
+                scratch = self._densify_scratch = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+            counts = torch.empty(8, dtype=torch.int32, device=dev)
+            capi.check(lib, lib.gsr_densify_select(C.byref(a), scratch.data_ptr(), counts.data_ptr(), stream), "gsr_densify_select")
+            n_keep, n_clone, n_child, n_split, n_clone_sel, n_new = counts.tolist()[:6]   # the one host read of the rebuild
+            del keep
+            arena = getattr(self, "_arena", None)
+            if arena is None or arena["capacity"] < n_new or arena["sets"][0]["params"]["xyz_"][0].device != dev:
+                grow = max(n_new, P)
+                self.reserve(int(grow * (1.25 if arena is None else 1.5)) + 64)
+                arena = self._arena
+            arena["cur"] ^= 1
+            dst = arena["sets"][arena["cur"]]
+            # at::normal(zeros, stds) of the reference (:731-734) is randn(2k,3) * stds: the same draws, the scale applied in-kernel
+            samples = torch.empty((2 * n_split, 3), device=dev).normal_(generator=generator) if n_split else None
+            g = capi.DensifyGatherArgs()
+            g.P, g.n_new, g.n_keep, g.n_clone, g.n_child, g.n_split = P, n_new, n_keep, n_clone, n_child, n_split
+            g.features_row_floats = int(self.features_.shape[1] * self.features_.shape[2])
+            olds, news = [], []
+            for i, name in enumerate(self._PARAM_NAMES):
+                old = getattr(self, name)
+                m, v = self.optimizer_.moments(old) if self.optimizer_ is not None and id(old) in self.optimizer_.state else (None, None)
+                outs = [b.narrow(0, 0, n_new) for b in dst["params"][name]]
+                src = old.detach()
+                assert src.is_contiguous()
+                g.param_in[i], g.param_out[i] = src.data_ptr(), outs[0].data_ptr()
                 if m is not None:
-                    m2, v2 = m[safe].clone(), v[safe].clone()
-                    m2[new_rows] = 0
-                    v2[new_rows] = 0
+                    g.exp_avg_in[i], g.exp_avg_sq_in[i] = m.data_ptr(), v.data_ptr()
+                    g.exp_avg_out[i], g.exp_avg_sq_out[i] = outs[1].data_ptr(), outs[2].data_ptr()
+                olds.append((old, src, m, v))
+                news.append(outs)
+            g.samples = samples.data_ptr() if samples is not None else None
+            stats = [b.narrow(0, 0, n_new) for b in dst["stats"]]
+            for k in range(3):
+                g.stats_out[k] = stats[k].data_ptr()
+            if n_new:
+                capi.check(lib, lib.gsr_densify_gather(C.byref(g), scratch.data_ptr(), stream), "gsr_densify_gather")
+        for name, (old, _, m, _), outs in zip(self._PARAM_NAMES, olds, news):
+            new = outs[0].detach().requires_grad_(True)
             setattr(self, name, new)
             if self.optimizer_ is not None:
-                self.optimizer_.replace_param(old, new, m2, v2)
-        n = index.shape[0]
-        dev = self.xyz_.device
-        return n, dev
+                if m is not None:
+                    self.optimizer_.replace_param(old, new, outs[1], outs[2])
+                else:
+                    self.optimizer_.replace_param(old, new, outs[1].zero_(), outs[2].zero_())
+        self.xyz_gradient_accum_, self.denom_, self.max_radii2D_ = stats
+        return n_keep, n_clone, n_child, n_split, n_clone_sel, n_new
 
     def prunePoints(self, mask):
-        """:588-642"""
-        keep = torch.nonzero(~mask).squeeze(1)
-        self._rebuild(keep)
-        self.xyz_gradient_accum_ = self.xyz_gradient_accum_[keep]
-        self.denom_ = self.denom_[keep]
-        self.max_radii2D_ = self.max_radii2D_[keep]
+        """:588-642: keep = ~mask for the six tensors, their moments and the three statistics arrays (which, unlike in
+        densifyAndPrune, keep their values)."""
+        P = self.xyz_.shape[0]
+        mask_u8 = mask.to(torch.uint8).contiguous()
+        old_stats = (self.xyz_gradient_accum_, self.denom_, self.max_radii2D_)
 
-    def densifyAndPrune(self, max_grad, min_opacity, extent, max_screen_size, generator=None, N=2):
-        """:795-815 (densifyAndClone :763-793, densifyAndSplit :716-761, prunePoints :588-642) in one rebuild."""
-        with torch.no_grad():
-            grads = self.xyz_gradient_accum_ / self.denom_
-            grads[grads.isnan()] = 0.0
-            g = grads.squeeze(-1)
-            scal = self.getScalingActivation()
-            smax = scal.max(dim=1).values
-            # the reference's thresholds are C++ float products / float arguments: evaluate them in fp32 too, or a Gaussian
-            # sitting exactly on a threshold is classified differently
-            import numpy as _np
-            f32 = _np.float32
-            max_grad, min_opacity = float(f32(max_grad)), float(f32(min_opacity))
-            big = smax > float(f32(self.percent_dense_) * f32(extent))
-            clone_mask = (g.abs() >= max_grad) & ~big          # frobenius_norm over the last dim of [P,1]
-            split_mask = (g >= max_grad) & big
-            P = self.xyz_.shape[0]
-            ar = torch.arange(P, device=self.xyz_.device)
-            keep_idx, clone_idx, split_idx = ar[~split_mask], ar[clone_mask], ar[split_mask]
-            rep = split_idx.repeat(N)
-            # children: position sampled from the parent Gaussian, scale / (0.8 N)
-            stds = scal[rep]
-            samples = torch.normal(torch.zeros_like(stds), stds, generator=generator)
-            q = self.rotation_.detach()[rep]
-            q = q / q.norm(dim=1, keepdim=True)
-            r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                             2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                             2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
-            child_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self.xyz_.detach()[rep]
-            child_scaling = torch.log(stds / (0.8 * N))
-            # new entries are marked by (-1 - source) so their Adam moments come out zero
-            index = torch.cat([keep_idx, clone_idx, rep])
-            is_new = torch.cat([torch.zeros_like(keep_idx, dtype=torch.bool), torch.ones_like(clone_idx, dtype=torch.bool),
-                                torch.ones_like(rep, dtype=torch.bool)])
-            # final prune (:805-813) evaluated on the would-be tensors
-            opac = torch.sigmoid(self.opacity_.detach()[index]).squeeze(-1)
-            prune = opac < min_opacity
-            if max_screen_size:
-                # max_radii2D is reset by densificationPostfix before the prune, so big_points_vs is always false
-                new_smax = torch.cat([smax[keep_idx], smax[clone_idx], torch.exp(child_scaling).max(dim=1).values])
-                prune = prune | (new_smax > float(f32(0.1) * f32(extent)))   # 0.1f * extent
-            sel = ~prune
-            child_pos_all = torch.arange(keep_idx.shape[0] + clone_idx.shape[0], index.shape[0], device=index.device)
-            new_pos = torch.cumsum(sel.to(torch.int64), 0) - 1
-            child_sel = sel[child_pos_all]
-            child_pos = new_pos[child_pos_all][child_sel]
-            index_f = index[sel]
-            is_new_f = is_new[sel]
-        gather_index = torch.where(is_new_f, -1 - index_f, index_f)
-        self._rebuild_with_sources(gather_index, {"xyz_": (child_pos, child_xyz[child_sel]),
-                                                  "scaling_": (child_pos, child_scaling[child_sel])})
-        n = gather_index.shape[0]
-        dev = self.xyz_.device
-        self.xyz_gradient_accum_ = torch.zeros((n, 1), device=dev)
-        self.denom_ = torch.zeros((n, 1), device=dev)
-        self.max_radii2D_ = torch.zeros(n, device=dev)
-        return dict(cloned=int(clone_idx.shape[0]), split=int(split_idx.shape[0]), pruned=int(prune.sum()), points=n,
-                    children_kept=int(child_sel.sum()))
+        def select(a):
+            a.prune_mask = mask_u8.data_ptr()
+            return mask_u8
+        self._compact(select)
+        keep = ~mask.bool()
+        self.xyz_gradient_accum_.copy_(old_stats[0][keep])
+        self.denom_.copy_(old_stats[1][keep])
+        self.max_radii2D_.copy_(old_stats[2][keep])
 
-    def _rebuild_with_sources(self, gather_index, overrides):
-        """gather_index >= 0: existing row (keeps its Adam moments); < 0: copy of row (-1 - value) with zero moments."""
-        new_rows = gather_index < 0
-        src = torch.where(new_rows, -1 - gather_index, gather_index)
-        for name in self._PARAM_NAMES:
-            old = getattr(self, name)
-            m, v = self.optimizer_.moments(old) if self.optimizer_ is not None else (None, None)
-            with torch.no_grad():
-                new = old.detach()[src].clone()
-                if name in overrides:
-                    pos, val = overrides[name]
-                    new[pos] = val
-                new.requires_grad_(True)
-                if m is not None:
-                    m2, v2 = m[src].clone(), v[src].clone()
-                    m2[new_rows] = 0
-                    v2[new_rows] = 0
-            setattr(self, name, new)
-            if self.optimizer_ is not None:
-                self.optimizer_.replace_param(old, new, m2, v2)
+    def densifyAndPrune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """:795-815 (densifyAndClone :763-793, densifyAndSplit :716-761 with N = 2, prunePoints :588-642) in one rebuild."""
+        P = self.xyz_.shape[0]
+        tensors = (self.xyz_gradient_accum_.contiguous(), self.denom_.contiguous(), self.scaling_.detach().contiguous(),
+                   self.opacity_.detach().contiguous())
+
+        def select(a):
+            a.xyz_gradient_accum, a.denom, a.scaling, a.opacity = (t.data_ptr() for t in tensors)
+            a.percent_dense, a.max_grad, a.min_opacity, a.extent = self.percent_dense_, max_grad, min_opacity, extent
+            a.max_screen_size = int(max_screen_size)
+            return tensors
+        n_keep, n_clone, n_child, n_split, n_clone_sel, n_new = self._compact(select, generator)
+        pruned = (P - n_split - n_keep) + (n_clone_sel - n_clone) + 2 * (n_split - n_child)
+        return dict(cloned=n_clone_sel, split=n_split, pruned=pruned, points=n_new, children_kept=2 * n_child)
 
     def resetOpacity(self, clamp_to=None):
         """src/gaussian_model.cpp:556-565 exactly as shipped: opacities_new = inverse_sigmoid(min(sigmoid(o), ones_like(sigmoid(o)

@@ -6,6 +6,7 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <array>
 #include <cmath>
 #include <memory>
 #include <vector>
@@ -81,11 +82,22 @@ public:
 	GaussianOptimizationParams opt_;
 	std::vector<AdamGroup> groups_;
 
+	// arena of the rebuilds (gaussian_model_densify.cpp): optional, created on the first rebuild otherwise
+	void reserve(int64_t capacity);
+
 private:
 	torch::Tensor& paramByIndex(int i);
 	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq);
-	void rebuildWithSources(const torch::Tensor& gather_index, const torch::Tensor& child_pos, const torch::Tensor& child_xyz,
-	                        const torch::Tensor& child_scaling);
+	// gsr_densify_select + one host read + gsr_densify_gather; returns kept, clones, child parents, split, clone-selected, rows
+	std::array<int64_t, 6> compact(struct gsr_densify_select_args& sel, c10::optional<at::Generator> generator);
+	static void* hostStream(const torch::Tensor& t);   // the current HIP stream of the tensor's device (null on the host)
+	struct Arena {
+		int64_t capacity = 0;
+		int cur = 0;
+		std::array<std::array<torch::Tensor, 3>, 5> params[2];   // [set][tensor][parameter, exp_avg, exp_avg_sq]
+		std::array<torch::Tensor, 3> stats[2];
+	} arena_;
+	torch::Tensor densify_scratch_;
 };
 
 // GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774) without the SLAM keyframe

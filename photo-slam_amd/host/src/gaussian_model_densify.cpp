@@ -5,9 +5,16 @@
 // Adam-state surgery as the reference, but every tensor is rebuilt ONCE per call: the reference copies each of the six
 // parameter tensors and their moments 4-6 times (clone -> cat -> split -> cat -> prune -> prune, each through
 // replaceTensorToOptimizer / catTensorstoOptimizer / prunePoints) and then empties the allocator cache.
+#include <array>
 #include <stdexcept>
+#include <string>
 
+#include "../../../include/gsr.h"
 #include "gaussian_model_lite.h"
+
+#ifndef GSR_HOST_NO_HIP
+#include <c10/hip/HIPStream.h>
+#endif
 #include "spatial.h"
 
 namespace {
@@ -90,41 +97,119 @@ void GaussianModel::resetOpacity()
 	replaceParam(2, fresh, torch::Tensor(), torch::Tensor());
 }
 
-// One gather per tensor.  gather_index >= 0: existing row (keeps its Adam moments); < 0: copy of row (-1 - value) with
-// zero moments; child_pos / child_xyz / child_scaling overwrite the rows of the split children.
-void GaussianModel::rebuildWithSources(const torch::Tensor& gather_index, const torch::Tensor& child_pos,
-                                       const torch::Tensor& child_xyz, const torch::Tensor& child_scaling)
+// ---- rebuilds as stream compaction (csrc/densify.hip, include/gsr.h) ------------------------------------------------
+// gsr_densify_select turns the per-Gaussian decisions into a gather plan on the device, the host reads the counts ONCE (it
+// has to size the new tensors), gsr_densify_gather rebuilds the five parameter tensors, their ten Adam moments and the
+// statistics in one launch, out of the live tensors into the idle half of an arena.
+
+// Two sets of [capacity, row] buffers for the parameters, their moments and the statistics: a growing map allocates
+// nothing until it outgrows the capacity (then the arena grows by 1.5x).  Created on the first rebuild with 25 % headroom
+// unless the caller reserved one.
+void GaussianModel::reserve(int64_t capacity)
 {
-	torch::NoGradGuard ng;
-	auto new_rows = gather_index < 0;
-	auto src = torch::where(new_rows, -1 - gather_index, gather_index);
-	for (int i = 0; i < 5; i++) {
-		auto old = paramByIndex(i).detach();
-		auto fresh = old.index_select(0, src);
-		if (child_pos.defined() && child_pos.numel()) {
-			if (i == 0) fresh.index_copy_(0, child_pos, child_xyz);
-			if (i == 3) fresh.index_copy_(0, child_pos, child_scaling);
+	const auto o = xyz_.options().requires_grad(false);
+	const std::vector<std::vector<int64_t>> rows = {{3}, {features_.size(1), features_.size(2)}, {1}, {3}, {4}};
+	for (int s = 0; s < 2; s++) {
+		for (int i = 0; i < 5; i++) {
+			std::vector<int64_t> shape = {capacity};
+			shape.insert(shape.end(), rows[i].begin(), rows[i].end());
+			for (int k = 0; k < 3; k++) arena_.params[s][i][k] = torch::empty(shape, o);
 		}
-		torch::Tensor m, v;
-		if (static_cast<size_t>(i) < groups_.size()) {
-			m = groups_[static_cast<size_t>(i)].exp_avg.index_select(0, src);
-			v = groups_[static_cast<size_t>(i)].exp_avg_sq.index_select(0, src);
-			m.index_put_({new_rows}, 0.0f);
-			v.index_put_({new_rows}, 0.0f);
-		}
-		replaceParam(i, fresh, m, v);
+		arena_.stats[s][0] = torch::empty({capacity, 1}, o);
+		arena_.stats[s][1] = torch::empty({capacity, 1}, o);
+		arena_.stats[s][2] = torch::empty({capacity}, o);
 	}
+	arena_.capacity = capacity;
+	arena_.cur = 0;
 }
 
-// src/gaussian_model.cpp:588-642
+namespace {
+void check_gsr(int st, const char* where)
+{
+	if (st != GSR_OK) throw std::runtime_error(std::string(where) + ": " + gsr_strerror(st) + " (" + gsr_last_hip_error_string() + ")");
+}
+}  // namespace
+
+void* GaussianModel::hostStream(const torch::Tensor& t)
+{
+#ifndef GSR_HOST_NO_HIP
+	if (t.is_cuda()) return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+#endif
+	return nullptr;
+}
+
+std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10::optional<at::Generator> generator)
+{
+	torch::NoGradGuard ng;
+	const int64_t P = xyz_.size(0);
+	sel.P = static_cast<int>(P);
+	void* stream = hostStream(xyz_);
+	const auto bytes = static_cast<int64_t>(gsr_densify_scratch_bytes(sel.P));
+	if (!densify_scratch_.defined() || densify_scratch_.numel() < bytes || densify_scratch_.device() != xyz_.device())
+		densify_scratch_ = torch::empty({bytes + bytes / 4 + 256}, xyz_.options().dtype(torch::kUInt8).requires_grad(false));
+	auto counts = torch::empty({8}, xyz_.options().dtype(torch::kInt32).requires_grad(false));
+	check_gsr(gsr_densify_select(&sel, reinterpret_cast<char*>(densify_scratch_.data_ptr<uint8_t>()), counts.data_ptr<int>(), stream),
+	          "gsr_densify_select");
+	auto host = counts.cpu();   // the one host read of the rebuild
+	const int* c = host.data_ptr<int>();
+	const int64_t n_keep = c[0], n_clone = c[1], n_child = c[2], n_split = c[3], n_clone_sel = c[4], n_new = c[5];
+	if (arena_.capacity < n_new || !arena_.params[0][0][0].defined() || arena_.params[0][0][0].device() != xyz_.device())
+		reserve(static_cast<int64_t>(std::max(n_new, P) * (arena_.capacity ? 1.5 : 1.25)) + 64);
+	arena_.cur ^= 1;
+	auto& dst = arena_.params[arena_.cur];
+	// at::normal(zeros, stds) of the reference (:731-734) is randn(2k,3) * stds: the same draws, the scale applied in-kernel
+	torch::Tensor samples;
+	if (n_split) samples = torch::empty({2 * n_split, 3}, xyz_.options().requires_grad(false)).normal_(0.0, 1.0, generator);
+	gsr_densify_gather_args g{};
+	g.P = sel.P;
+	g.n_new = (int)n_new; g.n_keep = (int)n_keep; g.n_clone = (int)n_clone; g.n_child = (int)n_child; g.n_split = (int)n_split;
+	g.features_row_floats = static_cast<int>(features_.size(1) * features_.size(2));
+	std::vector<torch::Tensor> keep_alive;
+	const bool have_state = groups_.size() == 5;
+	std::array<std::array<torch::Tensor, 3>, 5> out;
+	for (int i = 0; i < 5; i++) {
+		auto src = paramByIndex(i).detach().contiguous();
+		keep_alive.push_back(src);
+		for (int k = 0; k < 3; k++) out[i][k] = dst[i][k].narrow(0, 0, n_new);
+		g.param_in[i] = src.data_ptr<float>();
+		g.param_out[i] = out[i][0].data_ptr<float>();
+		if (have_state) {
+			g.exp_avg_in[i] = groups_[i].exp_avg.data_ptr<float>();
+			g.exp_avg_sq_in[i] = groups_[i].exp_avg_sq.data_ptr<float>();
+			g.exp_avg_out[i] = out[i][1].data_ptr<float>();
+			g.exp_avg_sq_out[i] = out[i][2].data_ptr<float>();
+		}
+	}
+	g.samples = samples.defined() ? samples.data_ptr<float>() : nullptr;
+	std::array<torch::Tensor, 3> stats;
+	for (int k = 0; k < 3; k++) {
+		stats[k] = arena_.stats[arena_.cur][k].narrow(0, 0, n_new);
+		g.stats_out[k] = stats[k].data_ptr<float>();
+	}
+	if (n_new) check_gsr(gsr_densify_gather(&g, reinterpret_cast<const char*>(densify_scratch_.data_ptr<uint8_t>()), stream), "gsr_densify_gather");
+	for (int i = 0; i < 5; i++) {
+		if (have_state) replaceParam(i, out[i][0], out[i][1], out[i][2]);
+		else replaceParam(i, out[i][0], torch::Tensor(), torch::Tensor());
+	}
+	xyz_gradient_accum_ = stats[0];
+	denom_ = stats[1];
+	max_radii2D_ = stats[2];
+	return {n_keep, n_clone, n_child, n_split, n_clone_sel, n_new};
+}
+
+// src/gaussian_model.cpp:588-642 (the statistics keep their values here, unlike in densifyAndPrune)
 void GaussianModel::prunePoints(torch::Tensor& mask)
 {
 	torch::NoGradGuard ng;
-	auto keep = torch::nonzero(~mask).squeeze(1);
-	rebuildWithSources(keep, torch::Tensor(), torch::Tensor(), torch::Tensor());
-	xyz_gradient_accum_ = xyz_gradient_accum_.index_select(0, keep);
-	denom_ = denom_.index_select(0, keep);
-	max_radii2D_ = max_radii2D_.index_select(0, keep);
+	auto m8 = mask.to(torch::kUInt8).contiguous();
+	auto old_accum = xyz_gradient_accum_, old_denom = denom_, old_max = max_radii2D_;
+	gsr_densify_select_args sel{};
+	sel.prune_mask = m8.data_ptr<uint8_t>();
+	compact(sel, c10::nullopt);
+	auto keep = ~mask.to(torch::kBool);
+	xyz_gradient_accum_.copy_(old_accum.index({keep}));
+	denom_.copy_(old_denom.index({keep}));
+	max_radii2D_.copy_(old_max.index({keep}));
 }
 
 // src/gaussian_model.cpp:795-815 with densifyAndClone (:763-793), densifyAndSplit (:716-761, N = 2) and the final
@@ -133,60 +218,24 @@ GaussianModel::DensifyResult GaussianModel::densifyAndPrune(float max_grad, floa
                                                             int max_screen_size, c10::optional<at::Generator> generator)
 {
 	torch::NoGradGuard ng;
-	const int N = 2;
-	auto grads = xyz_gradient_accum_ / denom_;
-	grads.index_put_({grads.isnan()}, 0.0f);
-	auto g = grads.squeeze(-1);
-	auto scal = getScalingActivation().detach();
-	auto smax = std::get<0>(scal.max(1));
-	auto big = smax > opt_.percent_dense_ * extent;
-	auto clone_mask = (g.abs() >= max_grad) & ~big;   // frobenius_norm over the last dimension of [P,1]
-	auto split_mask = (g >= max_grad) & big;
-	const auto P = xyz_.size(0);
-	auto ar = torch::arange(P, torch::TensorOptions().dtype(torch::kLong).device(xyz_.device()));
-	auto keep_idx = ar.index({~split_mask}), clone_idx = ar.index({clone_mask}), split_idx = ar.index({split_mask});
-	auto rep = split_idx.repeat({N});
-	// children: position sampled from the parent Gaussian, scale / (0.8 N)
-	auto stds = scal.index_select(0, rep);
-	auto samples = at::normal(torch::zeros_like(stds), stds, generator);
-	auto q = rotation_.detach().index_select(0, rep);
-	q = q / q.norm(2, {1}, true);
-	auto r = q.select(1, 0), x = q.select(1, 1), y = q.select(1, 2), z = q.select(1, 3);
-	auto R = torch::stack({1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-	                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-	                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)}, 1).reshape({-1, 3, 3});
-	auto child_xyz = torch::bmm(R, samples.unsqueeze(-1)).squeeze(-1) + xyz_.detach().index_select(0, rep);
-	auto child_scaling = torch::log(stds / (0.8 * N));
-	auto index = torch::cat({keep_idx, clone_idx, rep});
-	auto is_new = torch::cat({torch::zeros_like(keep_idx, torch::kBool), torch::ones_like(clone_idx, torch::kBool),
-	                          torch::ones_like(rep, torch::kBool)});
-	// the final prune (:805-813), evaluated on the would-be tensors
-	auto opac = torch::sigmoid(opacity_.detach().index_select(0, index)).squeeze(-1);
-	auto prune = opac < min_opacity;
-	if (max_screen_size) {
-		// max_radii2D is reset by densificationPostfix before the prune, so big_points_vs is always false there
-		auto new_smax = torch::cat({smax.index_select(0, keep_idx), smax.index_select(0, clone_idx),
-		                            std::get<0>(torch::exp(child_scaling).max(1))});
-		prune = prune | (new_smax > 0.1f * extent);   // float product, as the reference
-	}
-	auto sel = ~prune;
-	const auto n_old = keep_idx.size(0) + clone_idx.size(0);
-	auto child_pos_all = torch::arange(n_old, index.size(0), ar.options());
-	auto new_pos = torch::cumsum(sel.to(torch::kLong), 0) - 1;
-	auto child_sel = sel.index_select(0, child_pos_all);
-	auto child_pos = new_pos.index_select(0, child_pos_all).index({child_sel});
-	auto index_f = index.index({sel});
-	auto is_new_f = is_new.index({sel});
-	auto gather_index = torch::where(is_new_f, -1 - index_f, index_f);
-	rebuildWithSources(gather_index, child_pos, child_xyz.index({child_sel}), child_scaling.index({child_sel}));
-	const auto n = gather_index.size(0);
-	xyz_gradient_accum_ = torch::zeros({n, 1}, xyz_.options().requires_grad(false));
-	denom_ = torch::zeros({n, 1}, xyz_.options().requires_grad(false));
-	max_radii2D_ = torch::zeros({n}, xyz_.options().requires_grad(false));
+	const int64_t P = xyz_.size(0);
+	auto accum = xyz_gradient_accum_.contiguous(), denom = denom_.contiguous();
+	auto scaling = scaling_.detach().contiguous(), opacity = opacity_.detach().contiguous();
+	gsr_densify_select_args sel{};
+	sel.xyz_gradient_accum = accum.data_ptr<float>();
+	sel.denom = denom.data_ptr<float>();
+	sel.scaling = scaling.data_ptr<float>();
+	sel.opacity = opacity.data_ptr<float>();
+	sel.percent_dense = opt_.percent_dense_;
+	sel.max_grad = max_grad;
+	sel.min_opacity = min_opacity;
+	sel.extent = extent;
+	sel.max_screen_size = max_screen_size;
+	const auto c = compact(sel, generator);
 	DensifyResult res;
-	res.cloned = clone_idx.size(0);
-	res.split = split_idx.size(0);
-	res.pruned = prune.sum().item<int64_t>();
-	res.points = n;
+	res.cloned = c[4];
+	res.split = c[3];
+	res.pruned = (P - c[3] - c[0]) + (c[4] - c[1]) + 2 * (c[3] - c[2]);
+	res.points = c[5];
 	return res;
 }

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "photo-slam_amd", "csrc")
 OUT = os.path.join(HERE, "libgsr_emu.so")
 SOURCES = ["gsr_api.hip", "preprocess.hip", "sort.hip", "binning.hip", "blend_fwd.hip", "blend_bwd.hip",
-           "preprocess_bwd.hip", "knn.hip", "train_ops.hip", "points.hip"]
+           "preprocess_bwd.hip", "knn.hip", "train_ops.hip", "points.hip", "densify.hip"]
 
 
 def build(force=False):

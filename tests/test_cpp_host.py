@@ -221,7 +221,7 @@ def run_map_maintenance_checks(ops, dev, lib_path):
         g.resetOpacity()
         ops.trainer_reset_opacity(h)
         assert torch.allclose(ops.trainer_params(h)[2], g.opacity_.detach(), rtol=1e-4, atol=1e-6)
-        assert not ops.trainer_moments(h)[2].any() and (torch.sigmoid(ops.trainer_params(h)[2]) <= 0.0100001).all()
+        assert not ops.trainer_moments(h)[2].any()   # (the values survive: tests/test_densify_reference.py pins the semantics)
         pm = torch.zeros(g.xyz_.shape[0], dtype=torch.bool, device=dev)
         pm[::3] = True
         g.prunePoints(pm)

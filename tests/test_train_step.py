@@ -280,10 +280,14 @@ def test_densify_and_prune_keeps_model_consistent(emu):
     for p in g.params():
         assert p.shape[0] == g.xyz_.shape[0] and p.requires_grad and p.is_leaf
     assert not g.denom_.any() and g.denom_.shape[0] == g.xyz_.shape[0]
-    # training continues on the new set; opacity reset clamps to 0.01
+    # training continues on the new set; the opacity reset as the reference ships it keeps the values and zeroes the
+    # opacity moments (tests/test_densify_reference.py); clamp_to=0.01 is the reset 3DGS intended, on request only
     loss = ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
     assert torch.isfinite(loss)
+    before = g.opacity_.detach().clone()
     g.resetOpacity()
+    assert torch.allclose(g.opacity_.detach(), before, rtol=1e-4, atol=1e-5) and not g.optimizer_.moments(g.opacity_)[0].any()
+    g.resetOpacity(clamp_to=0.01)
     assert float(torch.sigmoid(g.opacity_).max()) <= 0.01 + 1e-6
     assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
 
