@@ -2,26 +2,29 @@
 """bench.py -- throughput of the hot path on synthetic Gaussian clouds (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W [--config C3]
-  (N>1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N > 1 without WORLD_SIZE in the environment: re-executes itself under torch.distributed.run, one rank per GPU over RCCL)
 
-A "step" is one full training iteration of GaussianMapper::trainForOneIteration on one keyframe
-per GPU: render (HIP rasterizer forward) -> masked L1 + 0.2*(1-SSIM) -> backward (HIP
-rasterizer backward) -> densification statistics -> [all-reduce of the 6 leaf gradients when
-N>1] -> Adam.  Inputs are resident in HBM before the timed region.  N=1 workload = the
-configuration BASELINE.json's metric is quoted on: 2M Gaussians at 1920x1080 (config C3).
+A "step" is one full training iteration of GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:614-774) on one
+keyframe per GPU: render (HIP rasterizer forward) -> masked L1 + 0.2*(1-SSIM) -> backward (HIP rasterizer backward) ->
+densification statistics -> [gradient exchange when N>1] -> Adam.  Inputs are resident in HBM before the timed region.
+N=1 workload = the configuration BASELINE.json's metric is quoted on: 2M Gaussians at 1920x1080 (config C3).
 
-The JSON line carries, besides the contract fields:
-  value            train iterations/s over all GPUs (keyframes optimised per second)
-  mpix_per_s       rendered Mpix/s of the rasterizer forward+backward alone (HIP-event time of
-                   the rasterizer stages inside the same timed steps)
-  roofline         dominant rasterizer kernel: algorithmic bytes / its HIP-event
-                   duration vs the 8 TB/s HBM peak; "stages" lists every stage the same way
-  cpu_baseline     the CPU oracle (port of the reference kernels) timed on the host cores on
-                   the same scene (rank 0, N=1 only)
+Protocol:
+  * `value` / `ms_per_step`: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize (driver contract).
+  * The workload is STATIONARY: the timed legs run with every learning rate multiplied by 0 (`config.learning_rates`) -- the
+    same kernels, the same bytes, the Adam moments update, the parameters do not move.  With the training learning rates
+    the synthetic scene inflates by ~1 %/step (fitting one noisy view with Adam's eps 1e-15 drags opacities and scales
+    away from the generated statistics), so a mean over the first 20 steps flattered the number; `training_lr_run` reports
+    that run too, K steps from the same start.
+  * `protocol`: per-step times from HIP events on the stream, 20 warm-up + median of >= 100 steps, next to the wall clock.
+  * `roofline`: the dominant rasterizer kernel's duration from HIP events INSIDE the timed region; the stage table comes
+    from the same (fused) program, recorded in further steps with events between all stages.
+  * `cpu_baseline`: the reference's train step on the host cores (oracle/cpu_trainer.py), rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -31,43 +34,98 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# committed counter profiles of the same build (tools/gpu_pmc.sh, tools/gpu_sq.sh): the newest set that exists
+PMC_FILES = ["profiles/r02_pmc_traffic_C3_raster_only.json", "profiles/r01_j_pmc_traffic_C3_raster_only.json"]
 
 
-def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, fused_sh_adam=False):
-    """Compulsory HBM bytes per stage (each array read/written once per stage that
-    needs it), restated for this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the
-    Adam step of the SH tensor (no gradient rows written; both moments read, parameter + moments written for every
-    Gaussian, the parameter row read for the culled ones too)."""
+def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
+                      touched_slots=None):
+    """Compulsory HBM bytes per stage (each array read/written once per stage that needs it), restated for
+    this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the Adam step of the SH tensor
+    (no gradient rows written; both moments read, parameter + moments written for every Gaussian, the parameter row read for
+    the culled ones too).  touched_slots: instance slots the backward blend wrote (48 B each, read back once by
+    preprocess_bwd together with R flag bytes); None leaves them out."""
     adam = 12 * M * (4 * P + (P - V)) if fused_sh_adam else 0
+    S = P if sorted_gaussians is None else sorted_gaussians
+    slots = 0 if touched_slots is None else 48 * touched_slots + R
     return {
         "preprocess_fwd": 52 * P + (12 * K + 67) * V,
-        "depth_sort": 4 * 16 * P,                    # 4 passes x (8 B read + 8 B write) over P pairs
-        "offset_scan": 12 * P,
-        "emit_instances": 20 * P + 8 * R,
+        "depth_sort": depth_passes * 16 * S,         # passes x (8 B read + 8 B write) over the sorted pairs
+        "offset_scan": 12 * S,
+        "emit_instances": 20 * S + 8 * R,
         "tile_sort": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 8 * T,
         "blend_fwd": 40 * R + 20 * Npix,
         "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
-        "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V) + adam,
+        "preprocess_bwd": 4 * P + 88 * V + (143 + 24 * K) * V + (64 + 12 * M) * (P - V) + adam + slots,
     }
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `python -m torch.distributed.run ... bench.py ...`."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def cpu_train_step_baseline(scene, args, W, H, quick=False):
+    """The reference's CPU train step (oracle/cpu_trainer.py) on the box's host cores: C1 in full (>= 100 iterations after
+    warm-up) and >= 3 measured iterations of the benchmarked configuration.  ~20-30 s of CPU work on the GPU box."""
+    from oracle import cpu_trainer, oracle
+    out = {}
+
+    def run(name, iterations, warmup):
+        cl = scene.make_config(name, seed=0)
+        cam = cl.cameras[0]
+        res, color, _ = oracle.forward(np.zeros(3, np.float32), cl.xyz, cl.get_opacity(), cam.viewmatrix, cam.projmatrix, cam.campos,
+                                       cam.tanfovx, cam.tanfovy, cam.H, cam.W, shs=cl.get_features(), sh_degree=3,
+                                       scales=cl.get_scaling(), rotations=cl.get_rotation())
+        res.free()
+        rng = np.random.default_rng(1234)
+        gt = np.clip(color + 0.1 * (rng.random(color.shape, dtype=np.float32) - 0.5), 0.0, 1.0)   # as the GPU run: this view + noise
+        t0 = time.perf_counter()
+        r = cpu_trainer.train(cl, cam, gt, iterations, warmup=warmup)
+        med = float(np.median(r["seconds"]))
+        return dict(config=name, gaussians=int(cl.xyz.shape[0]), width=cam.W, height=cam.H, iterations=iterations, warmup=warmup,
+                    s_per_iteration_median=round(med, 4), iters_per_s=round(1.0 / med, 4),
+                    mpix_per_s_fwd_bwd=None, wall_s=round(time.perf_counter() - t0, 1), loss_first=round(r["losses"][0], 5),
+                    loss_last=round(r["losses"][-1], 5), loss_ops=r["loss_ops"], torch_threads=r["threads"],
+                    oracle_threads=r["oracle_threads"])
+    out["C1"] = run("C1", 20 if quick else 100, 2 if quick else 5)
+    main_cfg = args.config if args.config != "C1" else None
+    if main_cfg:
+        out[main_cfg] = run(main_cfg, 3, 1)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override the number of Gaussians (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="20 instead of 100 CPU iterations of C1")
     ap.add_argument("--raster-only", action="store_true", help="time rasterizer fwd+bwd only (no loss/optimizer)")
     ap.add_argument("--host", default="cpp", choices=["cpp", "py"],
                     help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
     ap.add_argument("--densify-interval", type=int, default=0,
                     help="run densifyAndPrune every N steps inside the timed region (0 = off; reference: 100); with several "
                          "ranks the Python host drives it (it reduces the per-view statistics over the ranks)")
+    ap.add_argument("--training-lr", action="store_true",
+                    help="time the main leg with the training learning rates (drifting synthetic workload) instead of the "
+                         "stationary one")
+    ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("GSR_BENCH_FORCE_DP") != "1":
+        self_launch(args)
     if args.densify_interval and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.host = "py"
 
@@ -84,9 +142,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # GSR_BENCH_SHARE_GPU=1 + GSR_BENCH_BACKEND=gloo: every rank on device 0 over gloo -- a functional check of the
@@ -123,11 +178,7 @@ def main():
     bg = torch.zeros(3, device=dev)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     pipe = GaussianPipelineParams()
-    # Ground truth = this view of the initial model + low-pass noise: a converged scene under refinement.  The values are
-    # not irrelevant to speed: Adam (eps 1e-15) moves every parameter by about its learning rate per step whatever the
-    # gradient scale, so fitting a single view drags opacities and scales away from the generated statistics and the blend
-    # kernels' work grows step by step (blend_bwd 0.53 -> 0.70 ms over 40 steps with this target, -> 0.80 ms with pure
-    # noise).  Throughput is therefore quoted for the default 5 + 20 steps from the generated state.
+    # Ground truth = this view of the initial model + low-pass noise: a converged scene under refinement.
     noise = torch.nn.functional.avg_pool2d(torch.rand(3, H, W, generator=gen).unsqueeze(0), 5, 1, 2).squeeze(0).to(dev)
     with torch.no_grad():
         gt = (GaussianRenderer.render(kf, H, W, g, pipe, bg)[0] + 0.1 * (noise - 0.5)).clamp_(0.0, 1.0)
@@ -155,12 +206,19 @@ def main():
             ops.trainer_set_options(handle, {"densify": 1.0, "cameras_extent": float(cl.extent), "seed": 0.0,
                                              "densify_from_iter": 0.0, "densification_interval": float(args.densify_interval)})
 
+    def set_lr_scale(s):
+        if ops is not None:
+            ops.trainer_set_options(handle, {"lr_scale": float(s)})
+        if g.optimizer_ is not None:
+            g.optimizer_.lr_scale = float(s)
+
     # The reference reads the loss on the host every iteration (EMA for logging, gaussian_mapper.cpp:701-705).  So does this
     # loop -- one step late: the value is copied to pinned memory behind the step's kernels and read while the NEXT step is
     # already queued, so the stream never drains for a log value.
     loss_pinned = [torch.zeros(1).pin_memory() for _ in range(2)]
     loss_ready = [torch.cuda.Event() for _ in range(2)]
     loss_state = {"n": 0, "ema": 0.0}
+    comm_ms = {"gather": [], "reduce": []}
 
     def read_loss_deferred(loss):
         k = loss_state["n"] & 1
@@ -176,14 +234,16 @@ def main():
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
             if dp and factored:
-                # view-factored exchange (trainer.ViewFactoredExchange): the colour gradients are gathered, the other four
-                # tensors reduced; the SH gradient is rebuilt from the views and applied while the reductions are on the links
+                # view-factored exchange (trainer.ViewFactoredExchange): the colour gradients are gathered in two halves, the
+                # other four tensors reduced; the SH gradient of each half is rebuilt from the views and applied while the
+                # next collective is on the links
                 grads = ops.trainer_grads(handle)
                 ex = ViewFactoredExchange(ops.trainer_sh_send_buffer(handle), kf.camera_center_,
                                           [(i, t) for i, t in enumerate(grads) if i != FEATURES_GROUP], world)
                 ops.trainer_finish_begin(handle)
-                centres, views = ex.gathered()
-                ops.trainer_features_step_from_views(handle, centres, views)   # rebuild + Adam in one pass; reads xyz: before ITS Adam
+                for first, (row0, centres, views) in enumerate(ex.gathered_parts()):
+                    # rebuild + Adam in one pass; reads xyz: before ITS Adam
+                    ops.trainer_features_step_from_views(handle, centres, views, row0, first == 0)
                 for i in ex.order():
                     ex.wait(i)                # stream-side wait: the host keeps queueing
                     ops.trainer_adam_group(handle, i)
@@ -212,59 +272,89 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, read_dominant=False):
+        """EXACTLY `steps` steps between barrier + synchronize; max over ranks.  Returns (seconds, dominant-kernel ms list)."""
+        dom = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+            if read_dominant:
+                v = capi.profile_read(lib)["blend_bwd"]      # waits only for events already recorded this step
+                if v >= 0:
+                    dom.append(v)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, dom
+
+    stationary = not args.training_lr
+    set_lr_scale(0.0 if stationary else 1.0)
     for _ in range(args.warmup):
         one_step()
     # Timed region: HIP events only around the backward blend, the dominant kernel (gsr_profile_enable(2)): every event
     # record is a ~5 us bubble in the stream, and eleven of them per step cost 2 % of the step they are meant to measure.
     capi.profile_enable(lib, 2)
-    dom_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        v = capi.profile_read(lib)["blend_bwd"]      # waits only for events already recorded this step
-        if v >= 0:
-            dom_ms.append(v)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # Stage table: the same step with events between all stages, outside the timed region -- and with the separate Adam pass
-    # on the SH tensor, so that the rasterizer stages (and the Mpix/s derived from them) contain no optimizer work.
-    if ops is not None:
-        ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})
-    ts.fused_sh_adam_ = False
+    elapsed, dom_ms = timed(args.steps, read_dominant=True)
+    capi.profile_enable(lib, 0)
+
+    # ---- per-step times from HIP events on the stream: 20 warm-up + median of >= 100 (SURVEY.md 8d)
+    n_med = max(args.median_steps, 0)
+    step_ms = []
+    if n_med:
+        for _ in range(max(0, 20 - args.warmup - args.steps)):
+            one_step()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+        barrier()
+        marks[0].record()
+        for i in range(n_med):
+            one_step()
+            marks[i + 1].record()
+        barrier()
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_med)]
+
+    # ---- stage table: the same (fused) program with events between all stages
     capi.profile_enable(lib, 1)
     stage_ms = {}
-    for _ in range(min(args.steps, 10)):
+    for _ in range(20):
         one_step()
         for k, v in capi.profile_read(lib).items():
             stage_ms.setdefault(k, []).append(v)
     torch.cuda.synchronize()
     capi.profile_enable(lib, 0)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # scene statistics of this rank's view (V, R) for the byte model
+    # ---- scene statistics of this rank's view (V, R) for the byte model -- of the stationary state the legs above ran on
     with torch.no_grad():
         img, _, vis, radii = GaussianRenderer.render(kf, H, W, g, pipe, bg)
         V = int(vis.sum().item())
     from photo_slam_amd import rasterize_points as rp  # noqa
-    # R: instances of the last forward = sum of tiles; recompute through the public wrapper
     R = rp.RasterizeGaussiansCUDA(bg, g.getXYZ().detach(), torch.empty(0, device=dev), g.getOpacityActivation().detach(),
                                   g.getScalingActivation().detach(), g.getRotationActivation().detach(), 1.0,
                                   torch.empty(0, device=dev), kf.world_view_transform_, kf.full_proj_transform_,
                                   kf.tanfovx_, kf.tanfovy_, H, W, g.getFeatures().detach(), 3, kf.camera_center_, False)[0]
+
+    # ---- the same K steps with the training learning rates (the drifting synthetic workload), for the record
+    train_run = None
+    if stationary and not args.raster_only:
+        set_lr_scale(1.0)
+        el2, _ = timed(args.steps)
+        train_run = {"steps": args.steps, "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                     "iters_per_s": round(world * args.steps / el2, 3),
+                     "note": "training learning rates from the same start: the synthetic scene inflates ~1 %/step (DESIGN.md section 7)"}
+
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
-    fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank (timed region)
-    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8)   # the stage table ran unfused (above)
+    fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank
+    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam)
     stages = {}
     for k, ms in stage_ms.items():
         ms = [m for m in ms if m >= 0]
         if not ms:
             continue
-        avg = float(np.mean(ms))
+        avg = float(np.median(ms))
         stages[k] = dict(ms=round(avg, 4), bytes=int(ab[k]), GBps=round(ab[k] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None)
     raster_ms = sum(s["ms"] for s in stages.values())
     dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
@@ -276,6 +366,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        lr_note = ("0 (stationary workload: every kernel runs and the Adam moments update, the parameters do not move)"
+                   if stationary else "training (GaussianOptimizationParams defaults; the synthetic scene drifts)")
         out = {
             "metric": "train iters/s (render + L1/SSIM loss + backward + Adam), 2M Gaussians @1080p"
             if args.config == "C3" else f"train iters/s, config {args.config}",
@@ -286,55 +378,71 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H,
-                       "visible": V, "instances": R, "keyframes_per_step": world, "sh_degree": 3,
+                       "visible": V, "instances": R, "instances_per_visible": round(R / max(V, 1), 2),
+                       "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": "single GPU" if not dp else
-                                      (f"dp{world} (one keyframe per GPU; one all-gather of 3 + one all-reduce of 11 floats/Gaussian, "
-                                       "SH gradient rebuilt per rank; densification statistics accumulate per rank)") if factored else
+                                      (f"dp{world} (one keyframe per GPU; camera centres + two all-gathers of 3 floats/Gaussian "
+                                       "+ one all-reduce of 11 floats/Gaussian, SH gradient rebuilt per rank; densification "
+                                       "statistics accumulate per rank)") if factored else
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
+                       "learning_rates": lr_note,
                        "sh_adam_fused_into_backward": fused_sh_adam,
-                       "gaussians_after": int(g.xyz_.shape[0]) if ops is None else P,
+                       "gaussians_after": int(g.xyz_.shape[0]) if ops is None else int(ops.trainer_params(handle)[0].shape[0]),
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic_C3_raster_only.json")
+        if step_ms:
+            s = np.sort(np.array(step_ms))
+            out["protocol"] = {"timed": "wall clock over exactly `steps` steps between barrier + synchronize (value, ms_per_step)",
+                               "median_ms_per_step": round(float(np.median(s)), 4), "p10_ms": round(float(s[len(s) // 10]), 4),
+                               "p90_ms": round(float(s[(9 * len(s)) // 10]), 4), "median_over_steps": len(s),
+                               "warmup_before_median": max(20, args.warmup + args.steps),
+                               "median_iters_per_s": round(world * 1e3 / float(np.median(s)), 3),
+                               "source": "one HIP event per step on the compute stream of rank 0"}
+        if train_run:
+            out["training_lr_run"] = train_run
+        if dp:
+            out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                           "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
+                           "exchange": "view-factored" if factored else "all-reduce"}
+        traffic = traffic_src = None
         # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, tools/gpu_pmc.sh), corrected as
-        # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only.
+        # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only, on the
+        # committed profile of the same build -- NOT in this run: the source file rides along.
         kernel_of = {"blend_bwd": "gsr::blend_bwd_kernel", "blend_fwd": "gsr::blend_fwd_kernel",
                      "preprocess_fwd": "gsr::preprocess_fwd_kernel", "preprocess_bwd": "gsr::preprocess_bwd_kernel"}
-        if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(pmc_file):
-            pm = json.load(open(pmc_file)).get(kernel_of[dom])
-            if pm:
-                traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
-        # the blend kernels are VALU-bound: their VALU issue utilisation from the SQ counters (tools/gpu_sq.sh, C3 only) rides along
-        valu = None
-        sq_file = os.path.join(ROOT, "profiles", "r01_j_sq_counters_C3_raster_only.json")
-        if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(sq_file):
-            sq = json.load(open(sq_file)).get(kernel_of[dom])
-            if sq and "valu_issue_utilisation" in sq:
-                valu = round(sq["valu_issue_utilisation"], 3)
+        for f in PMC_FILES:
+            if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(os.path.join(ROOT, f)):
+                pm = json.load(open(os.path.join(ROOT, f))).get(kernel_of[dom])
+                if pm:
+                    traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
+                    traffic_src = f
+                    break
         if dom:
             a = stages[dom]["GBps"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic, "valu_issue_utilisation": valu,
+                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_source": traffic_src and f"{traffic_src} (rocprofv3 --pmc of the same build; not measured in this run)",
                                "raster_fwd_bwd_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "stage_table_source": "median of 20 further steps of the SAME program with HIP events between all "
+                                                     "stages (preprocess_bwd carries the fused Adam step of the SH tensor when "
+                                                     "config.sh_adam_fused_into_backward); the dominant kernel's entry is its mean "
+                                                     "duration inside the timed region",
                                "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle
-            t1 = time.perf_counter()
-            ores, ocolor, oradii = oracle.forward(np.zeros(3, np.float32), cl.xyz, cl.get_opacity(), cam.viewmatrix,
-                                                  cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, H, W,
-                                                  shs=cl.get_features(), sh_degree=3, scales=cl.get_scaling(),
-                                                  rotations=cl.get_rotation())
-            oracle.backward(ores, np.ones((3, H, W), np.float32))
-            cpu_s = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(W * H / cpu_s / 1e6, 3), "unit": "Mpix/s (rasterizer fwd+bwd)",
-                                   "cores": oracle.get_threads(), "kind": "port",
-                                   "sample": f"1 forward+backward of the same {args.config} view (initial parameters), "
-                                             f"{cpu_s:.1f} s, OpenMP over Gaussians/tiles",
-                                   "iters_per_s_raster_only": round(1.0 / cpu_s, 4)}
+            base = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline)
+            main = base.get(args.config, base["C1"])
+            out["cpu_baseline"] = {
+                "value": main["iters_per_s"], "unit": "iters/s (full train step)", "cores": main["oracle_threads"],
+                "kind": "port",
+                "sample": (f"{main['iterations']} measured iterations (+{main['warmup']} warm-up) of the reference's train step "
+                           f"(src/gaussian_trainer.cpp:45-133) at {main['config']}: CPU oracle rasterizer (port of the reference "
+                           f"kernels, pinned bit for bit to them) behind the autograd Function, LibTorch-CPU activations / loss "
+                           f"({main['loss_ops']}) / Adam; median {main['s_per_iteration_median']} s per iteration; C1 in full "
+                           f"({base['C1']['iterations']} iterations) under `runs`"),
+                "runs": base}
     if dp:
         dist.destroy_process_group()
     # RCCL writes its version banner to C stdout, which is block-buffered on a pipe and would otherwise land AFTER the

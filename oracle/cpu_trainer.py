@@ -1,0 +1,139 @@
+"""The reference's train step on the HOST cores: "the reference CPU LibTorch path" of BASELINE.json configs[0].
+
+TEST / BENCHMARK INFRASTRUCTURE ONLY (bench.py's cpu_baseline leg and tests import it; the product never does).
+
+The reference has no CPU rasterizer (cuda_rasterizer/ is CUDA only), so the step is assembled as SURVEY.md 8(d) prescribes:
+the CPU oracle (oracle/gsr_oracle.c, pinned bit for bit to the reference's kernel sources compiled for the host) behind the
+same autograd Function shape as GaussianRasterizerFunction (src/gaussian_rasterizer.cpp:28-180), and around it LibTorch-CPU
+ops exactly as the reference composes them:
+
+  GaussianTrainer::trainingOnce, src/gaussian_trainer.cpp:45-133 ( = GaussianMapper::trainForOneIteration,
+  src/gaussian_mapper.cpp:614-774 without the SLAM keyframe scheduling):
+    updateLearningRate -> GaussianRenderer::render (activations sigmoid / exp / normalize, getFeatures = cat(dc.clone(),
+    rest.clone()), src/gaussian_renderer.cpp:23-149, src/gaussian_model.cpp:48-71) -> (1 - lambda) L1 + lambda (1 - SSIM)
+    (include/loss_utils.h; the reference's OWN header compiled into torch ops when oracle/_ref/libref_loss.so exists, its
+    pinned torch mirror otherwise) -> backward -> max_radii2D / addDensificationStats (:109-117) -> Adam with six groups,
+    eps 1e-15 (src/gaussian_model.cpp:477-510; torch.optim.Adam runs the same ATen kernels torch::optim::Adam does) ->
+    zero_grad.
+
+torch.set_num_threads(host cores) for the ATen part, OpenMP over Gaussians / tiles inside the oracle.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import oracle
+
+
+def _loss_ops():
+    """(l1_loss, ssim, kind): the reference's include/loss_utils.h behind torch ops if the library was built (it travels to
+    the GPU boxes prebuilt), else the torch mirror pinned against it by tests/test_reference_pinning.py."""
+    from . import build_ref
+    path = build_ref.build_loss()
+    if path and os.path.exists(path):
+        try:
+            torch.ops.load_library(path)
+            ops = torch.ops.photoslam_reference
+            return ops.l1_loss, ops.ssim, "reference header include/loss_utils.h"
+        except Exception:
+            pass
+    import importlib
+    lu = importlib.import_module("photo_slam_amd.loss_utils")
+    return lu.l1_loss, lu.ssim, "torch mirror of include/loss_utils.h"
+
+
+class OracleRasterizerFunction(torch.autograd.Function):
+    """GaussianRasterizerFunction (src/gaussian_rasterizer.cpp:28-180) on the CPU oracle: same inputs, same gradient slots
+    (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, cam, bg, sh_degree):
+        n = lambda t: np.ascontiguousarray(t.detach().numpy())
+        res, color, radii = oracle.forward(bg, n(means3D), n(opacities), cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx,
+                                           cam.tanfovy, cam.H, cam.W, shs=n(sh), sh_degree=sh_degree, scales=n(scales),
+                                           rotations=n(rotations))
+        ctx.res = res
+        ctx.mark_non_differentiable(r := torch.from_numpy(radii))
+        return torch.from_numpy(color), r
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        g = oracle.backward(ctx.res, np.ascontiguousarray(grad_color.numpy()))
+        ctx.res.free()
+        t = torch.from_numpy
+        return (t(g["dL_dmeans3D"]), t(g["dL_dmeans2D"]), t(g["dL_dsh"]), t(g["dL_dopacity"]), t(g["dL_dscales"]),
+                t(g["dL_drotations"]), None, None, None)
+
+
+class CpuModel:
+    """The six leaves of GaussianModel (include/gaussian_model.h:146-155) + Adam as trainingSetup builds it."""
+
+    def __init__(self, cloud, spatial_lr_scale):
+        leaf = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
+        self.xyz, self.features_dc, self.features_rest = leaf(cloud.xyz), leaf(cloud.features_dc), leaf(cloud.features_rest)
+        self.opacity, self.scaling, self.rotation = leaf(cloud.opacity), leaf(cloud.scaling), leaf(cloud.rotation)
+        P = self.xyz.shape[0]
+        self.max_radii2D = torch.zeros(P)
+        self.xyz_gradient_accum = torch.zeros(P, 1)
+        self.denom = torch.zeros(P, 1)
+        self.spatial_lr_scale = spatial_lr_scale
+        f32 = lambda x: float(np.float32(x))
+        # GaussianOptimizationParams defaults (include/gaussian_parameters.h:61-96), src/gaussian_model.cpp:477-510
+        self.lr_init, self.lr_final, self.max_steps = f32(0.00016) * spatial_lr_scale, f32(0.0000016) * spatial_lr_scale, 30000
+        self.optimizer = torch.optim.Adam([
+            dict(params=[self.xyz], lr=self.lr_init), dict(params=[self.features_dc], lr=f32(0.0025)),
+            dict(params=[self.features_rest], lr=f32(0.0025) / 20.0), dict(params=[self.opacity], lr=f32(0.05)),
+            dict(params=[self.scaling], lr=f32(0.005)), dict(params=[self.rotation], lr=f32(0.001))], lr=0.0, eps=1e-15)
+
+    def update_learning_rate(self, step):
+        """exponLrFunc, src/gaussian_model.cpp:1118-1131"""
+        t = min(max(step / self.max_steps, 0.0), 1.0)
+        lr = float(np.exp(np.log(self.lr_init) * (1 - t) + np.log(self.lr_final) * t))
+        self.optimizer.param_groups[0]["lr"] = lr
+        return lr
+
+
+def render(model, cam, bg, sh_degree=3):
+    """GaussianRenderer::render, src/gaussian_renderer.cpp:23-149 (compute_cov3D_ / convert_SHs_ off, as every shipped config)"""
+    means2D = torch.zeros_like(model.xyz, requires_grad=True)     # screenspace_points, :41-48
+    features = torch.cat([model.features_dc.clone(), model.features_rest.clone()], 1)   # getFeatures, gaussian_model.cpp:63-66
+    color, radii = OracleRasterizerFunction.apply(model.xyz, means2D, features, torch.sigmoid(model.opacity),
+                                                  torch.exp(model.scaling), torch.nn.functional.normalize(model.rotation), cam,
+                                                  bg, sh_degree)
+    return color, means2D, radii > 0, radii
+
+
+def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=None):
+    """Runs warmup + iterations steps; returns dict(seconds per iteration list, loss list, ...).  gt_image: [3,H,W] numpy."""
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    oracle.build()
+    l1_loss, ssim, loss_kind = _loss_ops()
+    model = CpuModel(cloud, cloud.extent)
+    gt = torch.from_numpy(np.ascontiguousarray(gt_image, np.float32))
+    bg = np.zeros(3, np.float32)
+    times, losses = [], []
+    raster_times = []
+    for it in range(1, warmup + iterations + 1):
+        t0 = time.perf_counter()
+        model.update_learning_rate(it)
+        image, viewspace, visibility, radii = render(model, cam, bg)
+        t_r = time.perf_counter()
+        Ll1 = l1_loss(image, gt)
+        loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt))
+        loss.backward()
+        with torch.no_grad():
+            losses.append(float(loss))      # ema_loss_for_log: the per-iteration host read, :92
+            model.max_radii2D[visibility] = torch.max(model.max_radii2D[visibility], radii[visibility].float())
+            model.xyz_gradient_accum[visibility] += torch.norm(viewspace.grad[visibility][:, :2], dim=-1, keepdim=True)
+            model.denom[visibility] += 1
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
+        dt = time.perf_counter() - t0
+        if it > warmup:
+            times.append(dt)
+            raster_times.append(t_r - t0)
+    return dict(seconds=times, forward_seconds=raster_times, losses=losses, loss_ops=loss_kind, threads=threads,
+                oracle_threads=oracle.get_threads(), model=model)

@@ -22,6 +22,9 @@ class FusedAdam:
     def __init__(self, groups, betas=(0.9, 0.999), eps=1e-15):
         self.param_groups = groups
         self.betas, self.eps = betas, eps
+        # multiplies every learning rate where it is consumed: 1 = training, 0 = a STATIONARY workload for throughput
+        # measurements (every kernel runs, the moments update, the parameters do not move; bench.py)
+        self.lr_scale = 1.0
         self.state = {}   # id(param) -> exp_avg, exp_avg_sq, step (per parameter, as torch::optim::AdamParamState)
 
     def step(self):
@@ -48,10 +51,10 @@ class FusedAdam:
                 st["step"] += 1
                 g = p.grad.contiguous()
                 capi.check(lib, lib.gsr_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                  st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]),
+                                                  st["exp_avg_sq"].data_ptr(), p.numel(), float(grp["lr"]) * self.lr_scale,
                                                   self.betas[0], self.betas[1], self.eps, st["step"],
                                                   int(grp.get("period", 0)), int(grp.get("split", 0)),
-                                                  float(grp.get("lr_tail", grp["lr"])), rp._stream_ptr(p)),
+                                                  float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, rp._stream_ptr(p)),
                            "gsr_adam_step")
 
     def begin_fused_step(self, i):
@@ -64,8 +67,8 @@ class FusedAdam:
         if st is None:
             st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
         st["step"] += 1
-        return dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=float(grp["lr"]),
-                    lr_tail=float(grp.get("lr_tail", grp["lr"])), beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+        return dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=float(grp["lr"]) * self.lr_scale,
+                    lr_tail=float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
                     step=st["step"])
 
     def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):

@@ -77,6 +77,9 @@ public:
 
 	int max_sh_degree_, active_sh_degree_;
 	float spatial_lr_scale_;
+	// Multiplies every learning rate where it is consumed.  1 = training.  0 = a STATIONARY workload for throughput
+	// measurements: every kernel runs and the Adam moments update, the parameters do not move (bench.py).
+	double lr_scale_ = 1.0;
 	torch::Tensor xyz_, features_, opacity_, scaling_, rotation_;
 	torch::Tensor max_radii2D_, xyz_gradient_accum_, denom_;
 	GaussianOptimizationParams opt_;
@@ -147,7 +150,10 @@ public:
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	// ... or rebuilds it and takes the Adam step of features_ in the same pass (gsr_sh_adam_from_views): the mean gradient
 	// never reaches HBM.  Replaces setFeaturesGradFromViews() + finishAdamGroup(1); same ordering constraint.
-	void stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
+	// row0 / first_part: the gathered views may arrive in parts (rows [row0, row0 + views.size(1)) of the Gaussians): each
+	// part is applied as soon as ITS all-gather has landed, while the next one is still on the links; the Adam step counter
+	// advances with the first part only.
+	void stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views, int64_t row0 = 0, bool first_part = true);
 	std::shared_ptr<GaussianModel> gaussians_;
 	torch::Tensor background_;
 	int iteration_ = 0;

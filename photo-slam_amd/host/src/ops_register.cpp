@@ -149,6 +149,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		if (k == "densify") t->densify_ = v != 0.0;
 		else if (k == "fused_sh_adam") t->fused_sh_adam_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
+		else if (k == "lr_scale") t->gaussians_->lr_scale_ = v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
 		else if (k == "prune_big_point_after_iter") t->prune_big_point_after_iter_ = (int)v;
 		else if (k == "seed") t->generator_ = make_generator(t->gaussians_->xyz_.device(), (int64_t)v);
@@ -211,9 +212,9 @@ void trainer_features_grad_from_views(int64_t h, torch::Tensor campos_views, tor
 {
 	get(h)->setFeaturesGradFromViews(campos_views, views);
 }
-void trainer_features_step_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views)
+void trainer_features_step_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views, int64_t row0, bool first_part)
 {
-	get(h)->stepFeaturesFromViews(campos_views, views);
+	get(h)->stepFeaturesFromViews(campos_views, views, row0, first_part);
 }
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
                                  int64_t M, double scale)

@@ -122,8 +122,8 @@ void GaussianModel::optimizerStepGroup(int group)
 	grad = grad.contiguous();
 	g.step++;
 	check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
-	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr, 0.9, 0.999, 1e-15, g.step, g.period,
-	                    g.split, g.period ? g.lr_tail : g.lr, stream_of(g.param)),
+	                    g.exp_avg_sq.data_ptr<float>(), g.param.numel(), g.lr * lr_scale_, 0.9, 0.999, 1e-15, g.step, g.period,
+	                    g.split, (g.period ? g.lr_tail : g.lr) * lr_scale_, stream_of(g.param)),
 	      "gsr_adam_step");
 }
 
@@ -171,8 +171,8 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		grp.step++;   // the step happens inside backward; optimizerStepGroup(1) then finds no gradient
 		sh_adam.exp_avg = grp.exp_avg;
 		sh_adam.exp_avg_sq = grp.exp_avg_sq;
-		sh_adam.lr = grp.lr;
-		sh_adam.lr_tail = grp.lr_tail;
+		sh_adam.lr = grp.lr * g->lr_scale_;
+		sh_adam.lr_tail = grp.lr_tail * g->lr_scale_;
 		sh_adam.step = grp.step;
 	}
 	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
@@ -207,26 +207,29 @@ void TrainStep::setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tens
 	                    static_cast<int>(g->features_.size(1)), 1.0f / static_cast<float>(dL_dcolor_views.size(0)));
 }
 
-void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views)
+void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views, int64_t row0, bool first_part)
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	if (iteration_ >= g->opt_.iterations_) return;
-	if (g->features_.size(1) != 16 || g->groups_.size() < 2) {   // other layouts: gradient tensor + separate pass
+	const int64_t P = g->xyz_.size(0), n = dL_dcolor_views.size(1);
+	if (row0 < 0 || row0 + n > P) throw std::runtime_error("stepFeaturesFromViews: the part exceeds the Gaussians");
+	if (g->features_.size(1) != 16 || g->groups_.size() < 2) {   // other layouts: gradient tensor + separate pass (whole batch only)
+		if (row0 != 0 || n != P) throw std::runtime_error("stepFeaturesFromViews: parts need the [P,16,3] SH layout");
 		setFeaturesGradFromViews(campos_views, dL_dcolor_views);
 		finishAdamGroup(1);
 		return;
 	}
 	auto& grp = g->groups_[1];
-	grp.step++;
+	if (first_part) grp.step++;
 	ShAdamStep a;
-	a.exp_avg = grp.exp_avg;
-	a.exp_avg_sq = grp.exp_avg_sq;
-	a.lr = grp.lr;
-	a.lr_tail = grp.lr_tail;
+	a.exp_avg = grp.exp_avg.narrow(0, row0, n);
+	a.exp_avg_sq = grp.exp_avg_sq.narrow(0, row0, n);
+	a.lr = grp.lr * g->lr_scale_;
+	a.lr_tail = grp.lr_tail * g->lr_scale_;
 	a.step = grp.step;
-	auto sh = g->features_.detach();
-	shAdamFromViews(g->xyz_.detach(), campos_views, dL_dcolor_views, g->active_sh_degree_,
+	auto sh = g->features_.detach().narrow(0, row0, n);
+	shAdamFromViews(g->xyz_.detach().narrow(0, row0, n), campos_views, dL_dcolor_views, g->active_sh_degree_,
 	                1.0f / static_cast<float>(dL_dcolor_views.size(0)), sh, a);
 }
 

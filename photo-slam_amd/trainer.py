@@ -88,12 +88,12 @@ class GradientReduction:
 class ViewFactoredExchange:
     """The same batch mean with 2.6x (8 ranks) to 4.2x (2 ranks) fewer bytes on the links.  81 % of
     the gradient is the [P,16,3] SH tensor, and one view's SH gradient is rank one per Gaussian: basis(dir) x dL_dcolor, with dir known to every rank.
-    So the ranks ALL-GATHER the 3-float colour gradients (rasterizer backward with sh_grad_view_) and the camera centres,
-    each rebuilds the mean SH gradient locally (gsr_sh_grad_from_views), and only the other four tensors (11 floats per
-    Gaussian) are all-reduced.  Per Gaussian a rank sends (N-1) * 12 + 2 (N-1)/N * 44 B instead of 2 (N-1)/N * 236 B.
+    So the ranks ALL-GATHER the 3-float colour gradients (rasterizer backward with sh_grad_view_; in PARTS row ranges) and
+    the camera centres, each rebuilds the mean SH gradient locally (gsr_sh_grad_from_views), and only the other four tensors
+    (11 floats per Gaussian) are all-reduced.  Per Gaussian a rank sends (N-1) * 12 + 2 (N-1)/N * 44 B instead of 2 (N-1)/N * 236 B.
 
     Usage: send, color_view = ViewFactoredExchange.send_buffer(P, device) before the render; color_view ([P,3], rows 0..P-1 of
-    send) is handed to the backward, the camera centre travels as row P of the same buffer -- ONE all-gather; others =
+    send) is handed to the backward (row P is a spare from the single-gather layout); others =
     [(index, grad), ...] of the remaining parameters (one all-reduce when they share a buffer, GradientReduction); after
     construction everything is in flight.  sh_gradient() / sh_adam_step() wait for the gather; they read means3D, so call
     them BEFORE Adam moves the positions."""
@@ -103,30 +103,57 @@ class ViewFactoredExchange:
         send = torch.empty((P + 1, 3), dtype=torch.float32, device=device)
         return send, send[:P]
 
+    PARTS = 2   # the colour gradients travel in this many all-gathers (by rows): the SH rebuild + Adam of one part runs while
+                # the next part is still on the links
+
     def __init__(self, send, camera_center, others, world_size):
         self.world_size_ = world_size
         P = send.size(0) - 1
-        send[P].copy_(camera_center.detach().reshape(3))
-        self.all_ = torch.empty((world_size, P + 1, 3), dtype=torch.float32, device=send.device)
+        dev = send.device
+        self.P_ = P
         self.nccl_ = dist.get_backend() == "nccl"
+        # the camera centres: 12 bytes per rank, their own (first) collective -- every part's rebuild needs all of them
+        self.centres_ = torch.empty((world_size, 3), dtype=torch.float32, device=dev)
+        centre = camera_center.detach().reshape(1, 3).to(torch.float32).contiguous()
+        n_parts = self.PARTS if P >= 4 * self.PARTS else 1
+        bounds = [((P * k // n_parts) // 4) * 4 if 0 < k < n_parts else (0 if k == 0 else P) for k in range(n_parts + 1)]
+        self.parts_ = []     # [row0, gathered [N, rows, 3], work or None]
         if self.nccl_:
-            self.gathers_ = [dist.all_gather_into_tensor(self.all_, send.unsqueeze(0), async_op=True)]
+            self.centre_work_ = dist.all_gather_into_tensor(self.centres_, centre, async_op=True)
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                out = torch.empty((world_size, b - a, 3), dtype=torch.float32, device=dev)
+                self.parts_.append([a, out, dist.all_gather_into_tensor(out, send[a:b].unsqueeze(0), async_op=True)])
         else:
             # gloo (the CPU test path) gathers host tensors
-            host = self.all_.cpu()
-            dist.all_gather_into_tensor(host, send.unsqueeze(0).cpu())
-            self.all_.copy_(host)
-            self.gathers_ = []
-        self.centres_, self.views_ = self.all_[:, P, :], self.all_[:, :P, :]   # strided views of the gathered buffer
+            self.centre_work_ = None
+            host = self.centres_.cpu()
+            dist.all_gather_into_tensor(host, centre.cpu())
+            self.centres_.copy_(host)
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                out = torch.empty((world_size, b - a, 3), dtype=torch.float32, device=dev)
+                host = out.cpu()
+                dist.all_gather_into_tensor(host, send[a:b].unsqueeze(0).cpu().contiguous())
+                out.copy_(host)
+                self.parts_.append([a, out, None])
         self.indices_ = [i for i, _ in others]
         self.reduction_ = GradientReduction([t for _, t in others], world_size)
 
+    def gathered_parts(self):
+        """Yields (first row, camera centres [N,3], colour gradients [N,rows,3]) part by part, each once ITS all-gather has
+        landed (stream-side wait: the host keeps queueing)."""
+        if self.centre_work_ is not None:
+            self.centre_work_.wait()
+            self.centre_work_ = None
+        for part in self.parts_:
+            if part[2] is not None:
+                part[2].wait()
+                part[2] = None
+            yield part[0], self.centres_, part[1]
+
     def gathered(self):
-        """(camera centres [N,3], colour gradients [N,P,3]) of all ranks, once the gathers have landed (stream-side wait)"""
-        for w in self.gathers_:
-            w.wait()
-        self.gathers_ = []
-        return self.centres_, self.views_
+        """(camera centres [N,3], colour gradients [N,P,3]) of all ranks in one tensor (a copy when the gather ran in parts)"""
+        parts = [v for _, _, v in self.gathered_parts()]
+        return self.centres_, parts[0] if len(parts) == 1 else torch.cat(parts, 1)
 
     def sh_gradient(self, means3D, degree, M, out=None):
         from . import rasterize_points as rp
@@ -134,11 +161,14 @@ class ViewFactoredExchange:
         return rp.shGradFromViews(means3D.detach(), centres, views, degree, M, 1.0 / self.world_size_, out)
 
     def sh_adam_step(self, means3D, degree, sh, sh_adam):
-        """The rebuild and the Adam step of the SH tensor in one pass (gsr_sh_adam_from_views): the mean gradient never
-        reaches HBM.  sh_adam: FusedAdam.begin_fused_step(FEATURES_GROUP)."""
+        """The rebuild and the Adam step of the SH tensor in one pass per part (gsr_sh_adam_from_views): the mean gradient
+        never reaches HBM.  sh_adam: FusedAdam.begin_fused_step(FEATURES_GROUP)."""
         from . import rasterize_points as rp
-        centres, views = self.gathered()
-        rp.shAdamFromViews(means3D.detach(), centres, views, degree, 1.0 / self.world_size_, sh.detach(), sh_adam)
+        m3, shd = means3D.detach(), sh.detach()
+        for row0, centres, views in self.gathered_parts():
+            n = views.size(1)
+            part = dict(sh_adam, exp_avg=sh_adam["exp_avg"][row0:row0 + n], exp_avg_sq=sh_adam["exp_avg_sq"][row0:row0 + n])
+            rp.shAdamFromViews(m3[row0:row0 + n], centres, views, degree, 1.0 / self.world_size_, shd[row0:row0 + n], part)
 
     def order(self):
         """parameter indices of the all-reduced tensors in completion order"""
@@ -148,7 +178,8 @@ class ViewFactoredExchange:
         self.reduction_.wait(self.indices_.index(index))
 
     def wait_all(self):
-        self.gathered()
+        for _ in self.gathered_parts():
+            pass
         self.reduction_.wait_all()
 
 

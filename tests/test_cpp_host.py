@@ -131,7 +131,7 @@ def run_trainer_checks(ops, dev, lib_path):
             ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
             ops.trainer_adam_group(h2, 1)
         else:         # rebuild + Adam in one pass (what bench.py does)
-            ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
+            ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0), 0, True)
         for i in (4, 0, 3, 2):
             ops.trainer_adam_group(h2, i)
         ops.trainer_finish_end(h2)

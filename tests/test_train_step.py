@@ -119,9 +119,10 @@ dist.init_process_group("gloo")
 rank, ws = dist.get_rank(), dist.get_world_size()
 cl = scene.make_cloud(300, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=ws)
 opt = GaussianOptimizationParams()
-densify = len(sys.argv) > 5 and sys.argv[5] == "densify"
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+densify = mode in ("densify", "late")
 if densify:
-    opt.densify_from_iter_, opt.densification_interval_, opt.densify_grad_threshold_ = 1, 2, 2e-5
+    opt.densify_from_iter_, opt.densification_interval_, opt.densify_grad_threshold_ = (1 if mode == "densify" else 10), 2, 2e-5
 g = GaussianModel.from_cloud(cl, device="cpu"); g.trainingSetup(opt)
 kf = GaussianKeyframe.from_camera(cl.cameras[rank], "cpu")
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
@@ -135,30 +136,27 @@ dist.barrier()
 '''
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
-def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
-    """2 ranks x 1 keyframe each == 1 process accumulating both keyframes' gradients (mean), with the view-factored
-    exchange (all-gather of the colour gradients + local SH rebuild, the default) and with the plain all-reduce."""
+def _launch(tmp_path, emu, n_ranks, port, *worker_args, extra=""):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+    script.write_text(WORKER + extra)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29511" if exchange == "factored" else "29513", str(script), ROOT, emu,
-                           str(tmp_path), exchange],
-                          env=env, timeout=600)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in ("xyz", "features", "opacity", "scaling", "rotation"):
-        assert np.array_equal(r0[k], r1[k]), f"replicas diverged on {k}"
-    # single-process reference: mean gradient of the two views, same Adam
-    cl, g, kfs = _setup(n_views=2)
-    opt = GaussianOptimizationParams()
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, emu, str(tmp_path)] +
+                          list(worker_args), env=env, timeout=900)
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(n_ranks)]
+
+
+def _single_process_batch(n_views, iterations=2):
+    """One process that accumulates the mean gradient of all keyframes of the batch, same Adam: what the ranks must equal."""
+    cl, g, kfs = _setup(n_views=n_views)
     mask = torch.ones(3, 32, 48)
     gts = []
-    for rank in range(2):
+    for rank in range(n_views):
         torch.manual_seed(100 + rank)
         gts.append(torch.rand(3, 32, 48))
     from photo_slam_amd import loss_utils
-    for it in range(1, 3):
+    per_view = None
+    for it in range(1, iterations + 1):
         g.updateLearningRate(it)
         grads = None
         stats = []
@@ -175,20 +173,57 @@ def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
             stats.append((gn, vis.float().unsqueeze(1), torch.where(vis, radii.float(), torch.zeros(300))))
         with torch.no_grad():
             for p, gr in zip(g.params(), grads):
-                p.grad = gr * 0.5
-            g.xyz_gradient_accum_ += stats[0][0] + stats[1][0]
-            g.denom_ += stats[0][1] + stats[1][1]
-            g.max_radii2D_ = torch.max(g.max_radii2D_, torch.max(stats[0][2], stats[1][2]))
+                p.grad = gr * (1.0 / n_views)
+            for gn, cnt, rad in stats:
+                g.xyz_gradient_accum_ += gn
+                g.denom_ += cnt
+                g.max_radii2D_ = torch.max(g.max_radii2D_, rad)
             g.optimizer_.step()
             g.optimizer_.zero_grad(set_to_none=True)
+    return g
+
+
+def _check_batch(ranks, g):
+    r0 = ranks[0]
+    for r in ranks[1:]:
+        for k in ("xyz", "features", "opacity", "scaling", "rotation"):
+            assert np.array_equal(r0[k], r[k]), f"replicas diverged on {k}"
     names = ["xyz", "features", "opacity", "scaling", "rotation"]
     for n, p in zip(names, g.params()):
         assert np.allclose(r0[n], p.detach().numpy(), rtol=1e-5, atol=1e-7), n
     # the statistics accumulate per rank (reduced only when densification consumes them): their SUM / MAX is the batch's
-    assert np.allclose(r0["accum"] + r1["accum"], g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
-    assert np.array_equal(r0["denom"] + r1["denom"], g.denom_.numpy())
-    assert np.array_equal(np.maximum(r0["maxr"], r1["maxr"]), g.max_radii2D_.numpy())
-    assert not np.array_equal(r0["denom"], r1["denom"])
+    assert np.allclose(sum(r["accum"] for r in ranks), g.xyz_gradient_accum_.numpy(), rtol=1e-5, atol=1e-9)
+    assert np.array_equal(sum(r["denom"] for r in ranks), g.denom_.numpy())
+    assert np.array_equal(np.maximum.reduce([r["maxr"] for r in ranks]), g.max_radii2D_.numpy())
+    assert not np.array_equal(ranks[0]["denom"], ranks[1]["denom"])
+
+
+@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+def test_keyframe_batch_data_parallel_gloo(emu, tmp_path, exchange):
+    """2 ranks x 1 keyframe each == 1 process accumulating both keyframes' gradients (mean), with the view-factored
+    exchange (all-gathers of the colour gradients + local SH rebuild, the default) and with the plain all-reduce."""
+    ranks = _launch(tmp_path, emu, 2, 29511 if exchange == "factored" else 29513, exchange)
+    _check_batch(ranks, _single_process_batch(2))
+
+
+def test_eight_keyframe_batch_gloo(emu, tmp_path):
+    """The shape of BASELINE config C4 -- a batch of EIGHT keyframes, one per rank (here 8 gloo ranks on the host, a scaled
+    cloud) -- against a single process that accumulates the eight views: replicas bit-identical, parameters equal."""
+    ranks = _launch(tmp_path, emu, 8, 29521, "factored")
+    _check_batch(ranks, _single_process_batch(8))
+
+
+def test_factored_exchange_steps_sh_on_a_non_densifying_interval_iteration(emu, tmp_path):
+    """densify on, densify_from_iter_ (10) beyond the iterations run, interval 2: iteration 2 is a multiple of the interval
+    but does NOT densify -- the factored exchange must still rebuild and apply the SH gradient there (it used to
+    drop the gathered views and skip the update).  Equal to the plain all-reduce run of the same schedule."""
+    a = _launch(tmp_path, emu, 2, 29523, "factored", "late")
+    fa = {k: a[0][k].copy() for k in a[0].files}
+    b = _launch(tmp_path, emu, 2, 29525, "allreduce", "late")
+    for k in ("xyz", "features", "opacity", "scaling", "rotation"):
+        assert fa[k].shape == b[0][k].shape and np.allclose(fa[k], b[0][k], rtol=1e-5, atol=1e-7), k
+    g3 = _single_process_batch(2, iterations=3)
+    assert np.allclose(fa["features"], g3.features_.detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
 def test_keyframe_batch_densification_gloo(emu, tmp_path):
@@ -290,6 +325,34 @@ def test_densify_and_prune_keeps_model_consistent(emu):
     g.resetOpacity(clamp_to=0.01)
     assert float(torch.sigmoid(g.opacity_).max()) <= 0.01 + 1e-6
     assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
+
+
+def test_reference_cpu_train_step_equals_the_hip_train_step(emu):
+    """a21 end to end: oracle/cpu_trainer.py -- the reference's step as it composes it (src/gaussian_trainer.cpp:45-133): CPU
+    oracle rasterizer behind the autograd Function, activations / cat(dc, rest) in ATen, the reference's loss_utils.h (or its
+    pinned mirror) through autograd, torch.optim.Adam with the six groups -- against TrainStep on the HIP kernels (emulated
+    here): fused activations, fused loss + gradient, SH Adam inside backward, fused Adam.  Four iterations, same parameters."""
+    from oracle import cpu_trainer
+    cl, g, kfs = _setup(P=400)
+    cam = cl.cameras[0]
+    torch.manual_seed(5)
+    gt = torch.rand(3, 32, 48)
+    r = cpu_trainer.train(cl, cam, gt.numpy(), 4, threads=2)
+    ref = r["model"]
+    ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+    losses = [float(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)).detach()) for _ in range(4)]
+    assert np.allclose(losses, r["losses"], rtol=2e-5), (losses, r["losses"])
+    want = dict(xyz_=ref.xyz, features_=torch.cat([ref.features_dc, ref.features_rest], 1), opacity_=ref.opacity,
+                scaling_=ref.scaling, rotation_=ref.rotation)
+    for name, w in want.items():
+        got = getattr(g, name).detach()
+        # Adam normalises every gradient to a step of about lr: a gradient whose SIGN is rounding noise flips the step, so
+        # compare in units of the learning rate (4 steps): the overwhelming majority must agree to 1e-3 of a step
+        lr = {"xyz_": 0.00016 * cl.extent, "features_": 0.0025, "opacity_": 0.05, "scaling_": 0.005, "rotation_": 0.001}[name]
+        err = (got - w.detach()).abs() / lr
+        assert float((err > 1e-2).float().mean()) < 2e-3, (name, float(err.max()), float((err > 1e-2).float().mean()))
+    assert torch.allclose(g.denom_, ref.denom) and torch.equal(g.max_radii2D_, ref.max_radii2D)
+    assert torch.allclose(g.xyz_gradient_accum_, ref.xyz_gradient_accum, rtol=1e-4, atol=1e-9)
 
 
 def test_fused_activations_match_the_reference_data_flow(emu):
