@@ -28,6 +28,10 @@ import socket
 import sys
 import time
 
+# the CPU baseline leg alternates between two OpenMP consumers (the oracle and ATen): spinning worker threads of the one
+# starve the other on a many-core host -- sleep instead (must be set before libgomp loads)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -80,7 +84,7 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False):
     from oracle import cpu_trainer, oracle
     out = {}
 
-    def run(name, iterations, warmup):
+    def run(name, iterations, warmup, budget_s):
         cl = scene.make_config(name, seed=0)
         cam = cl.cameras[0]
         res, color, _ = oracle.forward(np.zeros(3, np.float32), cl.xyz, cl.get_opacity(), cam.viewmatrix, cam.projmatrix, cam.campos,
@@ -90,17 +94,19 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False):
         rng = np.random.default_rng(1234)
         gt = np.clip(color + 0.1 * (rng.random(color.shape, dtype=np.float32) - 0.5), 0.0, 1.0)   # as the GPU run: this view + noise
         t0 = time.perf_counter()
-        r = cpu_trainer.train(cl, cam, gt, iterations, warmup=warmup)
+        r = cpu_trainer.train(cl, cam, gt, iterations, warmup=warmup, time_budget_s=budget_s)
         med = float(np.median(r["seconds"]))
-        return dict(config=name, gaussians=int(cl.xyz.shape[0]), width=cam.W, height=cam.H, iterations=iterations, warmup=warmup,
+        return dict(config=name, gaussians=int(cl.xyz.shape[0]), width=cam.W, height=cam.H, iterations=len(r["seconds"]),
+                    iterations_requested=iterations, time_budget_s=budget_s, warmup=warmup,
                     s_per_iteration_median=round(med, 4), iters_per_s=round(1.0 / med, 4),
                     mpix_per_s_fwd_bwd=None, wall_s=round(time.perf_counter() - t0, 1), loss_first=round(r["losses"][0], 5),
                     loss_last=round(r["losses"][-1], 5), loss_ops=r["loss_ops"], torch_threads=r["threads"],
+                    phase_s_median=dict(zip(("render_forward", "loss_forward", "backward", "stats_and_adam"), r["phase_seconds_median"])),
                     oracle_threads=r["oracle_threads"])
-    out["C1"] = run("C1", 20 if quick else 100, 2 if quick else 5)
+    out["C1"] = run("C1", 20 if quick else 100, 2 if quick else 5, 10.0 if quick else 40.0)
     main_cfg = args.config if args.config != "C1" else None
     if main_cfg:
-        out[main_cfg] = run(main_cfg, 3, 1)
+        out[main_cfg] = run(main_cfg, 3, 1, 60.0)
     return out
 
 
@@ -113,6 +119,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of Gaussians (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="20 instead of 100 CPU iterations of C1")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU train-step baseline (no GPU work)")
     ap.add_argument("--raster-only", action="store_true", help="time rasterizer fwd+bwd only (no loss/optimizer)")
     ap.add_argument("--host", default="cpp", choices=["cpp", "py"],
                     help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
@@ -124,6 +131,12 @@ def main():
                          "stationary one")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        import __graft_entry__ as entry
+        entry.load_package()
+        from photo_slam_amd import scene
+        print(json.dumps(cpu_train_step_baseline(scene, args, 0, 0, quick=args.quick_cpu_baseline)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("GSR_BENCH_FORCE_DP") != "1":
         self_launch(args)
     if args.densify_interval and int(os.environ.get("WORLD_SIZE", "1")) > 1:

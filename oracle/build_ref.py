@@ -170,8 +170,55 @@ def build_densify(force=False):
     return dict(MODEL_OUT)
 
 
+LINK_OUT = {"emu": os.path.join(OUT_DIR, "ref_link_consumer_emu"), "hip": os.path.join(OUT_DIR, "ref_link_consumer_hip")}
+
+
+def build_link_consumer(force=False):
+    """oracle/_ref/ref_link_consumer_{emu,hip}: tests/ref_link/consumer.cpp compiled against the REFERENCE's declarations
+    (include/rasterize_points.h as it is; include/gaussian_rasterizer.h without its `#include "gaussian_model.h"` line,
+    written to oracle/_ref/gen/ and deleted after the compile) and linked against this repository's host library -- the
+    emulator build for this container, the HIP build for the GPU boxes (where the reference tree does not exist: the
+    prebuilt binary travels).  Returns {"emu": path, "hip": path} (None where absent)."""
+    have = {k: (v if os.path.exists(v) else None) for k, v in LINK_OUT.items()}
+    hdr = os.path.join(REF, "include", "gaussian_rasterizer.h")
+    if not os.path.exists(hdr):
+        return have
+    import shutil
+    import torch
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, os.path.join(root, "photo-slam_amd", "host"))
+    import build_host
+    src = os.path.join(root, "tests", "ref_link", "consumer.cpp")
+    libs = {"emu": build_host.build("emu"), "hip": build_host.build("hip")}
+    deps = [src, hdr, os.path.join(REF, "include", "rasterize_points.h"), __file__] + list(libs.values())
+    if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in LINK_OUT.values()):
+        return have
+    text = open(hdr).read()
+    assert text.count('#include "gaussian_model.h"') == 1
+    os.makedirs(GEN, exist_ok=True)
+    with open(os.path.join(GEN, "gaussian_rasterizer.h"), "w") as f:
+        f.write(f'#line 1 "{hdr}"\n' + text.replace('#include "gaussian_model.h"', "/* gaussian_model.h: not needed by these declarations */"))
+    base = os.path.dirname(torch.__file__)
+    inc = [os.path.join(base, "include"), os.path.join(base, "include", "torch", "csrc", "api", "include")]
+    libdir = os.path.join(base, "lib")
+    try:
+        for kind, out in LINK_OUT.items():
+            lib = libs[kind]
+            extra = ["-ltorch_hip", "-lc10_hip"] if kind == "hip" else []
+            # GEN first: "gaussian_rasterizer.h" resolves to the generated copy, "rasterize_points.h" to the reference's own file
+            subprocess.check_call(["g++", "-std=c++17", "-O1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
+                                   "-I" + GEN, "-I" + os.path.join(REF, "include")] + ["-I" + i for i in inc] +
+                                  [src, "-o", out, "-L" + os.path.dirname(lib), "-l" + os.path.basename(lib)[3:-3], "-L" + libdir,
+                                   "-ltorch", "-ltorch_cpu", "-lc10"] + extra +
+                                  ["-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--no-as-needed"])
+    finally:
+        shutil.rmtree(GEN, ignore_errors=True)
+    return dict(LINK_OUT)
+
+
 if __name__ == "__main__":
     r = build(force="--force" in sys.argv)
     print(r if r else "reference sources not available and no prebuilt library")
     print(build_loss(force="--force" in sys.argv))
     print(build_densify(force="--force" in sys.argv))
+    print(build_link_consumer(force="--force" in sys.argv))

@@ -105,10 +105,12 @@ def render(model, cam, bg, sh_degree=3):
     return color, means2D, radii > 0, radii
 
 
-def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=None):
-    """Runs warmup + iterations steps; returns dict(seconds per iteration list, loss list, ...).  gt_image: [3,H,W] numpy."""
+def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=None, time_budget_s=None, min_iterations=3):
+    """Runs warmup + iterations steps (fewer when time_budget_s runs out, but at least min_iterations measured ones);
+    returns dict(seconds per iteration list, loss list, ...).  gt_image: [3,H,W] numpy."""
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
+    t_start = time.perf_counter()
     oracle.build()
     l1_loss, ssim, loss_kind = _loss_ops()
     model = CpuModel(cloud, cloud.extent)
@@ -116,6 +118,7 @@ def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=
     bg = np.zeros(3, np.float32)
     times, losses = [], []
     raster_times = []
+    phases = []   # (render forward, loss forward, backward (loss + rasterizer), statistics + Adam) seconds
     for it in range(1, warmup + iterations + 1):
         t0 = time.perf_counter()
         model.update_learning_rate(it)
@@ -123,7 +126,9 @@ def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=
         t_r = time.perf_counter()
         Ll1 = l1_loss(image, gt)
         loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt))
+        t_l = time.perf_counter()
         loss.backward()
+        t_b = time.perf_counter()
         with torch.no_grad():
             losses.append(float(loss))      # ema_loss_for_log: the per-iteration host read, :92
             model.max_radii2D[visibility] = torch.max(model.max_radii2D[visibility], radii[visibility].float())
@@ -135,5 +140,9 @@ def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=
         if it > warmup:
             times.append(dt)
             raster_times.append(t_r - t0)
+            phases.append((t_r - t0, t_l - t_r, t_b - t_l, t0 + dt - t_b))
+            if time_budget_s is not None and len(times) >= min_iterations and time.perf_counter() - t_start > time_budget_s:
+                break
     return dict(seconds=times, forward_seconds=raster_times, losses=losses, loss_ops=loss_kind, threads=threads,
-                oracle_threads=oracle.get_threads(), model=model)
+                oracle_threads=oracle.get_threads(), model=model,
+                phase_seconds_median=[round(float(np.median([p[k] for p in phases])), 4) for k in range(4)])

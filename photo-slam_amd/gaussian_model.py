@@ -223,6 +223,18 @@ class GaussianModel:
     def getOpacityActivation(self):
         return torch.sigmoid(self.opacity_)
 
+    def getCovarianceActivation(self, scaling_modifier=1):
+        """src/gaussian_model.cpp:73-96: Sigma = (R S)(R S)^T, R = build_rotation(rotation_) (the quaternion is normalised
+        there, include/general_utils.h:33-57), S = diag(scaling_modifier * exp(scaling_)); entries xx xy xz yy yz zz."""
+        q = self.rotation_ / torch.sqrt((self.rotation_ * self.rotation_).sum(1, keepdim=True))
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.getScalingActivation()).unsqueeze(1)
+        cov = torch.bmm(L, L.transpose(1, 2))
+        return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+
     def setShDegree(self, sh):
         self.active_sh_degree_ = min(max(sh, 0), self.max_sh_degree_)
 

@@ -47,28 +47,39 @@ class GaussianRenderer:
             screenspace_points.retain_grad()
         except Exception:
             pass
+        # SH evaluated in torch (convert_SHs_) or colours given: the rasterizer sees no SH tensor, so the SH extensions are off
+        sh_in_rasterizer = not use_override_color and not pipe.convert_SHs_
+        raw = 7 if fuse_activations and not pipe.compute_cov3D_ else 0
         raster_settings = GaussianRasterizationSettings(
             image_height, image_width, viewpoint_camera.tanfovx_, viewpoint_camera.tanfovy_, bg_color, scaling_modifier,
             viewpoint_camera.world_view_transform_, viewpoint_camera.full_proj_transform_, pc.active_sh_degree_,
-            viewpoint_camera.camera_center_, False, 7 if fuse_activations else 0,
-            None if use_override_color else sh_grad_view, None if use_override_color else sh_adam, view_stats)
+            viewpoint_camera.camera_center_, False, raw,
+            sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats)
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points
-        if pipe.compute_cov3D_:
-            raise NotImplementedError("compute_cov3D: pass cov3D_precomp to GaussianRasterizer.forward directly")
-        if fuse_activations:
-            opacity, scales, rotations = pc.opacity_, pc.scaling_, pc.rotation_
+        opacity = pc.opacity_ if raw else pc.getOpacityActivation()
+        scales = rotations = cov3D_precomp = None
+        if pipe.compute_cov3D_:                                        # src/gaussian_renderer.cpp:78-86
+            cov3D_precomp = pc.getCovarianceActivation()
         else:
-            opacity = pc.getOpacityActivation()
-            scales = pc.getScalingActivation()
-            rotations = pc.getRotationActivation()
+            scales = pc.scaling_ if raw else pc.getScalingActivation()
+            rotations = pc.rotation_ if raw else pc.getRotationActivation()
         has_shs = has_color_precomp = False
         shs = colors_precomp = None
         if use_override_color:
             colors_precomp, has_color_precomp = override_color, True
+        elif pipe.convert_SHs_:                                        # :106-113: SH -> RGB in torch
+            from . import sh_utils
+            K = (pc.max_sh_degree_ + 1) ** 2
+            shs_view = pc.getFeatures().transpose(1, 2).reshape(-1, 3, K)
+            dir_pp = pc.getXYZ() - viewpoint_camera.camera_center_.reshape(1, 3)
+            dir_pp_normalized = dir_pp / torch.norm(dir_pp, dim=1, keepdim=True)
+            sh2rgb = sh_utils.eval_sh(pc.active_sh_degree_, shs_view, dir_pp_normalized)
+            colors_precomp, has_color_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0), True
         else:
             shs, has_shs = pc.getFeatures(), True
-        rendered_image, radii = rasterizer(means3D, means2D, opacity, has_shs, has_color_precomp, True, True, False,
-                                           shs, colors_precomp, scales, rotations, None)
+        has_sr = not pipe.compute_cov3D_
+        rendered_image, radii = rasterizer(means3D, means2D, opacity, has_shs, has_color_precomp, has_sr, has_sr,
+                                           pipe.compute_cov3D_, shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rendered_image, screenspace_points, radii > 0, radii

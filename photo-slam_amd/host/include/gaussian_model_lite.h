@@ -62,7 +62,7 @@ public:
 	torch::Tensor getOpacityActivation() { return torch::sigmoid(opacity_); }
 	// one [P,16,3] leaf instead of cat(features_dc.clone(), features_rest.clone()) (gaussian_model.cpp:63-66)
 	torch::Tensor getFeatures() { return features_; }
-	torch::Tensor getCovarianceActivation();
+	torch::Tensor getCovarianceActivation(int scaling_modifier = 1);   // :73-96
 
 	void trainingSetup(const GaussianOptimizationParams& opt);   // src/gaussian_model.cpp:477-510
 	float updateLearningRate(int step);                          // :1118-1131 (exponLrFunc)

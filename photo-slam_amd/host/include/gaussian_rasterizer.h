@@ -1,11 +1,14 @@
-// gaussian_rasterizer.h -- GaussianRasterizationSettings / GaussianRasterizerFunction /
-// rasterizeGaussians / GaussianRasterizer with the reference's declarations
-// (include/gaussian_rasterizer.h:25-127) so GaussianRenderer::render and the mapper call sites
-// (src/gaussian_renderer.cpp:51-66,129-148) compile unchanged.
+// gaussian_rasterizer.h -- GaussianRasterizationSettings / GaussianRasterizerFunction / rasterizeGaussians /
+// GaussianRasterizer declared EXACTLY as the reference declares them (include/gaussian_rasterizer.h:25-127): same members
+// in the same order (= the same object layout), same signatures (= the same mangled symbols), so that
+// GaussianRenderer::render and the mapper call sites (src/gaussian_renderer.cpp:51-66,129-148) compile unchanged AND an
+// object compiled against the reference's header links and runs against libphotoslam_host.so
+// (tests/test_reference_link.py).  This repository's extensions live in the separate *Ex types below.
 #pragma once
 #include <torch/torch.h>
 
 #include <tuple>
+#include <vector>
 
 #include "rasterize_points.h"
 
@@ -29,14 +32,6 @@ struct GaussianRasterizationSettings {
 	int sh_degree_;
 	torch::Tensor campos_;
 	bool prefiltered_;
-	int raw_params_ = 0;   // extension: GSR_RAW_* mask (activations fused into the rasterizer), see include/gsr.h
-	// extension: a [P,3] tensor that receives the clamp-masked colour gradient in backward; sh then gets no gradient from
-	// autograd -- the view-factored exchange of the data-parallel step rebuilds it (shGradFromViews)
-	torch::Tensor sh_grad_view_;
-	// extension, optimizer-in-backward for the SH tensor (rasterize_points.h): set exp_avg to enable
-	ShAdamStep sh_adam_;
-	// extension: {xyz_gradient_accum, denom, max_radii2D} -- backward adds this view's densification statistics itself
-	std::vector<torch::Tensor> view_stats_;
 };
 
 class GaussianRasterizerFunction : public torch::autograd::Function<GaussianRasterizerFunction> {
@@ -74,4 +69,42 @@ public:
 
 public:
 	GaussianRasterizationSettings raster_settings_;
+};
+
+// ---- extensions of this repository (none of them alters the types above) ------------------------------------------------
+struct GaussianRasterizationExtensions {
+	int raw_params_ = 0;   // GSR_RAW_* mask (activations fused into the rasterizer), see include/gsr.h
+	// a [P,3] tensor that receives the clamp-masked colour gradient in backward; sh then gets no gradient from autograd --
+	// the view-factored exchange of the data-parallel step rebuilds it (shGradFromViews)
+	torch::Tensor sh_grad_view_;
+	// optimizer-in-backward for the SH tensor (rasterize_points.h): set exp_avg to enable
+	ShAdamStep sh_adam_;
+	// {xyz_gradient_accum, denom, max_radii2D} -- backward adds this view's densification statistics itself
+	std::vector<torch::Tensor> view_stats_;
+};
+
+class GaussianRasterizerFunctionEx : public torch::autograd::Function<GaussianRasterizerFunctionEx> {
+public:
+	static torch::autograd::tensor_list forward(torch::autograd::AutogradContext* ctx, torch::Tensor means3D,
+	                                            torch::Tensor means2D, torch::Tensor sh, torch::Tensor colors_precomp,
+	                                            torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+	                                            torch::Tensor cov3Ds_precomp, GaussianRasterizationSettings raster_settings,
+	                                            GaussianRasterizationExtensions extensions);
+	static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
+	                                             torch::autograd::tensor_list grad_out_color);
+};
+
+// GaussianRasterizer with the extensions: same forward() contract and exception texts
+class GaussianRasterizerEx : public GaussianRasterizer {
+public:
+	GaussianRasterizerEx(GaussianRasterizationSettings& raster_settings, const GaussianRasterizationExtensions& extensions)
+	    : GaussianRasterizer(raster_settings), extensions_(extensions)
+	{
+	}
+	std::tuple<torch::Tensor, torch::Tensor> forward(torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities,
+	                                                 bool has_shs, bool has_colors_precomp, bool has_scales,
+	                                                 bool has_rotations, bool has_cov3D_precomp, torch::Tensor shs,
+	                                                 torch::Tensor colors_precomp, torch::Tensor scales,
+	                                                 torch::Tensor rotations, torch::Tensor cov3D_precomp);
+	GaussianRasterizationExtensions extensions_;
 };

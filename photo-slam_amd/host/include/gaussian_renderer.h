@@ -15,6 +15,7 @@
 #include <tuple>
 
 #include "gaussian_rasterizer.h"
+#include "sh_utils.h"
 
 #ifdef PHOTOSLAM_TREE
 #include "gaussian_keyframe.h"
@@ -35,9 +36,9 @@ public:
 	    std::shared_ptr<Keyframe> viewpoint_camera, int image_height, int image_width, std::shared_ptr<Model> pc,
 	    GaussianPipelineParams& pipe, torch::Tensor& bg_color, torch::Tensor& override_color,
 	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false,
-	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationSettings::sh_grad_view_ */,
-	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationSettings::sh_adam_ */,
-	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationSettings::view_stats_ */)
+	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationExtensions::sh_grad_view_ */,
+	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationExtensions::sh_adam_ */,
+	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationExtensions::view_stats_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -51,22 +52,25 @@ public:
 		                                              scaling_modifier, viewpoint_camera->world_view_transform_,
 		                                              viewpoint_camera->full_proj_transform_, pc->active_sh_degree_,
 		                                              viewpoint_camera->camera_center_, false);
-		raster_settings.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
-		if (!use_override_color) raster_settings.sh_grad_view_ = sh_grad_view;
-		if (!use_override_color) raster_settings.sh_adam_ = sh_adam;
-		raster_settings.view_stats_ = view_stats;
-		GaussianRasterizer rasterizer(raster_settings);
+		// SH evaluated in torch (convert_SHs_) or colours given: the rasterizer sees no SH tensor, so the SH extensions are off
+		const bool sh_in_rasterizer = !use_override_color && !pipe.convert_SHs_;
+		GaussianRasterizationExtensions ext;
+		ext.raw_params_ = (fuse_activations && !pipe.compute_cov3D_) ? 7 : 0;
+		if (sh_in_rasterizer) ext.sh_grad_view_ = sh_grad_view;
+		if (sh_in_rasterizer) ext.sh_adam_ = sh_adam;
+		ext.view_stats_ = view_stats;
+		GaussianRasterizerEx rasterizer(raster_settings, ext);
 
 		auto means3D = pc->getXYZ();
-		auto opacity = raster_settings.raw_params_ ? pc->opacity_ : pc->getOpacityActivation();
+		auto opacity = ext.raw_params_ ? pc->opacity_ : pc->getOpacityActivation();
 		bool has_scales = false, has_rotations = false, has_cov3D_precomp = false;
 		torch::Tensor scales, rotations, cov3D_precomp;
 		if (pipe.compute_cov3D_) {
 			cov3D_precomp = pc->getCovarianceActivation();
 			has_cov3D_precomp = true;
 		} else {
-			scales = raster_settings.raw_params_ ? pc->scaling_ : pc->getScalingActivation();
-			rotations = raster_settings.raw_params_ ? pc->rotation_ : pc->getRotationActivation();
+			scales = ext.raw_params_ ? pc->scaling_ : pc->getScalingActivation();
+			rotations = ext.raw_params_ ? pc->rotation_ : pc->getRotationActivation();
 			has_scales = has_rotations = true;
 		}
 		bool has_shs = false, has_color_precomp = false;
@@ -74,9 +78,16 @@ public:
 		if (use_override_color) {
 			colors_precomp = override_color;
 			has_color_precomp = true;
+		} else if (pipe.convert_SHs_) {
+			// src/gaussian_renderer.cpp:106-113: SH -> RGB in torch, handed to the rasterizer as colors_precomp
+			const int max_coeffs = (pc->max_sh_degree_ + 1) * (pc->max_sh_degree_ + 1);
+			auto shs_view = pc->getFeatures().transpose(1, 2).reshape({-1, 3, max_coeffs});
+			auto dir_pp = pc->getXYZ() - viewpoint_camera->camera_center_.reshape({1, 3});
+			auto dir_pp_normalized = dir_pp / torch::norm(dir_pp, 2, {1}, /*keepdim=*/true);
+			auto sh2rgb = sh_utils::eval_sh(pc->active_sh_degree_, shs_view, dir_pp_normalized);
+			colors_precomp = torch::clamp_min(sh2rgb + 0.5, 0.0);
+			has_color_precomp = true;
 		} else {
-			// convert_SHs_ (SH evaluated in torch, include/sh_utils.h) is not used by any shipped config;
-			// the rasterizer evaluates SH itself
 			shs = pc->getFeatures();
 			has_shs = true;
 		}

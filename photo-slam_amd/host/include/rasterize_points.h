@@ -1,7 +1,8 @@
-// rasterize_points.h -- LibTorch boundary of the MI355X rasterizer, source-compatible with the
-// reference's include/rasterize_points.h:18-65 (same free functions, argument order and return
-// tuples), so src/gaussian_rasterizer.cpp / src/operate_points.cu of Photo-SLAM compile against it
-// unchanged.  On a ROCm build of LibTorch torch::kCUDA *is* the HIP device.
+// rasterize_points.h -- LibTorch boundary of the MI355X rasterizer.  RasterizeGaussiansCUDA, RasterizeGaussiansBackwardCUDA and
+// markVisible are declared with EXACTLY the parameter lists of the reference's include/rasterize_points.h:18-65: the
+// same mangled symbols, so an object compiled against the reference header links against libphotoslam_host.so
+// (tests/test_reference_link.py does that).  The extensions of this repository are separate OVERLOADS with extra,
+// non-defaulted parameters.  On a ROCm build of LibTorch torch::kCUDA *is* the HIP device.
 // Implementation: src/rasterize_points.cpp on top of the C-ABI in include/gsr.h (libgsr_hip.so).
 #pragma once
 #include <torch/torch.h>
@@ -16,7 +17,15 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-    const bool prefiltered, const int raw_params = 0 /* extension: GSR_RAW_* mask, see include/gsr.h */);
+    const bool prefiltered);
+// overload with the extension parameter raw_params: GSR_RAW_* mask, see include/gsr.h
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
+    const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+    const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+    const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
+    const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
+    const bool prefiltered, const int raw_params);
 
 // Extension, optimizer-in-backward for the SH tensor (gsr_sh_adam of include/gsr.h): when exp_avg is defined, backward applies
 // this Adam step to `sh` IN PLACE instead of computing dL_dsh (which then comes back undefined).
@@ -35,15 +44,25 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
                                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
                                const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer);
+// overload with the extension parameters (all four, no defaults)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
                                const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                               const int raw_params = 0,
-                               /* extension: a [P,3] float tensor that receives the clamp-masked colour gradient; dL_dsh is
-                                  then NOT computed and comes back undefined (gsr_backward_args.dL_dcolor_view) */
-                               const torch::Tensor& dL_dcolor_view = torch::Tensor(),
-                               const ShAdamStep& sh_adam = ShAdamStep(),
-                               /* extension: {xyz_gradient_accum, denom, max_radii2D} (P floats each), updated in place with
-                                  this view's densification statistics (gsr_backward_args.stat_*); empty = off */
-                               const std::vector<torch::Tensor>& view_stats = {});
+                               const int raw_params,
+                               /* a [P,3] float tensor that receives the clamp-masked colour gradient; dL_dsh is then NOT
+                                  computed and comes back undefined (gsr_backward_args.dL_dcolor_view); undefined = off */
+                               const torch::Tensor& dL_dcolor_view,
+                               const ShAdamStep& sh_adam,
+                               /* {xyz_gradient_accum, denom, max_radii2D} (P floats each), updated in place with this
+                                  view's densification statistics (gsr_backward_args.stat_*); empty = off */
+                               const std::vector<torch::Tensor>& view_stats);
 
 // gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
 // [n_views,P,3] dL_dcolor_view tensors and the [n_views,3] camera centres; scale = 1/n_views for the batch mean

@@ -9,28 +9,30 @@ torch::Tensor GaussianRasterizer::markVisibleGaussians(torch::Tensor& positions)
 	return markVisible(positions, raster_settings_.viewmatrix_, raster_settings_.projmatrix_);
 }
 
-torch::autograd::tensor_list GaussianRasterizerFunction::forward(
-    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
-    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
-    torch::Tensor cov3Ds_precomp, GaussianRasterizationSettings s)
+namespace {
+
+// shared by GaussianRasterizerFunction (the reference's contract: no extensions) and GaussianRasterizerFunctionEx
+torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor sh,
+                                          torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales,
+                                          torch::Tensor rotations, torch::Tensor cov3Ds_precomp,
+                                          const GaussianRasterizationSettings& s, const GaussianRasterizationExtensions& e)
 {
-	(void)means2D;  // only its gradient slot matters
 	auto r = RasterizeGaussiansCUDA(s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_,
 	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
-	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, s.raw_params_);
+	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, e.raw_params_);
 	ctx->saved_data["num_rendered"] = std::get<0>(r);
 	ctx->saved_data["scale_modifier"] = static_cast<double>(s.scale_modifier_);
 	ctx->saved_data["tanfovx"] = static_cast<double>(s.tanfovx_);
 	ctx->saved_data["tanfovy"] = static_cast<double>(s.tanfovy_);
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
-	ctx->saved_data["raw_params"] = s.raw_params_;
-	if (s.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = s.sh_grad_view_;
-	if (!s.view_stats_.empty()) ctx->saved_data["view_stats"] = s.view_stats_;
-	if (s.sh_adam_.exp_avg.defined()) {
-		ctx->saved_data["sh_adam_m"] = s.sh_adam_.exp_avg;
-		ctx->saved_data["sh_adam_v"] = s.sh_adam_.exp_avg_sq;
-		ctx->saved_data["sh_adam_h"] = std::vector<double>{s.sh_adam_.lr, s.sh_adam_.lr_tail, s.sh_adam_.beta1, s.sh_adam_.beta2,
-		                                                   s.sh_adam_.eps, static_cast<double>(s.sh_adam_.step)};
+	ctx->saved_data["raw_params"] = e.raw_params_;
+	if (e.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = e.sh_grad_view_;
+	if (!e.view_stats_.empty()) ctx->saved_data["view_stats"] = e.view_stats_;
+	if (e.sh_adam_.exp_avg.defined()) {
+		ctx->saved_data["sh_adam_m"] = e.sh_adam_.exp_avg;
+		ctx->saved_data["sh_adam_v"] = e.sh_adam_.exp_avg_sq;
+		ctx->saved_data["sh_adam_h"] = std::vector<double>{e.sh_adam_.lr, e.sh_adam_.lr_tail, e.sh_adam_.beta1, e.sh_adam_.beta2,
+		                                                   e.sh_adam_.eps, static_cast<double>(e.sh_adam_.step)};
 	}
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
@@ -41,8 +43,9 @@ torch::autograd::tensor_list GaussianRasterizerFunction::forward(
 	return {color, radii};
 }
 
-torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autograd::AutogradContext* ctx,
-                                                                  torch::autograd::tensor_list grad_outputs)
+// n_extra: undefined gradients for the trailing non-tensor inputs (raster_settings [, extensions])
+torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list grad_outputs,
+                                           int n_extra)
 {
 	const int num_rendered = static_cast<int>(ctx->saved_data["num_rendered"].toInt());
 	const float scale_modifier = static_cast<float>(ctx->saved_data["scale_modifier"].toDouble());
@@ -73,21 +76,22 @@ torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autogra
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();
 	};
-	return {std::get<3>(g) /*means3D*/,
-	        std::get<0>(g) /*means2D*/,
-	        opt(std::get<5>(g), v[10]) /*sh*/,
-	        opt(std::get<1>(g), v[4]) /*colors_precomp*/,
-	        std::get<2>(g) /*opacities*/,
-	        opt(std::get<6>(g), v[6]) /*scales*/,
-	        opt(std::get<7>(g), v[7]) /*rotations*/,
-	        opt(std::get<4>(g), v[8]) /*cov3Ds_precomp*/,
-	        torch::Tensor() /*raster_settings*/};
+	torch::autograd::tensor_list out = {std::get<3>(g) /*means3D*/,
+	                                    std::get<0>(g) /*means2D*/,
+	                                    opt(std::get<5>(g), v[10]) /*sh*/,
+	                                    opt(std::get<1>(g), v[4]) /*colors_precomp*/,
+	                                    std::get<2>(g) /*opacities*/,
+	                                    opt(std::get<6>(g), v[6]) /*scales*/,
+	                                    opt(std::get<7>(g), v[7]) /*rotations*/,
+	                                    opt(std::get<4>(g), v[8]) /*cov3Ds_precomp*/};
+	for (int i = 0; i < n_extra; i++) out.push_back(torch::Tensor());
+	return out;
 }
 
-std::tuple<torch::Tensor, torch::Tensor> GaussianRasterizer::forward(
-    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, bool has_shs, bool has_colors_precomp,
-    bool has_scales, bool has_rotations, bool has_cov3D_precomp, torch::Tensor shs, torch::Tensor colors_precomp,
-    torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3D_precomp)
+// GaussianRasterizer::forward, src/gaussian_rasterizer.cpp:182-234: the XOR validation and the empty optionals
+void validate_and_fill(const torch::Tensor& means3D, bool has_shs, bool has_colors_precomp, bool has_scales, bool has_rotations,
+                       bool has_cov3D_precomp, torch::Tensor& shs, torch::Tensor& colors_precomp, torch::Tensor& scales,
+                       torch::Tensor& rotations, torch::Tensor& cov3D_precomp)
 {
 	if (has_shs == has_colors_precomp)
 		throw std::runtime_error("Please provide excatly one of either SHs or precomputed colors!");
@@ -100,7 +104,61 @@ std::tuple<torch::Tensor, torch::Tensor> GaussianRasterizer::forward(
 	if (!has_scales) scales = empty;
 	if (!has_rotations) rotations = empty;
 	if (!has_cov3D_precomp) cov3D_precomp = empty;
+}
+
+}  // namespace
+
+torch::autograd::tensor_list GaussianRasterizerFunction::forward(
+    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+    torch::Tensor cov3Ds_precomp, GaussianRasterizationSettings s)
+{
+	(void)means2D;  // only its gradient slot matters
+	return forward_impl(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, s,
+	                    GaussianRasterizationExtensions());
+}
+
+torch::autograd::tensor_list GaussianRasterizerFunction::backward(torch::autograd::AutogradContext* ctx,
+                                                                  torch::autograd::tensor_list grad_outputs)
+{
+	return backward_impl(ctx, grad_outputs, 1);
+}
+
+torch::autograd::tensor_list GaussianRasterizerFunctionEx::forward(
+    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+    torch::Tensor cov3Ds_precomp, GaussianRasterizationSettings s, GaussianRasterizationExtensions e)
+{
+	(void)means2D;
+	return forward_impl(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, s, e);
+}
+
+torch::autograd::tensor_list GaussianRasterizerFunctionEx::backward(torch::autograd::AutogradContext* ctx,
+                                                                    torch::autograd::tensor_list grad_outputs)
+{
+	return backward_impl(ctx, grad_outputs, 2);
+}
+
+std::tuple<torch::Tensor, torch::Tensor> GaussianRasterizer::forward(
+    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, bool has_shs, bool has_colors_precomp,
+    bool has_scales, bool has_rotations, bool has_cov3D_precomp, torch::Tensor shs, torch::Tensor colors_precomp,
+    torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3D_precomp)
+{
+	validate_and_fill(means3D, has_shs, has_colors_precomp, has_scales, has_rotations, has_cov3D_precomp, shs, colors_precomp,
+	                  scales, rotations, cov3D_precomp);
 	auto result = rasterizeGaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
 	                                 raster_settings_);
+	return std::make_tuple(result[0], result[1]);
+}
+
+std::tuple<torch::Tensor, torch::Tensor> GaussianRasterizerEx::forward(
+    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, bool has_shs, bool has_colors_precomp,
+    bool has_scales, bool has_rotations, bool has_cov3D_precomp, torch::Tensor shs, torch::Tensor colors_precomp,
+    torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3D_precomp)
+{
+	validate_and_fill(means3D, has_shs, has_colors_precomp, has_scales, has_rotations, has_cov3D_precomp, shs, colors_precomp,
+	                  scales, rotations, cov3D_precomp);
+	auto result = GaussianRasterizerFunctionEx::apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+	                                                  cov3D_precomp, raster_settings_, extensions_);
 	return std::make_tuple(result[0], result[1]);
 }

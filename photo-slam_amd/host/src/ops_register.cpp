@@ -125,6 +125,21 @@ torch::Tensor trainer_render_and_backward(int64_t h, torch::Tensor view, torch::
 {
 	return get(h)->renderAndBackward(make_kf(view, proj, campos, fovx, fovy, H, W), gt, mask).detach();
 }
+// GaussianRenderer::render on the trainer's model with the pipeline flags of GaussianPipelineParams (convert_SHs_,
+// compute_cov3D_: src/gaussian_renderer.cpp:78-113): (image, radii); the image is attached to the model's leaves
+std::tuple<torch::Tensor, torch::Tensor> trainer_render(int64_t h, torch::Tensor view, torch::Tensor proj, torch::Tensor campos,
+                                                        double fovx, double fovy, int64_t H, int64_t W, bool convert_SHs,
+                                                        bool compute_cov3D, bool fuse_activations)
+{
+	auto t = get(h);
+	GaussianPipelineParams pipe;
+	pipe.convert_SHs_ = convert_SHs;
+	pipe.compute_cov3D_ = compute_cov3D;
+	torch::Tensor override_color;
+	auto pkg = GaussianRenderer::render(make_kf(view, proj, campos, fovx, fovy, H, W), (int)H, (int)W, t->gaussians_, pipe,
+	                                    t->background_, override_color, 1.0f, false, fuse_activations);
+	return std::make_tuple(std::get<0>(pkg), std::get<3>(pkg));
+}
 void trainer_finish(int64_t h) { get(h)->finishOneIteration(); }
 void trainer_finish_begin(int64_t h) { get(h)->finishBegin(); }
 void trainer_adam_group(int64_t h, int64_t group) { get(h)->finishAdamGroup(static_cast<int>(group)); }
@@ -246,6 +261,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("neighborhood_keypoints", &neighborhood_keypoints);
 	m.def("trainer_create", &trainer_create);
 	m.def("trainer_render_and_backward", &trainer_render_and_backward);
+	m.def("trainer_render", &trainer_render);
 	m.def("trainer_finish", &trainer_finish);
 	m.def("trainer_finish_begin", &trainer_finish_begin);
 	m.def("trainer_adam_group", &trainer_adam_group);

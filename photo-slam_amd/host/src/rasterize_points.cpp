@@ -53,6 +53,36 @@ void check(int status, const char* where)
 
 }  // namespace
 
+// the reference's exact parameter lists (include/rasterize_points.h:18-37, :39-60): same mangled names
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
+    const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+    const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+    const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
+    const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
+    const bool prefiltered)
+{
+	return RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+	                              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+	                              prefiltered, /*raw_params=*/0);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
+{
+	return RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+	                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+	                                      geomBuffer, R, binningBuffer, imageBuffer, /*raw_params=*/0, torch::Tensor(),
+	                                      ShAdamStep(), std::vector<torch::Tensor>());
+}
+
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
     const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
     const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,

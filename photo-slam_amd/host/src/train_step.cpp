@@ -72,9 +72,19 @@ GaussianModel::GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor fea
 	denom_ = torch::zeros({P, 1}, xyz_.options());
 }
 
-torch::Tensor GaussianModel::getCovarianceActivation()
+// src/gaussian_model.cpp:73-96: Sigma = (R S)(R S)^T with R = build_rotation(rotation_) (include/general_utils.h:33-57: the
+// quaternion is normalised there), S = diag(scaling_modifier * exp(scaling_)); the six entries xx xy xz yy yz zz
+torch::Tensor GaussianModel::getCovarianceActivation(int scaling_modifier)
 {
-	throw std::runtime_error("compute_cov3D is not used by the shipped configs; pass scales/rotations");
+	auto q = rotation_ / torch::sqrt((rotation_ * rotation_).sum(1, /*keepdim=*/true));
+	auto r = q.select(1, 0), x = q.select(1, 1), y = q.select(1, 2), z = q.select(1, 3);
+	auto R = torch::stack({1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+	                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+	                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)}, 1).reshape({-1, 3, 3});
+	auto L = R * (scaling_modifier * getScalingActivation()).unsqueeze(1);   // R diag(s): column j scaled by s_j
+	auto cov = torch::bmm(L, L.transpose(1, 2));
+	return torch::stack({cov.select(1, 0).select(1, 0), cov.select(1, 0).select(1, 1), cov.select(1, 0).select(1, 2),
+	                     cov.select(1, 1).select(1, 1), cov.select(1, 1).select(1, 2), cov.select(1, 2).select(1, 2)}, 1);
 }
 
 void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)

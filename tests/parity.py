@@ -258,7 +258,10 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
         finally:
             rp._LIB_OVERRIDE = None
         for a_, b_ in ((sh, p_ref), (m1, m_ref), (v1, v_ref)):
-            assert np.allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-6, atol=1e-9)
+            # the two kernels live in translation units built with / without FMA contraction: last-bit differences, which a
+            # purely relative bound turns into failures where b1 m and (1 - b1) g nearly cancel -- bound them by the array's scale
+            b_ = b_.cpu().numpy()
+            assert np.allclose(a_.cpu().numpy(), b_, rtol=1e-6, atol=1e-6 * float(np.abs(b_).max()))
         assert np.abs(sh.cpu().numpy() - cl.get_features()).max() > 1e-5
     return rel_l1(out, want)
 

@@ -291,6 +291,53 @@ def run_densify_schedule_checks(ops, dev, lib_path):
     ops.trainer_destroy(h)
 
 
+def run_pipeline_flag_checks(ops, dev, lib_path):
+    """GaussianPipelineParams::convert_SHs_ / compute_cov3D_ (src/gaussian_renderer.cpp:78-113) in both hosts: the image and
+    the gradients equal the default data flow (SH and covariance evaluated inside the rasterizer, whose arithmetic is pinned
+    to the reference kernels) -- the SH colour to rounding, the gradients to 1e-4."""
+    import math
+    cl, t = _scene(dev, P=500)
+    cam = cl.cameras[0]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    dpix = torch.from_numpy(np.random.default_rng(1).standard_normal((3, cam.H, cam.W)).astype(np.float32)).to(dev)
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    kf = GaussianKeyframe.from_camera(cam, dev)
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        results = {}
+        for flags in ((False, False), (True, False), (False, True), (True, True)):
+            g = GaussianModel.from_cloud(cl, device=dev)
+            g.active_sh_degree_ = 3
+            pipe = GaussianPipelineParams(convert_SHs_=flags[0], compute_cov3D_=flags[1])
+            img, vsp, vis, radii = GaussianRenderer.render(kf, cam.H, cam.W, g, pipe, bg, fuse_activations=False)
+            (img * dpix).sum().backward()
+            py = (img.detach(), radii, [p.grad.clone() for p in g.params()])
+            h = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                                   g.rotation_.detach(), 3, float(cl.extent), bg)
+            img_c, radii_c = ops.trainer_render(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy, cam.H, cam.W,
+                                                flags[0], flags[1], False)
+            (img_c * dpix).sum().backward()
+            cpp = [x.clone() for x in ops.trainer_grads(h)]
+            assert torch.equal(radii_c, radii) and torch.allclose(img_c.detach(), py[0], atol=1e-6), flags
+            for a, b in zip(cpp, py[2]):
+                assert float((a - b).abs().sum() / (b.abs().sum() + 1e-30)) < 1e-5, flags
+            ops.trainer_destroy(h)
+            results[flags] = py
+        base = results[(False, False)]
+        for flags, (img, radii, grads) in results.items():
+            assert torch.equal(radii, base[1]), flags          # the covariance built in torch gives the same radii here
+            assert torch.allclose(img, base[0], atol=2e-6), flags
+            for a, b in zip(grads, base[2]):
+                rel = float((a - b).abs().sum() / (b.abs().sum() + 1e-30))
+                assert rel < 1e-4, (flags, rel)
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def test_cpp_pipeline_flags_match_python_and_the_default_flow(emu_lib_path):
+    run_pipeline_flag_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
+
+
 def test_cpp_map_maintenance_matches_python(emu_lib_path):
     run_map_maintenance_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
 
@@ -315,6 +362,7 @@ def test_cpp_host_layer_on_gpu():
     run_rasterize_checks(ops, torch.device("cuda:0"), None)
     run_trainer_checks(ops, torch.device("cuda:0"), None)
     run_map_maintenance_checks(ops, torch.device("cuda:0"), None)
+    run_pipeline_flag_checks(ops, torch.device("cuda:0"), None)
 
 
 def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
