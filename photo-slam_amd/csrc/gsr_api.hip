@@ -187,14 +187,17 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, NUM_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 	GSR_HIP(hipEventRecord(t_sync.ev, stream));
 
-	// depth order (stable: equal depths keep ascending Gaussian id)
+	// depth order (stable: equal depths keep ascending Gaussian id).  The first pass reads all P keys and drops the culled
+	// Gaussians (key 0xFFFFFFFF, RADIX_INVALID_KEY), leaving V in g.visible; the other three passes and the scan run over the
+	// V visible ones only (V = 0.47 P at C3).  order[V..P) is undefined, offsets[V..P) = R: the culled Gaussians used to sort
+	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
-	                            g.sort_scratch, stream, &kres, &vres)) != GSR_OK)
+	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);
-	if ((st = launch_scan_u32(g.tiles_touched, g.order, g.offsets, P, false, g.scan_scratch, stream)) != GSR_OK) return st;
+	if ((st = launch_scan_u32(g.tiles_touched, g.order, g.offsets, P, false, g.scan_scratch, stream, g.visible)) != GSR_OK) return st;
 	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));

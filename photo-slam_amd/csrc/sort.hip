@@ -34,12 +34,16 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* to
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ staged,
-                   uint32_t* __restrict__ block_sums, int n, int items_per_block)
+                   uint32_t* __restrict__ block_sums, int n, int items_per_block, const uint32_t* __restrict__ n_dev)
 {
+	// n_dev (nullable): only the first *n_dev elements exist (the rest of the gather list is undefined): they count as zeros
 	__shared__ uint32_t s_wave[4];
 	const int base = blockIdx.x * items_per_block;
-	const int end = min(n, base + items_per_block);
+	const int end_all = min(n, base + items_per_block);
+	const int end = n_dev ? min(end_all, (int)*n_dev) : end_all;
 	uint32_t acc = 0;
+	if (staged && n_dev)
+		for (int i = max(base, end) + (int)threadIdx.x; i < end_all; i += SCAN_THREADS) staged[i] = 0u;
 	// a gathered input (in[gather[i]]: one 64-byte line per element, measured 10x the linear traffic) is staged in the output
 	// array here, so that the apply pass reads it linearly instead of gathering a second time
 	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) {
@@ -87,13 +91,15 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 }
 
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
-                    uint32_t* scratch, hipStream_t stream)
+                    uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev)
 {
+	// n_dev (nullable, needs `gather`): elements from *n_dev on count as zeros (their gather indices are undefined)
+	if (n_dev && !gather) return GSR_ERR_INVALID_ARG;
 	if (n <= 0) return GSR_OK;
 	const int ipb = scan_items_per_block(n);
 	const int nb = div_up(n, ipb);
 	uint32_t* staged = gather ? out : nullptr;
-	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, staged, scratch, n, ipb);
+	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, staged, scratch, n, ipb, n_dev);
 	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, gather ? (const uint32_t*)out : in, (const uint32_t*)nullptr, out,
 	           (const uint32_t*)scratch, n, ipb, inclusive ? 1 : 0);
@@ -108,10 +114,15 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 // consecutive elements, so the original order inside a digit is (wave, round, lane).
 
 __global__ void __launch_bounds__(SORT_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks)
+radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks,
+                  const uint32_t* __restrict__ n_dev, int skip_invalid)
 {
+	// n_dev (nullable): the number of elements lives on the device (the compacted depth sort: set by the first pass's
+	// scatter); blocks beyond it still write their (all-zero) histogram columns.  skip_invalid: keys equal to
+	// RADIX_INVALID_KEY are no elements at all (culled Gaussians: never counted, never scattered).
 	__shared__ uint32_t s_hist[RADIX_BINS];
 	s_hist[threadIdx.x] = 0;
+	if (n_dev) n = min(n, (int)*n_dev);
 	__syncthreads();
 	const uint32_t dmask = (1u << nbits) - 1u;
 	const int wbase = blockIdx.x * SORT_CHUNK + wave_id() * SORT_ITEMS_PER_WAVE;
@@ -127,7 +138,7 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 		const int i = wbase + r * 64 + lane_id();
 		// one LDS atomic per key: even 64 lanes on one bin (64 serialised adds) cost less than the ~60 VALU of a ballot
 		// match; only the scatter kernel needs the match, for its stable ranks
-		if (i < n) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
+		if (i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY)) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
 	}
 	__syncthreads();
 	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
@@ -156,8 +167,10 @@ radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tota
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
-                     const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks)
+                     const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks,
+                     const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out)
 {
+	if (n_dev) n = min(n, (int)*n_dev);
 	__shared__ uint32_t s_whist[4][RADIX_BINS];  // per-wave digit counts, then per-wave running write cursors
 	__shared__ uint32_t s_gbase[RADIX_BINS];     // global position of local element i of digit d = s_gbase[d] + i
 	__shared__ uint32_t s_wave[4];
@@ -184,10 +197,12 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
 		val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
 	}
+	uint32_t live = 0xFFFFu;   // bit r: element r of this lane exists (in range and, when skip_invalid, not the invalid key)
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const int i = wbase + r * 64 + l;
-		const bool valid = i < n;
+		const bool valid = i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY);
+		if (!valid) live &= ~(1u << r);
 		const uint32_t d = (key[r] >> shift) & dmask;
 		const unsigned long long m = wave_match_digit(d, nbits, valid);
 		const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt()), size = (uint32_t)__popcll(m);
@@ -200,10 +215,10 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
 	// Phase B: thread d owns digit d.  Local layout of the chunk = digits ascending, inside a digit
 	// waves ascending, inside a wave original order.
+	uint32_t block_total;   // elements of this chunk that exist (the same value in every thread)
 	{
 		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
 		const uint32_t tot = c0 + c1 + c2 + c3;
-		uint32_t block_total;
 		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
 		uint32_t all;
 		const uint32_t digit_base = block_excl_scan_256(totals[tid], &all, s_wave);   // elements with a smaller digit
@@ -212,14 +227,15 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		s_whist[2][tid] = lstart + c0 + c1;
 		s_whist[3][tid] = lstart + c0 + c1 + c2;
 		s_gbase[tid] = digit_base + hist_rows[(size_t)tid * nblocks + blockIdx.x] - lstart;
+		if (count_out && blockIdx.x == 0 && tid == 0) *count_out = all;   // the elements that exist: later passes run over them only
 	}
 	__syncthreads();
+	// (block_total is the same in every thread: block_excl_scan_256 returns the block sum to all)
 
 	// Phase C: stable placement into the LDS tile.
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
-		const int i = wbase + r * 64 + l;
-		const bool valid = i < n;
+		const bool valid = (live >> r) & 1u;
 		const uint32_t d = (key[r] >> shift) & dmask;
 		const uint32_t rank = place[r] & 0xFFu, size = place[r] >> 8;
 		uint32_t cursor = 0;
@@ -235,7 +251,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 	__syncthreads();
 
 	// Phase D: write the locally sorted tile; lanes of a digit run hit consecutive addresses.
-	const int count = min(SORT_CHUNK, n - cbase);
+	const int count = (int)block_total;
 	for (int i = tid; i < count; i += SORT_THREADS) {
 		const uint32_t k = s_keys[i];
 		const uint32_t d = (k >> shift) & dmask;
@@ -247,8 +263,10 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
-                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res)
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count)
 {
+	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
+	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
 	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
 	*keys_res = (passes % 2) ? keys_pong : keys_ping;
 	*vals_res = (passes % 2) ? vals_pong : vals_ping;
@@ -271,10 +289,12 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		const int nbits = min(RADIX_BITS, end_bit - shift);
 		uint32_t* kout = (p % 2 == 0) ? keys_pong : keys_ping;
 		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
-		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb);
+		const uint32_t* n_dev = (compact_count && p > 0) ? compact_count : nullptr;
+		const int skip = (compact_count && p == 0) ? 1 : 0;
+		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip);
 		GSR_LAUNCH(radix_row_prefix_kernel, RADIX_BINS, SCAN_THREADS, stream, hist, totals, nb);
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
-		           (const uint32_t*)hist, (const uint32_t*)totals, nb);
+		           (const uint32_t*)hist, (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr);
 		kin = kout;
 		vin = vout;
 	}

@@ -19,6 +19,7 @@ constexpr int SORT_CHUNK = 4 * SORT_ITEMS_PER_WAVE;
 constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
+constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
 
 constexpr int SCAN_THREADS = 256;
 
@@ -62,6 +63,7 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
+	uint32_t* visible;        // [1] number of visible Gaussians V, left by the first pass of the depth sort
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -82,6 +84,7 @@ struct GeometryState {
 		g.sort_vals_b = c.take<uint32_t>(P);
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
+		g.visible = c.take<uint32_t>(32);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
@@ -148,14 +151,19 @@ static inline bool result_in_a(int passes) { return (passes % 2) == 0; }
 static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((uint32_t)tiles), RADIX_BITS); }
 
 // ---- device launchers (one per translation unit) ------------------------------------
+// n_dev (nullable, with gather only): a device word; elements from *n_dev on count as zeros (their gather indices are undefined)
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
-                    uint32_t* scratch, hipStream_t stream);
+                    uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
 // Pass 0 reads (keys_in, vals_in) -- read-only, vals_in == nullptr means value = index -- and writes the
 // pong buffers; later passes alternate ping <- pong <- ping.  *keys_res / *vals_res receive the buffers
 // holding the result (pong for an odd number of passes, ping for an even one).
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
-                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res);
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
+                      uint32_t* compact_count = nullptr);
+// compact_count (nullable, a device word): keys equal to RADIX_INVALID_KEY are "no element": the first pass drops them and
+// leaves the number of remaining elements in *compact_count; the later passes read it and touch that many elements only.
+// The result buffers then hold that many sorted pairs followed by undefined content.
 
 }  // namespace gsr
