@@ -118,7 +118,7 @@ MODEL_OUT = {"cpu": os.path.join(OUT_DIR, "libref_densify.so"), "cuda": os.path.
 # the member functions of GaussianModel that oracle/ref_densify.cpp compiles, extracted verbatim by name
 MODEL_FUNCTIONS = ["getScalingActivation", "getXYZ", "getOpacityActivation", "trainingSetup", "resetOpacity",
                    "replaceTensorToOptimizer", "prunePoints", "densificationPostfix", "densifyAndSplit", "densifyAndClone",
-                   "densifyAndPrune", "addDensificationStats", "percentDense", "setPercentDense"]
+                   "densifyAndPrune", "addDensificationStats", "percentDense", "setPercentDense", "loadPly", "savePly"]
 ADAM_KEY = "c10::guts::to_string(param.unsafeGetTensorImpl())"   # LibTorch <= 2.1 state key (src/gaussian_model.cpp:571,598,670)
 
 
@@ -142,7 +142,8 @@ def build_densify(force=False):
     have = {k: (v if os.path.exists(v) else None) for k, v in MODEL_OUT.items()}
     if not os.path.exists(MODEL_SRC):
         return have
-    deps = (src, MODEL_SRC, os.path.join(REF, "include", "general_utils.h"), os.path.join(REF, "include", "gaussian_parameters.h"),
+    deps = (src, MODEL_SRC, os.path.join(REF, "third_party", "tinyply", "tinyply.h"),
+            os.path.join(REF, "include", "general_utils.h"), os.path.join(REF, "include", "gaussian_parameters.h"),
             os.path.join(REF, "src", "gaussian_parameters.cpp"), __file__)
     if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in MODEL_OUT.values()):
         return have

@@ -2,7 +2,8 @@
  * ref_densify.cpp -- torch ops around the REFERENCE's own map-maintenance code: the member functions
  *   GaussianModel::{getXYZ, getScalingActivation, getOpacityActivation, trainingSetup, resetOpacity,
  *   replaceTensorToOptimizer, prunePoints, densificationPostfix, densifyAndSplit, densifyAndClone, densifyAndPrune,
- *   addDensificationStats, percentDense, setPercentDense}            (src/gaussian_model.cpp:48-71, 477-510, 553-831, 1090-1100)
+ *   addDensificationStats, percentDense, setPercentDense, loadPly, savePly}
+ *                                                      (src/gaussian_model.cpp:48-71, 477-510, 553-831, 838-1047, 1090-1100)
  * are extracted VERBATIM, by name, from /root/reference/src/gaussian_model.cpp by oracle/build_ref.py into a generated
  * include file (oracle/_ref/gen/ref_gaussian_model_functions.inc, deleted after the compile) and compiled here against
  * LibTorch.  The only rewrite is the Adam state key: `c10::guts::to_string(param.unsafeGetTensorImpl())` (LibTorch <= 2.1
@@ -44,6 +45,11 @@ inline void refEmptyCache() {}
 
 #include "general_utils.h"        /* the reference's own headers */
 #include "gaussian_parameters.h"
+#define TINYPLY_IMPLEMENTATION    /* third_party/tinyply/tinyply.cpp does exactly this */
+#include "third_party/tinyply/tinyply.h"
+#include <cstring>
+#include <fstream>
+#include <iostream>
 
 #define GAUSSIAN_MODEL_TENSORS_TO_VEC                        \
     this->Tensor_vec_xyz_ = {this->xyz_};                    \
@@ -72,6 +78,10 @@ public:
 	void addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter);
 	float percentDense();
 	void setPercentDense(const float percent_dense);
+	void loadPly(std::filesystem::path ply_path);
+	void savePly(std::filesystem::path result_path);
+	int active_sh_degree_ = 0;
+	int max_sh_degree_ = 3;
 
 	torch::DeviceType device_type_ = REF_DEVICE;
 	torch::Tensor xyz_, features_dc_, features_rest_, scaling_, rotation_, opacity_;
@@ -246,7 +256,24 @@ TensorList ref_adam_step(TensorList params, TensorList grads, TensorList exp_avg
 
 }  // namespace
 
+/* GaussianModel::savePly / loadPly of the reference (tinyply): the checkpoint format is pinned against THEIR writer / reader */
+void ref_save_ply(TensorList params, std::string path)
+{
+	auto z1 = torch::zeros({params[0].size(0), 1}, params[0].options());
+	auto g = make_model(params, {}, {}, {}, z1, z1, z1.squeeze(1), z1.squeeze(1).to(torch::kInt32), 0.01, 1.0);
+	g->savePly(path);
+}
+TensorList ref_load_ply(std::string path, int64_t max_sh_degree)
+{
+	GaussianModel g;
+	g.max_sh_degree_ = (int)max_sh_degree;
+	g.loadPly(path);
+	return {g.xyz_, g.features_dc_, g.features_rest_, g.opacity_, g.scaling_, g.rotation_, torch::tensor({(int64_t)g.active_sh_degree_})};
+}
+
 #define REF_MODEL_OPS(m)                                              \
+	m.def("save_ply", &ref_save_ply);                                 \
+	m.def("load_ply", &ref_load_ply);                                 \
 	m.def("densify_and_prune", &ref_densify_and_prune);               \
 	m.def("reset_opacity", &ref_reset_opacity);                       \
 	m.def("prune_points", &ref_prune_points);                         \

@@ -57,3 +57,14 @@ def prune_points(ops, st, mask):
 
 def adam_step(ops, st, grads, spatial_lr_scale=1.0, xyz_lr=-1.0):
     return State.from_dump(ops.adam_step(st.params, list(grads), st.exp_avg, st.exp_avg_sq, st.steps, spatial_lr_scale, xyz_lr))
+
+
+def save_ply(ops, params, path):
+    """the reference's GaussianModel::savePly (tinyply) on the six tensors (reference order: xyz, f_dc, f_rest, opacity, scaling, rotation)"""
+    ops.save_ply(list(params), str(path))
+
+
+def load_ply(ops, path, max_sh_degree=3):
+    """the reference's GaussianModel::loadPly -> (xyz, f_dc [P,1,3], f_rest [P,M-1,3], opacity, scaling, rotation, active degree)"""
+    out = ops.load_ply(str(path), max_sh_degree)
+    return out[:6], int(out[6])

@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SRCS = ["rasterize_points.cpp", "gaussian_rasterizer.cpp", "train_step.cpp", "gaussian_model_densify.cpp", "operate_points.cpp", "ops_register.cpp"]
+SRCS = ["rasterize_points.cpp", "gaussian_rasterizer.cpp", "train_step.cpp", "gaussian_model_densify.cpp", "ply_io.cpp", "operate_points.cpp",
+        "ops_register.cpp"]
 
 
 def _torch_paths():

@@ -9,6 +9,7 @@
 #include <array>
 #include <cmath>
 #include <memory>
+#include <string>
 #include <vector>
 
 struct GaussianOptimizationParams {  // include/gaussian_parameters.h:61-96 defaults
@@ -87,6 +88,10 @@ public:
 
 	// arena of the rebuilds (gaussian_model_densify.cpp): optional, created on the first rebuild otherwise
 	void reserve(int64_t capacity);
+	// checkpoint interchange with the reference and with Inria viewers (src/ply_io.cpp; src/gaussian_model.cpp:838-1047)
+	void savePly(const std::string& result_path);
+	void loadPly(const std::string& ply_path);
+	torch::Device device_ = torch::kCPU;   // where loadPly() / createFromPcd() put a model that has no tensors yet
 
 private:
 	torch::Tensor& paramByIndex(int i);

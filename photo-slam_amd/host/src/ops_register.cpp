@@ -191,6 +191,19 @@ std::vector<int64_t> trainer_last_densify(int64_t h)
 	auto r = get(h)->last_densify_;
 	return {r.cloned, r.split, r.pruned, r.points};
 }
+void trainer_save_ply(int64_t h, std::string path) { get(h)->gaussians_->savePly(path); }
+// a fresh trainer from a PLY checkpoint (GaussianModel::loadPly): the tensors land on the device of `bg`
+int64_t trainer_create_from_ply(std::string path, int64_t sh_degree, double spatial_lr_scale, torch::Tensor bg)
+{
+	auto g = std::make_shared<GaussianModel>((int)sh_degree);
+	g->device_ = bg.device();
+	g->loadPly(path);
+	g->spatial_lr_scale_ = (float)spatial_lr_scale;
+	g->trainingSetup(GaussianOptimizationParams());
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_trainers[g_next] = std::make_shared<TrainStep>(g, bg);
+	return g_next++;
+}
 void trainer_reset_opacity(int64_t h) { get(h)->gaussians_->resetOpacity(); }
 void trainer_prune_points(int64_t h, torch::Tensor mask) { get(h)->gaussians_->prunePoints(mask); }
 void trainer_one_up_sh_degree(int64_t h) { get(h)->gaussians_->oneUpShDegree(); }
@@ -273,6 +286,8 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_set_options", &trainer_set_options);
 	m.def("trainer_densify_and_prune", &trainer_densify_and_prune);
 	m.def("trainer_last_densify", &trainer_last_densify);
+	m.def("trainer_save_ply", &trainer_save_ply);
+	m.def("trainer_create_from_ply", &trainer_create_from_ply);
 	m.def("trainer_reset_opacity", &trainer_reset_opacity);
 	m.def("trainer_prune_points", &trainer_prune_points);
 	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
