@@ -86,6 +86,9 @@ int gsr_forward(const gsr_forward_args* args,
  * gsr_backward_args.sh_adam).  torch::optim::Adam semantics as gsr_adam_step; the first 3 floats of a row
  * (features_dc) use lr, the other 45 (features_rest) lr_tail. */
 typedef struct gsr_sh_adam {
+	float* param;                /* [P,16,3]: the SH tensor itself, UPDATED IN PLACE; gsr_backward requires param == shs (the
+	                                const input pointer of the reference's parameter list stays const: the write goes
+	                                through this one) */
 	float* exp_avg;              /* [P,16,3] */
 	float* exp_avg_sq;           /* [P,16,3] */
 	double lr, lr_tail, beta1, beta2, eps;   /* double like torch::optim::AdamOptions: the bias corrections 1 - beta^step are
@@ -134,8 +137,8 @@ typedef struct gsr_backward_args {
 	 * dL_dmean3D is computed as usual. */
 	float* dL_dcolor_view;
 	/* Extension, optimizer-in-backward for the SH tensor (NULL = the reference contract).  When set, dL_dsh is NOT written
-	 * (and may be NULL): the kernel that produces the gradient rows applies this step's Adam update to `shs` IN PLACE
-	 * (shs is written despite its const type) and to the two moment tensors, for every Gaussian (culled ones with a zero
+	 * (and may be NULL): the kernel that produces the gradient rows applies this step's Adam update to sh_adam->param (which
+	 * must be the same tensor as shs) IN PLACE and to the two moment tensors, for every Gaussian (culled ones with a zero
 	 * gradient, as a dense optimizer does) -- the 192 B/Gaussian gradient row never round-trips through HBM.  Only for
 	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise); mutually exclusive with dL_dcolor_view. */
 	const gsr_sh_adam* sh_adam;
@@ -167,8 +170,9 @@ int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
                            float* dL_dsh, void* stream);
 
 /* The same with the optimizer fused in (as gsr_backward_args.sh_adam): instead of writing dL_dsh, this step's Adam update with
- * that batch-mean gradient is applied to shs [P,16,3] IN PLACE and to the two moment tensors.  16-byte aligned [P,16,3]
- * tensors only (GSR_ERR_UNSUPPORTED otherwise).  Reads means3D: call it before the positions' own update. */
+ * that batch-mean gradient is applied to shs [P,16,3] IN PLACE and to the two moment tensors (sh_adam->param must be shs or
+ * NULL).  16-byte aligned [P,16,3] tensors only (GSR_ERR_UNSUPPORTED otherwise).  Reads means3D: call it before the
+ * positions' own update. */
 int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                            long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
                            float* shs, const gsr_sh_adam* sh_adam, void* stream);

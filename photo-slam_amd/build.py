@@ -36,7 +36,7 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    d += [os.path.join(HERE, "..", "include", f) for f in ("gsr.h", "gsr_stages.h")]
+    d += [os.path.join(HERE, "..", "include", "gsr.h")]
     return d
 
 

@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI (include/gsr.h, include/gsr_stages.h).
+"""ctypes binding of the C-ABI (include/gsr.h).
 
 The product library is photo-slam_amd/libgsr_hip.so (hand-written HIP for gfx950).  There is
 NO CPU fallback: if the library is missing, `load()` raises.  (The test-suite may pass the
@@ -35,7 +35,7 @@ class ForwardArgs(C.Structure):
 
 
 class ShAdam(C.Structure):
-    _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("lr_tail", C.c_double),
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("lr_tail", C.c_double),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int)]
 
 
@@ -70,28 +70,14 @@ class DensifyGatherArgs(C.Structure):
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 
 
-class GeometryView(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("depth_key", "tiles_touched", "radii", "rect", "rec", "cov3D", "clamped",
-                                          "order", "offsets")]
-
-
-class BinningView(C.Structure):
-    _fields_ = [("point_list", C.c_void_p), ("tile_keys", C.c_void_p)]
-
-
-class ImageView(C.Structure):
-    _fields_ = [("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("ranges", C.c_void_p)]
-
-
-# every symbol include/gsr.h and include/gsr_stages.h declare
+# every symbol include/gsr.h declares
 EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
     "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
     "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_densify_scratch_bytes",
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
-    "gsr_neighborhood_depth_pinhole", "gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_scan_scratch_bytes",
-    "gsr_stage_scan_u32", "gsr_sort_scratch_bytes", "gsr_stage_radix_sort_pairs",
+    "gsr_neighborhood_depth_pinhole",
 ]
 
 _libs = {}
@@ -120,8 +106,7 @@ def load(path=None):
     L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.gsr_knn_mean_dist2.restype = i32
     L.gsr_knn_mean_dist2.argtypes = [i32, vp, vp, ALLOC_FN, vp, vp]
-    for n in ("gsr_geometry_bytes", "gsr_binning_bytes", "gsr_knn_scratch_bytes", "gsr_scan_scratch_bytes",
-              "gsr_sort_scratch_bytes"):
+    for n in ("gsr_geometry_bytes", "gsr_binning_bytes", "gsr_knn_scratch_bytes"):
         getattr(L, n).restype = sz
         getattr(L, n).argtypes = [i32]
     L.gsr_image_bytes.restype = sz
@@ -161,16 +146,6 @@ def load(path=None):
     L.gsr_reproject_depth_pinhole.argtypes = [i32, i32, f32, f32, f32, f32, vp, vp, vp, vp]
     L.gsr_neighborhood_depth_pinhole.restype = i32
     L.gsr_neighborhood_depth_pinhole.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp]
-    L.gsr_view_geometry.restype = i32
-    L.gsr_view_geometry.argtypes = [vp, i32, C.POINTER(GeometryView)]
-    L.gsr_view_binning.restype = i32
-    L.gsr_view_binning.argtypes = [vp, i32, i32, i32, C.POINTER(BinningView)]
-    L.gsr_view_image.restype = i32
-    L.gsr_view_image.argtypes = [vp, i32, i32, C.POINTER(ImageView)]
-    L.gsr_stage_scan_u32.restype = i32
-    L.gsr_stage_scan_u32.argtypes = [vp, vp, i32, i32, vp, vp]
-    L.gsr_stage_radix_sort_pairs.restype = i32
-    L.gsr_stage_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     _libs[path] = L
     return L
 

@@ -1,4 +1,4 @@
-// gsr_api.hip -- the C-ABI of libgsr_hip.so (include/gsr.h, include/gsr_stages.h):
+// gsr_api.hip -- the C-ABI of libgsr_hip.so (include/gsr.h):
 // argument validation, scratch carving, and the launch sequence of the forward and
 // backward passes on the caller's HIP stream.
 //
@@ -11,7 +11,6 @@
 #include <cmath>
 #include "kernels.h"
 #include "shrows.h"
-#include "../../include/gsr_stages.h"
 
 #include <stdio.h>
 #include <string.h>
@@ -33,9 +32,9 @@ struct HostSync {
 	hipEvent_t ev = nullptr;
 	int init()
 	{
-		if (pinned) return GSR_OK;
-		GSR_HIP(hipHostMalloc((void**)&pinned, NUM_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
-		GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		if (pinned && ev) return GSR_OK;
+		if (!pinned) GSR_HIP(hipHostMalloc((void**)&pinned, NUM_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
+		if (!ev) GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));   // a failure here is retried by the next call
 		return GSR_OK;
 	}
 };
@@ -116,12 +115,6 @@ size_t gsr_geometry_bytes(int P) { return geometry_bytes(P < 0 ? 0 : P); }
 size_t gsr_binning_bytes(int R) { return binning_bytes(R < 0 ? 0 : R); }
 size_t gsr_image_bytes(int W, int H) { return (W <= 0 || H <= 0) ? 0 : image_bytes(W, H); }
 size_t gsr_knn_scratch_bytes(int P) { return knn_scratch_bytes(P < 0 ? 0 : P); }
-size_t gsr_scan_scratch_bytes(int n) { return scan_scratch_elems(n < 0 ? 0 : n) * sizeof(uint32_t); }
-size_t gsr_sort_scratch_bytes(int n)
-{
-	const size_t m = (size_t)(n < 0 ? 0 : n);
-	return (sort_scratch_elems((int)m) + 2 * m + 64) * sizeof(uint32_t);  // histograms + one temp (key, value) buffer pair
-}
 
 const char* gsr_strerror(int status)
 {
@@ -305,7 +298,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.adam = AdamScalars{};
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
-		pb.adam_param = const_cast<float*>(a->shs);
+		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input
+		pb.adam_param = o.param;
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
 		pb.adam = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
 	}
@@ -336,6 +330,7 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 	if (P == 0) return GSR_OK;
 	if (!means3D || !campos || !dL_dcolor_views || !shs || !o || !o->exp_avg || !o->exp_avg_sq || o->step < 1)
 		return GSR_ERR_INVALID_ARG;
+	if (o->param && o->param != shs) return GSR_ERR_INVALID_ARG;
 	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, adam_scalars(o->lr, o->lr_tail, o->beta1, o->beta2, o->eps, o->step)};
 	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
 	                                 nullptr, &ra, (hipStream_t)stream_);
@@ -390,58 +385,6 @@ int gsr_knn_mean_dist2(int P, const float* points, float* meanDists, gsr_alloc_f
 	char* scratch = scratchBuffer(scratch_ctx, knn_scratch_bytes(P));
 	if (!scratch) return GSR_ERR_ALLOC;
 	return launch_knn(P, points, meanDists, scratch, (hipStream_t)stream);
-}
-
-// ---------------------------------------------------------------- gsr_stages.h
-int gsr_view_geometry(char* geom_buffer, int P, gsr_geometry_view* out)
-{
-	if (!geom_buffer || P < 0 || !out) return GSR_ERR_INVALID_ARG;
-	GeometryState g = GeometryState::carve(geom_buffer, (size_t)P);
-	out->depth_key = g.depth_key; out->tiles_touched = g.tiles_touched; out->radii = g.radii; out->rect = g.rect;
-	out->rec = reinterpret_cast<float*>(g.rec); out->cov3D = g.cov3D; out->clamped = g.clamped; out->order = g.order;
-	out->offsets = g.offsets;
-	return GSR_OK;
-}
-int gsr_view_binning(char* binning_buffer, int R, int width, int height, gsr_binning_view* out)
-{
-	if (!binning_buffer || R < 0 || !out || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
-	BinningState b = BinningState::carve(binning_buffer, (size_t)R);
-	const int passes = tile_sort_passes(div_up(width, TILE) * div_up(height, TILE));
-	out->point_list = (passes % 2) ? b.vals_b : b.vals_a;
-	out->tile_keys = (passes % 2) ? b.keys_b : b.keys_a;
-	return GSR_OK;
-}
-int gsr_view_image(char* image_buffer, int width, int height, gsr_image_view* out)
-{
-	if (!image_buffer || !out || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
-	const size_t T = (size_t)div_up(width, TILE) * div_up(height, TILE);
-	ImageState im = ImageState::carve(image_buffer, (size_t)width * height, T);
-	out->final_T = im.final_T; out->n_contrib = im.n_contrib; out->ranges = reinterpret_cast<uint32_t*>(im.ranges);
-	return GSR_OK;
-}
-int gsr_stage_scan_u32(const uint32_t* in, uint32_t* out, int n, int inclusive, char* scratch, void* stream)
-{
-	if (n < 0 || (n > 0 && (!in || !out || !scratch))) return GSR_ERR_INVALID_ARG;
-	return launch_scan_u32(in, nullptr, out, n, inclusive != 0, reinterpret_cast<uint32_t*>(scratch), (hipStream_t)stream);
-}
-int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out, int n,
-                               int begin_bit, int end_bit, char* scratch, void* stream_)
-{
-	if (n < 0 || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit) return GSR_ERR_INVALID_ARG;
-	if (n == 0) return GSR_OK;
-	if (!keys_in || !keys_out || !values_out || !scratch) return GSR_ERR_INVALID_ARG;
-	hipStream_t stream = (hipStream_t)stream_;
-	const int passes = div_up(end_bit - begin_bit, RADIX_BITS);
-	// keys_in/values_in are only read; a temp pair carved from scratch is the other half of the
-	// ping-pong, arranged so that the final pass lands in (keys_out, values_out).
-	uint32_t* sc = reinterpret_cast<uint32_t*>(scratch);
-	uint32_t* tmp_k = sc + sort_scratch_elems(n);
-	uint32_t* tmp_v = tmp_k + n;
-	uint32_t *kp, *vp, *kq, *vq;  // ping, pong
-	if (passes % 2) { kq = keys_out; vq = values_out; kp = tmp_k; vp = tmp_v; }
-	else            { kp = keys_out; vp = values_out; kq = tmp_k; vq = tmp_v; }
-	uint32_t *kres, *vres;
-	return launch_radix_sort(keys_in, values_in, kp, vp, kq, vq, n, begin_bit, end_bit, sc, stream, &kres, &vres);
 }
 
 }  // extern "C"

@@ -241,6 +241,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		}
 		gsr_sh_adam adam{};
 		if (fused_adam) {
+			adam.param = const_cast<float*>(a.shs);   // the caller handed `sh` over for the in-place update (ShAdamStep contract)
 			adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
 			adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
 			adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
@@ -315,6 +316,7 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 	if (P == 0) return;
 	F32 m3(means3D);
 	gsr_sh_adam adam{};
+	adam.param = sh.data_ptr<float>();
 	adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
 	adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
 	adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;

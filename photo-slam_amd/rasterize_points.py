@@ -178,7 +178,7 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
                     raise RuntimeError("view_stats tensors must be contiguous float32 with num_points elements")
             a.stat_grad_accum, a.stat_denom, a.stat_max_radii = (t.data_ptr() for t in view_stats)
         if sh_adam is not None:
-            adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
+            adam = capi.ShAdam(sh.data_ptr(), sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
                                float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]),
                                float(sh_adam["eps"]), int(sh_adam["step"]))
             a.sh_adam = C.pointer(adam)
@@ -238,7 +238,7 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
             raise RuntimeError("sh and its moments must be contiguous float32 (num_points, M, 3) tensors")
     if P != 0:
         k1, p1 = _ptr(means3D)
-        adam = capi.ShAdam(sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
+        adam = capi.ShAdam(sh.data_ptr(), sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
                            float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]), float(sh_adam["eps"]),
                            int(sh_adam["step"]))
         st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, pc, sc, pv, sv, float(scale),

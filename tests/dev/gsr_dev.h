@@ -1,13 +1,14 @@
 /*
- * gsr_stages.h -- stage-level entry points of libgsr_hip.so, used by the parity tests
- * to compare every intermediate of the pipeline with the oracle (tile rectangles, sort
- * order, tile ranges, n_contrib, ...) and to exercise the scan / radix-sort building
- * blocks at sizes the full pipeline does not reach in a unit test.
- * Same conventions as gsr.h (device pointers, explicit stream, int status).
+ * gsr_dev.h -- TEST-ONLY introspection of the rasterizer (tests/dev/libgsr_dev.so, and part of the emulator build): typed
+ * views into the opaque scratch buffers of gsr_forward, so that the parity tests can compare every intermediate of the
+ * pipeline with the oracle (tile rectangles, sort order, tile ranges, n_contrib, ...), and the scan / radix-sort building
+ * blocks at sizes the full pipeline does not reach in a unit test.  NOT part of the product: libgsr_hip.so exports none of
+ * these; libgsr_dev.so is a thin host-side library that links against it.  The scratch layout is an implementation detail
+ * and may change with any commit.  Same conventions as gsr.h (device pointers, explicit stream, int status).
  */
-#ifndef GSR_STAGES_H
-#define GSR_STAGES_H
-#include "gsr.h"
+#ifndef GSR_DEV_H
+#define GSR_DEV_H
+#include "../../include/gsr.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -49,7 +50,8 @@ int gsr_stage_scan_u32(const uint32_t* in, uint32_t* out, int n, int inclusive, 
 /* Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit,end_bit)
  * (the cub::DeviceRadixSort::SortPairs replacement, rasterizer_impl.cu:303-308 and
  * simple_knn.cu:210-213).  values_in == NULL means values = 0..n-1.  Inputs are only
- * read; the result is in keys_out/values_out.  scratch: gsr_sort_scratch_bytes(n). */
+ * read and must not alias the outputs (GSR_ERR_INVALID_ARG: with an odd number of passes the first pass scatters straight
+ * into the output pair); the result is in keys_out/values_out.  scratch: gsr_sort_scratch_bytes(n). */
 size_t gsr_sort_scratch_bytes(int n);
 int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
                                int n, int begin_bit, int end_bit, char* scratch, void* stream);

@@ -13,9 +13,10 @@ SOURCES = ["gsr_api.hip", "preprocess.hip", "sort.hip", "binning.hip", "blend_fw
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu.cpp")]
+    dev = os.path.join(ROOT, "tests", "dev")   # the test-only introspection hooks are part of the emulator library
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu.cpp"), os.path.join(dev, "gsr_dev.cpp")]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
-        os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "gsr.h"), os.path.join(ROOT, "include", "gsr_stages.h")]
+        os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "gsr.h"), os.path.join(dev, "gsr_dev.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     objs = []
@@ -24,7 +25,7 @@ def build(force=False):
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         os.makedirs(os.path.dirname(o), exist_ok=True)
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-DGSR_EMU", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-               "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-sign-compare", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o]
+               "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-sign-compare", "-I", HERE, "-I", CSRC, "-I", dev, "-x", "c++", "-c", s, "-o", o]
         procs.append((subprocess.Popen(cmd), cmd))
         objs.append(o)
     for p, cmd in procs:

@@ -13,8 +13,14 @@ import ctypes as C
 import numpy as np
 import torch
 
+import os
+import sys
+
 from photo_slam_amd import capi
 from photo_slam_amd import rasterize_points as rp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev"))
+import devapi  # noqa: E402  (tests/dev: the TEST-ONLY introspection of the scratch buffers)
 
 RGB_L1_TOL = 1e-4
 GRAD_REL_L1_TOL = 1e-4      # north_star: "within 1e-4 L1 on rendered RGB / gradients" (measured: 3e-7 ... 6e-7)
@@ -53,6 +59,7 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
     rp._LIB_OVERRIDE = lib_path
     try:
         lib = capi.load(lib_path)
+        dlib = devapi.load(lib_path)
         empty = torch.empty(0, device=dev)
         P = cl.xyz.shape[0]
         a = dict(background=_t(bg, dev), means3D=_t(cl.xyz, dev),
@@ -67,9 +74,9 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
         r = BackendResult()
         r.R, r.out_color, r.radii = R, color.cpu().numpy(), radii.cpu().numpy()
         if P:
-            gv, bv, iv = capi.GeometryView(), capi.BinningView(), capi.ImageView()
-            capi.check(lib, lib.gsr_view_geometry(C.c_void_p(geom.data_ptr()), P, C.byref(gv)), "view_geometry")
-            capi.check(lib, lib.gsr_view_image(C.c_void_p(img.data_ptr()), cam.W, cam.H, C.byref(iv)), "view_image")
+            gv, bv, iv = devapi.GeometryView(), devapi.BinningView(), devapi.ImageView()
+            capi.check(lib, dlib.gsr_view_geometry(C.c_void_p(geom.data_ptr()), P, C.byref(gv)), "view_geometry")
+            capi.check(lib, dlib.gsr_view_image(C.c_void_p(img.data_ptr()), cam.W, cam.H, C.byref(iv)), "view_image")
             r.depth_key = _slice(geom, gv.depth_key, P, np.uint32)
             r.tiles_touched = _slice(geom, gv.tiles_touched, P, np.uint32)
             r.rect = _slice(geom, gv.rect, 4 * P, np.uint16).reshape(P, 4)
@@ -83,7 +90,7 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
             r.n_contrib = _slice(img, iv.n_contrib, cam.W * cam.H, np.uint32).reshape(cam.H, cam.W)
             r.ranges = _slice(img, iv.ranges, 2 * T, np.uint32).reshape(T, 2)
             if R:
-                capi.check(lib, lib.gsr_view_binning(C.c_void_p(binning.data_ptr()), R, cam.W, cam.H, C.byref(bv)), "view_binning")
+                capi.check(lib, dlib.gsr_view_binning(C.c_void_p(binning.data_ptr()), R, cam.W, cam.H, C.byref(bv)), "view_binning")
                 r.point_list = _slice(binning, bv.point_list, R, np.uint32)
                 r.tile_keys = _slice(binning, bv.tile_keys, R, np.uint32)
             else:

@@ -1,12 +1,18 @@
-"""Helpers to call the stage-level C-ABI entry points (include/gsr_stages.h) and the kNN /
+"""Helpers to call the TEST-ONLY stage-level entry points (tests/dev/gsr_dev.h) and the kNN /
 markVisible wrappers on a given build (HIP library on the GPU, emulator on the host)."""
 import ctypes as C
 
 import numpy as np
 import torch
 
+import os
+import sys
+
 from photo_slam_amd import capi
 from photo_slam_amd import rasterize_points as rp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev"))
+import devapi  # noqa: E402
 
 
 def _stream(dev):
@@ -14,18 +20,18 @@ def _stream(dev):
 
 
 def scan_u32(lib_path, dev, values, inclusive):
-    lib = capi.load(lib_path)
+    lib = devapi.load(lib_path)
     n = int(values.shape[0])
     src = torch.from_numpy(values.astype(np.uint32).view(np.int32)).to(dev)
     out = torch.zeros_like(src)
     scratch = torch.empty(int(lib.gsr_scan_scratch_bytes(n)) + 16, dtype=torch.uint8, device=dev)
     st = lib.gsr_stage_scan_u32(src.data_ptr(), out.data_ptr(), n, int(inclusive), scratch.data_ptr(), _stream(dev))
-    capi.check(lib, st, "gsr_stage_scan_u32")
+    capi.check(capi.load(lib_path), st, "gsr_stage_scan_u32")
     return out.cpu().numpy().view(np.uint32)
 
 
 def radix_sort_pairs(lib_path, dev, keys, values, begin_bit, end_bit):
-    lib = capi.load(lib_path)
+    lib = devapi.load(lib_path)
     n = int(keys.shape[0])
     k_in = torch.from_numpy(keys.astype(np.uint32).view(np.int32)).to(dev)
     v_in = None if values is None else torch.from_numpy(values.astype(np.uint32).view(np.int32)).to(dev)
@@ -34,7 +40,7 @@ def radix_sort_pairs(lib_path, dev, keys, values, begin_bit, end_bit):
     scratch = torch.empty(int(lib.gsr_sort_scratch_bytes(n)) + 16, dtype=torch.uint8, device=dev)
     st = lib.gsr_stage_radix_sort_pairs(k_in.data_ptr(), None if v_in is None else v_in.data_ptr(), k_out.data_ptr(),
                                         v_out.data_ptr(), n, begin_bit, end_bit, scratch.data_ptr(), _stream(dev))
-    capi.check(lib, st, "gsr_stage_radix_sort_pairs")
+    capi.check(capi.load(lib_path), st, "gsr_stage_radix_sort_pairs")
     assert np.array_equal(k_in.cpu().numpy().view(np.uint32), keys.astype(np.uint32)), "keys_in was modified"
     return k_out.cpu().numpy().view(np.uint32), v_out.cpu().numpy().view(np.uint32)
 

@@ -1,5 +1,5 @@
 """The C-ABI library loads on a machine without a GPU and exports every function that
-include/gsr.h and include/gsr_stages.h declare (no compute calls here)."""
+include/gsr.h declares (no compute calls here); the test-only introspection hooks live in tests/dev, NOT in the product."""
 import ctypes
 import os
 import re
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for h in ("gsr.h", "gsr_stages.h"):
+    for h in ("gsr.h",):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", src))
@@ -34,6 +34,14 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.gsr_backend() == b"hip-gfx950"
     lib.gsr_strerror.restype = ctypes.c_char_p
     assert lib.gsr_strerror(-3) == b"HIP runtime error"
+
+
+def test_product_library_exports_no_test_hooks():
+    if not os.path.exists(capi.HIP_LIB_PATH):
+        pytest.skip("libgsr_hip.so not built")
+    lib = ctypes.CDLL(capi.HIP_LIB_PATH)
+    for n in ("gsr_view_geometry", "gsr_view_binning", "gsr_view_image", "gsr_stage_scan_u32", "gsr_stage_radix_sort_pairs"):
+        assert not hasattr(lib, n), n
 
 
 def test_product_loader_has_no_fallback(tmp_path):
