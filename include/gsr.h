@@ -39,6 +39,20 @@ typedef enum gsr_status {
  * (cuda_rasterizer/rasterizer.h:36-38). */
 typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
 
+/* Extension: Adam state of the [P,16,3] SH tensor for the fused update inside gsr_backward (see
+ * gsr_backward_args.sh_adam).  torch::optim::Adam semantics as gsr_adam_step; the first 3 floats of a row
+ * (features_dc) use lr, the other 45 (features_rest) lr_tail. */
+typedef struct gsr_sh_adam {
+	float* param;                /* [P,16,3]: the SH tensor itself, UPDATED IN PLACE; gsr_backward requires param == shs (the
+	                                const input pointer of the reference's parameter list stays const: the write goes
+	                                through this one) */
+	float* exp_avg;              /* [P,16,3] */
+	float* exp_avg_sq;           /* [P,16,3] */
+	double lr, lr_tail, beta1, beta2, eps;   /* double like torch::optim::AdamOptions: the bias corrections 1 - beta^step are
+	                                            formed in double as torch does (0.999f instead of 0.999 is 1e-5 of the step) */
+	int step;                    /* >= 1: the step being taken (bias correction) */
+} gsr_sh_adam;
+
 /* Rasterizer::forward parameter list, cuda_rasterizer/rasterizer.h:35-59, 1:1. */
 typedef struct gsr_forward_args {
 	int P, D, M;                 /* #Gaussians, active SH degree, SH coeffs per channel stored */
@@ -82,19 +96,6 @@ int gsr_forward(const gsr_forward_args* args,
                 gsr_alloc_fn imageBuffer, void* image_ctx,
                 void* stream, int* num_rendered);
 
-/* Extension: Adam state of the [P,16,3] SH tensor for the fused update inside gsr_backward (see
- * gsr_backward_args.sh_adam).  torch::optim::Adam semantics as gsr_adam_step; the first 3 floats of a row
- * (features_dc) use lr, the other 45 (features_rest) lr_tail. */
-typedef struct gsr_sh_adam {
-	float* param;                /* [P,16,3]: the SH tensor itself, UPDATED IN PLACE; gsr_backward requires param == shs (the
-	                                const input pointer of the reference's parameter list stays const: the write goes
-	                                through this one) */
-	float* exp_avg;              /* [P,16,3] */
-	float* exp_avg_sq;           /* [P,16,3] */
-	double lr, lr_tail, beta1, beta2, eps;   /* double like torch::optim::AdamOptions: the bias corrections 1 - beta^step are
-	                                            formed in double as torch does (0.999f instead of 0.999 is 1e-5 of the step) */
-	int step;                    /* >= 1: the step being taken (bias correction) */
-} gsr_sh_adam;
 
 /* Rasterizer::backward parameter list, cuda_rasterizer/rasterizer.h:61-91. */
 typedef struct gsr_backward_args {
@@ -139,7 +140,10 @@ typedef struct gsr_backward_args {
 	/* Extension, optimizer-in-backward for the SH tensor (NULL = the reference contract).  When set, dL_dsh is NOT written
 	 * (and may be NULL): the kernel that produces the gradient rows applies this step's Adam update to sh_adam->param (which
 	 * must be the same tensor as shs) IN PLACE and to the two moment tensors, for every Gaussian (culled ones with a zero
-	 * gradient, as a dense optimizer does) -- the 192 B/Gaussian gradient row never round-trips through HBM.  Only for
+	 * gradient, as a dense optimizer does) -- the 192 B/Gaussian gradient row never round-trips through HBM.  The rows of
+	 * the Gaussians this view culls do not depend on the backward pass at all (zero gradient): gsr_backward updates them on
+	 * a second HIP stream it owns, concurrently with the VALU-bound backward blend that leaves HBM nearly idle, and joins
+	 * that stream before it returns (environment GSR_SH_ADAM_SIDE_STREAM=0: everything on the caller's stream).  Only for
 	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise); mutually exclusive with dL_dcolor_view. */
 	const gsr_sh_adam* sh_adam;
 	/* Extension (all three or none; NULL = the reference contract): the densification statistics of this view, updated by

@@ -13,6 +13,7 @@
 #include "shrows.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace gsr {
@@ -30,6 +31,22 @@ void set_last_hip_error(int err, const char* what)
 struct HostSync {
 	uint32_t* pinned = nullptr;
 	hipEvent_t ev = nullptr;
+	// second stream for HBM-bound work that runs next to the VALU-bound blend (the culled rows of the fused SH Adam step, gsr_backward), with the
+	// events that fork it from and join it to the caller's stream
+	hipStream_t side = nullptr;
+	hipEvent_t fork = nullptr, join = nullptr;
+	int init_side()
+	{
+		if (!side) {
+			// lowest priority: the blend kernel on the caller's stream keeps the first claim on wave slots
+			int lo = 0, hi = 0;
+			GSR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+			GSR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
+		}
+		if (!fork) GSR_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+		if (!join) GSR_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+		return GSR_OK;
+	}
 	int init()
 	{
 		if (pinned && ev) return GSR_OK;
@@ -39,6 +56,12 @@ struct HostSync {
 	}
 };
 static thread_local HostSync t_sync;
+// GSR_SH_ADAM_SIDE_STREAM=0: no second stream (A/B timing, debugging)
+static bool side_stream_enabled()
+{
+	static const bool on = [] { const char* e = getenv("GSR_SH_ADAM_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+	return on;
+}
 
 // Optional per-stage HIP-event timing (gsr_profile_*): events are recorded on the caller's
 // stream between the stages of gsr_forward / gsr_backward, so bench.py can price each kernel
@@ -260,6 +283,24 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
 	t_prof.bwd_done = false;
+	// Fused Adam step of the SH tensor: the rows of the CULLED Gaussians carry a zero gradient, i.e. their update does not
+	// depend on anything this pass computes.  It runs on a second stream from here on -- HBM-bound streaming (1152 B per culled
+	// Gaussian) next to the VALU-bound backward blend, which leaves HBM nearly idle -- and is joined at the end; the row kernel
+	// behind preprocess_bwd then updates the visible rows only.  (Only the radii of the forward pass are read.)
+	bool side_busy = false;
+	if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled() &&
+	    !((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg) |
+	       reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg_sq)) & 15)) {
+		const gsr_sh_adam& o = *a->sh_adam;
+		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;
+		if ((st = t_sync.init_side()) != GSR_OK) return st;
+		const RowAdam ra = {o.param, o.exp_avg, o.exp_avg_sq, adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step)};
+		GSR_HIP(hipEventRecord(t_sync.fork, stream));
+		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
+		if ((st = launch_sh_adam_culled(P, a->radii ? a->radii : g.radii, ra, t_sync.side)) != GSR_OK) return st;
+		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
+		side_busy = true;
+	}
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
 	// every API output is written exactly once by preprocess_bwd
@@ -296,14 +337,17 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.stat_accum = a->stat_grad_accum; pb.stat_denom = a->stat_denom; pb.stat_max_radii = a->stat_max_radii;
 	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
 	pb.adam = AdamScalars{};
+	pb.adam_skip_culled = 0;
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
 		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input
 		pb.adam_param = o.param;
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
 		pb.adam = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
+		pb.adam_skip_culled = side_busy ? 1 : 0;
 	}
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
+	if (side_busy) GSR_HIP(hipStreamWaitEvent(stream, t_sync.join, 0));   // whatever follows on the caller's stream sees the whole update
 	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on != 0;
 	return GSR_OK;

@@ -117,6 +117,7 @@ struct PreprocessBwdParams {
 	float* adam_exp_avg;
 	float* adam_exp_avg_sq;
 	AdamScalars adam;
+	int adam_skip_culled;     // the culled Gaussians' rows already took this step (the culled rows of the fused SH Adam step, gsr_backward)
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
@@ -124,6 +125,9 @@ struct RowAdam;   // shrows.h: Adam state + scalars of the fused row update (nul
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                               long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
                               float* dL_dsh, const RowAdam* adam, hipStream_t stream);
+
+// this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
+int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

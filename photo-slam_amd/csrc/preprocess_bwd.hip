@@ -18,6 +18,7 @@
 // and rewritten by the SH kernel), mean2D 12, colour 12 (re-read once), opacity 4, cov3D 24, SH 12M, scale 12, rot 16.
 #include "state.h"
 #include "wave64.h"
+#include <stdlib.h>
 #include "kernels.h"
 #include "shrows.h"
 #include "partials.h"
@@ -101,7 +102,10 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 					wave_store_rows(reinterpret_cast<float4*>(p.dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 				} else if (MODE == 2) {
 					const RowAdam ra = {p.adam_param, p.adam_exp_avg, p.adam_exp_avg_sq, p.adam};
-					wave_adam_rows(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
+					// the rows of this half that step here: all of them, or only the visible ones when the culled Gaussians
+					// took the step in gsr_forward (their rows then are neither read nor written)
+					const uint32_t rows = p.adam_skip_culled ? (uint32_t)(m >> (h * STAGE_ROWS)) : 0xFFFFFFFFu;
+					wave_adam_rows(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w], rows);
 				} else {
 					wave_fence();   // the next pass refills the slice
 				}
@@ -410,6 +414,58 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		p.dL_dscale[3 * (size_t)idx + 2] = g_scale[2];
 		reinterpret_cast<float4*>(p.dL_drot)[idx] = dq;
 	}
+}
+
+// The Adam step of the SH rows of the culled Gaussians (zero gradient: m <- b1 m, v <- b2 v, p <- p - step m / (sqrt(v) c + eps)),
+// the arithmetic of wave_adam_rows with g = 0.  One thread per float4 of a row (12 per row); rows of visible Gaussians are
+// not touched.  HBM-bound streaming (576 B read + 576 B written per culled Gaussian) meant to run on a second stream next to
+// the VALU-bound backward blend (gsr_backward).
+__device__ __forceinline__ void sh_adam_culled_item(long long t, const int* __restrict__ radii, const RowAdam& a)
+{
+	const long long row = t / ROW_F4;
+	if (radii[row] > 0) return;
+	const int col = (int)(t - row * ROW_F4);
+	const size_t i = (size_t)t;
+	float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
+	float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
+	float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+	float* pp = &pv.x; float* mp = &mv.x; float* vp = &vv.x;
+	const float ss_first = col == 0 ? a.s.step_size : a.s.step_size_tail;
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		const float ss = e < 3 ? ss_first : a.s.step_size_tail;
+		const float g = 0.f;
+		mp[e] = a.s.b1 * mp[e] + a.s.omb1 * g;
+		vp[e] = a.s.b2 * vp[e] + a.s.omb2 * g * g;
+		pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.s.inv_sqrt_bc2 + a.s.eps);
+	}
+	store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
+	store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
+	store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+}
+
+__global__ void __launch_bounds__(256)
+sh_adam_culled_kernel(int P, const int* __restrict__ radii, const RowAdam a)
+{
+	// grid-stride over the float4s of the tensor: the grid is kept SMALL on purpose (launch_sh_adam_culled) -- this kernel
+	// shares the machine with the backward blend and must not take its wave slots
+	const long long items = (long long)P * ROW_F4, stride = (long long)gridDim.x * 256;
+	for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < items; t += stride)
+		sh_adam_culled_item(t, radii, a);
+}
+
+int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream)
+{
+	if (P <= 0) return GSR_OK;
+	if ((reinterpret_cast<uintptr_t>(adam.param) | reinterpret_cast<uintptr_t>(adam.exp_avg) | reinterpret_cast<uintptr_t>(adam.exp_avg_sq)) & 15)
+		return GSR_ERR_UNSUPPORTED;
+	const long long items = (long long)P * ROW_F4;
+	static const int max_blocks = [] { const char* e = getenv("GSR_SH_ADAM_SIDE_BLOCKS"); return e ? atoi(e) : 256; }();   // measured at C3: 256 blocks 1.927 ms / step, 1024: 1.954, 2048: 2.075, no side stream: 2.004
+	long long blocks = (items + 255) / 256;
+	if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+	GSR_LAUNCH(sh_adam_culled_kernel, (int)blocks, 256, stream, P, radii, adam);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
 }
 
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)

@@ -78,7 +78,9 @@ struct RowAdam {
 	float* exp_avg_sq;
 	AdamScalars s;
 };
-__device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD])
+// row_mask: bit r clear = row r of the stage is left alone (it took its step elsewhere: gsr_backward, side stream)
+__device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD],
+                                               uint32_t row_mask = 0xFFFFFFFFu)
 {
 	const int l = lane_id();
 	const int slot = l >> 4, col = l & 15;
@@ -90,7 +92,7 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 #endif
 #pragma unroll GSR_ADAM_UNROLL
 	for (int k = 0; k < STAGE_ROWS / 4; k++) {
-		if (col < ROW_F4 && 4 * k + slot < nrows) {
+		if (col < ROW_F4 && 4 * k + slot < nrows && ((row_mask >> (4 * k + slot)) & 1u)) {
 			const size_t i = base + (size_t)(4 * k * ROW_F4);
 			const float4 gv = s_rows[4 * k + slot][col];
 			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);

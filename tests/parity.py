@@ -276,7 +276,8 @@ def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed
 def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0, sh_degree=3):
     """Optimizer-in-backward for the SH tensor (gsr_backward_args.sh_adam) against backward + gsr_adam_step: same
     parameter and moments after the step (same arithmetic; rtol 1e-6 for the two translation units' contraction), every
-    other gradient unchanged."""
+    other gradient unchanged.  (Inside gsr_backward the culled Gaussians' rows are updated by a second kernel on the
+    library's side stream, the visible ones by the row kernel: both halves are covered by the comparison.)"""
     rng = np.random.default_rng(seed)
     cam = cl.cameras[0]
     dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)

@@ -120,7 +120,8 @@ def test_view_factored_sh_gradient(dev, degree, coeffs, n_views):
 
 @pytest.mark.gpu
 def test_fused_sh_adam(dev):
-    # optimizer-in-backward for the SH tensor == backward + gsr_adam_step (parity.check_fused_sh_adam)
+    # optimizer-in-backward for the SH tensor == backward + gsr_adam_step (parity.check_fused_sh_adam); the culled Gaussians'
+    # rows are updated on the library's second stream, the visible ones by the row kernel
     cl = scene.make_cloud(50000, 320, 240, 250.0, 250.0, seed=14, scale_k=0.15)
     parity.check_fused_sh_adam(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
 

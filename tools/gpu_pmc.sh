@@ -5,7 +5,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 python __graft_entry__.py > gpurun_out/build.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --raster-only --no-cpu-baseline > /tmp/pmc_$c.log 2>&1)
+  (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --raster-only --no-cpu-baseline --median-steps 0 > /tmp/pmc_$c.log 2>&1)
   tail -2 /tmp/pmc_$c.log | cut -c1-200
   find /tmp/pmc_$c -name "*counter_collection.csv" | head -2
 done
