@@ -103,7 +103,7 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False):
                     loss_last=round(r["losses"][-1], 5), loss_ops=r["loss_ops"], torch_threads=r["threads"],
                     phase_s_median=dict(zip(("render_forward", "loss_forward", "backward", "stats_and_adam"), r["phase_seconds_median"])),
                     oracle_threads=r["oracle_threads"])
-    out["C1"] = run("C1", 20 if quick else 100, 2 if quick else 5, 10.0 if quick else 40.0)
+    out["C1"] = run("C1", 20 if quick else 100, 2 if quick else 5, 10.0 if quick else 80.0)
     main_cfg = args.config if args.config != "C1" else None
     if main_cfg:
         out[main_cfg] = run(main_cfg, 3, 1, 60.0)
@@ -130,6 +130,7 @@ def main():
                     help="time the main leg with the training learning rates (drifting synthetic workload) instead of the "
                          "stationary one")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
+    ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         import __graft_entry__ as entry
@@ -337,6 +338,21 @@ def main():
         for k, v in capi.profile_read(lib).items():
             stage_ms.setdefault(k, []).append(v)
     torch.cuda.synchronize()
+    # ---- the rasterizer alone: the same legs with the SH Adam step as a separate pass (not fused into backward), so that
+    # "rendered Mpix/s (fwd+bwd)" prices rasterizer work only; reported next to the fused program's figures, never as `value`
+    unfused_ms = {}
+    if not dp and not args.raster_only:
+        if ops is not None:
+            ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})
+        ts.fused_sh_adam_ = False
+        for _ in range(12):
+            one_step()
+            for k, v in capi.profile_read(lib).items():
+                unfused_ms.setdefault(k, []).append(v)
+        torch.cuda.synchronize()
+        if ops is not None:
+            ops.trainer_set_options(handle, {"fused_sh_adam": 1.0})
+        ts.fused_sh_adam_ = True
     capi.profile_enable(lib, 0)
 
     # ---- scene statistics of this rank's view (V, R) for the byte model -- of the stationary state the legs above ran on
@@ -406,6 +422,16 @@ def main():
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
             "raster_fwd_bwd_ms": round(raster_ms, 4),
         }
+        if unfused_ms:
+            # rasterizer stages without optimizer work (SH Adam as a separate pass): medians of 12 further steps
+            ab_u = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=False)
+            u = {k: float(np.median([m for m in ms if m >= 0])) for k, ms in unfused_ms.items() if any(m >= 0 for m in ms)}
+            ums = sum(u.values())
+            out["rasterizer_only"] = {"fwd_bwd_ms": round(ums, 4), "mpix_per_s": round(world * W * H / (ums * 1e-3) / 1e6, 1),
+                                      "hbm_frac": round(sum(ab_u.values()) / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "stages_ms": {k: round(v, 4) for k, v in u.items()},
+                                      "note": "same step with the SH Adam update as a separate pass after backward: the stage "
+                                              "events then bracket rasterizer work only (mpix_per_s above includes the fused update)"}
         if step_ms:
             s = np.sort(np.array(step_ms))
             out["protocol"] = {"timed": "wall clock over exactly `steps` steps between barrier + synchronize (value, ms_per_step)",
@@ -414,6 +440,8 @@ def main():
                                "warmup_before_median": max(20, args.warmup + args.steps),
                                "median_iters_per_s": round(world * 1e3 / float(np.median(s)), 3),
                                "source": "one HIP event per step on the compute stream of rank 0"}
+            if args.dump_steps:
+                out["protocol"]["step_ms"] = [round(float(x), 3) for x in step_ms]
         if train_run:
             out["training_lr_run"] = train_run
         if dp:
@@ -433,6 +461,13 @@ def main():
                     traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
                     traffic_src = f
                     break
+        if dom == "blend_bwd" and fused_sh_adam and os.environ.get("GSR_SH_ADAM_SIDE_STREAM", "1") != "0":
+            # the culled Gaussians' half of the fused SH Adam step streams 1152 B per culled Gaussian on the library's second
+            # stream WHILE blend_bwd runs (gsr_backward): the HBM bytes moved in blend_bwd's window are both kernels'
+            side_bytes = 1152 * (P - V)
+            stages[dom]["concurrent"] = {"kernel": "sh_adam_culled_kernel (side stream, 1152 B per culled Gaussian)",
+                                         "bytes": int(side_bytes),
+                                         "combined_GBps_if_fully_overlapped": round((ab[dom] + side_bytes) / (stages[dom]["ms"] * 1e-3) / 1e9, 1)}
         if dom:
             a = stages[dom]["GBps"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",

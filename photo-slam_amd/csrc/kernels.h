@@ -93,8 +93,11 @@ struct PreprocessBwdParams {
 	const float* campos;    // [3] device
 	float focal_x, focal_y, tan_fovx, tan_fovy;
 	const uint32_t* tiles_touched;   // [P] length of each Gaussian's run of instance slots (0 = culled)
-	const float* partials;    // [R][12] per-instance gradient slots written by the backward blend (blend.h)
-	const uint8_t* touched;   // [R + 64] 1 where a slot was written
+	float* partials;          // [R][12] per-instance gradient slots written by the backward blend (blend.h); the totals of the
+	                          // long runs are folded into their first slots (long_run_sums_kernel)
+	uint8_t* touched;         // [R + 64] 1 where a slot was written
+	const uint32_t* long_runs;       // ids of the Gaussians with more than LONG_RUN slots (listed by the forward preprocess)
+	const uint32_t* long_run_count;  // device word
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)

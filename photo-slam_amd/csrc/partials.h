@@ -1,10 +1,11 @@
 // partials.h -- the per-Gaussian end of the atomic-free gradient hand-off (blend.h): sum a Gaussian's contiguous run of
 // per-instance gradient slots, written and flagged by the backward blend, in a fixed order (bit-reproducible).
-// Called by every lane of the wave from wave-uniform control flow; lane = Gaussian (id order, so the few screen-filling
-// splats are spread over many waves).  Runs of up to 64 slots are summed by their owner lane -- 16 flag bytes per load,
-// squeezed to a bit mask, then one iteration per TOUCHED slot (about 1 in 5: the rest lie behind their tile's last
-// contributor or blend into no pixel); longer runs are summed by the whole wave (strided 48-byte slots, then a DPP
-// reduction) so that a 3000-tile splat costs 50 iterations, not 3000.
+// Lane = Gaussian.  Runs of up to LONG_RUN (64) slots are summed by their owner lane -- 16 flag bytes per load, squeezed to a
+// bit mask, then one iteration per TOUCHED slot (about 1 in 5: the rest lie behind their tile's last contributor or blend
+// into no pixel).  Longer runs (screen-filling splats; listed by the forward preprocess) are summed beforehand by
+// long_run_sums_kernel, one WAVE per run (strided 48-byte slots, then a DPP reduction: a 3000-tile splat costs 50 iterations),
+// which leaves the total in the run's first slot: wherever such Gaussians sit in the arrays -- densification appends the
+// children of split Gaussians consecutively -- no wave of the backward preprocess inherits their work.
 //   a[0..2] dL_dcolor   a[3], a[4] sum w dx, sum w dy   a[5..7] sum w dx dx, w dx dy, w dy dy   a[8] sum w
 #pragma once
 #include "state.h"
@@ -19,7 +20,7 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 	const float4* part4 = reinterpret_cast<const float4*>(partials);
 #pragma unroll
 	for (int c = 0; c < 9; c++) a[c] = 0.f;
-	if (cnt != 0u && cnt <= 64u) {
+	if (cnt != 0u && cnt <= LONG_RUN) {
 		// the run's flags, 16 bytes per load, squeezed to one bit per slot: the loop below then runs once per TOUCHED
 		// slot (~1 in 5) and its loads do not wait for one another (a byte-flag test per slot serialises on memory latency)
 		unsigned long long live = 0ull;
@@ -45,26 +46,42 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 			a[8] += z;
 		}
 	}
-	unsigned long long big = wave_ballot(cnt > 64u);
-	while (big) {
-		const int b = __ffsll((long long)big) - 1;
-		big &= big - 1ull;
-		const uint32_t bfirst = wave_readlane_u32(first, b), bcnt = wave_readlane_u32(cnt, b);
-		float v[9];
+	// a longer run was summed by long_run_sums_kernel (one wave per run), which left the total in the run's FIRST slot
+	if (cnt > LONG_RUN && touched[first]) {
+		const float4 x = part4[3 * (size_t)first], y = part4[3 * (size_t)first + 1];
+		const float z = part4[3 * (size_t)first + 2].x;
+		a[0] = x.x; a[1] = x.y; a[2] = x.z; a[3] = x.w;
+		a[4] = y.x; a[5] = y.y; a[6] = y.z; a[7] = y.w;
+		a[8] = z;
+	}
+}
+
+// One wave per listed run: sum its touched slots in a fixed order, store the total in the run's first slot and flag it.
+__device__ __forceinline__ void wave_sum_long_run(uint32_t first, uint32_t cnt, float* __restrict__ partials, uint8_t* __restrict__ touched)
+{
+	const int l = lane_id();
+	float4* part4 = reinterpret_cast<float4*>(partials);
+	float v[9];
 #pragma unroll
-		for (int c = 0; c < 9; c++) v[c] = 0.f;
-		const float4* src = part4 + 3 * (size_t)bfirst;
-		for (uint32_t i = (uint32_t)l; i < bcnt; i += 64u) {
-			if (!touched[bfirst + i]) continue;
-			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
-			const float z = src[3 * (size_t)i + 2].x;
-			v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-			v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
-			v[8] += z;
-		}
-		wave_reduce9_f32(v);  // totals in lane 63
-#pragma unroll
-		for (int c = 0; c < 9; c++) a[c] = wave_writelane_f32(a[c], wave_readlane_f32(v[c], 63), b);
+	for (int c = 0; c < 9; c++) v[c] = 0.f;
+	const float4* src = part4 + 3 * (size_t)first;
+	bool any = false;
+	for (uint32_t i = (uint32_t)l; i < cnt; i += 64u) {
+		if (!touched[first + i]) continue;
+		any = true;
+		const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
+		const float z = src[3 * (size_t)i + 2].x;
+		v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+		v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+		v[8] += z;
+	}
+	const bool some = wave_ballot(any) != 0ull;
+	wave_reduce9_f32(v);  // totals in lane 63; every lane has read its slots by now (the reduction is a rendezvous)
+	if (l == 63) {
+		part4[3 * (size_t)first] = make_float4(v[0], v[1], v[2], v[3]);
+		part4[3 * (size_t)first + 1] = make_float4(v[4], v[5], v[6], v[7]);
+		reinterpret_cast<float*>(part4 + 3 * (size_t)first + 2)[0] = v[8];
+		touched[first] = some ? 1 : 0;
 	}
 }
 

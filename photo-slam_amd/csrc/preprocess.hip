@@ -246,6 +246,16 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	// can overlap the depth sort.
 	const uint32_t wsum = wave_sum_u32(my_tiles);
 	if (lane_id() == 0 && wsum) atomicAdd(&g.counters[(blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS - 1)], wsum);
+	// Gaussians whose run of instance slots is too long for one lane of the backward preprocess (state.h: LONG_RUN): listed
+	// here, one atomic per wave that has any (a few thousand entries at C3); the list order is irrelevant to the results
+	const unsigned long long lm = wave_ballot(in_range && my_tiles > LONG_RUN);
+	if (lm) {
+		const int leader = __ffsll((long long)lm) - 1;
+		uint32_t base = 0;
+		if (lane_id() == leader) base = atomicAdd(&g.visible[1], (uint32_t)__popcll(lm));
+		base = wave_shfl_u32(base, leader);
+		if ((lm >> lane_id()) & 1ull) g.long_runs[base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)idx;
+	}
 }
 
 // checkFrustum, cuda_rasterizer/rasterizer_impl.cu:54-66

@@ -468,8 +468,25 @@ int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStrea
 	return GSR_OK;
 }
 
+// The runs of more than LONG_RUN instance slots (partials.h): one wave per run, a fixed grid that strides over the list the
+// forward preprocess left (its length lives on the device).
+constexpr int LRS_BLOCKS = 512;
+__global__ void __launch_bounds__(256)
+long_run_sums_kernel(const PreprocessBwdParams p)
+{
+	const uint32_t n = *p.long_run_count;
+	const uint32_t waves = (uint32_t)gridDim.x * 4u;
+	for (uint32_t e = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_id(); e < n; e += waves) {
+		const uint32_t g = p.long_runs[e];
+		const uint32_t cnt = p.tiles_touched[g];
+		const uint32_t first = __float_as_uint(p.rec[3 * (size_t)g + 2].w);
+		wave_sum_long_run(first, cnt, p.partials, p.touched);
+	}
+}
+
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
+	if (p.partials) GSR_LAUNCH(long_run_sums_kernel, LRS_BLOCKS, 256, stream, p);
 	const bool factored = p.dL_dcolor_view != nullptr;
 	const bool adam = p.adam_exp_avg != nullptr;
 	const bool rows_ok = p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0) &&

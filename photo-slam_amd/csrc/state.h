@@ -19,7 +19,12 @@ constexpr int SORT_CHUNK = 4 * SORT_ITEMS_PER_WAVE;
 constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
-constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
+constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
+// A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length;
+// longer runs (screen-filling splats) are listed by the forward preprocess and summed one WAVE per run by their own kernel
+// (partials.h) -- densification appends the children of split (large) Gaussians consecutively, and 64 of them in one wave
+// turned that wave into the kernel's tail (measured: preprocess_bwd 140 -> 450 us after ten densifications at C3).
+constexpr uint32_t LONG_RUN = 64;   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
 
 constexpr int SCAN_THREADS = 256;
 
@@ -63,7 +68,9 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
-	uint32_t* visible;        // [1] number of visible Gaussians V, left by the first pass of the depth sort
+	uint32_t* visible;        // [32] [0] number of visible Gaussians V, left by the first pass of the depth sort;
+	                          //      [1] number of entries of long_runs (zeroed at the start of the forward pass)
+	uint32_t* long_runs;      // [P]  ids of the Gaussians that touch more than LONG_RUN tiles, in no particular order
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -85,6 +92,7 @@ struct GeometryState {
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.visible = c.take<uint32_t>(32);
+		g.long_runs = c.take<uint32_t>(P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}

@@ -188,6 +188,29 @@ def test_single_huge_splat_and_opaque_wall(emu_lib_path, oracle):
     parity.compare(r, ores, ocolor, oradii, ograds, cam)
 
 
+def test_long_runs_of_instance_slots(emu_lib_path, oracle):
+    """Gaussians that touch more than 64 tiles (state.h LONG_RUN): their per-instance gradient slots are summed by
+    long_run_sums_kernel, one wave per run, from the list the forward preprocess leaves -- here 70 of them CONSECUTIVE in
+    index order at the end of the arrays (what densification produces: the children of split Gaussians), more than one
+    wave of the backward preprocess holds, next to small ones; runs of exactly 64 and 65 tiles sit on the threshold."""
+    W, H = 176, 160   # 11 x 10 = 110 tiles
+    cl = scene.make_cloud(200, W, H, 0.8 * W, 0.8 * W, seed=31, scale_k=0.35)
+    cam = cl.cameras[0]
+    fwd = cam.viewmatrix[:3, 2]
+    rng = np.random.default_rng(3)
+    big = np.arange(130, 200)
+    cl.xyz[big] = cam.campos + (1.5 + rng.random((70, 1)).astype(np.float32)) * fwd + 0.3 * rng.standard_normal((70, 3)).astype(np.float32)
+    cl.scaling[big] = np.log(0.25 + 0.6 * rng.random((70, 3))).astype(np.float32)
+    cl.opacity[big] = -2.0 + rng.standard_normal((70, 1)).astype(np.float32)   # translucent: every layer contributes
+    bg = np.array([0.1, 0.3, 0.2], np.float32)
+    dpix = rng.standard_normal((3, H, W)).astype(np.float32)
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+    tt = ores.tiles_touched
+    assert (tt[big] > 64).sum() >= 40 and (tt > 64).sum() < 200 and ((tt > 0) & (tt <= 64)).sum() > 20, np.sort(tt)[-80:]
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix)
+    parity.compare(r, ores, ocolor, oradii, ograds, cam)
+
+
 def test_invalid_argument_combinations(emu_lib_path):
     lib = capi.load(emu_lib_path)
     a = capi.ForwardArgs()
