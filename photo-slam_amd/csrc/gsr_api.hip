@@ -186,7 +186,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
 	GSR_HIP(hipMemsetAsync(g.counters, 0, NUM_COUNTERS * sizeof(uint32_t), stream));
-	GSR_HIP(hipMemsetAsync(g.visible, 0, 32 * sizeof(uint32_t), stream));   // [1]: the length of the long-run list
+	GSR_HIP(hipMemsetAsync(g.long_counts, 0, (size_t)LONG_LISTS * LONG_COUNT_STRIDE * sizeof(uint32_t), stream));
 	PROF_FWD(0);
 
 	PreprocessParams pp;
@@ -329,7 +329,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
 	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
-	pb.long_runs = g.long_runs; pb.long_run_count = g.visible + 1;
+	pb.long_runs = g.long_runs; pb.long_counts = g.long_counts; pb.long_capacity = g.long_capacity;
 	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
 	pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;

@@ -96,8 +96,9 @@ struct PreprocessBwdParams {
 	float* partials;          // [R][12] per-instance gradient slots written by the backward blend (blend.h); the totals of the
 	                          // long runs are folded into their first slots (long_run_sums_kernel)
 	uint8_t* touched;         // [R + 64] 1 where a slot was written
-	const uint32_t* long_runs;       // ids of the Gaussians with more than LONG_RUN slots (listed by the forward preprocess)
-	const uint32_t* long_run_count;  // device word
+	const uint32_t* long_runs;       // ids of the Gaussians with more than LONG_RUN slots, LONG_LISTS sub-lists (forward preprocess)
+	const uint32_t* long_counts;     // entries per sub-list (device)
+	uint32_t long_capacity;
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)

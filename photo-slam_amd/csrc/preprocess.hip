@@ -35,6 +35,7 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 
 #endif
 constexpr int FWD_ROWS = GSR_FWD_STAGE_ROWS;   // SH rows staged per pass and wave
 constexpr int PRE_THREADS = 128;               // 2 waves per workgroup
+static_assert(PRE_THREADS == LONG_LIST_BLOCK, "the long-run sub-lists are sized per preprocess block (state.h)");
 
 __global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
@@ -252,9 +253,11 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	if (lm) {
 		const int leader = __ffsll((long long)lm) - 1;
 		uint32_t base = 0;
-		if (lane_id() == leader) base = atomicAdd(&g.visible[1], (uint32_t)__popcll(lm));
+		const uint32_t list = (uint32_t)blockIdx.x % (uint32_t)LONG_LISTS;
+		if (lane_id() == leader) base = atomicAdd(&g.long_counts[list * LONG_COUNT_STRIDE], (uint32_t)__popcll(lm));
 		base = wave_shfl_u32(base, leader);
-		if ((lm >> lane_id()) & 1ull) g.long_runs[base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)idx;
+		if ((lm >> lane_id()) & 1ull)
+			g.long_runs[(size_t)list * g.long_capacity + base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)idx;
 	}
 }
 

@@ -474,10 +474,12 @@ constexpr int LRS_BLOCKS = 512;
 __global__ void __launch_bounds__(256)
 long_run_sums_kernel(const PreprocessBwdParams p)
 {
-	const uint32_t n = *p.long_run_count;
-	const uint32_t waves = (uint32_t)gridDim.x * 4u;
-	for (uint32_t e = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_id(); e < n; e += waves) {
-		const uint32_t g = p.long_runs[e];
+	// wave -> (sub-list, position): consecutive waves take different sub-lists, waves/LONG_LISTS of them share one
+	const uint32_t wave = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_id(), waves = (uint32_t)gridDim.x * 4u;
+	const uint32_t list = wave % (uint32_t)LONG_LISTS;
+	const uint32_t n = p.long_counts[list * LONG_COUNT_STRIDE];
+	for (uint32_t e = wave / (uint32_t)LONG_LISTS; e < n; e += waves / (uint32_t)LONG_LISTS) {
+		const uint32_t g = p.long_runs[(size_t)list * p.long_capacity + e];
 		const uint32_t cnt = p.tiles_touched[g];
 		const uint32_t first = __float_as_uint(p.rec[3 * (size_t)g + 2].w);
 		wave_sum_long_run(first, cnt, p.partials, p.touched);

@@ -24,7 +24,13 @@ constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
 // longer runs (screen-filling splats) are listed by the forward preprocess and summed one WAVE per run by their own kernel
 // (partials.h) -- densification appends the children of split (large) Gaussians consecutively, and 64 of them in one wave
 // turned that wave into the kernel's tail (measured: preprocess_bwd 140 -> 450 us after ten densifications at C3).
-constexpr uint32_t LONG_RUN = 64;   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
+constexpr uint32_t LONG_RUN = 64;
+constexpr int LONG_LISTS = 64, LONG_COUNT_STRIDE = 32, LONG_LIST_BLOCK = 128;   // LONG_LIST_BLOCK = threads of a preprocess_fwd block
+static inline size_t long_list_capacity(size_t P)
+{
+	const size_t blocks = (P + LONG_LIST_BLOCK - 1) / LONG_LIST_BLOCK;
+	return ((blocks + LONG_LISTS - 1) / LONG_LISTS) * LONG_LIST_BLOCK;
+}   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
 
 constexpr int SCAN_THREADS = 256;
 
@@ -68,9 +74,13 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
-	uint32_t* visible;        // [32] [0] number of visible Gaussians V, left by the first pass of the depth sort;
-	                          //      [1] number of entries of long_runs (zeroed at the start of the forward pass)
-	uint32_t* long_runs;      // [P]  ids of the Gaussians that touch more than LONG_RUN tiles, in no particular order
+	uint32_t* visible;        // [32] [0] number of visible Gaussians V, left by the first pass of the depth sort
+	// ids of the Gaussians that touch more than LONG_RUN tiles, in LONG_LISTS sub-lists (preprocess block b appends to
+	// sub-list b % LONG_LISTS, whose capacity long_list_capacity(P) covers all its blocks): one global counter would
+	// serialise a few thousand same-address atomics (~12 ns each) inside preprocess_fwd
+	uint32_t* long_runs;      // [LONG_LISTS * long_list_capacity(P)]
+	uint32_t* long_counts;    // [LONG_LISTS * LONG_COUNT_STRIDE] entries per sub-list, one cache line apart (zeroed per forward)
+	uint32_t  long_capacity;  // long_list_capacity(P)
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -92,7 +102,9 @@ struct GeometryState {
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.visible = c.take<uint32_t>(32);
-		g.long_runs = c.take<uint32_t>(P);
+		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
+		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
+		g.long_capacity = (uint32_t)long_list_capacity(P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
