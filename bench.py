@@ -38,8 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# committed counter profiles of the same build (tools/gpu_pmc.sh, tools/gpu_sq.sh): the newest set that exists
-PMC_FILES = ["profiles/r02_pmc_traffic_C3_raster_only.json", "profiles/r01_j_pmc_traffic_C3_raster_only.json"]
+# committed counter profiles of the same build (tools/gpu_pmc.sh, tools/gpu_sq.sh): newest set first (names sort by round + tag)
+import glob
+PMC_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_C3_raster_only.json"))),
+                   reverse=True)
 
 
 def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
