@@ -19,8 +19,8 @@ ARCH = "gfx950"
 # (source, extra flags)
 SOURCES = [
     ("gsr_api.hip", []),
-    ("preprocess.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),       # SLP packing inflates live ranges: see shrows.h
-    ("preprocess_bwd.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("preprocess.hip", ["-ffp-contract=off"]),
+    ("preprocess_bwd.hip", ["-ffp-contract=off"]),
     ("knn.hip", ["-ffp-contract=off"]),
     ("points.hip", ["-ffp-contract=off"]),
     ("densify.hip", ["-ffp-contract=off"]),
@@ -30,13 +30,18 @@ SOURCES = [
     ("blend_bwd.hip", []),
     ("train_ops.hip", []),
 ]
-COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall",
-          "-Wno-unused-function", "-Wno-unused-variable"]
+# -fno-slp-vectorize everywhere: on gfx950 the SLP vectoriser's v_pk_*_f32 pairings cost more issue cycles than the two plain
+# instructions they replace (pk_fma 5.6 against 2 x 2.5 for v_fmac, profiles/r02_a_valu_rate.json) AND need v_mov_b32s to
+# pair their operands (loss_fwd: 298 pk_fma + 254 mov instead of 625 v_fmac); measured per kernel at C3: blend_fwd 221 -> 210 us,
+# blend_bwd 592 -> 578 us, loss 134 -> 126 us (tools/gpu_r2m.sh).  The packed adds of the backward blend's butterfly are
+# written by hand (blend.h) and stay.
+COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-fno-slp-vectorize",
+          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    d += [os.path.join(HERE, "..", "include", "gsr.h")]
+    d += [os.path.join(HERE, "..", "include", "gsr.h"), os.path.abspath(__file__)]   # the flags live in this file
     return d
 
 

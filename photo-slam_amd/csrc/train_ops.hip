@@ -15,21 +15,24 @@
 
 namespace gsr {
 
-#ifndef GSR_LOSS_TILE_Y
-#define GSR_LOSS_TILE_Y 32
-#endif
 constexpr int LT = 32;                  // output tile width
-constexpr int LTY = GSR_LOSS_TILE_Y;    // output tile height (8 row groups per column: LTY / 8 outputs per thread)
+constexpr int LTY = 32;                 // output tile height (8 row groups per column: LTY / 8 outputs per thread)
 constexpr int LH = 5;                   // window half width (11 taps)
-constexpr int LR = LT + 2 * LH;         // 42: input tile width with halo
-constexpr int LRY = LTY + 2 * LH;       // input tile height with halo
-constexpr int LRP = LR + 1;             // padded pitch
+constexpr int LRY = LTY + 2 * LH;       // 42 input rows with halo
+// Staged input tile: columns x0-8 .. x0+39 (the halo x0-5 .. x0+36 padded to 16-byte vectors: with W % 4 == 0 every vector
+// lies inside or outside the image as a whole and is moved by one global_load_dwordx4 + one ds_write_b128)
+constexpr int SX0 = 8;
+constexpr int SW4 = 12;                 // float4 per staged row
+constexpr int SP4 = 13;                 // staged row pitch in float4 (52 floats)
+constexpr int HP4 = 9;                  // pitch of a horizontally filtered row in float4 (36 floats for 32 columns)
+constexpr int HP = 4 * HP4;
 
 struct LossParams {
 	const float* rendered;  // [3,H,W]
 	const float* gt;        // [3,H,W]
 	const float* mask;      // [3,H,W] or null
 	int W, H;
+	int vec;                // W % 4 == 0 and every plane 16-byte aligned: stage with 16-byte vectors
 	float lambda_dssim;
 	float g[11];            // normalised 1-D window
 	float* dmaps;           // [3][3,H,W]: dL/dmu1, dL/de11, dL/de12 (already scaled by -lambda/N)
@@ -63,78 +66,163 @@ __device__ __forceinline__ float block_sum_256(float v, float* s4)
 }
 
 // Both passes are separable 11-tap convolutions over a 32x32 output tile with a 5-pixel halo.  Every thread produces
-// FOUR consecutive outputs of a row (horizontal pass) or of a column (vertical pass) from 14 inputs held in
-// registers: 3.5 LDS reads per output and tap set instead of 11 (the first version, one output per thread, was
-// LDS-issue bound: 86 k ds_read_b32 per tile).
+// FOUR consecutive outputs of a row (horizontal pass: 42 rows x 8 groups = 336 units over 256 threads) or of a column
+// (vertical pass) from 14 inputs held in registers.  Both kernels are bound by VALU + LDS issue with little overlap between
+// the two (few resident waves, three barrier-separated phases), so the LDS side is kept short: rows are staged and read back
+// as 16-byte vectors (a unit's 14-float window = the aligned 20 floats around it), the horizontally filtered rows are written
+// as 16-byte vectors INTO THE MEMORY OF THE STAGED TILE (behind a barrier: every unit has read its inputs by then;
+// 30 KB instead of 42 KB per workgroup: 5 resident workgroups per CU instead of 3), and products / reciprocals that do not
+// depend on the tap or output are hoisted.
 constexpr int LG = 4;              // outputs per thread in the horizontal pass
-constexpr int LW = LG + 2 * LH;    // 14 inputs feed them
 constexpr int LGV = LTY / 8;       // outputs per thread in the vertical pass (256 threads = 32 columns x 8 row groups)
 constexpr int LWV = LGV + 2 * LH;
+constexpr int H_UNITS = LRY * (LT / LG);   // 336
+static_assert(H_UNITS > 256 && H_UNITS <= 512, "two horizontal units per thread at most");
+
+// Stage NA planes (row pitch W) of the tile at (x0, y0) into s[a][LRY][SP4]; plane 0 is multiplied by mask if given.
+template <int NA>
+__device__ __forceinline__ void loss_stage_tile(const float* const (&src)[NA], const float* mask, int W, int H, int vec, int x0,
+                                                int y0, float4* s, int tid)
+{
+	if (vec) {
+		for (int i = tid; i < LRY * SW4; i += 256) {
+			const int r = i / SW4, q = i - r * SW4;
+			const int gx = x0 - SX0 + 4 * q, gy = y0 - LH + r;
+			const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+			const size_t o = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+			for (int a = 0; a < NA; a++) {
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (in) {
+					v = *reinterpret_cast<const float4*>(src[a] + o);
+					if (a == 0 && mask) {
+						const float4 m = *reinterpret_cast<const float4*>(mask + o);
+						v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+					}
+				}
+				s[(a * LRY + r) * SP4 + q] = v;
+			}
+		}
+	} else {
+		float* sf = reinterpret_cast<float*>(s);
+		for (int i = tid; i < LRY * SW4 * 4; i += 256) {
+			const int r = i / (SW4 * 4), c = i - r * (SW4 * 4);
+			const int gx = x0 - SX0 + c, gy = y0 - LH + r;
+			const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+			const size_t o = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+			for (int a = 0; a < NA; a++) {
+				float v = 0.f;
+				if (in) {
+					v = src[a][o];
+					if (a == 0 && mask) v *= mask[o];
+				}
+				sf[(a * LRY + r) * (SP4 * 4) + c] = v;
+			}
+		}
+	}
+}
+
+// the aligned 20 floats around the 14-float window of horizontal unit (r, g): window element t sits at [3 + t]
+__device__ __forceinline__ void loss_load_window(const float4* plane, int r, int g, float (&w)[20])
+{
+#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		const float4 v = plane[r * SP4 + g + k];
+		w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+	}
+}
 
 // Pass 1: window statistics -> SSIM map value + the three derivative maps, and L1 / SSIM partial sums.
 __global__ void __launch_bounds__(256)
 loss_fwd_kernel(const LossParams p)
 {
-	__shared__ float s_x[LRY][LRP], s_y[LRY][LRP];
-	__shared__ float s_h[5][LRY][LT + 1];
+	// staged x, y: 2 x 42 x 13 float4; then the five filtered maps: 5 x 42 x 9 float4 in the same memory
+	__shared__ float4 s_mem[5 * LRY * HP4];
+	static_assert(5 * LRY * HP4 >= 2 * LRY * SP4, "the filtered maps cover the staged tile");
 	__shared__ float s_red[4];
 	const int ch = (int)blockIdx.z;
 	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
 	const size_t plane = (size_t)p.W * p.H;
-	const float* R = p.rendered + ch * plane;
-	const float* G = p.gt + ch * plane;
-	const float* Mk = p.mask ? p.mask + ch * plane : nullptr;
 	const int tid = (int)threadIdx.x;
-	for (int i = tid; i < LRY * LR; i += 256) {
-		const int r = i / LR, c = i - r * LR;
-		const int gx = x0 - LH + c, gy = y0 - LH + r;
-		float xv = 0.f, yv = 0.f;
-		if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.H) {
-			const size_t o = (size_t)gy * p.W + gx;
-			xv = R[o] * (Mk ? Mk[o] : 1.f);
-			yv = G[o];
-		}
-		s_x[r][c] = xv;
-		s_y[r][c] = yv;
+	{
+		const float* const src[2] = {p.rendered + ch * plane, p.gt + ch * plane};
+		loss_stage_tile<2>(src, p.mask ? p.mask + ch * plane : nullptr, p.W, p.H, p.vec, x0, y0, s_mem, tid);
 	}
 	__syncthreads();
-	// horizontal pass: LRY rows x (LT / LG) groups of LG columns
-	for (int u = tid; u < LRY * (LT / LG); u += 256) {
-		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
-		float xv[LW], yv[LW];
+	float l1_sum = 0.f, ssim_sum = 0.f;
+	// horizontal pass: unit u = (row r, group g of LG columns)
+	auto h_unit = [&](const float (&xw)[20], const float (&yw)[20], int r, int g, float4 (&out)[5]) {
+		float xx[14], yy[14], xy[14];
 #pragma unroll
-		for (int t = 0; t < LW; t++) {
-			xv[t] = s_x[r][c0 + t];
-			yv[t] = s_y[r][c0 + t];
+		for (int t = 0; t < 14; t++) {
+			const float x = xw[3 + t], y = yw[3 + t];
+			xx[t] = x * x; yy[t] = y * y; xy[t] = x * y;
 		}
+		float acc[5][LG];
 #pragma unroll
 		for (int o = 0; o < LG; o++) {
 			float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
 			for (int t = 0; t < 11; t++) {
-				const float x = xv[o + t], y = yv[o + t], gw = p.g[t];
-				a0 += gw * x;
-				a1 += gw * y;
-				a2 += gw * x * x;
-				a3 += gw * y * y;
-				a4 += gw * x * y;
+				const float gw = p.g[t];
+				a0 += gw * xw[3 + o + t];
+				a1 += gw * yw[3 + o + t];
+				a2 += gw * xx[o + t];
+				a3 += gw * yy[o + t];
+				a4 += gw * xy[o + t];
 			}
-			s_h[0][r][c0 + o] = a0; s_h[1][r][c0 + o] = a1; s_h[2][r][c0 + o] = a2; s_h[3][r][c0 + o] = a3; s_h[4][r][c0 + o] = a4;
+			acc[0][o] = a0; acc[1][o] = a1; acc[2][o] = a2; acc[3][o] = a3; acc[4][o] = a4;
+		}
+#pragma unroll
+		for (int k = 0; k < 5; k++) out[k] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+		// L1 term of the four output pixels of this unit (interior rows only): output column c is staged column c + 8
+		const int gy = y0 + r - LH;
+		if (r >= LH && r < LH + LTY && gy < p.H) {
+#pragma unroll
+			for (int o = 0; o < LG; o++)
+				if (x0 + 4 * g + o < p.W) l1_sum += fabsf(xw[SX0 + o] - yw[SX0 + o]);
+		}
+	};
+	{
+		const float4* s_x = s_mem;
+		const float4* s_y = s_mem + LRY * SP4;
+		float xw[20], yw[20];
+		float4 out1[5], out2[5];
+		const int r1 = tid >> 3, g1 = tid & 7;
+		loss_load_window(s_x, r1, g1, xw);
+		loss_load_window(s_y, r1, g1, yw);
+		h_unit(xw, yw, r1, g1, out1);
+		const bool two = tid + 256 < H_UNITS;
+		const int r2 = (tid + 256) >> 3;
+		if (two) {
+			loss_load_window(s_x, r2, g1, xw);
+			loss_load_window(s_y, r2, g1, yw);
+		}
+		// every unit has read its inputs: the filtered maps may overwrite the staged tile.  (The second unit's inputs cross the
+		// barrier, not its results: 126 instead of 138 VGPRs, i.e. 4 instead of 3 waves per SIMD.)
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < 5; k++) s_mem[(k * LRY + r1) * HP4 + g1] = out1[k];
+		if (two) {
+			h_unit(xw, yw, r2, g1, out2);
+#pragma unroll
+			for (int k = 0; k < 5; k++) s_mem[(k * LRY + r2) * HP4 + g1] = out2[k];
 		}
 	}
 	__syncthreads();
 	const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 	const float inv_n = 1.0f / (3.0f * (float)plane);
-	float l1_sum = 0.f, ssim_sum = 0.f;
 	{
-		// vertical pass: thread = (column c, group of LG rows)
+		// vertical pass: thread = (column c, group of LGV rows)
+		const float* s_h = reinterpret_cast<const float*>(s_mem);
 		const int c = tid & (LT - 1), r0 = (tid >> 5) * LGV;
 		float st[5][LGV];
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
 			float col[LWV];
 #pragma unroll
-			for (int t = 0; t < LWV; t++) col[t] = s_h[k][r0 + t][c];
+			for (int t = 0; t < LWV; t++) col[t] = s_h[(k * LRY + r0 + t) * HP + c];
 #pragma unroll
 			for (int o = 0; o < LGV; o++) {
 				float a = 0.f;
@@ -144,6 +232,7 @@ loss_fwd_kernel(const LossParams p)
 			}
 		}
 		const int gx = x0 + c;
+		const float gS = -p.lambda_dssim * inv_n;   // dL/dS = -lambda / N ; chain to (mu1, e11, e12)
 #pragma unroll
 		for (int o = 0; o < LGV; o++) {
 			const int gy = y0 + r0 + o;
@@ -153,16 +242,13 @@ loss_fwd_kernel(const LossParams p)
 				const float sig1 = e11 - mu1_sq, sig2 = e22 - mu2_sq, sig12 = e12 - mu12;
 				const float A = 2.f * mu12 + C1, B = 2.f * sig12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sig1 + sig2 + C2;
 				const float invCD = 1.0f / (Cc * D);
+				const float invC = D * invCD, invD = Cc * invCD;   // one division per pixel
 				const float S = A * B * invCD;
 				ssim_sum += S;
-				const float xv = s_x[r0 + o + LH][c + LH], yv = s_y[r0 + o + LH][c + LH];
-				l1_sum += fabsf(xv - yv);
-				// dL/dS = -lambda / N ; chain to (mu1, e11, e12)
-				const float gS = -p.lambda_dssim * inv_n;
-				const float dmu1 = 2.f * mu2 * (B - A) * invCD - 2.f * mu1 * S * (1.0f / Cc - 1.0f / D);
+				const float dmu1 = 2.f * mu2 * (B - A) * invCD - 2.f * mu1 * S * (invC - invD);
 				const size_t oo = (size_t)gy * p.W + gx;
 				p.dmaps[(0 * 3 + ch) * plane + oo] = gS * dmu1;
-				p.dmaps[(1 * 3 + ch) * plane + oo] = gS * (-S / D);
+				p.dmaps[(1 * 3 + ch) * plane + oo] = gS * (-S * invD);
 				p.dmaps[(2 * 3 + ch) * plane + oo] = gS * (2.f * A * invCD);
 			}
 		}
@@ -176,80 +262,10 @@ loss_fwd_kernel(const LossParams p)
 	}
 }
 
-// Pass 2: dL/dx = G*(dL/dmu1) + 2x G*(dL/de11) + y G*(dL/de12) + (1-lambda)/N sign(x-y), times mask.
-__global__ void __launch_bounds__(256)
-loss_bwd_kernel(const LossParams p)
+// The loss value from the per-workgroup partial sums of pass 1, in a fixed order.  Run by ONE workgroup of pass 2 (pass 1 is
+// complete by then): a launch of its own cost 9 us for 3 us of work.
+__device__ __forceinline__ void loss_finalize(const LossParams& p, float* s_red)
 {
-	__shared__ float s_d[3][LRY][LRP];
-	__shared__ float s_h[3][LRY][LT + 1];
-	const int ch = (int)blockIdx.z;
-	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
-	const size_t plane = (size_t)p.W * p.H;
-	const int tid = (int)threadIdx.x;
-	for (int i = tid; i < LRY * LR; i += 256) {
-		const int r = i / LR, c = i - r * LR;
-		const int gx = x0 - LH + c, gy = y0 - LH + r;
-		const bool in = gx >= 0 && gx < p.W && gy >= 0 && gy < p.H;
-		const size_t o = in ? (size_t)gy * p.W + gx : 0;
-#pragma unroll
-		for (int k = 0; k < 3; k++) s_d[k][r][c] = in ? p.dmaps[(k * 3 + ch) * plane + o] : 0.f;
-	}
-	__syncthreads();
-	for (int u = tid; u < LRY * (LT / LG); u += 256) {
-		const int r = u / (LT / LG), c0 = (u - r * (LT / LG)) * LG;
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			float v[LW];
-#pragma unroll
-			for (int t = 0; t < LW; t++) v[t] = s_d[k][r][c0 + t];
-#pragma unroll
-			for (int o = 0; o < LG; o++) {
-				float a = 0.f;
-#pragma unroll
-				for (int t = 0; t < 11; t++) a += p.g[t] * v[o + t];
-				s_h[k][r][c0 + o] = a;
-			}
-		}
-	}
-	__syncthreads();
-	const float inv_n = 1.0f / (3.0f * (float)plane);
-	{
-		const int c = tid & (LT - 1), r0 = (tid >> 5) * LGV;
-		float cv[3][LGV];
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			float col[LWV];
-#pragma unroll
-			for (int t = 0; t < LWV; t++) col[t] = s_h[k][r0 + t][c];
-#pragma unroll
-			for (int o = 0; o < LGV; o++) {
-				float a = 0.f;
-#pragma unroll
-				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
-				cv[k][o] = a;
-			}
-		}
-		const int gx = x0 + c;
-#pragma unroll
-		for (int o = 0; o < LGV; o++) {
-			const int gy = y0 + r0 + o;
-			if (gx < p.W && gy < p.H) {
-				const size_t oo = ch * plane + (size_t)gy * p.W + gx;
-				const float m = p.mask ? p.mask[oo] : 1.f;
-				const float xv = p.rendered[oo] * m, yv = p.gt[oo];
-				const float d = xv - yv;
-				const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-				const float gx_ = cv[0][o] + 2.f * xv * cv[1][o] + yv * cv[2][o] + (1.0f - p.lambda_dssim) * inv_n * sgn;
-				p.grad[oo] = gx_ * m;
-			}
-		}
-	}
-}
-
-__global__ void __launch_bounds__(256)
-loss_final_kernel(const LossParams p)
-{
-	__shared__ float s_red[4];
 	float a = 0.f, b = 0.f;
 	for (int i = (int)threadIdx.x; i < p.nblocks; i += 256) {
 		a += p.partial[i];
@@ -261,6 +277,97 @@ loss_final_kernel(const LossParams p)
 		const float inv_n = 1.0f / (3.0f * (float)p.W * (float)p.H);
 		p.loss[0] = (1.0f - p.lambda_dssim) * (l1 * inv_n) + p.lambda_dssim * (1.0f - ss * inv_n);
 	}
+}
+
+// Pass 2: dL/dx = G*(dL/dmu1) + 2x G*(dL/de11) + y G*(dL/de12) + (1-lambda)/N sign(x-y), times mask.
+__global__ void __launch_bounds__(256)
+loss_bwd_kernel(const LossParams p)
+{
+	// staged derivative maps: 3 x 42 x 13 float4; then their filtered rows: 3 x 42 x 9 float4 in the same memory
+	__shared__ float4 s_mem[3 * LRY * SP4];
+	__shared__ float s_red[4];
+	const int ch = (int)blockIdx.z;
+	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
+	const size_t plane = (size_t)p.W * p.H;
+	const int tid = (int)threadIdx.x;
+	{
+		const float* const src[3] = {p.dmaps + (0 * 3 + ch) * plane, p.dmaps + (1 * 3 + ch) * plane, p.dmaps + (2 * 3 + ch) * plane};
+		loss_stage_tile<3>(src, nullptr, p.W, p.H, p.vec, x0, y0, s_mem, tid);
+	}
+	__syncthreads();
+	auto h_unit = [&](const float (&w)[20], float4& out) {
+		float a[LG];
+#pragma unroll
+		for (int o = 0; o < LG; o++) {
+			float acc = 0.f;
+#pragma unroll
+			for (int t = 0; t < 11; t++) acc += p.g[t] * w[3 + o + t];
+			a[o] = acc;
+		}
+		out = make_float4(a[0], a[1], a[2], a[3]);
+	};
+	{
+		float w[20];
+		float4 out1[3], out2[3];
+		const int r1 = tid >> 3, g1 = tid & 7;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			loss_load_window(s_mem + k * LRY * SP4, r1, g1, w);
+			h_unit(w, out1[k]);
+		}
+		const bool two = tid + 256 < H_UNITS;
+		const int r2 = (tid + 256) >> 3;
+		if (two) {
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				loss_load_window(s_mem + k * LRY * SP4, r2, g1, w);
+				h_unit(w, out2[k]);
+			}
+		}
+		__syncthreads();   // every unit has read its inputs: the filtered rows may overwrite the staged maps
+#pragma unroll
+		for (int k = 0; k < 3; k++) s_mem[(k * LRY + r1) * HP4 + g1] = out1[k];
+		if (two) {
+#pragma unroll
+			for (int k = 0; k < 3; k++) s_mem[(k * LRY + r2) * HP4 + g1] = out2[k];
+		}
+	}
+	__syncthreads();
+	const float inv_n = 1.0f / (3.0f * (float)plane);
+	{
+		const float* s_h = reinterpret_cast<const float*>(s_mem);
+		const int c = tid & (LT - 1), r0 = (tid >> 5) * LGV;
+		float cv[3][LGV];
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			float col[LWV];
+#pragma unroll
+			for (int t = 0; t < LWV; t++) col[t] = s_h[(k * LRY + r0 + t) * HP + c];
+#pragma unroll
+			for (int o = 0; o < LGV; o++) {
+				float a = 0.f;
+#pragma unroll
+				for (int t = 0; t < 11; t++) a += p.g[t] * col[o + t];
+				cv[k][o] = a;
+			}
+		}
+		const int gx = x0 + c;
+		const float l1w = (1.0f - p.lambda_dssim) * inv_n;
+#pragma unroll
+		for (int o = 0; o < LGV; o++) {
+			const int gy = y0 + r0 + o;
+			if (gx < p.W && gy < p.H) {
+				const size_t oo = ch * plane + (size_t)gy * p.W + gx;
+				const float m = p.mask ? p.mask[oo] : 1.f;
+				const float xv = p.rendered[oo] * m, yv = p.gt[oo];
+				const float d = xv - yv;
+				const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+				const float gx_ = cv[0][o] + 2.f * xv * cv[1][o] + yv * cv[2][o] + l1w * sgn;
+				p.grad[oo] = gx_ * m;
+			}
+		}
+	}
+	if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0) loss_finalize(p, s_red);
 }
 
 // ------------------------------------------------------------------ Adam
@@ -361,6 +468,9 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 	hipStream_t stream = (hipStream_t)stream_;
 	LossParams p;
 	p.rendered = rendered; p.gt = gt; p.mask = mask; p.W = width; p.H = height; p.lambda_dssim = lambda_dssim;
+	// 16-byte staging: every row of every plane (inputs and the derivative maps in `scratch`) starts on a 16-byte boundary
+	p.vec = (width % 4 == 0) && !((reinterpret_cast<uintptr_t>(rendered) | reinterpret_cast<uintptr_t>(gt) |
+	                              reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(scratch)) & 15);
 	// gaussian(11, 1.5) normalised, include/loss_utils.h:49-62
 	float sum = 0.f;
 	for (int x = 0; x < 11; x++) {
@@ -378,7 +488,6 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 	p.loss = loss;
 	GSR_LAUNCH(loss_fwd_kernel, dim3(gx, gy, 3), 256, stream, p);
 	GSR_LAUNCH(loss_bwd_kernel, dim3(gx, gy, 3), 256, stream, p);
-	GSR_LAUNCH(loss_final_kernel, 1, 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

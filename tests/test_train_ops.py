@@ -36,7 +36,7 @@ def check_loss(dev, H, W, use_mask, seed):
     assert err <= 1e-5 * gref.abs().max().item() + 1e-10, (err, gref.abs().max().item())
 
 
-@pytest.mark.parametrize("H,W,use_mask", [(32, 32, False), (45, 70, True), (9, 11, True)])
+@pytest.mark.parametrize("H,W,use_mask", [(32, 32, False), (45, 70, True), (9, 11, True), (40, 72, True), (70, 36, False)])
 def test_fused_loss_matches_autograd(emu, H, W, use_mask):
     check_loss(torch.device("cpu"), H, W, use_mask, H * W)
 

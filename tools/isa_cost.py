@@ -68,7 +68,7 @@ def visit_loop(asm, kernel):
 
 def analyse(src, kernel, flags):
     out = subprocess.check_output(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-                                   "-fno-gpu-rdc", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"] + flags,
+                                   "-fno-gpu-rdc", "-fno-slp-vectorize", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"] + flags,
                                   stderr=subprocess.DEVNULL, text=True)
     name = next(l.split(":")[0] for l in out.splitlines() if re.match(r"^_Z\w*" + kernel + r"\w*:", l))
     body = visit_loop(out, name)
