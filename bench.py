@@ -45,13 +45,18 @@ PMC_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROO
 
 
 def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
-                      touched_slots=None):
+                      touched_slots=None, lazy_window=0):
     """Compulsory HBM bytes per stage (each array read/written once per stage that needs it), restated for
     this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the Adam step of the SH tensor
     (no gradient rows written; both moments read, parameter + moments written for every Gaussian, the parameter row read for
     the culled ones too).  touched_slots: instance slots the backward blend wrote (48 B each, read back once by
-    preprocess_bwd together with R flag bytes); None leaves them out."""
-    adam = 12 * M * (4 * P + (P - V)) if fused_sh_adam else 0
+    preprocess_bwd together with R flag bytes); None leaves them out.  lazy_window: the culled rows take their zero-gradient
+    steps `lazy_window` at a time (gsr_sh_adam_lazy): per step, moments read + parameter and moments written for the VISIBLE
+    rows, and a full read-modify-write of 1/lazy_window of the culled ones."""
+    if fused_sh_adam and lazy_window >= 2:
+        adam = 12 * M * (5 * V + 6 * (P - V) // lazy_window - P)   # (- P: the stage's gradient rows are not written)
+    else:
+        adam = 12 * M * (4 * P + (P - V)) if fused_sh_adam else 0
     S = P if sorted_gaussians is None else sorted_gaussians
     slots = 0 if touched_slots is None else 48 * touched_slots + R
     return {
@@ -131,6 +136,9 @@ def main():
     ap.add_argument("--training-lr", action="store_true",
                     help="time the main leg with the training learning rates (drifting synthetic workload) instead of the "
                          "stationary one")
+    ap.add_argument("--sh-adam-window", type=int, default=32,
+                    help="lazy Adam steps for the SH rows of culled Gaussians, at most this many at a time (gsr_sh_adam_lazy; "
+                         "0 = every row steps eagerly at every iteration)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -202,7 +210,7 @@ def main():
     if args.densify_interval:
         opt.densification_interval_, opt.densify_from_iter_ = args.densify_interval, 0
     ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent,
-                   densify=bool(args.densify_interval), factored_exchange=factored)
+                   densify=bool(args.densify_interval), factored_exchange=factored, lazy_sh_adam_window=args.sh_adam_window)
 
     ops = None
     if args.host == "cpp" and not args.raster_only:
@@ -214,6 +222,7 @@ def main():
                                     g.rotation_.detach(), 3, float(cl.extent), bg)
         import math
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+        ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window)})
         if dp:
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and factored:
@@ -309,7 +318,11 @@ def main():
 
     stationary = not args.training_lr
     set_lr_scale(0.0 if stationary else 1.0)
-    for _ in range(args.warmup):
+    # lazy SH Adam (--sh-adam-window): the rotating catch-up of the culled rows reaches its steady state (every flushed row
+    # `window` steps behind) after `window` steps -- the steps that the requested warm-up does not cover are run before it,
+    # untimed, so that the timed region does a steady state's work per step
+    priming = max(0, (args.sh_adam_window if not (dp or args.raster_only) else 0) - args.warmup)
+    for _ in range(priming + args.warmup):
         one_step()
     # Timed region: HIP events only around the backward blend, the dominant kernel (gsr_profile_enable(2)): every event
     # record is a ~5 us bubble in the stream, and eleven of them per step cost 2 % of the step they are meant to measure.
@@ -379,7 +392,8 @@ def main():
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
     fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank
-    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam)
+    lazy_window = args.sh_adam_window if fused_sh_adam and args.sh_adam_window >= 2 else 0
+    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam, lazy_window=lazy_window)
     stages = {}
     for k, ms in stage_ms.items():
         ms = [m for m in ms if m >= 0]
@@ -404,7 +418,7 @@ def main():
             if args.config == "C3" else f"train iters/s, config {args.config}",
             "value": round(world * args.steps / elapsed, 3),
             "unit": "iters/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "priming_steps_before_warmup": priming,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -419,6 +433,7 @@ def main():
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "learning_rates": lr_note,
                        "sh_adam_fused_into_backward": fused_sh_adam,
+                       "sh_adam_lazy_window": lazy_window,
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else int(ops.trainer_params(handle)[0].shape[0]),
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,
@@ -464,10 +479,11 @@ def main():
                     traffic_src = f
                     break
         if dom == "blend_bwd" and fused_sh_adam and os.environ.get("GSR_SH_ADAM_SIDE_STREAM", "1") != "0":
-            # the culled Gaussians' half of the fused SH Adam step streams 1152 B per culled Gaussian on the library's second
-            # stream WHILE blend_bwd runs (gsr_backward): the HBM bytes moved in blend_bwd's window are both kernels'
-            side_bytes = 1152 * (P - V)
-            stages[dom]["concurrent"] = {"kernel": "sh_adam_culled_kernel (side stream, 1152 B per culled Gaussian)",
+            # while blend_bwd runs, the library's second stream streams SH rows of culled Gaussians (gsr_backward): eagerly
+            # all of them (1152 B each), lazily this step's 1/window of them
+            side_bytes = 1152 * (P - V) // (lazy_window if lazy_window else 1)
+            stages[dom]["concurrent"] = {"kernel": ("sh_adam_lazy_kernel (side stream, 1152 B per culled Gaussian of this step's 1/%d of the row blocks)" % lazy_window)
+                                                   if lazy_window else "sh_adam_culled_kernel (side stream, 1152 B per culled Gaussian)",
                                          "bytes": int(side_bytes),
                                          "combined_GBps_if_fully_overlapped": round((ab[dom] + side_bytes) / (stages[dom]["ms"] * 1e-3) / 1e9, 1)}
         if dom:

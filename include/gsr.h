@@ -39,6 +39,29 @@ typedef enum gsr_status {
  * (cuda_rasterizer/rasterizer.h:36-38). */
 typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
 
+/* Extension of the extension below: LAZY Adam steps for the SH rows of culled Gaussians (NULL in gsr_sh_adam = every row takes
+ * every step when it happens).  A Gaussian the view culls gets a zero SH gradient, and a zero-gradient Adam step of a row --
+ * m <- b1 m, v <- b2 v, p <- p - step_size m / (sqrt(v) / sqrt(1 - b2^t) + eps) -- depends on nothing but the row and the
+ * step's scalars.  With row_step set the library takes such steps LATER, several at a time with the row in registers: the
+ * same arithmetic in the same order (results bit-identical to the eager update, tests/test_lazy_sh_adam.py), one HBM round
+ * trip of the row's 1152 bytes instead of one per step.  row_step[i] = number of Adam steps row i has taken.  A row is
+ * brought up to date
+ *   - by gsr_forward when it becomes visible, BEFORE its coefficients are evaluated (pass the same gsr_sh_adam to
+ *     gsr_forward_args.sh_adam and gsr_backward_args.sh_adam of a step);
+ *   - by gsr_backward for a rotating 1/window of the row blocks per step, so that no row ever lags by more than `window`
+ *     steps (the past learning rates the caller has to remember);
+ *   - by gsr_sh_adam_flush for all rows: REQUIRED before anything else reads or writes the tensor or its moments (densify /
+ *     prune, save, a dense optimizer step, another exchange mode).
+ * Contract: when the first lazy step `step` is taken every row_step[i] == step - 1; from then on every step's forward and
+ * backward get the struct with the same `window` until a flush. */
+#define GSR_SH_LAZY_WINDOW 32
+typedef struct gsr_sh_adam_lazy {
+	int* row_step;                          /* [P] device ints, read and written */
+	int window;                             /* 2 .. GSR_SH_LAZY_WINDOW */
+	double lr_past[GSR_SH_LAZY_WINDOW];     /* [k-1] = lr of Adam step (step - k), k = 1 .. window-1 (entries of steps < 1 unused) */
+	double lr_tail_past[GSR_SH_LAZY_WINDOW];
+} gsr_sh_adam_lazy;
+
 /* Extension: Adam state of the [P,16,3] SH tensor for the fused update inside gsr_backward (see
  * gsr_backward_args.sh_adam).  torch::optim::Adam semantics as gsr_adam_step; the first 3 floats of a row
  * (features_dc) use lr, the other 45 (features_rest) lr_tail. */
@@ -51,6 +74,7 @@ typedef struct gsr_sh_adam {
 	double lr, lr_tail, beta1, beta2, eps;   /* double like torch::optim::AdamOptions: the bias corrections 1 - beta^step are
 	                                            formed in double as torch does (0.999f instead of 0.999 is 1e-5 of the step) */
 	int step;                    /* >= 1: the step being taken (bias correction) */
+	const gsr_sh_adam_lazy* lazy; /* NULL = eager: every row takes the step in gsr_backward */
 } gsr_sh_adam;
 
 /* Rasterizer::forward parameter list, cuda_rasterizer/rasterizer.h:35-59, 1:1. */
@@ -78,6 +102,10 @@ typedef struct gsr_forward_args {
 	 * in-kernel: sigmoid(opacity), exp(scaling), normalize(rotation).  Saves the ~13 elementwise ATen launches
 	 * (forward + autograd) GaussianRenderer::render otherwise spends per step. */
 	int raw_params;
+	/* Extension (NULL = the reference contract; consulted only when sh_adam->lazy is set, see gsr_sh_adam_lazy): the SH
+	 * rows of visible Gaussians that lag behind (sh_adam->step - 1) take their missed zero-gradient Adam steps before their
+	 * coefficients are evaluated -- the forward pass then WRITES sh_adam->param (== shs), the moments and row_step. */
+	const gsr_sh_adam* sh_adam;
 } gsr_forward_args;
 
 #define GSR_RAW_OPACITY 1   /* opacities are logits */
@@ -160,6 +188,11 @@ typedef struct gsr_backward_args {
  * which removes the reference's 300 B/Gaussian torch::zeros pass
  * (src/rasterize_points.cu:149-157).  No host synchronisation. */
 int gsr_backward(const gsr_backward_args* args, void* stream);
+
+/* Lazy SH Adam (gsr_sh_adam_lazy): every row of the [P,16,3] tensor takes the zero-gradient steps it is behind, up to and
+ * including adam->step = the number of Adam steps the tensor has taken (adam->lr / lr_tail belong to that step, lr_past[k-1] to
+ * step - k); afterwards row_step[i] == adam->step for all i and tensor and moments are what the eager update leaves. */
+int gsr_sh_adam_flush(int P, const gsr_sh_adam* adam, void* stream);
 
 /* The SH gradient of a keyframe batch from its per-view colour gradients (no counterpart in the reference, which trains
  * on one view per step):   dL_dsh[i][k][ch] = scale * sum_v basis_k(normalize(means3D[i] - campos[v])) * views[v][i][ch]

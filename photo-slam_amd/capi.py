@@ -31,12 +31,39 @@ class ForwardArgs(C.Structure):
                 ("scale_modifier", C.c_float), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
-                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("raw_params", C.c_int)]
+                ("out_color", C.c_void_p), ("radii", C.c_void_p), ("raw_params", C.c_int), ("sh_adam", C.c_void_p)]
+
+
+SH_LAZY_WINDOW = 32   # GSR_SH_LAZY_WINDOW
+
+
+class ShAdamLazy(C.Structure):
+    _fields_ = [("row_step", C.c_void_p), ("window", C.c_int), ("lr_past", C.c_double * SH_LAZY_WINDOW),
+                ("lr_tail_past", C.c_double * SH_LAZY_WINDOW)]
 
 
 class ShAdam(C.Structure):
     _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("lr_tail", C.c_double),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int), ("lazy", C.POINTER(ShAdamLazy))]
+
+
+def make_sh_adam(sh, d):
+    """gsr_sh_adam from the dict the Python host passes around: exp_avg, exp_avg_sq, lr, lr_tail, beta1, beta2, eps, step and --
+    lazy mode (gsr_sh_adam_lazy) -- row_step (int32 [P]), window, lr_past / lr_tail_past (most recent step first).  Returns
+    (struct, objects to keep alive)."""
+    adam = ShAdam(sh.data_ptr(), d["exp_avg"].data_ptr(), d["exp_avg_sq"].data_ptr(), float(d["lr"]), float(d["lr_tail"]),
+                  float(d["beta1"]), float(d["beta2"]), float(d["eps"]), int(d["step"]), None)
+    keep = [adam]
+    if d.get("row_step") is not None:
+        z = ShAdamLazy()
+        z.row_step = d["row_step"].data_ptr()
+        z.window = int(d["window"])
+        for k, (a, b) in enumerate(zip(d.get("lr_past", ()), d.get("lr_tail_past", ()))):
+            if k < SH_LAZY_WINDOW:
+                z.lr_past[k], z.lr_tail_past[k] = float(a), float(b)
+        adam.lazy = C.pointer(z)
+        keep.append(z)
+    return adam, keep
 
 
 class BackwardArgs(C.Structure):
@@ -73,7 +100,7 @@ RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 # every symbol include/gsr.h declares
 EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
-    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
+    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_sh_adam_flush", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
     "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_densify_scratch_bytes",
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
@@ -102,6 +129,8 @@ def load(path=None):
     L.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.c_longlong, f32, vp, vp]
     L.gsr_sh_adam_from_views.restype = i32
     L.gsr_sh_adam_from_views.argtypes = [i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.c_longlong, f32, vp, C.POINTER(ShAdam), vp]
+    L.gsr_sh_adam_flush.restype = i32
+    L.gsr_sh_adam_flush.argtypes = [i32, C.POINTER(ShAdam), vp]
     L.gsr_mark_visible.restype = i32
     L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.gsr_knn_mean_dist2.restype = i32

@@ -128,6 +128,30 @@ static int validate_common(int P, int D, int M, int W, int H, const void* shs, c
 	return GSR_OK;
 }
 
+// gsr_sh_adam with ->lazy set -> the device-side description: the scalars of Adam step (step - k) at [k], formed exactly as
+// adam_scalars forms them for the eager step.  shs: the tensor the rasterizer call works on (must be o.param).
+static int make_lazy_adam(const gsr_sh_adam& o, const float* shs, int M, LazyAdam& la)
+{
+	const gsr_sh_adam_lazy& z = *o.lazy;
+	if (!o.param || (shs && o.param != shs) || !o.exp_avg || !o.exp_avg_sq || !z.row_step || o.step < 1 || z.window < 2 ||
+	    z.window > GSR_SH_LAZY_WINDOW)
+		return GSR_ERR_INVALID_ARG;
+	if (M != 16 || ((reinterpret_cast<uintptr_t>(o.param) | reinterpret_cast<uintptr_t>(o.exp_avg) | reinterpret_cast<uintptr_t>(o.exp_avg_sq)) & 15))
+		return GSR_ERR_UNSUPPORTED;
+	static_assert(GSR_SH_LAZY_WINDOW == LAZY_WINDOW_MAX, "gsr.h and kernels.h agree on the window");
+	la.param = o.param; la.exp_avg = o.exp_avg; la.exp_avg_sq = o.exp_avg_sq;
+	la.row_step = z.row_step; la.step = o.step; la.window = z.window;
+	for (int k = 0; k < LAZY_WINDOW_MAX; k++) {
+		AdamScalars s{};
+		if (k < z.window && o.step - k >= 1)
+			s = adam_scalars(k == 0 ? o.lr : z.lr_past[k - 1], k == 0 ? o.lr_tail : z.lr_tail_past[k - 1], o.beta1, o.beta2, o.eps, o.step - k);
+		la.t.step_size[k] = s.step_size; la.t.step_size_tail[k] = s.step_size_tail; la.t.inv_sqrt_bc2[k] = s.inv_sqrt_bc2;
+	}
+	const AdamScalars c = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
+	la.t.b1 = c.b1; la.t.b2 = c.b2; la.t.omb1 = c.omb1; la.t.omb2 = c.omb2; la.t.eps = c.eps;
+	return GSR_OK;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -198,6 +222,11 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.focal_y = H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:221-222
 	pp.focal_x = W / (2.0f * a->tan_fovx);
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii; pp.raw_params = a->raw_params;
+	pp.lazy = LazyAdam{};
+	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
+		if (!a->shs) return GSR_ERR_INVALID_ARG;
+		if ((st = make_lazy_adam(*a->sh_adam, a->shs, a->M, pp.lazy)) != GSR_OK) return st;
+	}
 	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
 
 	PROF_FWD(1);
@@ -289,7 +318,32 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// Gaussian) next to the VALU-bound backward blend, which leaves HBM nearly idle -- and is joined at the end; the row kernel
 	// behind preprocess_bwd then updates the visible rows only.  (Only the radii of the forward pass are read.)
 	bool side_busy = false;
-	if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled() &&
+	const bool lazy = a->sh_adam && a->sh_adam->lazy;
+	LazyAdam la{};
+	if (lazy) {
+		// lazy mode (gsr_sh_adam_lazy): the culled rows do NOT take this step now; a rotating 1/window of the row blocks catches
+		// up instead (launched behind the backward blend, below)
+		if (a->dL_dcolor_view || !a->shs) return GSR_ERR_INVALID_ARG;
+		if ((st = make_lazy_adam(*a->sh_adam, a->shs, a->M, la)) != GSR_OK) return st;
+	}
+	// This step's slice of the lazy rows: 1/window of the culled rows, each taking `window` zero-gradient steps in registers --
+	// little traffic (72 MB at C3), mostly arithmetic -- on the second stream if there is one; its rows are disjoint from the
+	// visible ones the per-Gaussian backward kernels update.
+	auto launch_lazy_slice = [&]() -> int {
+		const int* radii = a->radii ? a->radii : g.radii;
+		if (!side_stream_enabled()) return launch_sh_adam_lazy(P, radii, la, stream);
+		int s2 = t_sync.init_side();
+		if (s2 != GSR_OK) return s2;
+		GSR_HIP(hipEventRecord(t_sync.fork, stream));
+		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
+		if ((s2 = launch_sh_adam_lazy(P, radii, la, t_sync.side)) != GSR_OK) return s2;
+		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
+		side_busy = true;
+		return GSR_OK;
+	};
+	if (lazy) {
+		// (launched behind the backward blend, below)
+	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled() &&
 	    !((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg) |
 	       reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg_sq)) & 15)) {
 		const gsr_sh_adam& o = *a->sh_adam;
@@ -318,6 +372,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
 	}
 	PROF_BWD(2);
+	// ... next to the HBM-bound per-Gaussian backward kernels that follow.  (Next to the VALU-bound blend it costs the same: the
+	// blend then takes 30 us longer and the kernels behind it 30 us less, tools/gpu_r2p.sh.)
+	if (lazy && (st = launch_lazy_slice()) != GSR_OK) return st;
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;
@@ -340,19 +397,31 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
 	pb.adam = AdamScalars{};
 	pb.adam_skip_culled = 0;
+	pb.lazy_row_step = nullptr; pb.lazy_step = 0;
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
 		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input
 		pb.adam_param = o.param;
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
 		pb.adam = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
-		pb.adam_skip_culled = side_busy ? 1 : 0;
+		pb.adam_skip_culled = (side_busy || lazy) ? 1 : 0;
+		if (lazy) { pb.lazy_row_step = la.row_step; pb.lazy_step = la.step; }
 	}
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	if (side_busy) GSR_HIP(hipStreamWaitEvent(stream, t_sync.join, 0));   // whatever follows on the caller's stream sees the whole update
 	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on != 0;
 	return GSR_OK;
+}
+
+int gsr_sh_adam_flush(int P, const gsr_sh_adam* adam, void* stream_)
+{
+	if (P < 0 || !adam || !adam->lazy) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	LazyAdam la{};
+	int st = make_lazy_adam(*adam, nullptr, 16, la);
+	if (st != GSR_OK) return st;
+	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_);
 }
 
 int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,

@@ -27,6 +27,23 @@ static inline AdamScalars adam_scalars(double lr, double lr_tail, double beta1, 
 	return a;
 }
 
+// Lazy Adam for the SH rows of culled Gaussians (gsr_sh_adam_lazy; the mechanism is described in shrows.h)
+constexpr int LAZY_WINDOW_MAX = 32;   // == GSR_SH_LAZY_WINDOW
+constexpr int LAZY_BLOCK_ROWS = 64;   // granularity of the rotating slice: row block b is due at steps s with s % window == b % window
+struct LazyAdamTable {                // [k]: the scalars of Adam step (step - k)
+	float step_size[LAZY_WINDOW_MAX], step_size_tail[LAZY_WINDOW_MAX], inv_sqrt_bc2[LAZY_WINDOW_MAX];
+	float b1, b2, omb1, omb2, eps;
+};
+struct LazyAdam {
+	float* param;        // [P][48]
+	float* exp_avg;
+	float* exp_avg_sq;
+	int* row_step;       // [P]; null = off
+	int step;            // the Adam step the tensor is taking (forward / backward) or has taken (flush)
+	int window;
+	LazyAdamTable t;
+};
+
 struct PreprocessParams {
 	int P, D, M;
 	const float* means3D;
@@ -45,6 +62,7 @@ struct PreprocessParams {
 	int grid_x, grid_y;
 	int* radii_out;  // caller's radii (nullable)
 	int raw_params;  // GSR_RAW_* mask: activations applied in-kernel
+	LazyAdam lazy;   // row_step != null: visible rows that lag behind (step - 1) are brought up to date before their SH evaluation
 };
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
@@ -121,7 +139,9 @@ struct PreprocessBwdParams {
 	float* adam_exp_avg;
 	float* adam_exp_avg_sq;
 	AdamScalars adam;
-	int adam_skip_culled;     // the culled Gaussians' rows already took this step (the culled rows of the fused SH Adam step, gsr_backward)
+	int adam_skip_culled;     // the culled Gaussians' rows take this step elsewhere (gsr_backward: side stream) or later (lazy)
+	int* lazy_row_step;       // lazy mode: row_step[i] = lazy_step for the rows updated here (the visible ones); null = off
+	int lazy_step;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
@@ -132,6 +152,10 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 
 // this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
 int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream);
+
+// lazy mode: the zero-gradient steps the rows of this step's slice of row blocks are behind, up to and including a.step, for
+// the rows with radii <= 0 (radii == null: every row of EVERY block -- gsr_sh_adam_flush)
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

@@ -42,6 +42,7 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 {
 	__shared__ float4 s_rows[PRE_THREADS / 64][FWD_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[PRE_THREADS / 64][64];
+	__shared__ uint32_t s_lag[PRE_THREADS / 64][64];   // lazy SH Adam: steps a listed row is behind (shrows.h)
 
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id();
@@ -178,27 +179,40 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 		const int ncoef = (p.D + 1) * (p.D + 1);
 		const bool rows_ok = (p.M * 3 == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0);
 		float rgb[3] = {0.f, 0.f, 0.f};
-		ShDir d = sh_dir(0.f, 0.f, 1.f);
-		if (vis) {
-			float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
+		// the view direction, formed where a lane evaluates its row (nine products that need not live across the staging)
+		auto direction = [&]() {
+			const float dx = px - p.campos[0], dy = py - p.campos[1], dz = pz - p.campos[2];
 			const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-			d = sh_dir(dx / len, dy / len, dz / len);
-		}
+			return sh_dir(dx / len, dy / len, dz / len);
+		};
 		if (rows_ok) {
 			const unsigned long long vmask = wave_ballot(vis);
 			const int nvis = __popcll(vmask);
 			const int rank = __popcll(vmask & lanemask_lt());
-			if (vis) s_list[w][rank] = (uint32_t)lane_id();
+			// lazy SH Adam (gsr_sh_adam_lazy): a visible row that is behind (step - 1) takes its missed zero-gradient steps first
+			int lag = 0;
+			if (p.lazy.row_step != nullptr && vis) {
+				lag = p.lazy.step - 1 - p.lazy.row_step[idx];
+				lag = lag < 0 ? 0 : (lag >= p.lazy.window ? p.lazy.window - 1 : lag);
+			}
+			const bool lagging = wave_ballot(lag > 0) != 0;   // wave-uniform, false on nearly every wave of a steady view
+			if (vis) {
+				s_list[w][rank] = (uint32_t)lane_id();
+				s_lag[w][rank] = (uint32_t)lag;
+			}
 			wave_fence();
-			const int nf4 = (3 * ncoef + 3) >> 2;
+			const int nf4 = lagging ? ROW_F4 : (3 * ncoef + 3) >> 2;   // whole rows where some must be updated
 			for (int r0 = 0; r0 < nvis; r0 += FWD_ROWS) {
 				const int count = (nvis - r0) < FWD_ROWS ? (nvis - r0) : FWD_ROWS;
 				wave_load_listed_rows(reinterpret_cast<const float4*>(p.shs), wave_first, nf4, r0, count, s_rows[w], s_list[w]);
-				if (vis && rank >= r0 && rank < r0 + count) sh_row_to_rgb(s_rows[w][rank - r0], ncoef, d, rgb);
+				if (lagging) wave_lazy_catch_up_listed(p.lazy, wave_first, r0, count, s_rows[w], s_list[w], s_lag[w]);
+				if (vis && rank >= r0 && rank < r0 + count) sh_row_to_rgb(s_rows[w][rank - r0], ncoef, direction(), rgb);
 				wave_fence();  // the next pass overwrites the slice
 			}
+			if (lag > 0) p.lazy.row_step[idx] = p.lazy.step - 1;
 		} else if (vis) {
 			const float* sh = p.shs + (size_t)idx * p.M * 3;
+			const ShDir d = direction();
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
 				if (k < ncoef) {

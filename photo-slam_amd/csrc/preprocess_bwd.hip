@@ -112,6 +112,7 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 			}
 		}
 	}
+	if (MODE == 2 && vis && p.lazy_row_step) p.lazy_row_step[idx] = p.lazy_step;   // lazy mode: this row has taken the step
 	if (vis) {
 		const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
 		const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
@@ -437,7 +438,7 @@ __device__ __forceinline__ void sh_adam_culled_item(long long t, const int* __re
 		const float g = 0.f;
 		mp[e] = a.s.b1 * mp[e] + a.s.omb1 * g;
 		vp[e] = a.s.b2 * vp[e] + a.s.omb2 * g * g;
-		pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.s.inv_sqrt_bc2 + a.s.eps);
+		pp[e] -= ss * adam_ratio(mp[e], vp[e], a.s.inv_sqrt_bc2, a.s.eps);
 	}
 	store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
 	store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
@@ -464,6 +465,55 @@ int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStrea
 	long long blocks = (items + 255) / 256;
 	if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
 	GSR_LAUNCH(sh_adam_culled_kernel, (int)blocks, 256, stream, P, radii, adam);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// Lazy mode (shrows.h): one workgroup per row block of LAZY_BLOCK_ROWS rows, one thread per 16-byte vector of the block
+// (64 rows x 12 vectors = 768 threads: the `window` dependent steps per element are latency-bound, so the parallelism is spent
+// across elements).  The blocks of this step's slice (all blocks when radii == null: flush) bring their rows with radii <= 0
+// up to a.step -- the zero-gradient steps (row_step, a.step] in one read-modify-write of the row.  The workgroup owns its
+// block: row_step is read by all threads before the barrier, written behind it.
+constexpr int LAZY_THREADS = LAZY_BLOCK_ROWS * ROW_F4;   // 768
+__global__ void __launch_bounds__(LAZY_THREADS)
+sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a)
+{
+	const bool all = radii == nullptr;
+	const long long b = all ? (long long)blockIdx.x : (long long)(a.step % a.window) + (long long)blockIdx.x * a.window;
+	const size_t row0 = (size_t)b * LAZY_BLOCK_ROWS;
+	const int item = (int)threadIdx.x;
+	const int rr = item / ROW_F4, col = item - rr * ROW_F4;
+	const size_t row = row0 + (size_t)rr;
+	const bool mine = row < (size_t)P && (all || radii[row] <= 0);
+	if (mine) {
+		int k_hi = a.step - 1 - a.row_step[row];
+		k_hi = k_hi >= a.window ? a.window - 1 : k_hi;
+		if (k_hi >= 0) {
+			const size_t i = row * ROW_F4 + col;
+			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
+			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
+			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+			lazy_zero_grad_steps(a.t, k_hi, 0, col, pv, mv, vv);
+			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+		}
+	}
+	__syncthreads();
+	if (mine && col == 0) a.row_step[row] = a.step;
+}
+
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream)
+{
+	if (P <= 0) return GSR_OK;
+	if (!a.row_step || a.window < 2 || a.window > LAZY_WINDOW_MAX || a.step < 1) return GSR_ERR_INVALID_ARG;
+	if ((reinterpret_cast<uintptr_t>(a.param) | reinterpret_cast<uintptr_t>(a.exp_avg) | reinterpret_cast<uintptr_t>(a.exp_avg_sq)) & 15)
+		return GSR_ERR_UNSUPPORTED;
+	const int nb = div_up(P, LAZY_BLOCK_ROWS);
+	// slice: the row blocks b with b % window == step % window
+	const int phase = a.step % a.window;
+	const int blocks = radii ? (nb > phase ? div_up(nb - phase, a.window) : 0) : nb;
+	if (blocks > 0) GSR_LAUNCH(sh_adam_lazy_kernel, blocks, LAZY_THREADS, stream, P, radii, a);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -20,6 +20,7 @@
 #pragma once
 #include "state.h"
 #include "wave64.h"
+#include "kernels.h"
 
 namespace gsr {
 
@@ -68,7 +69,23 @@ __device__ __forceinline__ void wave_store_rows(float4* __restrict__ gbase, size
 	wave_fence();
 }
 
-// One Adam step (train_ops.hip: adam_kernel, same arithmetic) on rows [first_row, first_row + nrows) whose GRADIENT sits in
+// The update term of one element, m / (sqrt(v) c2 + eps), for the SH rows (eager, culled and lazy paths alike -- they must
+// agree bit for bit): v_sqrt_f32 and v_rcp_f32 (1 ulp each) instead of the correctly rounded expansions the compiler emits
+// for sqrtf and '/'.  The term is multiplied by a step size of ~1e-3 before it meets a parameter of ~1e-1..1: its relative
+// error of 2e-7 is 1e-9 of the parameter, far below the parameter's own rounding (6e-8), and against torch::optim::Adam the
+// result stays within one ulp of the parameter (tests/test_train_step.py, tests/test_gpu_parity.py).  It matters because the
+// zero-gradient steps of the culled rows run next to other kernels on a second stream: the expansions cost ~90 issue cycles per
+// element and step (51 M element-steps per step at C3), this form 31.
+__device__ __forceinline__ float adam_ratio(float m, float v, float c2, float eps)
+{
+#ifdef GSR_EMU
+	return m * (1.0f / (sqrtf(v) * c2 + eps));
+#else
+	return m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * c2 + eps);
+#endif
+}
+
+// One Adam step (train_ops.hip: adam_kernel, same formula) on rows [first_row, first_row + nrows) whose GRADIENT sits in
 // s_rows: the movers read parameter and moments from global (four whole rows = 768 contiguous bytes per instruction and
 // array), update them and write them back; the gradient never reaches HBM.  The first 3 floats of a row (features_dc) use
 // step_size, the other 45 (features_rest) step_size_tail.
@@ -104,11 +121,73 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 				const float ss = e < 3 ? ss_first : a.s.step_size_tail;
 				mp[e] = a.s.b1 * mp[e] + a.s.omb1 * gp[e];
 				vp[e] = a.s.b2 * vp[e] + a.s.omb2 * gp[e] * gp[e];
-				pp[e] -= ss * mp[e] / (sqrtf(vp[e]) * a.s.inv_sqrt_bc2 + a.s.eps);
+				pp[e] -= ss * adam_ratio(mp[e], vp[e], a.s.inv_sqrt_bc2, a.s.eps);
 			}
 			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
 			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
 			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+		}
+	}
+	wave_fence();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lazy Adam for rows whose gradient is zero (gsr_sh_adam_lazy, include/gsr.h).  A Gaussian the view culls gets a zero SH
+// gradient, and a zero-gradient Adam step of a row depends on nothing but the row itself and the step's scalars:
+//   m <- b1 m;  v <- b2 v;  p <- p - step_size m / (sqrt(v) c + eps)
+// so it can be taken LATER, several at a time with the row in registers -- the same arithmetic in the same order, one HBM
+// round trip instead of one per step.  row_step[i] counts the Adam steps row i has taken; a row is brought up to date
+//   * by the forward pass when it becomes visible (before its coefficients are evaluated),
+//   * by the backward pass of every `window`-th step (a rotating slice of the row blocks), so that no row lags by more than
+//     `window` steps and the table of past scalars stays short,
+//   * by gsr_sh_adam_flush (all rows) before anybody else reads the tensor or its moments.
+// (LazyAdamTable / LazyAdam: kernels.h)
+
+// The zero-gradient Adam steps (step - k_hi) .. (step - k_lo), oldest first, on one 16-byte vector of a row (col = its index
+// in the row: .x .y .z of vector 0 are features_dc).  The expressions are those of wave_adam_rows with g = 0.
+__device__ __forceinline__ void lazy_zero_grad_steps(const LazyAdamTable& t, int k_hi, int k_lo, int col, float4& pv, float4& mv,
+                                                     float4& vv)
+{
+	float* pp = &pv.x; float* mp = &mv.x; float* vp = &vv.x;
+	for (int k = k_hi; k >= k_lo; k--) {
+		const float tail = t.step_size_tail[k];
+		const float ss_first = col == 0 ? t.step_size[k] : tail;
+		const float c2 = t.inv_sqrt_bc2[k];
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const float ss = e < 3 ? ss_first : tail;
+			const float g = 0.f;
+			mp[e] = t.b1 * mp[e] + t.omb1 * g;
+			vp[e] = t.b2 * vp[e] + t.omb2 * g * g;
+			pp[e] -= ss * adam_ratio(mp[e], vp[e], c2, t.eps);
+		}
+	}
+}
+
+// Forward pass: rows j = 0 .. count-1 of the stage belong to the lanes s_list[list_first + j] of the wave and lag
+// s_lag[list_first + j] steps behind (step - 1); the whole rows (ROW_F4 vectors) sit in s_rows.  The movers bring the lagging
+// ones up to date in HBM (parameter and moments) and in the stage.
+__device__ __forceinline__ void wave_lazy_catch_up_listed(const LazyAdam& a, size_t first_row, int list_first, int count,
+                                                          float4 (*s_rows)[ROW_F4_PAD], const uint32_t* s_list, const uint32_t* s_lag)
+{
+	const int l = lane_id();
+	const int slot = l >> 4, col = l & 15;
+	wave_fence();
+	for (int j0 = 0; j0 < count; j0 += 4) {
+		const int j = j0 + slot;
+		if (col < ROW_F4 && j < count) {
+			const int lag = (int)s_lag[list_first + j];
+			if (lag > 0) {
+				const size_t i = (first_row + s_list[list_first + j]) * ROW_F4 + col;
+				float4 pv = s_rows[j][col];
+				float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
+				float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+				lazy_zero_grad_steps(a.t, lag, 1, col, pv, mv, vv);
+				store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
+				store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
+				store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+				s_rows[j][col] = pv;
+			}
 		}
 	}
 	wave_fence();

@@ -45,6 +45,7 @@ class FusedAdam:
             for p in grp["params"]:
                 if p.grad is None:
                     continue
+                self.sync_lazy(p)   # a dense step: every row must be up to date first
                 st = self.state.get(id(p))
                 if st is None:
                     st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
@@ -57,23 +58,63 @@ class FusedAdam:
                                                   float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, rp._stream_ptr(p)),
                            "gsr_adam_step")
 
-    def begin_fused_step(self, i):
+    def begin_fused_step(self, i, lazy_window=0):
         """Arguments of the fused update of single-tensor group i (GaussianRasterizationSettings.sh_adam_): advances the
         parameter's step counter -- the update itself happens inside the rasterizer's backward, and step_group(i) then finds
-        no gradient and does nothing."""
+        no gradient and does nothing.
+        lazy_window >= 2: the zero-gradient steps of the culled Gaussians' rows are taken lazily (gsr_sh_adam_lazy,
+        include/gsr.h): the dict then carries row_step / window / the past learning rates, goes to the rasterizer's forward
+        AND backward, and end_fused_step() must follow the backward pass; sync_lazy() brings every row up to date."""
         grp = self.param_groups[i]
         (p,) = grp["params"]
         st = self.state.get(id(p))
         if st is None:
             st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
+        lazy = lazy_window >= 2 and p.dim() == 3 and p.size(1) == 16 and p.is_contiguous()
+        if not lazy or st.get("window", lazy_window) != lazy_window:
+            self.sync_lazy(p)
+        if lazy and "row_step" not in st:   # every row has taken the st["step"] steps so far
+            st["row_step"] = torch.full((p.size(0),), st["step"], dtype=torch.int32, device=p.device)
+            st["lr_hist"], st["window"] = [], int(lazy_window)
         st["step"] += 1
-        return dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=float(grp["lr"]) * self.lr_scale,
-                    lr_tail=float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                    step=st["step"])
+        d = dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=float(grp["lr"]) * self.lr_scale,
+                 lr_tail=float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                 step=st["step"])
+        if lazy:
+            d.update(row_step=st["row_step"], window=st["window"], lr_past=[a for a, _ in st["lr_hist"]],
+                     lr_tail_past=[b for _, b in st["lr_hist"]])
+        return d
+
+    def end_fused_step(self, i, d):
+        """After the backward pass of a lazy fused step: its learning rates join the history the later catch-ups need."""
+        if d is None or d.get("row_step") is None:
+            return
+        (p,) = self.param_groups[i]["params"]
+        st = self.state[id(p)]
+        st["lr_hist"].insert(0, (d["lr"], d["lr_tail"]))
+        del st["lr_hist"][st["window"]:]
+
+    def is_lazy(self, p):
+        st = self.state.get(id(p))
+        return st is not None and "row_step" in st
+
+    def sync_lazy(self, p):
+        """Lazy mode: every row of p takes the zero-gradient steps it is behind (gsr_sh_adam_flush: the same arithmetic,
+        bit-identical to the eager update) and the lazy state is dropped.  No-op otherwise."""
+        st = self.state.get(id(p))
+        if st is None or "row_step" not in st:
+            return
+        row_step, hist, window = st.pop("row_step"), st.pop("lr_hist"), st.pop("window")
+        if hist:
+            rp.shAdamFlush(p.detach(), dict(exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], lr=hist[0][0], lr_tail=hist[0][1],
+                                            beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=st["step"],
+                                            row_step=row_step, window=window, lr_past=[a for a, _ in hist[1:]],
+                                            lr_tail_past=[b for _, b in hist[1:]]))
 
     def replace_param(self, old, new, exp_avg=None, exp_avg_sq=None):
         """Swap a parameter tensor (densify / prune / opacity reset): the Adam moments are replaced by the given
         tensors, or by zeros; the step counter carries over (replaceTensorToOptimizer, src/gaussian_model.cpp:567-586)."""
+        self.sync_lazy(old)
         for grp in self.param_groups:
             grp["params"] = [new if p is old else p for p in grp["params"]]
         prev = self.state.pop(id(old), None)
@@ -82,6 +123,7 @@ class FusedAdam:
                                    step=prev["step"] if prev else 0)
 
     def moments(self, p):
+        self.sync_lazy(p)
         st = self.state.get(id(p))
         if st is None:
             return torch.zeros_like(p), torch.zeros_like(p)
@@ -128,6 +170,25 @@ class GaussianModel:
         self.device_ = torch.device(device)
         self.spatial_lr_scale_ = 1.0
         self.optimizer_ = None
+        self._features = None
+        self._in_lazy_step = False   # set by the train step around its own render call
+
+    # features_: the [P,16,3] SH leaf.  With lazy Adam steps for the rows of culled Gaussians (FusedAdam.begin_fused_step,
+    # gsr_sh_adam_lazy) rows of it may be behind between train steps: every read from outside the fused step brings them up
+    # to date first.
+    @property
+    def features_(self):
+        if not self._in_lazy_step:
+            self.sync_features()
+        return self._features
+
+    @features_.setter
+    def features_(self, value):
+        self._features = value
+
+    def sync_features(self):
+        if self.optimizer_ is not None and self._features is not None:
+            self.optimizer_.sync_lazy(self._features)
 
     # ---- construction
     @classmethod

@@ -44,7 +44,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rp.RasterizeGaussiansCUDA(
             s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_, cov3Ds_precomp,
             s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_, s.image_height_, s.image_width_, sh, s.sh_degree_,
-            s.campos_, s.prefiltered_, s.raw_params_)
+            s.campos_, s.prefiltered_, s.raw_params_, s.sh_adam_)   # sh_adam_: lazy mode brings visible rows up to date first
         ctx.num_rendered = num_rendered
         ctx.raster_settings = s
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,

@@ -62,7 +62,12 @@ public:
 	torch::Tensor getRotationActivation() { return torch::nn::functional::normalize(rotation_); }
 	torch::Tensor getOpacityActivation() { return torch::sigmoid(opacity_); }
 	// one [P,16,3] leaf instead of cat(features_dc.clone(), features_rest.clone()) (gaussian_model.cpp:63-66)
-	torch::Tensor getFeatures() { return features_; }
+	// (lazy SH Adam: outside the fused train step the rows are brought up to date first, see syncFeatures())
+	torch::Tensor getFeatures()
+	{
+		if (!in_lazy_step_) syncFeatures();
+		return features_;
+	}
 	torch::Tensor getCovarianceActivation(int scaling_modifier = 1);   // :73-96
 
 	void trainingSetup(const GaussianOptimizationParams& opt);   // src/gaussian_model.cpp:477-510
@@ -74,7 +79,23 @@ public:
 	void optimizerStepGroup(int group);
 	void zeroGrad();
 	void addDensificationStats(torch::Tensor& viewspace_point_tensor, torch::Tensor& update_filter);  // :817-831
-	std::vector<torch::Tensor> params() { return {xyz_, features_, opacity_, scaling_, rotation_}; }
+	std::vector<torch::Tensor> params()
+	{
+		syncFeatures();
+		return {xyz_, features_, opacity_, scaling_, rotation_};
+	}
+
+	// Lazy Adam steps for the SH rows of culled Gaussians (gsr_sh_adam_lazy, include/gsr.h; TrainStep::lazy_sh_adam_window_).
+	// While features_row_step_ is defined, rows of features_ and of its two moment tensors may be up to `window` zero-gradient
+	// steps behind (row i has taken features_row_step_[i] of groups_[1].step steps).  syncFeatures() takes the missing steps
+	// (gsr_sh_adam_flush: the same arithmetic, bit-identical to the eager update) and drops the state; everything that reads
+	// or rewrites features_ or its moments outside the fused train step calls it first (getFeatures(), params(), the dense
+	// optimizer step, densify / prune, savePly, the data-parallel exchange).
+	void syncFeatures();
+	torch::Tensor features_row_step_;                            // [P] int32 or undefined (= every row is up to date)
+	std::vector<std::pair<double, double>> features_lr_hist_;    // (lr, lr_tail) of the Adam steps since the state exists, newest first
+	int features_lazy_window_ = 0;
+	bool in_lazy_step_ = false;                                  // set by TrainStep around its own render call
 
 	int max_sh_degree_, active_sh_degree_;
 	float spatial_lr_scale_;
@@ -149,6 +170,10 @@ public:
 	// reach HBM, 0.13 ms of a 2.3 ms step at C3); same arithmetic as the separate pass.  Not used on an iteration that
 	// densifies (the reference skips that optimizer step) nor with the factored exchange.
 	bool fused_sh_adam_ = true;
+	// ... and the zero-gradient steps of the culled Gaussians' rows taken lazily, at most this many at a time (2 .. 32; 0 = every
+	// row at every step): one HBM round trip of a culled row per `window` steps instead of one per step (1.2 GB per step at
+	// C3), results bit-identical (GaussianModel::syncFeatures, tests/test_lazy_sh_adam.py)
+	int lazy_sh_adam_window_ = 32;
 	bool factored_exchange_ = false;
 	torch::Tensor sh_send_;        // [P + 1, 3]: rows 0 .. P-1 = sh_grad_view_, row P = this view's camera centre (one all-gather)
 	torch::Tensor sh_grad_view_;

@@ -10,6 +10,20 @@
 #include <tuple>
 #include <vector>
 
+// Extension, optimizer-in-backward for the SH tensor (gsr_sh_adam of include/gsr.h): when exp_avg is defined, backward applies
+// this Adam step to `sh` IN PLACE instead of computing dL_dsh (which then comes back undefined).
+// Lazy mode (gsr_sh_adam_lazy): with row_step defined the rows of culled Gaussians take their zero-gradient steps later,
+// several at a time -- the SAME struct then goes to the forward overload below (rows that become visible are brought up to
+// date before they are evaluated) and to backward, and shAdamFlush must run before anything else touches sh or the moments.
+struct ShAdamStep {
+	torch::Tensor exp_avg, exp_avg_sq;   // [P,16,3], contiguous
+	double lr = 0.0, lr_tail = 0.0, beta1 = 0.9, beta2 = 0.999, eps = 1e-15;   // double, as torch::optim::AdamOptions
+	int step = 0;
+	torch::Tensor row_step;              // lazy mode: [P] int32, the Adam steps each row has taken; undefined = eager
+	int window = 0;                      // lazy mode: 2 .. GSR_SH_LAZY_WINDOW
+	std::vector<double> lr_past, lr_tail_past;   // lazy mode: [k-1] = the learning rates of step (step - k)
+};
+
 // (num_rendered, out_color[3,H,W], radii[P] i32, geomBuffer u8, binningBuffer u8, imgBuffer u8)
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
     const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
@@ -26,14 +40,14 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
     const bool prefiltered, const int raw_params);
-
-// Extension, optimizer-in-backward for the SH tensor (gsr_sh_adam of include/gsr.h): when exp_avg is defined, backward applies
-// this Adam step to `sh` IN PLACE instead of computing dL_dsh (which then comes back undefined).
-struct ShAdamStep {
-	torch::Tensor exp_avg, exp_avg_sq;   // [P,16,3], contiguous
-	double lr = 0.0, lr_tail = 0.0, beta1 = 0.9, beta2 = 0.999, eps = 1e-15;   // double, as torch::optim::AdamOptions
-	int step = 0;
-};
+// ... and the lazy SH Adam state (only consulted when sh_adam.row_step is defined; `sh` is then updated in place)
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
+    const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+    const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+    const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
+    const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
+    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam);
 
 // (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -72,5 +86,9 @@ torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor&
 // gsr_sh_adam_from_views: the same rebuild with this step's Adam update of `sh` [P,16,3] applied in place (no gradient tensor)
 void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views, const torch::Tensor& dL_dcolor_views,
                      const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam);
+
+// gsr_sh_adam_flush: lazy mode -- every row of `sh` takes the zero-gradient steps it is behind, up to sh_adam.step = the number
+// of Adam steps the tensor has taken (sh_adam.lr / lr_tail belong to that step)
+void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam);
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);

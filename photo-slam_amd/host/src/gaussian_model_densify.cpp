@@ -44,6 +44,8 @@ void GaussianModel::createFromPcd(torch::Tensor points, torch::Tensor colors, fl
 	auto opacities = inverse_sigmoid(0.1 * torch::ones({n, 1}, o));
 	auto leaf = [](torch::Tensor t) { return t.contiguous().set_requires_grad(true); };
 	xyz_ = leaf(pts.clone());
+	features_row_step_ = torch::Tensor();   // a new SH tensor: no lazy state
+	features_lr_hist_.clear();
 	features_ = leaf(features);
 	scaling_ = leaf(scales);
 	rotation_ = leaf(rots);
@@ -74,6 +76,7 @@ torch::Tensor& GaussianModel::paramByIndex(int i)
 // hyper-parameters, the moments are the given tensors or zeros.
 void GaussianModel::replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq)
 {
+	if (group == 1) syncFeatures();
 	fresh = fresh.contiguous().set_requires_grad(true);
 	paramByIndex(group) = fresh;
 	if (static_cast<size_t>(group) < groups_.size()) {
@@ -141,6 +144,7 @@ void* GaussianModel::hostStream(const torch::Tensor& t)
 std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10::optional<at::Generator> generator)
 {
 	torch::NoGradGuard ng;
+	syncFeatures();   // the gather copies rows of features_ and of its moments: none may be behind (lazy SH Adam)
 	const int64_t P = xyz_.size(0);
 	sel.P = static_cast<int>(P);
 	void* stream = hostStream(xyz_);

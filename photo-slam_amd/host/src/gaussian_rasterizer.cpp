@@ -19,7 +19,8 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 {
 	auto r = RasterizeGaussiansCUDA(s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_,
 	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
-	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, e.raw_params_);
+	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, e.raw_params_,
+	                                e.sh_adam_ /* lazy mode: visible rows are brought up to date first */);
 	ctx->saved_data["num_rendered"] = std::get<0>(r);
 	ctx->saved_data["scale_modifier"] = static_cast<double>(s.scale_modifier_);
 	ctx->saved_data["tanfovx"] = static_cast<double>(s.tanfovx_);
@@ -33,6 +34,12 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 		ctx->saved_data["sh_adam_v"] = e.sh_adam_.exp_avg_sq;
 		ctx->saved_data["sh_adam_h"] = std::vector<double>{e.sh_adam_.lr, e.sh_adam_.lr_tail, e.sh_adam_.beta1, e.sh_adam_.beta2,
 		                                                   e.sh_adam_.eps, static_cast<double>(e.sh_adam_.step)};
+		if (e.sh_adam_.row_step.defined()) {   // lazy mode
+			ctx->saved_data["sh_adam_row_step"] = e.sh_adam_.row_step;
+			ctx->saved_data["sh_adam_window"] = e.sh_adam_.window;
+			ctx->saved_data["sh_adam_lr_past"] = e.sh_adam_.lr_past;
+			ctx->saved_data["sh_adam_lr_tail_past"] = e.sh_adam_.lr_tail_past;
+		}
 	}
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
@@ -63,6 +70,12 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 		sh_adam.lr = h[0]; sh_adam.lr_tail = h[1];
 		sh_adam.beta1 = h[2]; sh_adam.beta2 = h[3];
 		sh_adam.eps = h[4]; sh_adam.step = static_cast<int>(h[5]);
+		if (ctx->saved_data.count("sh_adam_row_step")) {
+			sh_adam.row_step = ctx->saved_data["sh_adam_row_step"].toTensor();
+			sh_adam.window = static_cast<int>(ctx->saved_data["sh_adam_window"].toInt());
+			sh_adam.lr_past = ctx->saved_data["sh_adam_lr_past"].toDoubleVector();
+			sh_adam.lr_tail_past = ctx->saved_data["sh_adam_lr_tail_past"].toDoubleVector();
+		}
 	}
 	std::vector<torch::Tensor> view_stats;
 	if (ctx->saved_data.count("view_stats")) view_stats = ctx->saved_data["view_stats"].toTensorVector();

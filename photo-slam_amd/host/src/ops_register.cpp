@@ -163,6 +163,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		const double v = kv.value();
 		if (k == "densify") t->densify_ = v != 0.0;
 		else if (k == "fused_sh_adam") t->fused_sh_adam_ = v != 0.0;
+		else if (k == "lazy_sh_adam_window") t->lazy_sh_adam_window_ = (int)v;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
 		else if (k == "lr_scale") t->gaussians_->lr_scale_ = v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
@@ -210,6 +211,7 @@ void trainer_one_up_sh_degree(int64_t h) { get(h)->gaussians_->oneUpShDegree(); 
 std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five groups, then exp_avg_sq
 {
 	std::vector<torch::Tensor> out;
+	get(h)->gaussians_->syncFeatures();
 	for (auto& g : get(h)->gaussians_->groups_) out.push_back(g.exp_avg);
 	for (auto& g : get(h)->gaussians_->groups_) out.push_back(g.exp_avg_sq);
 	return out;

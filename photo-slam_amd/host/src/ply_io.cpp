@@ -32,6 +32,7 @@ std::vector<std::string> property_names(int64_t n_rest)
 void GaussianModel::savePly(const std::string& result_path)
 {
 	torch::NoGradGuard ng;
+	syncFeatures();
 	const int64_t P = xyz_.size(0), M = features_.size(1);
 	auto cpu = [](const torch::Tensor& t) { return t.detach().to(torch::kCPU, torch::kFloat32).contiguous(); };
 	auto xyz = cpu(xyz_);
@@ -109,6 +110,8 @@ void GaussianModel::loadPly(const std::string& ply_path)
 	const auto dev = xyz_.defined() ? xyz_.device() : device_;
 	auto leaf = [&](torch::Tensor t) { return t.contiguous().to(dev).set_requires_grad(true); };
 	xyz_ = leaf(take({"x", "y", "z"}));
+	features_row_step_ = torch::Tensor();   // a new SH tensor: no lazy state
+	features_lr_hist_.clear();
 	features_ = leaf(torch::cat({f_dc, f_rest}, 1));   // one [P, M, 3] leaf (the reference: features_dc_ | features_rest_)
 	opacity_ = leaf(take({"opacity"}));
 	scaling_ = leaf(take(scale_names));

@@ -51,6 +51,31 @@ void check(int status, const char* where)
 	throw std::runtime_error(msg);
 }
 
+// ShAdamStep -> gsr_sh_adam (+ gsr_sh_adam_lazy when row_step is defined); `lazy` must outlive the call that gets `adam`
+void fill_sh_adam(const ShAdamStep& s, float* param, gsr_sh_adam& adam, gsr_sh_adam_lazy& lazy)
+{
+	adam = gsr_sh_adam{};
+	adam.param = param;
+	adam.exp_avg = s.exp_avg.data_ptr<float>();
+	adam.exp_avg_sq = s.exp_avg_sq.data_ptr<float>();
+	adam.lr = s.lr; adam.lr_tail = s.lr_tail;
+	adam.beta1 = s.beta1; adam.beta2 = s.beta2; adam.eps = s.eps;
+	adam.step = s.step;
+	if (s.row_step.defined()) {
+		if (s.row_step.scalar_type() != torch::kInt32 || !s.row_step.is_contiguous() || s.row_step.numel() != s.exp_avg.size(0) ||
+		    s.row_step.device() != s.exp_avg.device())
+			throw std::runtime_error("sh_adam.row_step must be a contiguous int32 [P] tensor on the device of the moments");
+		lazy = gsr_sh_adam_lazy{};
+		lazy.row_step = s.row_step.data_ptr<int>();
+		lazy.window = s.window;
+		for (size_t k = 0; k < GSR_SH_LAZY_WINDOW; k++) {
+			lazy.lr_past[k] = k < s.lr_past.size() ? s.lr_past[k] : 0.0;
+			lazy.lr_tail_past[k] = k < s.lr_tail_past.size() ? s.lr_tail_past[k] : 0.0;
+		}
+		adam.lazy = &lazy;
+	}
+}
+
 }  // namespace
 
 // the reference's exact parameter lists (include/rasterize_points.h:18-37, :39-60): same mangled names
@@ -90,6 +115,19 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
     const bool prefiltered, const int raw_params)
+{
+	return RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+	                              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+	                              prefiltered, raw_params, ShAdamStep());
+}
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
+    const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+    const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+    const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+    const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
+    const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
+    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam)
 {
 	if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
 		AT_ERROR("means3D must have dimensions (num_points, 3)");
@@ -134,6 +172,16 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 		a.raw_params = raw_params;
 		a.out_color = out_color.data_ptr<float>();
 		a.radii = radii.data_ptr<int>();
+		gsr_sh_adam adam{};
+		gsr_sh_adam_lazy lazy{};
+		if (sh_adam.row_step.defined()) {   // lazy SH Adam: the forward pass brings visible rows up to date (in place)
+			if (!sh_adam.exp_avg.defined() || !sh.defined() || sh.scalar_type() != torch::kFloat32 || !sh.is_contiguous() ||
+			    !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() || sh_adam.exp_avg.sizes() != sh.sizes() ||
+			    sh_adam.exp_avg_sq.sizes() != sh.sizes())
+				throw std::runtime_error("lazy sh_adam needs contiguous float32 sh and moments of one shape");
+			fill_sh_adam(sh_adam, const_cast<float*>(a.shs), adam, lazy);
+			a.sh_adam = &adam;
+		}
 		check(gsr_forward(&a, resize_tensor, &geomBuffer, resize_tensor, &binningBuffer, resize_tensor, &imgBuffer,
 		                  current_stream(means3D), &rendered),
 		      "RasterizeGaussiansCUDA");
@@ -240,13 +288,10 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 			a.stat_max_radii = view_stats[2].data_ptr<float>();
 		}
 		gsr_sh_adam adam{};
+		gsr_sh_adam_lazy lazy{};
 		if (fused_adam) {
-			adam.param = const_cast<float*>(a.shs);   // the caller handed `sh` over for the in-place update (ShAdamStep contract)
-			adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
-			adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
-			adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
-			adam.beta1 = sh_adam.beta1; adam.beta2 = sh_adam.beta2; adam.eps = sh_adam.eps;
-			adam.step = sh_adam.step;
+			// the caller handed `sh` over for the in-place update (ShAdamStep contract)
+			fill_sh_adam(sh_adam, const_cast<float*>(a.shs), adam, lazy);
 			a.sh_adam = &adam;
 		}
 		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
@@ -325,6 +370,19 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 	check(gsr_sh_adam_from_views(P, degree, static_cast<int>(sh.size(1)), va.n_views, m3.ptr, va.campos, va.campos_stride,
 	                             va.views, va.view_stride, scale, sh.data_ptr<float>(), &adam, current_stream(means3D)),
 	      "shAdamFromViews");
+}
+
+void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam)
+{
+	torch::NoGradGuard ng;
+	if (!sh_adam.row_step.defined() || !sh_adam.exp_avg.defined() || sh.dim() != 3 || sh.size(1) != 16 || !sh.is_contiguous() ||
+	    sh.scalar_type() != torch::kFloat32 || !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() ||
+	    sh_adam.exp_avg.sizes() != sh.sizes() || sh_adam.exp_avg_sq.sizes() != sh.sizes())
+		throw std::runtime_error("shAdamFlush needs a contiguous float32 [P,16,3] tensor, its moments and row_step");
+	gsr_sh_adam adam{};
+	gsr_sh_adam_lazy lazy{};
+	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
+	check(gsr_sh_adam_flush(static_cast<int>(sh.size(0)), &adam, current_stream(sh)), "shAdamFlush");
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)

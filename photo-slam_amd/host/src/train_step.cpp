@@ -123,12 +123,39 @@ float GaussianModel::updateLearningRate(int step)
 	return lr;
 }
 
+void GaussianModel::syncFeatures()
+{
+	if (!features_row_step_.defined()) return;
+	torch::NoGradGuard ng;
+	auto row_step = features_row_step_;
+	features_row_step_ = torch::Tensor();   // (first: the calls below may come back here)
+	if (!features_lr_hist_.empty() && groups_.size() > 1) {
+		auto& grp = groups_[1];
+		ShAdamStep s;
+		s.exp_avg = grp.exp_avg;
+		s.exp_avg_sq = grp.exp_avg_sq;
+		s.step = grp.step;   // the steps the tensor has taken; the newest entry of the history belongs to it
+		s.lr = features_lr_hist_[0].first;
+		s.lr_tail = features_lr_hist_[0].second;
+		s.row_step = row_step;
+		s.window = features_lazy_window_;
+		for (size_t k = 1; k < features_lr_hist_.size(); k++) {
+			s.lr_past.push_back(features_lr_hist_[k].first);
+			s.lr_tail_past.push_back(features_lr_hist_[k].second);
+		}
+		auto sh = features_.detach();
+		shAdamFlush(sh, s);
+	}
+	features_lr_hist_.clear();
+}
+
 void GaussianModel::optimizerStepGroup(int group)
 {
 	torch::NoGradGuard ng;
 	auto& g = groups_.at(static_cast<size_t>(group));
 	auto grad = g.param.grad();
 	if (!grad.defined()) return;
+	if (group == 1) syncFeatures();   // a dense step of the SH tensor: every row must be up to date first
 	grad = grad.contiguous();
 	g.step++;
 	check(gsr_adam_step(g.param.data_ptr<float>(), grad.data_ptr<float>(), g.exp_avg.data_ptr<float>(),
@@ -175,28 +202,52 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	ShAdamStep sh_adam;
 	const auto& o = g->opt_;
 	const bool rebuilds = densifyDue();
+	bool lazy = false;
 	if (fused_sh_adam_ && !factored_exchange_ && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
 	    g->features_.size(1) == 16) {
 		auto& grp = g->groups_[1];
+		lazy = lazy_sh_adam_window_ >= 2 && g->features_.is_contiguous();
+		if (lazy && g->features_row_step_.defined() && g->features_lazy_window_ != lazy_sh_adam_window_) g->syncFeatures();
+		if (lazy && !g->features_row_step_.defined()) {   // every row has taken the grp.step steps so far
+			g->features_row_step_ = torch::full({g->features_.size(0)}, grp.step, g->features_.options().dtype(torch::kInt32).requires_grad(false));
+			g->features_lazy_window_ = lazy_sh_adam_window_;
+			g->features_lr_hist_.clear();
+		}
 		grp.step++;   // the step happens inside backward; optimizerStepGroup(1) then finds no gradient
 		sh_adam.exp_avg = grp.exp_avg;
 		sh_adam.exp_avg_sq = grp.exp_avg_sq;
 		sh_adam.lr = grp.lr * g->lr_scale_;
 		sh_adam.lr_tail = grp.lr_tail * g->lr_scale_;
 		sh_adam.step = grp.step;
+		if (lazy) {
+			sh_adam.row_step = g->features_row_step_;
+			sh_adam.window = g->features_lazy_window_;
+			for (const auto& h : g->features_lr_hist_) {
+				sh_adam.lr_past.push_back(h.first);
+				sh_adam.lr_tail_past.push_back(h.second);
+			}
+		}
 	}
+	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
 	// registers
 	std::vector<torch::Tensor> view_stats;
 	if (iteration_ < o.densify_until_iter_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
+	g->in_lazy_step_ = lazy;
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
 	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats);
+	g->in_lazy_step_ = false;
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);
 	last_radii_ = std::get<3>(pkg);
 	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_, /*is_root=*/true);
 	loss.backward();
+	if (lazy) {   // the step is taken: its learning rates join the history the later catch-ups need
+		auto& hist = g->features_lr_hist_;
+		hist.insert(hist.begin(), {sh_adam.lr, sh_adam.lr_tail});
+		if (static_cast<int>(hist.size()) > g->features_lazy_window_) hist.pop_back();
+	}
 	return loss;
 }
 
@@ -212,6 +263,7 @@ void TrainStep::setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tens
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
+	g->syncFeatures();
 	g->features_.mutable_grad() =
 	    shGradFromViews(g->xyz_.detach(), campos_views, dL_dcolor_views, g->active_sh_degree_,
 	                    static_cast<int>(g->features_.size(1)), 1.0f / static_cast<float>(dL_dcolor_views.size(0)));
@@ -222,6 +274,7 @@ void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor 
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	if (iteration_ >= g->opt_.iterations_) return;
+	g->syncFeatures();
 	const int64_t P = g->xyz_.size(0), n = dL_dcolor_views.size(1);
 	if (row0 < 0 || row0 + n > P) throw std::runtime_error("stepFeaturesFromViews: the part exceeds the Gaussians");
 	if (g->features_.size(1) != 16 || g->groups_.size() < 2) {   // other layouts: gradient tensor + separate pass (whole batch only)

@@ -66,9 +66,11 @@ def _resize_functional(t):
 
 def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                           prefiltered, raw_params=0):
+                           prefiltered, raw_params=0, sh_adam=None):
     """raw_params (extension, default 0 = reference contract): GSR_RAW_* mask -- opacity / scales / rotations are the
-    model's raw parameters and are activated in-kernel (include/gsr.h)."""
+    model's raw parameters and are activated in-kernel (include/gsr.h).
+    sh_adam (extension, default None): the dict RasterizeGaussiansBackwardCUDA takes; only its lazy mode (row_step set,
+    gsr_sh_adam_lazy) concerns the forward pass: visible rows that lag behind take their missed zero-gradient steps first."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # AT_ERROR, rasterize_points.cu:57-59
     lib = _lib()
@@ -99,6 +101,12 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
             setattr(a, name, p)
         a.out_color = out_color.data_ptr()
         a.radii = radii.data_ptr()
+        if sh_adam is not None and sh_adam.get("row_step") is not None:
+            if sh is None or not sh.is_contiguous() or sh.dtype != torch.float32:
+                raise RuntimeError("lazy sh_adam needs a contiguous float32 sh tensor (it is updated in place)")
+            adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
+            keep.append(adam_keep)
+            a.sh_adam = C.cast(C.pointer(adam), C.c_void_p)
         cbs = [_resize_functional(b) for b in (geomBuffer, binningBuffer, imgBuffer)]
         n = C.c_int(0)
         st = lib.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream_ptr(means3D), C.byref(n))
@@ -178,9 +186,7 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
                     raise RuntimeError("view_stats tensors must be contiguous float32 with num_points elements")
             a.stat_grad_accum, a.stat_denom, a.stat_max_radii = (t.data_ptr() for t in view_stats)
         if sh_adam is not None:
-            adam = capi.ShAdam(sh.data_ptr(), sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
-                               float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]),
-                               float(sh_adam["eps"]), int(sh_adam["step"]))
+            adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
             a.sh_adam = C.pointer(adam)
         a.dL_dcolor_view = dL_dcolor_view.data_ptr() if factored else None
         a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
@@ -238,12 +244,23 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
             raise RuntimeError("sh and its moments must be contiguous float32 (num_points, M, 3) tensors")
     if P != 0:
         k1, p1 = _ptr(means3D)
-        adam = capi.ShAdam(sh.data_ptr(), sh_adam["exp_avg"].data_ptr(), sh_adam["exp_avg_sq"].data_ptr(), float(sh_adam["lr"]),
-                           float(sh_adam["lr_tail"]), float(sh_adam["beta1"]), float(sh_adam["beta2"]), float(sh_adam["eps"]),
-                           int(sh_adam["step"]))
+        adam, adam_keep = capi.make_sh_adam(sh, {k: v for k, v in sh_adam.items() if k != "row_step"})
         st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, pc, sc, pv, sv, float(scale),
                                         C.c_void_p(sh.data_ptr()), C.byref(adam), _stream_ptr(means3D))
         capi.check(lib, st, "shAdamFromViews")
+
+
+def shAdamFlush(sh, sh_adam):
+    """gsr_sh_adam_flush (include/gsr.h): every row of `sh` takes the zero-gradient Adam steps it is behind, up to and including
+    sh_adam["step"] = the number of steps the tensor has taken (lr / lr_tail belong to that step)."""
+    lib = _lib()
+    _check_device(lib, sh, sh_adam["exp_avg"], sh_adam["exp_avg_sq"], sh_adam["row_step"])
+    if not sh.is_contiguous() or sh.dtype != torch.float32 or sh.dim() != 3 or sh.size(1) != 16:
+        raise RuntimeError("shAdamFlush needs a contiguous float32 [P,16,3] tensor")
+    with torch.no_grad():
+        adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
+        st = lib.gsr_sh_adam_flush(int(sh.size(0)), C.byref(adam), _stream_ptr(sh))
+        capi.check(lib, st, "shAdamFlush")
 
 
 def markVisible(means3D, viewmatrix, projmatrix):

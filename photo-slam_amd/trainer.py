@@ -190,7 +190,8 @@ def allreduce_mean(tensors, world_size):
 
 class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
-                 densify_min_opacity=0.005, prune_big_point_after_iter=30000, seed=0, factored_exchange=True, fused_sh_adam=True):
+                 densify_min_opacity=0.005, prune_big_point_after_iter=30000, seed=0, factored_exchange=True, fused_sh_adam=True,
+                 lazy_sh_adam_window=32):
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
         self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
         self.densify_, self.densify_min_opacity_ = densify, densify_min_opacity
@@ -205,6 +206,9 @@ class TrainStep:
         # world_size == 1: the Adam step of the SH tensor runs inside the rasterizer's backward (its 192 B/Gaussian gradient
         # row never reaches HBM); same arithmetic, same result as the separate pass
         self.fused_sh_adam_ = fused_sh_adam
+        # ... and the zero-gradient steps of the culled Gaussians' rows taken lazily, at most this many at a time (0 = every
+        # row at every step): TrainStep::lazy_sh_adam_window_ of the C++ host
+        self.lazy_sh_adam_window_ = lazy_sh_adam_window
         self.ema_loss_for_log_ = 0.0
 
     def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
@@ -220,18 +224,24 @@ class TrainStep:
         rebuilds = bool(self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and
                         opt.densification_interval_ and it % opt.densification_interval_ == 0)
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
-                g.features_.size(1) == 16 and g.optimizer_ is not None:
-            sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP)
+                g._features.size(1) == 16 and g.optimizer_ is not None:
+            sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)
         # this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D.  With
         # several ranks they accumulate PER RANK and are reduced only when densification consumes them (below): SUM and MAX
         # commute with the accumulation over iterations, so nothing crosses the links for them on the other 99 of 100 steps
         view_stats = (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_) if it < opt.densify_until_iter_ else None
-        rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
-            viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-            sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats)
+        g._in_lazy_step = sh_adam is not None and sh_adam.get("row_step") is not None
+        try:
+            rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
+                viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
+                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats)
+        finally:
+            g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
         loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_, is_root=True)
         loss.backward()                                                  # :699
+        if sh_adam is not None:
+            g.optimizer_.end_fused_step(FEATURES_GROUP, sh_adam)
         with torch.no_grad():
             reduction = None
             if self.world_size_ > 1:

@@ -338,3 +338,84 @@ def check_fused_view_stats(lib_path, dev, cl, bg, seed=0):
     assert np.allclose(stats[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=1e-6, atol=0)
     assert np.array_equal(stats[1].cpu().numpy(), ref[1].cpu().numpy()) and np.array_equal(stats[2].cpu().numpy(), ref[2].cpu().numpy())
     assert np.array_equal(stats[1].cpu().numpy(), den0 + vis) and np.array_equal(stats[0].cpu().numpy()[~vis], acc0[~vis])
+
+
+def check_lazy_sh_adam(lib_path, dev, cl, cams, bg, steps=11, window=4, seed=0, sh_degree=3, zero_gradient=False, exact=True):
+    """Lazy Adam steps for the SH rows of culled Gaussians (gsr_sh_adam_lazy) against the eager fused update, over a
+    sequence of steps whose views (hence culled sets) change and whose learning rates differ per step: the same image at
+    every step (a row is brought up to date before it is evaluated), no row ever more than `window` steps behind, and after
+    gsr_sh_adam_flush the tensor and both moments equal the eager ones BIT FOR BIT.
+    On the GPU two runs of the same backward pass differ in the last bits (the order of the four quad-waves' LDS adds in the
+    backward blend), so the eager and the lazy trajectory are bit-comparable there only with zero_gradient (dL_dpix = 0:
+    every row takes zero-gradient steps, the visible ones in the row kernel); with gradients exact=False compares to
+    1e-5 of the value range."""
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        rng = np.random.default_rng(seed)
+        empty = torch.empty(0, device=dev)
+        P = cl.xyz.shape[0]
+        feats = _features(cl, None)
+        M = feats.shape[1]
+        m0 = (0.01 * rng.standard_normal((P, M, 3))).astype(np.float32)
+        v0 = (1e-4 * rng.random((P, M, 3))).astype(np.float32)
+        step0 = 5   # the tensor has taken five steps already (bias corrections far from 1)
+        state = {k: dict(sh=_t(feats.copy(), dev).clone(), m=_t(m0.copy(), dev).clone(), v=_t(v0.copy(), dev).clone()) for k in ("eager", "lazy")}
+        row_step = torch.full((P,), step0, dtype=torch.int32, device=dev)
+        common = dict(background=_t(bg, dev), means3D=_t(cl.xyz, dev), colors=empty, opacity=_t(cl.get_opacity(), dev),
+                      scales=_t(cl.get_scaling(), dev), rotations=_t(cl.get_rotation(), dev), scale_modifier=1.0, cov3D_precomp=empty,
+                      degree=sh_degree, prefiltered=False)
+        lrs = []   # most recent step first
+        seen_lag = 0
+        culled_sets = set()
+        for it in range(steps):
+            cam = cams[it % len(cams)] if it != 3 else cams[0]   # one repeated view in the sequence
+            step = step0 + it + 1
+            lr = 0.0025 * (1.0 + 0.1 * it)
+            dpix = _t(rng.standard_normal((3, cam.H, cam.W)).astype(np.float32) * (0.0 if zero_gradient else 1.0), dev)
+            view = dict(viewmatrix=_t(cam.viewmatrix, dev), projmatrix=_t(cam.projmatrix, dev), tan_fovx=cam.tanfovx,
+                        tan_fovy=cam.tanfovy, image_height=cam.H, image_width=cam.W, campos=_t(cam.campos, dev))
+            images = {}
+            for mode in ("eager", "lazy"):
+                s = state[mode]
+                adam = dict(exp_avg=s["m"], exp_avg_sq=s["v"], lr=lr, lr_tail=lr / 20, beta1=0.9, beta2=0.999, eps=1e-15, step=step)
+                if mode == "lazy":
+                    adam.update(row_step=row_step, window=window, lr_past=[x for x in lrs], lr_tail_past=[x / 20 for x in lrs])
+                R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(sh=s["sh"], sh_adam=adam if mode == "lazy" else None,
+                                                                               **common, **view)
+                images[mode] = color.cpu().numpy()
+                rp.RasterizeGaussiansBackwardCUDA(common["background"], common["means3D"], radii, empty, common["scales"],
+                                                  common["rotations"], 1.0, empty, view["viewmatrix"], view["projmatrix"],
+                                                  cam.tanfovx, cam.tanfovy, dpix, s["sh"], sh_degree, view["campos"], geom, R,
+                                                  binning, img, sh_adam=adam)
+                if mode == "lazy":
+                    rs = row_step.cpu().numpy()
+                    vis = radii.cpu().numpy() > 0
+                    assert (rs[vis] == step).all()
+                    assert rs.max() <= step and step - rs.min() <= window, (step, rs.min())
+                    seen_lag = max(seen_lag, int(step - rs.min()))
+                    culled_sets.add(hash((~vis).tobytes()))
+                    assert vis.any() and (~vis).any()
+            if exact:
+                assert np.array_equal(images["eager"], images["lazy"]), f"step {step}: a stale SH row was evaluated"
+            else:
+                assert np.abs(images["eager"] - images["lazy"]).max() < 1e-5, f"step {step}: a stale SH row was evaluated"
+            lrs.insert(0, lr)
+        assert seen_lag >= min(2, window - 1) and len(culled_sets) >= 2   # rows did fall behind, and the culled set did change
+        lazy = state["lazy"]
+        # not flushed yet: rows that are behind differ from the eager state
+        assert (lazy["sh"] - state["eager"]["sh"]).abs().max() > 1e-6
+        last = step0 + steps
+        rp.shAdamFlush(lazy["sh"], dict(exp_avg=lazy["m"], exp_avg_sq=lazy["v"], lr=lrs[0], lr_tail=lrs[0] / 20, beta1=0.9, beta2=0.999,
+                                        eps=1e-15, step=last, row_step=row_step, window=window, lr_past=lrs[1:],
+                                        lr_tail_past=[x / 20 for x in lrs[1:]]))
+        if dev.type != "cpu":
+            torch.cuda.synchronize()
+        assert (row_step.cpu().numpy() == last).all()
+        for k in ("sh", "m", "v"):
+            a, b = lazy[k].cpu().numpy(), state["eager"][k].cpu().numpy()
+            if exact:
+                assert np.array_equal(a, b), (k, np.abs(a - b).max())
+            else:
+                assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, np.abs(a - b).max())
+    finally:
+        rp._LIB_OVERRIDE = None

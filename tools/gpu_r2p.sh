@@ -1,0 +1,25 @@
+#!/bin/bash
+# round-2 session P: the lazy rows' slice kernel with one thread per vector (768-thread workgroups): placement A/B, interleaved
+# twice against run-to-run drift, and per-kernel times
+mkdir -p gpurun_out; export TMPDIR=/tmp
+python __graft_entry__.py > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
+run() {
+  timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric"' | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+s = d['roofline']['stages']
+print('  ms/step', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'blend_bwd', s['blend_bwd']['ms'], 'preprocess_bwd', s['preprocess_bwd']['ms'])
+"
+}
+for rep in 1 2; do
+echo "behind the blend, window 32"; run
+echo "next to the blend, window 32"; GSR_LAZY_FORK_EARLY=1 run
+echo "behind the blend, window 16"; run --sh-adam-window 16
+echo "eager"; run --sh-adam-window 0
+done
+cd /tmp; rm -rf /tmp/prof_p; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o r --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --median-steps 0 --no-cpu-baseline > /dev/null 2>&1
+python - <<'PY'
+import csv, glob
+f = glob.glob('/tmp/prof_p/**/*kernel_stats.csv', recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:12]: print(' ', r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3, 1), 'us')
+PY
