@@ -6,6 +6,7 @@ mkdir -p $OUT; export TMPDIR=/tmp
 python __graft_entry__.py > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
 ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_driver_cmd_C3.log 2>&1; grep "^{\"metric\"" $OUT/bench_driver_cmd_C3.log > $OUT/bench_driver_cmd_C3.json; grep real $OUT/bench_driver_cmd_C3.log; cut -c1-400 $OUT/bench_driver_cmd_C3.json
 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_full_C3.json 2>/dev/null
+timeout 300 python bench.py --sh-adam-window 0 --no-cpu-baseline > $OUT/bench_full_C3_eager_sh_adam.json 2>/dev/null
 timeout 300 python bench.py --raster-only --no-cpu-baseline > $OUT/bench_raster_only_C3.json 2>/dev/null
 for c in C2 C4 C5; do timeout 300 python bench.py --config $c --no-cpu-baseline > $OUT/bench_full_$c.json 2>/dev/null; python -c "
 import json,sys; d=json.load(open('$OUT/bench_full_$c.json')); print('$c', d['value'], 'it/s', d['protocol']['median_ms_per_step'], 'ms median')"; done
