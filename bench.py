@@ -402,7 +402,12 @@ def main():
         avg = float(np.median(ms))
         stages[k] = dict(ms=round(avg, 4), bytes=int(ab[k]), GBps=round(ab[k] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None)
     raster_ms = sum(s["ms"] for s in stages.values())
-    dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
+    # the dominant KERNEL: every stage is one kernel except the sorts / scans (3-12 launches) and "preprocess_bwd", which with
+    # the Adam step of the SH tensor fused in is three kernels (long_run_sums, preprocess_bwd, sh_bwd_rows: the largest of them
+    # 0.3 ms) -- those are not candidates
+    multi = {"depth_sort", "offset_scan", "tile_sort", "preprocess_bwd"}
+    single = [k for k in stages if k not in multi]
+    dom = max(single, key=lambda k: stages[k]["ms"]) if single else None
     if dom == "blend_bwd" and dom_ms:
         # the dominant kernel's duration inside the timed region replaces the stage-table value
         avg = float(np.mean(dom_ms))
