@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--sh-adam-window", type=int, default=32,
                     help="lazy Adam steps for the SH rows of culled Gaussians, at most this many at a time (gsr_sh_adam_lazy; "
                          "0 = every row steps eagerly at every iteration)")
+    ap.add_argument("--no-fused-geom-adam", action="store_true",
+                    help="xyz / opacity / scaling / rotation step in four separate Adam passes instead of inside the backward kernels")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -210,7 +212,8 @@ def main():
     if args.densify_interval:
         opt.densification_interval_, opt.densify_from_iter_ = args.densify_interval, 0
     ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent,
-                   densify=bool(args.densify_interval), factored_exchange=factored, lazy_sh_adam_window=args.sh_adam_window)
+                   densify=bool(args.densify_interval), factored_exchange=factored, lazy_sh_adam_window=args.sh_adam_window,
+                   fused_geom_adam=not args.no_fused_geom_adam)
 
     ops = None
     if args.host == "cpp" and not args.raster_only:
@@ -222,7 +225,8 @@ def main():
                                     g.rotation_.detach(), 3, float(cl.extent), bg)
         import math
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
-        ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window)})
+        ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window),
+                                         "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
         if dp:
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and factored:
@@ -439,6 +443,7 @@ def main():
                        "learning_rates": lr_note,
                        "sh_adam_fused_into_backward": fused_sh_adam,
                        "sh_adam_lazy_window": lazy_window,
+                       "geometry_adam_fused_into_backward": bool(fused_sh_adam and not args.no_fused_geom_adam),
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else int(ops.trainer_params(handle)[0].shape[0]),
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
             "mpix_per_s": round(world * W * H / (raster_ms * 1e-3) / 1e6, 1) if raster_ms > 0 else None,

@@ -77,6 +77,23 @@ typedef struct gsr_sh_adam {
 	const gsr_sh_adam_lazy* lazy; /* NULL = eager: every row takes the step in gsr_backward */
 } gsr_sh_adam;
 
+/* Extension: optimizer-in-backward for the four per-Gaussian geometry tensors (see gsr_backward_args.geom_adam).  One entry per
+ * tensor: torch::optim::Adam semantics as gsr_adam_step, each tensor with its own learning rate and step counter. */
+typedef struct gsr_adam_tensor {
+	float* param;                /* UPDATED IN PLACE */
+	float* exp_avg;
+	float* exp_avg_sq;
+	double lr;
+	int step;                    /* >= 1: the step being taken */
+} gsr_adam_tensor;
+typedef struct gsr_geom_adam {
+	gsr_adam_tensor xyz;         /* [P,3]; param must be means3D */
+	gsr_adam_tensor opacity;     /* [P]   the raw opacity (logits) */
+	gsr_adam_tensor scaling;     /* [P,3]; param must be scales (log-scales) */
+	gsr_adam_tensor rotation;    /* [P,4]; param must be rotations (unnormalised quaternions) */
+	double beta1, beta2, eps;
+} gsr_geom_adam;
+
 /* Rasterizer::forward parameter list, cuda_rasterizer/rasterizer.h:35-59, 1:1. */
 typedef struct gsr_forward_args {
 	int P, D, M;                 /* #Gaussians, active SH degree, SH coeffs per channel stored */
@@ -146,13 +163,15 @@ typedef struct gsr_backward_args {
 	char* binning_buffer;
 	char* image_buffer;
 	const float* dL_dpix;        /* [3,H,W] */
-	float* dL_dmean2D;           /* [P,3]  (.z stays 0) */
+	float* dL_dmean2D;           /* [P,3]  (.z stays 0); NULL is accepted (a caller that fuses the densification statistics,
+	                                stat_* below, has no other use for it) */
 	float* dL_dconic;            /* [P,4]  the reference's [P,2,2] (.z = 0); internal to the reference's wrapper
 	                                (rasterize_points.cu:152), so NULL is accepted */
 	float* dL_dopacity;          /* [P]   */
 	float* dL_dcolor;            /* [P,3] */
 	float* dL_dmean3D;           /* [P,3] */
-	float* dL_dcov3D;            /* [P,6] */
+	float* dL_dcov3D;            /* [P,6]; NULL is accepted when cov3D_precomp is NULL (the gradient continues into scales and
+	                                rotations inside the kernel) */
 	float* dL_dsh;               /* [P,M,3] or NULL when shs is NULL */
 	float* dL_dscale;            /* [P,3] or NULL when scales is NULL */
 	float* dL_drot;              /* [P,4] or NULL when scales is NULL */
@@ -180,6 +199,14 @@ typedef struct gsr_backward_args {
 	float* stat_grad_accum;
 	float* stat_denom;
 	float* stat_max_radii;
+	/* Extension, optimizer-in-backward for xyz / opacity / scaling / rotation (NULL = the reference contract).  The kernels that
+	 * hold these four gradients in registers apply this step's Adam update instead of writing them: dL_dopacity, dL_dscale and
+	 * dL_drot are NOT written (and may be NULL), dL_dmean3D is still required but only as scratch between two kernels.  Saves
+	 * the 88 B per Gaussian gradient round trip and four optimizer launches.  Needs raw_params == GSR_RAW_OPACITY |
+	 * GSR_RAW_SCALING | GSR_RAW_ROTATION (the gradients must be those of the tensors being stepped), scales + rotations (no
+	 * cov3D_precomp) and the 16-byte aligned [P,16,3] SH layout (GSR_ERR_UNSUPPORTED otherwise); every Gaussian steps, culled
+	 * ones with a zero gradient as a dense optimizer does. */
+	const gsr_geom_adam* geom_adam;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.

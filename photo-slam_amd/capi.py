@@ -66,6 +66,26 @@ def make_sh_adam(sh, d):
     return adam, keep
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("step", C.c_int)]
+
+
+class GeomAdam(C.Structure):
+    """gsr_geom_adam: xyz, opacity, scaling, rotation"""
+    _fields_ = [("xyz", AdamTensor), ("opacity", AdamTensor), ("scaling", AdamTensor), ("rotation", AdamTensor),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
+def make_geom_adam(d):
+    """gsr_geom_adam from dict(tensors=[(param, exp_avg, exp_avg_sq, lr, step) x 4 in the order xyz, opacity, scaling, rotation],
+    beta1, beta2, eps)."""
+    g = GeomAdam()
+    for name, (p, m, v, lr, step) in zip(("xyz", "opacity", "scaling", "rotation"), d["tensors"]):
+        setattr(g, name, AdamTensor(p.data_ptr(), m.data_ptr(), v.data_ptr(), float(lr), int(step)))
+    g.beta1, g.beta2, g.eps = float(d["beta1"]), float(d["beta2"]), float(d["eps"])
+    return g
+
+
 class BackwardArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("R", C.c_int), ("background", C.c_void_p),
                 ("width", C.c_int), ("height", C.c_int), ("means3D", C.c_void_p), ("shs", C.c_void_p),
@@ -78,7 +98,8 @@ class BackwardArgs(C.Structure):
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int),
                 ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam)),
-                ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p)]
+                ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p),
+                ("geom_adam", C.POINTER(GeomAdam))]
 
 class DensifySelectArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("scaling", C.c_void_p),

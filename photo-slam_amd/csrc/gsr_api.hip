@@ -292,16 +292,16 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	if (a->P == 0) return GSR_OK;
 	if (st != GSR_OK) return st;
 	if (!a->background || !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos || !a->geom_buffer ||
-	    !a->image_buffer || !a->dL_dpix || !a->dL_dmean2D || !a->dL_dopacity || !a->dL_dcolor ||
-	    !a->dL_dmean3D || !a->dL_dcov3D || a->R < 0)
+	    !a->image_buffer || !a->dL_dpix || !a->dL_dcolor || !a->dL_dmean3D || a->R < 0)
 		return GSR_ERR_INVALID_ARG;
+	if (!a->dL_dopacity && !a->geom_adam) return GSR_ERR_INVALID_ARG;   // (dL_dmean2D / dL_dcov3D: nullable, see gsr.h)
 	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view && !a->sh_adam) return GSR_ERR_INVALID_ARG;
 	if ((a->stat_grad_accum != nullptr) != (a->stat_denom != nullptr) || (a->stat_denom != nullptr) != (a->stat_max_radii != nullptr))
 		return GSR_ERR_INVALID_ARG;
 	if (a->sh_adam && (!a->shs || a->dL_dcolor_view || !a->sh_adam->exp_avg || !a->sh_adam->exp_avg_sq || a->sh_adam->step < 1))
 		return GSR_ERR_INVALID_ARG;
 	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
-	if (a->scales && (!a->dL_dscale || !a->dL_drot)) return GSR_ERR_INVALID_ARG;
+	if (a->scales && (!a->dL_dscale || !a->dL_drot) && !a->geom_adam) return GSR_ERR_INVALID_ARG;
 	if (a->R > 0 && !a->binning_buffer) return GSR_ERR_INVALID_ARG;
 	hipStream_t stream = (hipStream_t)stream_;
 	const int P = a->P, W = a->width, H = a->height, R = a->R;
@@ -407,6 +407,27 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		pb.adam_skip_culled = (side_busy || lazy) ? 1 : 0;
 		if (lazy) { pb.lazy_row_step = la.row_step; pb.lazy_step = la.step; }
 	}
+	pb.geom = GeomAdam{};
+	if (a->geom_adam) {
+		const gsr_geom_adam& o = *a->geom_adam;
+		const int all_raw = GSR_RAW_OPACITY | GSR_RAW_SCALING | GSR_RAW_ROTATION;
+		const gsr_adam_tensor* ts[4] = {&o.xyz, &o.opacity, &o.scaling, &o.rotation};
+		for (const gsr_adam_tensor* t : ts)
+			if (!t->param || !t->exp_avg || !t->exp_avg_sq || t->step < 1) return GSR_ERR_INVALID_ARG;
+		if ((a->raw_params & all_raw) != all_raw || a->cov3D_precomp || o.xyz.param != a->means3D || o.scaling.param != a->scales ||
+		    o.rotation.param != a->rotations || !a->dL_dmean3D || a->dL_dcolor_view)
+			return GSR_ERR_INVALID_ARG;
+		if ((reinterpret_cast<uintptr_t>(o.rotation.param) | reinterpret_cast<uintptr_t>(o.rotation.exp_avg) |
+		     reinterpret_cast<uintptr_t>(o.rotation.exp_avg_sq)) & 15)
+			return GSR_ERR_UNSUPPORTED;
+		auto fill = [&](const gsr_adam_tensor& t, GeomAdamTensor& g) {
+			g.param = t.param; g.exp_avg = t.exp_avg; g.exp_avg_sq = t.exp_avg_sq;
+			g.s = adam_scalars(t.lr, t.lr, o.beta1, o.beta2, o.eps, t.step);
+		};
+		pb.geom.on = 1;
+		fill(o.xyz, pb.geom.xyz); fill(o.opacity, pb.geom.opacity); fill(o.scaling, pb.geom.scaling); fill(o.rotation, pb.geom.rotation);
+	}
+	if (!a->dL_dcov3D && a->cov3D_precomp) return GSR_ERR_INVALID_ARG;
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
 	if (side_busy) GSR_HIP(hipStreamWaitEvent(stream, t_sync.join, 0));   // whatever follows on the caller's stream sees the whole update
 	PROF_BWD(3);

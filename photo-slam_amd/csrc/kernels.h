@@ -96,6 +96,18 @@ struct BlendBwdParams {
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
 
+// Fused Adam steps of the four per-Gaussian geometry tensors (gsr_geom_adam): on == 0 = off
+struct GeomAdamTensor {
+	float* param;
+	float* exp_avg;
+	float* exp_avg_sq;
+	AdamScalars s;
+};
+struct GeomAdam {
+	int on;
+	GeomAdamTensor xyz, opacity, scaling, rotation;
+};
+
 struct PreprocessBwdParams {
 	int P, D, M;
 	const float* means3D;
@@ -119,12 +131,12 @@ struct PreprocessBwdParams {
 	uint32_t long_capacity;
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
-	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0)
+	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0); nullable
 	float* dL_dconic;         // [P,4]  nullable
 	float* dL_dopacity;       // [P]
 	float* dL_dcolor;         // [P,3]
-	float* dL_dmean3D;        // [P,3]
-	float* dL_dcov3D;         // [P,6]
+	float* dL_dmean3D;        // [P,3]  (with geom.on: scratch between the two kernels, not an output)
+	float* dL_dcov3D;         // [P,6]  nullable
 	float* dL_dsh;            // [P,M,3] nullable
 	float* dL_dcolor_view;    // [P,3] nullable: view-factored mode (gsr.h) -- the clamp-masked colour gradient INSTEAD of dL_dsh
 	float* dL_dscale;         // [P,3] nullable
@@ -142,6 +154,8 @@ struct PreprocessBwdParams {
 	int adam_skip_culled;     // the culled Gaussians' rows take this step elsewhere (gsr_backward: side stream) or later (lazy)
 	int* lazy_row_step;       // lazy mode: row_step[i] = lazy_step for the rows updated here (the visible ones); null = off
 	int lazy_step;
+	// optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_backward_args.geom_adam): their gradients are not written
+	GeomAdam geom;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)

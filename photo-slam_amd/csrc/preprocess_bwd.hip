@@ -29,6 +29,39 @@ namespace gsr {
 constexpr int PRB_THREADS = 128;
 constexpr int SHB_THREADS = 64;    // one wave x 6.5 KiB of row staging per workgroup
 
+// One Adam step of row idx of a [P,N] geometry tensor with the gradient in registers (gsr_geom_adam): the thread that holds
+// the gradient applies it -- the gradient is not written and not read back, the four separate passes disappear.
+template <int N>
+__device__ __forceinline__ void geom_adam_row(const GeomAdamTensor& t, size_t idx, const float (&g)[N])
+{
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		const size_t i = (size_t)N * idx + k;
+		const float m = t.s.b1 * t.exp_avg[i] + t.s.omb1 * g[k];
+		const float v = t.s.b2 * t.exp_avg_sq[i] + t.s.omb2 * g[k] * g[k];
+		t.exp_avg[i] = m;
+		t.exp_avg_sq[i] = v;
+		t.param[i] -= t.s.step_size * adam_ratio(m, v, t.s.inv_sqrt_bc2, t.s.eps);
+	}
+}
+__device__ __forceinline__ void geom_adam_row4(const GeomAdamTensor& t, size_t idx, const float4& g4)
+{
+	float4 pv = reinterpret_cast<const float4*>(t.param)[idx];
+	float4 mv = reinterpret_cast<const float4*>(t.exp_avg)[idx];
+	float4 vv = reinterpret_cast<const float4*>(t.exp_avg_sq)[idx];
+	float* pp = &pv.x; float* mp = &mv.x; float* vp = &vv.x;
+	const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		mp[k] = t.s.b1 * mp[k] + t.s.omb1 * g[k];
+		vp[k] = t.s.b2 * vp[k] + t.s.omb2 * g[k] * g[k];
+		pp[k] -= t.s.step_size * adam_ratio(mp[k], vp[k], t.s.inv_sqrt_bc2, t.s.eps);
+	}
+	reinterpret_cast<float4*>(t.param)[idx] = pv;
+	reinterpret_cast<float4*>(t.exp_avg)[idx] = mv;
+	reinterpret_cast<float4*>(t.exp_avg_sq)[idx] = vv;
+}
+
 // SH backward for aligned 48-float rows; DEG = active SH degree.  FACTORED (gsr_backward_args.dL_dcolor_view): the
 // gradient rows are not produced -- the clamp-masked colour gradient leaves instead (12 B instead of 192 B per Gaussian)
 // and gsr_sh_grad_from_views rebuilds dL_dsh for the whole keyframe batch after the exchange.
@@ -113,6 +146,7 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		}
 	}
 	if (MODE == 2 && vis && p.lazy_row_step) p.lazy_row_step[idx] = p.lazy_step;   // lazy mode: this row has taken the step
+	float gm[3] = {0.f, 0.f, 0.f};
 	if (vis) {
 		const float dLx = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
 		const float dLy = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
@@ -121,10 +155,17 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		// dL_dmean3D (the reference's order of the three contributions, backward.cu:271-273,384,137)
 		const float sum2 = ox * ox + oy * oy + oz * oz;
 		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-		p.dL_dmean3D[3 * (size_t)idx + 0] += ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
-		p.dL_dmean3D[3 * (size_t)idx + 1] += (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
-		p.dL_dmean3D[3 * (size_t)idx + 2] += (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+		gm[0] = p.dL_dmean3D[3 * (size_t)idx + 0] + ((+sum2 - ox * ox) * dLx - oy * ox * dLy - oz * ox * dLz) * invsum32;
+		gm[1] = p.dL_dmean3D[3 * (size_t)idx + 1] + (-ox * oy * dLx + (sum2 - oy * oy) * dLy - oz * oy * dLz) * invsum32;
+		gm[2] = p.dL_dmean3D[3 * (size_t)idx + 2] + (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
+		if (!p.geom.on) {
+			p.dL_dmean3D[3 * (size_t)idx + 0] = gm[0];
+			p.dL_dmean3D[3 * (size_t)idx + 1] = gm[1];
+			p.dL_dmean3D[3 * (size_t)idx + 2] = gm[2];
+		}
 	}
+	// the position's gradient is complete here: its Adam step (zero gradient for culled Gaussians, as a dense optimizer)
+	if (p.geom.on && in_range) geom_adam_row<3>(p.geom.xyz, (size_t)idx, gm);
 }
 
 // ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel
@@ -183,13 +224,20 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	}
 	const float gcx = ga1.y, gcy = ga1.z, gcz = ga1.w;
 	if (in_range) {
-		p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w;
-		p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x;
-		p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+		if (p.dL_dmean2D) {
+			p.dL_dmean2D[3 * (size_t)idx + 0] = ga0.w;
+			p.dL_dmean2D[3 * (size_t)idx + 1] = ga1.x;
+			p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+		}
 		p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
 		p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
 		p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
-		p.dL_dopacity[idx] = g_opacity;
+		if (p.geom.on) {
+			const float go[1] = {g_opacity};
+			geom_adam_row<1>(p.geom.opacity, (size_t)idx, go);
+		} else {
+			p.dL_dopacity[idx] = g_opacity;
+		}
 		if (p.dL_dconic) reinterpret_cast<float4*>(p.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcz);
 	}
 	if (p.stat_accum && vis) {
@@ -339,8 +387,10 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		p.dL_dmean3D[3 * (size_t)idx + 0] = gmx;
 		p.dL_dmean3D[3 * (size_t)idx + 1] = gmy;
 		p.dL_dmean3D[3 * (size_t)idx + 2] = gmz;
+		if (p.dL_dcov3D) {
 #pragma unroll
-		for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+			for (int i = 0; i < 6; i++) p.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+		}
 	}
 
 	// ------------------------------------------------------------------ cov3D backward, backward.cu:278-341
@@ -409,7 +459,10 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			dq.w = (dq.w - z * qg) / qn;
 		}
 	}
-	if (in_range && p.dL_dscale) {
+	if (in_range && p.geom.on) {
+		geom_adam_row<3>(p.geom.scaling, (size_t)idx, g_scale);
+		geom_adam_row4(p.geom.rotation, (size_t)idx, dq);
+	} else if (in_range && p.dL_dscale) {
 		p.dL_dscale[3 * (size_t)idx + 0] = g_scale[0];
 		p.dL_dscale[3 * (size_t)idx + 1] = g_scale[1];
 		p.dL_dscale[3 * (size_t)idx + 2] = g_scale[2];
@@ -545,6 +598,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 	                     (factored || adam || (p.dL_dsh && (reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0));
 	if (adam && (!rows_ok || factored || ((reinterpret_cast<uintptr_t>(p.adam_exp_avg) | reinterpret_cast<uintptr_t>(p.adam_exp_avg_sq)) & 15)))
 		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
+	if (p.geom.on && !(rows_ok && p.D >= 0 && p.D <= 3 && p.scales && p.rotations && p.dL_dmean3D))
+		return GSR_ERR_UNSUPPORTED;   // the fused geometry step lives in the two-kernel path of the reference's SH layout
 	const int grid = div_up(p.P, PRB_THREADS);
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
 		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);

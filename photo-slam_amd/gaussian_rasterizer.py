@@ -33,6 +33,11 @@ class GaussianRasterizationSettings:
     sh_adam_: dict = None
     # extension: (xyz_gradient_accum, denom, max_radii2D) -- backward adds this view's densification statistics itself
     view_stats_: tuple = None
+    # extension, optimizer-in-backward for xyz / opacity / scaling / rotation: dict(tensors=[(param, exp_avg, exp_avg_sq, lr,
+    # step)] x 4, beta1, beta2, eps) -- backward applies their Adam steps in place (gsr_backward_args.geom_adam) and autograd
+    # gets None for the four; training_outputs_only_: the viewspace gradient and dL_dcov3D are not written either
+    geom_adam_: dict = None
+    training_outputs_only_: bool = False
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -61,9 +66,10 @@ class GaussianRasterizerFunction(torch.autograd.Function):
          dL_drotations) = rp.RasterizeGaussiansBackwardCUDA(
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
-            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_, s.sh_adam_, s.view_stats_)
+            ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_, s.sh_adam_, s.view_stats_,
+            s.geom_adam_, s.training_outputs_only_)
         # order of src/gaussian_rasterizer.cpp:159-179
-        def g(t, like):
+        def g(t, like):   # (None where an extension took the gradient's place)
             return t if like.numel() and t is not None else None
         return (dL_dmeans3D, dL_dmeans2D, g(dL_dsh, sh), g(dL_dcolors, colors_precomp), dL_dopacity,
                 g(dL_dscales, scales), g(dL_drotations, rotations), g(dL_dcov3D, cov3Ds_precomp), None)

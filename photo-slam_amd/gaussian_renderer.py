@@ -34,14 +34,16 @@ class GaussianKeyframe:
 class GaussianRenderer:
     @staticmethod
     def render(viewpoint_camera, image_height, image_width, pc, pipe, bg_color, override_color=None,
-               scaling_modifier=1.0, use_override_color=False, fuse_activations=True, sh_grad_view=None, sh_adam=None, view_stats=None):
+               scaling_modifier=1.0, use_override_color=False, fuse_activations=True, sh_grad_view=None, sh_adam=None, view_stats=None,
+               geom_adam=None):
         """returns (render, viewspace_points, visibility_filter, radii)
 
         fuse_activations (extension; False = the reference data flow): hand the raw opacity / scaling / rotation
         leaves to the rasterizer, which applies sigmoid / exp / normalize in preprocess and their chain rule in the
         backward preprocess -- same result, ~13 fewer elementwise launches and 3 fewer [P,*] temporaries per step.
 
-        sh_grad_view, sh_adam, view_stats (extensions; None = the reference data flow): see GaussianRasterizationSettings."""
+        sh_grad_view, sh_adam, view_stats, geom_adam (extensions; None = the reference data flow): see
+        GaussianRasterizationSettings."""
         screenspace_points = torch.zeros_like(pc.getXYZ(), requires_grad=True)
         try:
             screenspace_points.retain_grad()
@@ -54,7 +56,8 @@ class GaussianRenderer:
             image_height, image_width, viewpoint_camera.tanfovx_, viewpoint_camera.tanfovy_, bg_color, scaling_modifier,
             viewpoint_camera.world_view_transform_, viewpoint_camera.full_proj_transform_, pc.active_sh_degree_,
             viewpoint_camera.camera_center_, False, raw,
-            sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats)
+            sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats,
+            geom_adam if raw == 7 else None, bool(geom_adam is not None and raw == 7))
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points

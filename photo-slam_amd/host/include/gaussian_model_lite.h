@@ -174,6 +174,10 @@ public:
 	// row at every step): one HBM round trip of a culled row per `window` steps instead of one per step (1.2 GB per step at
 	// C3), results bit-identical (GaussianModel::syncFeatures, tests/test_lazy_sh_adam.py)
 	int lazy_sh_adam_window_ = 32;
+	// The Adam steps of xyz / opacity / scaling / rotation inside the backward kernels that hold their gradients
+	// (gsr_backward_args.geom_adam): the 88 B per Gaussian gradient round trip and four optimizer launches disappear; on the
+	// same iterations as fused_sh_adam_.  The viewspace gradient and dL_dcov3D are then not written either.
+	bool fused_geom_adam_ = true;
 	bool factored_exchange_ = false;
 	torch::Tensor sh_send_;        // [P + 1, 3]: rows 0 .. P-1 = sh_grad_view_, row P = this view's camera centre (one all-gather)
 	torch::Tensor sh_grad_view_;

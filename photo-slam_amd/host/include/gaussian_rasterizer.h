@@ -81,6 +81,9 @@ struct GaussianRasterizationExtensions {
 	ShAdamStep sh_adam_;
 	// {xyz_gradient_accum, denom, max_radii2D} -- backward adds this view's densification statistics itself
 	std::vector<torch::Tensor> view_stats_;
+	// optimizer-in-backward for xyz / opacity / scaling / rotation (rasterize_points.h): fill param to enable; those four then
+	// get no gradient from autograd
+	GeomAdamStep geom_adam_;
 };
 
 class GaussianRasterizerFunctionEx : public torch::autograd::Function<GaussianRasterizerFunctionEx> {

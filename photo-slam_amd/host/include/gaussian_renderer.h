@@ -38,7 +38,8 @@ public:
 	    float scaling_modifier = 1.0f, bool use_override_color = false, bool fuse_activations = false,
 	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationExtensions::sh_grad_view_ */,
 	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationExtensions::sh_adam_ */,
-	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationExtensions::view_stats_ */)
+	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationExtensions::view_stats_ */,
+	    GeomAdamStep geom_adam = GeomAdamStep() /* extension: GaussianRasterizationExtensions::geom_adam_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -59,6 +60,8 @@ public:
 		if (sh_in_rasterizer) ext.sh_grad_view_ = sh_grad_view;
 		if (sh_in_rasterizer) ext.sh_adam_ = sh_adam;
 		ext.view_stats_ = view_stats;
+		// the fused geometry step needs the raw leaves in the rasterizer (it steps opacity_ / scaling_ / rotation_ themselves)
+		if (ext.raw_params_ == 7 && !pipe.compute_cov3D_) ext.geom_adam_ = geom_adam;
 		GaussianRasterizerEx rasterizer(raster_settings, ext);
 
 		auto means3D = pc->getXYZ();

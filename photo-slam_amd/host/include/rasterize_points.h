@@ -49,6 +49,19 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
     const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam);
 
+// Extension, optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_geom_adam of include/gsr.h): when param is
+// filled (four entries each, in that order), backward applies this Adam step to the four tensors IN PLACE instead of computing
+// their gradients (which then come back undefined).  Needs raw_params == 7 and scales / rotations (no cov3D_precomp).
+// training_outputs_only: dL_dmeans2D and dL_dcov3D are not written either (undefined) -- for a caller that fuses the
+// densification statistics (view_stats).
+struct GeomAdamStep {
+	std::vector<torch::Tensor> param, exp_avg, exp_avg_sq;   // xyz [P,3], opacity [P,1], scaling [P,3], rotation [P,4]
+	std::vector<double> lr;
+	std::vector<int64_t> step;
+	double beta1 = 0.9, beta2 = 0.999, eps = 1e-15;
+	bool training_outputs_only = false;
+};
+
 // (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
@@ -77,6 +90,18 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                /* {xyz_gradient_accum, denom, max_radii2D} (P floats each), updated in place with this
                                   view's densification statistics (gsr_backward_args.stat_*); empty = off */
                                const std::vector<torch::Tensor>& view_stats);
+// ... and the fused geometry step (GeomAdamStep above)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                               const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam,
+                               const std::vector<torch::Tensor>& view_stats, const GeomAdamStep& geom_adam);
 
 // gsr_sh_grad_from_views (include/gsr.h): the [P,M,3] SH gradient of a keyframe batch from the gathered
 // [n_views,P,3] dL_dcolor_view tensors and the [n_views,3] camera centres; scale = 1/n_views for the batch mean

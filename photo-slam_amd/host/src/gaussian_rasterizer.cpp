@@ -41,6 +41,15 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 			ctx->saved_data["sh_adam_lr_tail_past"] = e.sh_adam_.lr_tail_past;
 		}
 	}
+	if (!e.geom_adam_.param.empty() || e.geom_adam_.training_outputs_only) {
+		const auto& ga = e.geom_adam_;
+		ctx->saved_data["geom_adam_p"] = ga.param;
+		ctx->saved_data["geom_adam_m"] = ga.exp_avg;
+		ctx->saved_data["geom_adam_v"] = ga.exp_avg_sq;
+		ctx->saved_data["geom_adam_lr"] = ga.lr;
+		ctx->saved_data["geom_adam_step"] = ga.step;
+		ctx->saved_data["geom_adam_h"] = std::vector<double>{ga.beta1, ga.beta2, ga.eps, ga.training_outputs_only ? 1.0 : 0.0};
+	}
 	auto color = std::get<1>(r);
 	auto radii = std::get<2>(r);
 	// same 14 tensors, same order as the reference (src/gaussian_rasterizer.cpp:87-100)
@@ -79,16 +88,28 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 	}
 	std::vector<torch::Tensor> view_stats;
 	if (ctx->saved_data.count("view_stats")) view_stats = ctx->saved_data["view_stats"].toTensorVector();
+	GeomAdamStep geom_adam;
+	if (ctx->saved_data.count("geom_adam_h")) {
+		geom_adam.param = ctx->saved_data["geom_adam_p"].toTensorVector();
+		geom_adam.exp_avg = ctx->saved_data["geom_adam_m"].toTensorVector();
+		geom_adam.exp_avg_sq = ctx->saved_data["geom_adam_v"].toTensorVector();
+		geom_adam.lr = ctx->saved_data["geom_adam_lr"].toDoubleVector();
+		geom_adam.step = ctx->saved_data["geom_adam_step"].toIntVector();
+		const auto h = ctx->saved_data["geom_adam_h"].toDoubleVector();
+		geom_adam.beta1 = h[0]; geom_adam.beta2 = h[1]; geom_adam.eps = h[2];
+		geom_adam.training_outputs_only = h[3] != 0.0;
+	}
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
 	                                        v[1] /*view*/, v[2] /*proj*/, tanfovx, tanfovy, grad_outputs[0], v[10] /*sh*/,
 	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params,
-	                                        sh_grad_view, sh_adam, view_stats);
+	                                        sh_grad_view, sh_adam, view_stats, geom_adam);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();
 	};
+	// (undefined where an extension took the gradient's place: fused optimizer steps, training_outputs_only)
 	torch::autograd::tensor_list out = {std::get<3>(g) /*means3D*/,
 	                                    std::get<0>(g) /*means2D*/,
 	                                    opt(std::get<5>(g), v[10]) /*sh*/,

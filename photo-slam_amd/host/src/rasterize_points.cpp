@@ -201,6 +201,24 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam,
                                const std::vector<torch::Tensor>& view_stats)
 {
+	return RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+	                                      viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+	                                      geomBuffer, R, binningBuffer, imageBuffer, raw_params, dL_dcolor_view, sh_adam, view_stats,
+	                                      GeomAdamStep());
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer,
+                               const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
+                               const int raw_params, const torch::Tensor& dL_dcolor_view, const ShAdamStep& sh_adam,
+                               const std::vector<torch::Tensor>& view_stats, const GeomAdamStep& geom_adam)
+{
 	const int P = static_cast<int>(means3D.size(0));
 	const int H = static_cast<int>(dL_dout_color.size(1));
 	const int W = static_cast<int>(dL_dout_color.size(2));
@@ -212,8 +230,24 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	// the gradients of the four small parameter tensors are slices of ONE buffer (rotation first: its float4 stores need
 	// the 16-byte alignment), so that a data-parallel driver reduces them over the ranks with a single collective; the
 	// buffer itself is not kept: autograd adopts a gradient only if nothing else references it
+	// the fused geometry step (GeomAdamStep): the four gradients are not computed (dL_dmeans3D stays as scratch)
+	const bool geom = !geom_adam.param.empty();
+	if (geom) {
+		if (geom_adam.param.size() != 4 || geom_adam.exp_avg.size() != 4 || geom_adam.exp_avg_sq.size() != 4 || geom_adam.lr.size() != 4 ||
+		    geom_adam.step.size() != 4 || !has_scales || dL_dcolor_view.defined())
+			throw std::runtime_error("geom_adam needs four tensors (xyz, opacity, scaling, rotation) with moments, learning rates and steps, scales / rotations, and no dL_dcolor_view");
+		for (size_t i = 0; i < 4; i++)
+			for (const auto* t : {&geom_adam.param[i], &geom_adam.exp_avg[i], &geom_adam.exp_avg_sq[i]})
+				if (!t->defined() || t->scalar_type() != torch::kFloat32 || !t->is_contiguous() || t->device() != means3D.device() ||
+				    t->sizes() != geom_adam.param[i].sizes() || t->size(0) != P)
+					throw std::runtime_error("geom_adam tensors must be contiguous float32 [num_points, ...] on the device of means3D");
+	}
+	const bool slim = geom_adam.training_outputs_only;
+	if (slim && !has_scales) throw std::runtime_error("training_outputs_only needs scales / rotations (dL_dcov3D is not written)");
 	torch::Tensor dL_drotations, dL_dmeans3D, dL_dscales, dL_dopacity;
-	{
+	if (geom) {
+		dL_dmeans3D = torch::empty({P, 3}, o);   // scratch between the two backward kernels
+	} else {
 		const int64_t n = P;
 		torch::Tensor flat = torch::empty({11 * n}, o);
 		dL_drotations = flat.narrow(0, 0, 4 * n).view({n, 4});
@@ -221,9 +255,12 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		dL_dscales = flat.narrow(0, 7 * n, 3 * n).view({n, 3});
 		dL_dopacity = flat.narrow(0, 10 * n, n).view({n, 1});
 	}
-	torch::Tensor dL_dmeans2D = torch::empty({P, 3}, o);
+	torch::Tensor dL_dmeans2D, dL_dcov3D;
+	if (!slim) {
+		dL_dmeans2D = torch::empty({P, 3}, o);
+		dL_dcov3D = torch::empty({P, 6}, o);
+	}
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, o);
-	torch::Tensor dL_dcov3D = torch::empty({P, 6}, o);
 	const bool factored = dL_dcolor_view.defined();
 	if (factored && (!has_sh || dL_dcolor_view.dim() != 2 || dL_dcolor_view.size(0) != P || dL_dcolor_view.size(1) != 3 ||
 	                 dL_dcolor_view.scalar_type() != torch::kFloat32 || !dL_dcolor_view.is_contiguous() ||
@@ -236,7 +273,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		throw std::runtime_error("sh_adam needs contiguous float32 sh and moments of one shape, step >= 1, and no dL_dcolor_view");
 	torch::Tensor dL_dsh;
 	if (!factored && !fused_adam) dL_dsh = has_sh ? torch::empty({P, M, 3}, o) : torch::zeros({P, M, 3}, o);
-	if (!has_scales) {
+	if (!has_scales && !geom) {
 		dL_dscales.zero_();
 		dL_drotations.zero_();
 	}
@@ -271,12 +308,12 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		a.binning_buffer = bin_c.numel() ? reinterpret_cast<char*>(bin_c.data_ptr()) : nullptr;
 		a.image_buffer = reinterpret_cast<char*>(img_c.data_ptr());
 		a.dL_dpix = dpix.ptr;
-		a.dL_dmean2D = dL_dmeans2D.data_ptr<float>();
+		a.dL_dmean2D = dL_dmeans2D.defined() ? dL_dmeans2D.data_ptr<float>() : nullptr;
 		a.dL_dconic = nullptr;  // internal to the reference's wrapper (rasterize_points.cu:152)
-		a.dL_dopacity = dL_dopacity.data_ptr<float>();
+		a.dL_dopacity = dL_dopacity.defined() ? dL_dopacity.data_ptr<float>() : nullptr;
 		a.dL_dcolor = dL_dcolors.data_ptr<float>();
 		a.dL_dmean3D = dL_dmeans3D.data_ptr<float>();
-		a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
+		a.dL_dcov3D = dL_dcov3D.defined() ? dL_dcov3D.data_ptr<float>() : nullptr;
 		a.dL_dsh = (has_sh && dL_dsh.defined()) ? dL_dsh.data_ptr<float>() : nullptr;
 		if (!view_stats.empty()) {
 			if (view_stats.size() != 3) throw std::runtime_error("view_stats: {xyz_gradient_accum, denom, max_radii2D}");
@@ -295,11 +332,25 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 			a.sh_adam = &adam;
 		}
 		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
-		a.dL_dscale = has_scales ? dL_dscales.data_ptr<float>() : nullptr;
-		a.dL_drot = has_scales ? dL_drotations.data_ptr<float>() : nullptr;
+		a.dL_dscale = (has_scales && !geom) ? dL_dscales.data_ptr<float>() : nullptr;
+		a.dL_drot = (has_scales && !geom) ? dL_drotations.data_ptr<float>() : nullptr;
 		a.raw_params = raw_params;
+		gsr_geom_adam ga{};
+		if (geom) {
+			gsr_adam_tensor* ts[4] = {&ga.xyz, &ga.opacity, &ga.scaling, &ga.rotation};
+			for (size_t i = 0; i < 4; i++) {
+				ts[i]->param = geom_adam.param[i].data_ptr<float>();
+				ts[i]->exp_avg = geom_adam.exp_avg[i].data_ptr<float>();
+				ts[i]->exp_avg_sq = geom_adam.exp_avg_sq[i].data_ptr<float>();
+				ts[i]->lr = geom_adam.lr[i];
+				ts[i]->step = static_cast<int>(geom_adam.step[i]);
+			}
+			ga.beta1 = geom_adam.beta1; ga.beta2 = geom_adam.beta2; ga.eps = geom_adam.eps;
+			a.geom_adam = &ga;
+		}
 		check(gsr_backward(&a, current_stream(means3D)), "RasterizeGaussiansBackwardCUDA");
 	}
+	if (geom) dL_dmeans3D = torch::Tensor();   // (was scratch)
 	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
 	                       dL_drotations);
 }

@@ -229,13 +229,28 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		}
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
+	GeomAdamStep geom_adam;
+	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5) {
+		// xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (trainingSetup); their steps happen inside backward, and
+		// optimizerStepGroup() then finds no gradient on them
+		for (int gi : {0, 2, 3, 4}) {
+			auto& grp = g->groups_[static_cast<size_t>(gi)];
+			grp.step++;
+			geom_adam.param.push_back(grp.param.detach());
+			geom_adam.exp_avg.push_back(grp.exp_avg);
+			geom_adam.exp_avg_sq.push_back(grp.exp_avg_sq);
+			geom_adam.lr.push_back(grp.lr * g->lr_scale_);
+			geom_adam.step.push_back(grp.step);
+		}
+		geom_adam.training_outputs_only = true;   // the statistics are fused (or over): nobody reads the viewspace gradient
+	}
 	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
 	// registers
 	std::vector<torch::Tensor> view_stats;
 	if (iteration_ < o.densify_until_iter_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 	g->in_lazy_step_ = lazy;
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
-	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats);
+	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats, geom_adam);
 	g->in_lazy_step_ = false;
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);

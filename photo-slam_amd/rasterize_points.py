@@ -118,7 +118,7 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                    geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None, sh_adam=None,
-                                   view_stats=None):
+                                   view_stats=None, geom_adam=None, training_outputs_only=False):
     """dL_dcolor_view (extension, default None = reference contract): a [P,3] float tensor that receives the clamp-masked
     colour gradient; dL_dsh is then NOT computed and None is returned in its place (view-factored gradient exchange,
     shGradFromViews below).
@@ -126,7 +126,14 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     update of `sh` is applied IN PLACE by the kernel that produces its gradient (gsr_backward_args.sh_adam); dL_dsh is then
     not computed and None is returned in its place.
     view_stats (extension, default None): (xyz_gradient_accum, denom, max_radii2D) float tensors with P elements, updated in
-    place with this view's densification statistics (gsr_backward_args.stat_*)."""
+    place with this view's densification statistics (gsr_backward_args.stat_*).
+    geom_adam (extension, default None): dict(tensors=[(param, exp_avg, exp_avg_sq, lr, step)] for xyz, opacity, scaling,
+    rotation, beta1, beta2, eps) -- this step's Adam update of the four geometry tensors is applied IN PLACE by the kernels
+    that hold their gradients (gsr_backward_args.geom_adam); dL_dopacity, dL_dmeans3D, dL_dscales and dL_drotations are then
+    not computed and None is returned in their places.
+    training_outputs_only (extension): dL_dmeans2D and dL_dcov3D are not written either (None returned) -- for a caller that
+    fuses the densification statistics (view_stats: the only consumer of dL_dmeans2D in a train step) and optimises scales /
+    rotations (no cov3D_precomp)."""
     lib = _lib()
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -191,6 +198,18 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         a.dL_dcolor_view = dL_dcolor_view.data_ptr() if factored else None
         a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
         a.dL_drot = dL_drotations.data_ptr() if has_scales else None
+        if training_outputs_only:
+            if not has_scales:
+                raise RuntimeError("training_outputs_only needs scales / rotations (dL_dcov3D is not written)")
+            a.dL_dmean2D = a.dL_dconic = a.dL_dcov3D = None
+        if geom_adam is not None:
+            for p_, m_, v_, _lr, _step in geom_adam["tensors"]:
+                for t in (p_, m_, v_):
+                    if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or t.shape != p_.shape:
+                        raise RuntimeError("geom_adam tensors must be contiguous float32 on the device of means3D")
+            ga = capi.make_geom_adam(geom_adam)
+            a.geom_adam = C.pointer(ga)
+            a.dL_dopacity = a.dL_dscale = a.dL_drot = None
         st = lib.gsr_backward(C.byref(a), _stream_ptr(means3D))
         capi.check(lib, st, "RasterizeGaussiansBackwardCUDA")
         if not has_sh and dL_dsh is not None:
@@ -198,6 +217,10 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
         if not has_scales:
             dL_dscales.zero_()
             dL_drotations.zero_()
+    if training_outputs_only:
+        dL_dmeans2D = dL_dcov3D = None
+    if geom_adam is not None:
+        dL_dopacity = dL_dmeans3D = dL_dscales = dL_drotations = None
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -191,7 +191,7 @@ def allreduce_mean(tensors, world_size):
 class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
                  densify_min_opacity=0.005, prune_big_point_after_iter=30000, seed=0, factored_exchange=True, fused_sh_adam=True,
-                 lazy_sh_adam_window=32):
+                 lazy_sh_adam_window=32, fused_geom_adam=True):
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
         self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
         self.densify_, self.densify_min_opacity_ = densify, densify_min_opacity
@@ -209,6 +209,9 @@ class TrainStep:
         # ... and the zero-gradient steps of the culled Gaussians' rows taken lazily, at most this many at a time (0 = every
         # row at every step): TrainStep::lazy_sh_adam_window_ of the C++ host
         self.lazy_sh_adam_window_ = lazy_sh_adam_window
+        # ... and the Adam steps of xyz / opacity / scaling / rotation inside the backward kernels that hold their gradients
+        # (TrainStep::fused_geom_adam_ of the C++ host), on the same iterations
+        self.fused_geom_adam_ = fused_geom_adam
         self.ema_loss_for_log_ = 0.0
 
     def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
@@ -216,7 +219,7 @@ class TrainStep:
         self.iteration_ += 1
         it = self.iteration_
         g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
-        sh_send = sh_view = sh_adam = None
+        sh_send = sh_view = sh_adam = geom_adam = None
         if self.world_size_ > 1 and self.factored_exchange_:
             sh_send, sh_view = ViewFactoredExchange.send_buffer(g.xyz_.size(0), g.xyz_.device)
         # this iteration densifies (src/gaussian_mapper.cpp:720-721; the fresh leaves have no gradient, so the reference's
@@ -226,6 +229,13 @@ class TrainStep:
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
                 g._features.size(1) == 16 and g.optimizer_ is not None:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)
+            if self.fused_geom_adam_ and len(g.optimizer_.param_groups) == 5:
+                # xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (GaussianModel.trainingSetup)
+                tensors = []
+                for gi in (0, 2, 3, 4):
+                    d = g.optimizer_.begin_fused_step(gi)
+                    tensors.append((g.optimizer_.param_groups[gi]["params"][0].detach(), d["exp_avg"], d["exp_avg_sq"], d["lr"], d["step"]))
+                geom_adam = dict(tensors=tensors, beta1=sh_adam["beta1"], beta2=sh_adam["beta2"], eps=sh_adam["eps"])
         # this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D.  With
         # several ranks they accumulate PER RANK and are reduced only when densification consumes them (below): SUM and MAX
         # commute with the accumulation over iterations, so nothing crosses the links for them on the other 99 of 100 steps
@@ -234,7 +244,7 @@ class TrainStep:
         try:
             rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
                 viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats)
+                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats, geom_adam=geom_adam)
         finally:
             g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)

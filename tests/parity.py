@@ -315,6 +315,71 @@ def check_fused_sh_adam(lib_path, dev, cl, bg, step=3, seed=0, sh_degree=3):
         assert np.allclose(m1.cpu().numpy()[culled], 0.9 * m0[culled], rtol=1e-6, atol=1e-12)
 
 
+def check_fused_geom_adam(lib_path, dev, cl, bg, seed=0, sh_degree=3):
+    """Optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_backward_args.geom_adam) against backward +
+    gsr_adam_step on the four gradients: same parameters and moments after the step (the fused form uses v_rcp / v_sqrt in
+    the update term: 1e-6 of the step), the outputs it leaves (dL_dcolors; the SH gradient) unchanged; and the nullable
+    outputs (training_outputs_only) change nothing else."""
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        lib = capi.load(lib_path)
+        rng = np.random.default_rng(seed)
+        cam = cl.cameras[0]
+        P = cl.xyz.shape[0]
+        empty = torch.empty(0, device=dev)
+        dpix = _t(rng.standard_normal((3, cam.H, cam.W)).astype(np.float32), dev)
+        raw = capi.RAW_OPACITY | capi.RAW_SCALING | capi.RAW_ROTATION
+        names = ("xyz", "opacity", "scaling", "rotation")
+        init = dict(xyz=cl.xyz, opacity=cl.opacity.reshape(P, 1), scaling=cl.scaling, rotation=cl.rotation)
+        lrs = dict(xyz=1.6e-4, opacity=0.05, scaling=0.005, rotation=0.001)
+        steps = dict(xyz=4, opacity=2, scaling=4, rotation=7)
+        mom = {n: ((0.01 * rng.standard_normal(init[n].shape)).astype(np.float32), (1e-4 * rng.random(init[n].shape)).astype(np.float32))
+               for n in names}
+        views = dict(viewmatrix=_t(cam.viewmatrix, dev), projmatrix=_t(cam.projmatrix, dev), campos=_t(cam.campos, dev))
+
+        def run(fused, only):
+            st = {n: [_t(init[n].copy(), dev).clone(), _t(mom[n][0].copy(), dev).clone(), _t(mom[n][1].copy(), dev).clone()] for n in names}
+            sh = _t(_features(cl, None), dev).clone()
+            R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(
+                _t(bg, dev), st["xyz"][0], empty, st["opacity"][0], st["scaling"][0], st["rotation"][0], 1.0, empty, views["viewmatrix"],
+                views["projmatrix"], cam.tanfovx, cam.tanfovy, cam.H, cam.W, sh, sh_degree, views["campos"], False, raw)
+            stats = [torch.zeros(P, device=dev) for _ in range(3)]
+            ga = dict(tensors=[(st[n][0], st[n][1], st[n][2], lrs[n], steps[n]) for n in names], beta1=0.9, beta2=0.999, eps=1e-15) if fused else None
+            g = rp.RasterizeGaussiansBackwardCUDA(_t(bg, dev), st["xyz"][0], radii, empty, st["scaling"][0], st["rotation"][0], 1.0, empty,
+                                                  views["viewmatrix"], views["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, sh, sh_degree,
+                                                  views["campos"], geom, R, binning, img, raw_params=raw, view_stats=stats, geom_adam=ga,
+                                                  training_outputs_only=only)
+            if dev.type != "cpu":
+                torch.cuda.synchronize()
+            return st, g, stats, radii.cpu().numpy()
+
+        st_ref, g_ref, stats_ref, radii = run(False, False)
+        grads = dict(xyz=g_ref[3], opacity=g_ref[2], scaling=g_ref[6], rotation=g_ref[7])
+        for n in names:   # the separate passes
+            p_, m_, v_ = st_ref[n]
+            gr = grads[n].contiguous()
+            capi.check(lib, lib.gsr_adam_step(p_.data_ptr(), gr.data_ptr(), m_.data_ptr(), v_.data_ptr(), p_.numel(), lrs[n], 0.9, 0.999,
+                                              1e-15, steps[n], 0, 0, lrs[n], None), "gsr_adam_step")
+        st_fus, g_fus, stats_fus, _ = run(True, True)
+        assert g_fus[0] is None and g_fus[2] is None and g_fus[3] is None and g_fus[4] is None and g_fus[6] is None and g_fus[7] is None
+        exact = dev.type == "cpu"
+        for a, b in ((g_fus[1], g_ref[1]), (g_fus[5], g_ref[5])) + tuple(zip(stats_fus, stats_ref)):
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert np.array_equal(a, b) if exact else rel_l1(a, b) < 2e-5
+        vis = radii > 0
+        assert vis.any() and (~vis).any()
+        for n in names:
+            for k, what in enumerate(("param", "exp_avg", "exp_avg_sq")):
+                a, b = st_fus[n][k].cpu().numpy(), st_ref[n][k].cpu().numpy()
+                # parameter: 2e-6 of a step, but not below one ulp of the largest value; moments: relative
+                tol = max(lrs[n] * (2e-6 if exact else 2e-3), 1.2e-7 * np.abs(b).max()) if k == 0 else (1e-6 if exact else 2e-4) * np.abs(b).max()
+                assert np.abs(a - b).max() <= tol, (n, what, np.abs(a - b).max(), tol)
+            moved = np.abs(st_fus[n][0].cpu().numpy() - init[n]).reshape(P, -1).max(1)
+            assert moved[vis].max() > 0.1 * lrs[n] and moved[~vis].max() > 0   # every Gaussian stepped, culled ones on their moments
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
 def check_fused_view_stats(lib_path, dev, cl, bg, seed=0):
     """gsr_backward_args.stat_* (the densification statistics of the view added inside backward) == gsr_densify_stats on
     the returned dL_dmean2D, starting from non-trivial accumulators."""

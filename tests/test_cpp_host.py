@@ -104,10 +104,11 @@ def run_trainer_checks(ops, dev, lib_path):
         ops.trainer_finish(h3)
     for a, b in zip(ops.trainer_params(h3), ops.trainer_params(h)):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
-    # (on the GPU two runs differ by the order of the blend's float atomics: the moments of tiny gradients see it first)
-    mtol = dict(rtol=1e-6, atol=1e-12) if dev.type == "cpu" else dict(rtol=1e-3, atol=1e-9)
+    # (the fused steps form the update term with v_rcp / v_sqrt: the parameters differ in the last bit after the first step,
+    # the later gradients -- and with them the moments -- at 1e-6 of their range; on the GPU two runs also differ by the order
+    # of the blend's LDS adds)
     for a, b in zip(ops.trainer_moments(h3), ops.trainer_moments(h)):
-        assert torch.allclose(a, b, **mtol)
+        assert torch.allclose(a, b, rtol=1e-5 if dev.type == "cpu" else 1e-3, atol=1e-6 * float(b.abs().max()))
     ops.trainer_destroy(h3)
     # the same three steps through the pieces of the data-parallel step with the view-factored exchange (a batch of one
     # view: the rebuilt SH gradient is this view's own), per-group Adam in the order bench.py uses

@@ -134,6 +134,10 @@ def test_fused_sh_adam(emu_lib_path, degree):
                                sh_degree=degree)
 
 
+def test_fused_geom_adam(emu_lib_path):
+    parity.check_fused_geom_adam(emu_lib_path, CPU, _scene(P=330, seed=25), np.array([0.1, 0.2, 0.3], np.float32))
+
+
 def test_fused_view_stats(emu_lib_path):
     parity.check_fused_view_stats(emu_lib_path, CPU, _scene(P=330, seed=24), np.array([0.1, 0.2, 0.3], np.float32))
 

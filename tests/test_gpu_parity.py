@@ -127,6 +127,12 @@ def test_fused_sh_adam(dev):
 
 
 @pytest.mark.gpu
+def test_fused_geom_adam(dev):
+    cl = scene.make_cloud(60_000, 320, 240, 250.0, 250.0, seed=12)
+    parity.check_fused_geom_adam(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
+
+
+@pytest.mark.gpu
 def test_fused_view_stats(dev):
     cl = scene.make_cloud(50000, 320, 240, 250.0, 250.0, seed=15, scale_k=0.15)
     parity.check_fused_view_stats(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
