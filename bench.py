@@ -45,18 +45,22 @@ PMC_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROO
 
 
 def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
-                      touched_slots=None, lazy_window=0):
+                      touched_slots=None, lazy_window=0, fused_geom_adam=False):
     """Compulsory HBM bytes per stage (each array read/written once per stage that needs it), restated for
     this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the Adam step of the SH tensor
     (no gradient rows written; both moments read, parameter + moments written for every Gaussian, the parameter row read for
     the culled ones too).  touched_slots: instance slots the backward blend wrote (48 B each, read back once by
     preprocess_bwd together with R flag bytes); None leaves them out.  lazy_window: the culled rows take their zero-gradient
     steps `lazy_window` at a time (gsr_sh_adam_lazy): per step, moments read + parameter and moments written for the VISIBLE
-    rows, and a full read-modify-write of 1/lazy_window of the culled ones."""
+    rows, and a full read-modify-write of 1/lazy_window of the culled ones.  fused_geom_adam: the stage also carries the Adam
+    steps of xyz / opacity / scaling / rotation (11 floats per Gaussian: parameter and two moments read and written, 264 B)
+    and no longer writes their gradients, the viewspace gradient and dL_dcov3D (80 B per Gaussian)."""
     if fused_sh_adam and lazy_window >= 2:
         adam = 12 * M * (5 * V + 6 * (P - V) // lazy_window - P)   # (- P: the stage's gradient rows are not written)
     else:
         adam = 12 * M * (4 * P + (P - V)) if fused_sh_adam else 0
+    if fused_geom_adam:
+        adam += (264 - 80) * P
     S = P if sorted_gaussians is None else sorted_gaussians
     slots = 0 if touched_slots is None else 48 * touched_slots + R
     return {
@@ -397,7 +401,8 @@ def main():
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
     fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank
     lazy_window = args.sh_adam_window if fused_sh_adam and args.sh_adam_window >= 2 else 0
-    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam, lazy_window=lazy_window)
+    ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam, lazy_window=lazy_window,
+                           fused_geom_adam=fused_sh_adam and not args.no_fused_geom_adam)
     stages = {}
     for k, ms in stage_ms.items():
         ms = [m for m in ms if m >= 0]
