@@ -209,8 +209,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
-	GSR_HIP(hipMemsetAsync(g.counters, 0, NUM_COUNTERS * sizeof(uint32_t), stream));
-	GSR_HIP(hipMemsetAsync(g.long_counts, 0, (size_t)LONG_LISTS * LONG_COUNT_STRIDE * sizeof(uint32_t), stream));
+	// (every tiny memset is a ~5 us kernel in the stream: the two zeroed arrays are adjacent, the tile ranges are zeroed by
+	// preprocess_fwd)
+	GSR_HIP(hipMemsetAsync(g.counters, 0, g.zeroed_bytes(), stream));
 	PROF_FWD(0);
 
 	PreprocessParams pp;
@@ -222,6 +223,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.focal_y = H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:221-222
 	pp.focal_x = W / (2.0f * a->tan_fovx);
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii; pp.raw_params = a->raw_params;
+	pp.ranges = im.ranges; pp.tiles = tiles;   // zeroed there: rasterizer_impl.cu:310
 	pp.lazy = LazyAdam{};
 	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
 		if (!a->shs) return GSR_ERR_INVALID_ARG;
@@ -255,7 +257,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if (!bin_chunk) return GSR_ERR_ALLOC;
 	BinningState bs = BinningState::carve(bin_chunk, (size_t)R);
 
-	GSR_HIP(hipMemsetAsync(im.ranges, 0, (size_t)tiles * sizeof(uint2), stream));  // rasterizer_impl.cu:310
+	// (im.ranges: zeroed by preprocess_fwd)
 	uint32_t* point_list = bs.vals_a;
 	if (R > 0) {
 		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;

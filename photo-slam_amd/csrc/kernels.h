@@ -62,6 +62,8 @@ struct PreprocessParams {
 	int grid_x, grid_y;
 	int* radii_out;  // caller's radii (nullable)
 	int raw_params;  // GSR_RAW_* mask: activations applied in-kernel
+	uint2* ranges;   // [tiles] per-tile instance ranges: zeroed here (identifyTileRanges fills only the tiles that have instances)
+	int tiles;
 	LazyAdam lazy;   // row_step != null: visible rows that lag behind (step - 1) are brought up to date before their SH evaluation
 };
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);

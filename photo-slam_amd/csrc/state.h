@@ -86,7 +86,6 @@ struct GeometryState {
 	{
 		GeometryState g;
 		Carver c(chunk);
-		g.counters = c.take<uint32_t>(NUM_COUNTERS);
 		g.depth_key = c.take<uint32_t>(P);
 		g.tiles_touched = c.take<uint32_t>(P);
 		g.radii = c.take<int>(P);
@@ -103,10 +102,17 @@ struct GeometryState {
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.visible = c.take<uint32_t>(32);
 		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
+		// the two arrays the forward pass has to find zeroed sit next to each other: ONE memset (zeroed_bytes())
+		g.counters = c.take<uint32_t>(NUM_COUNTERS);
 		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
 		g.long_capacity = (uint32_t)long_list_capacity(P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
+	}
+	// [counters, end of long_counts): zeroed per forward pass
+	size_t zeroed_bytes() const
+	{
+		return (size_t)(reinterpret_cast<const char*>(long_counts + (size_t)LONG_LISTS * LONG_COUNT_STRIDE) - reinterpret_cast<const char*>(counters));
 	}
 };
 

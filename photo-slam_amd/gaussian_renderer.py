@@ -44,7 +44,8 @@ class GaussianRenderer:
 
         sh_grad_view, sh_adam, view_stats, geom_adam (extensions; None = the reference data flow): see
         GaussianRasterizationSettings."""
-        screenspace_points = torch.zeros_like(pc.getXYZ(), requires_grad=True)
+        # (with the fused geometry step nobody reads its gradient and the rasterizer never reads its values: no zero fill then)
+        screenspace_points = (torch.empty_like if geom_adam is not None else torch.zeros_like)(pc.getXYZ(), requires_grad=True)
         try:
             screenspace_points.retain_grad()
         except Exception:
@@ -85,4 +86,5 @@ class GaussianRenderer:
         has_sr = not pipe.compute_cov3D_
         rendered_image, radii = rasterizer(means3D, means2D, opacity, has_shs, has_color_precomp, has_sr, has_sr,
                                            pipe.compute_cov3D_, shs, colors_precomp, scales, rotations, cov3D_precomp)
-        return rendered_image, screenspace_points, radii > 0, radii
+        # (visibility_filter is one more launch: with the fused geometry step its consumers are fused too -- None then)
+        return rendered_image, screenspace_points, (None if geom_adam is not None else radii > 0), radii

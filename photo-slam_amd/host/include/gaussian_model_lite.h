@@ -191,7 +191,8 @@ public:
 	std::shared_ptr<GaussianModel> gaussians_;
 	torch::Tensor background_;
 	int iteration_ = 0;
-	torch::Tensor last_viewspace_, last_visibility_, last_radii_;
+	torch::Tensor last_viewspace_, last_visibility_ /* undefined when the step fused its consumers: last_radii_ > 0 */, last_radii_;
+	torch::Tensor root_grad_;   // the constant 1 handed to loss.backward()
 };
 
 // loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)

@@ -44,7 +44,11 @@ public:
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
 		// dummy input whose gradient is dL/dmean2D (the densification statistic)
-		auto screenspace_points = torch::zeros_like(pc->getXYZ(), torch::TensorOptions().requires_grad(true));
+		// (with geom_adam.training_outputs_only nobody reads its gradient and the rasterizer never reads its values: the 12 P
+		// bytes are then not even zero-filled)
+		auto screenspace_points = geom_adam.training_outputs_only
+		                              ? torch::empty_like(pc->getXYZ(), torch::TensorOptions().requires_grad(true))
+		                              : torch::zeros_like(pc->getXYZ(), torch::TensorOptions().requires_grad(true));
 		screenspace_points.retain_grad();
 
 		const float tanfovx = std::tan(viewpoint_camera->FoVx_ * 0.5f);
@@ -99,6 +103,9 @@ public:
 		                                 cov3D_precomp);
 		auto rendered_image = std::get<0>(result);
 		auto radii = std::get<1>(result);
-		return std::make_tuple(rendered_image, screenspace_points, radii > 0, radii);
+		// (visibility_filter = radii > 0 is one more launch: a caller that fused everything that consumes it -- the statistics,
+		// geom_adam.training_outputs_only -- gets an undefined tensor and derives it from radii if it ever wants it)
+		return std::make_tuple(rendered_image, screenspace_points,
+		                       geom_adam.training_outputs_only ? torch::Tensor() : (radii > 0), radii);
 	}
 };

@@ -257,7 +257,9 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	last_visibility_ = std::get<2>(pkg);
 	last_radii_ = std::get<3>(pkg);
 	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_, /*is_root=*/true);
-	loss.backward();
+	// the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward()
+	if (!root_grad_.defined() || root_grad_.device() != loss.device()) root_grad_ = torch::ones_like(loss).detach();
+	loss.backward(root_grad_);
 	if (lazy) {   // the step is taken: its learning rates join the history the later catch-ups need
 		auto& hist = g->features_lr_hist_;
 		hist.insert(hist.begin(), {sh_adam.lr, sh_adam.lr_tail});

@@ -249,7 +249,10 @@ class TrainStep:
             g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
         loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_, is_root=True)
-        loss.backward()                                                  # :699
+        # :699 (the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward())
+        if getattr(self, "_root_grad", None) is None or self._root_grad.device != loss.device:
+            self._root_grad = torch.ones_like(loss).detach()
+        loss.backward(self._root_grad)
         if sh_adam is not None:
             g.optimizer_.end_fused_step(FEATURES_GROUP, sh_adam)
         with torch.no_grad():
