@@ -362,7 +362,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
 	// every API output is written exactly once by preprocess_bwd
 	// R bytes of flags instead of 48 R bytes of slots (+ the 64 pad bytes: the reader's byte->bit squeeze needs every byte 0/1)
-	if (R > 0) GSR_HIP(hipMemsetAsync(bs.touched, 0, (size_t)R + 64, stream));
+	if (R > 0) GSR_HIP(hipMemsetAsync(bs.touched, 0, touched_clear_bytes((size_t)R), stream));
 	PROF_BWD(1);
 	if (R > 0) {
 		BlendBwdParams bp;

@@ -116,6 +116,8 @@ struct GeometryState {
 	}
 };
 
+static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }
+
 struct BinningState {
 	uint32_t* keys_a;        // [R] tile id per instance (ping)
 	uint32_t* vals_a;        // [R] Gaussian id per instance (ping)
@@ -135,7 +137,9 @@ struct BinningState {
 		b.vals_b = c.take<uint32_t>(R);
 		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
 		b.partials = c.take<float>(12 * R);
-		b.touched = c.take<uint8_t>(R + 64);   // readers fetch flags 16 bytes at a time
+		// readers fetch flags 16 bytes at a time (+ 64); the clear covers touched_clear_bytes(R): a multiple of 256 bytes, because
+		// the runtime splits a memset of any other size into two kernels (body + tail, 5 us each)
+		b.touched = c.take<uint8_t>(touched_clear_bytes(R));
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}

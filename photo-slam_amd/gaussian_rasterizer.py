@@ -50,6 +50,7 @@ class GaussianRasterizerFunction(torch.autograd.Function):
             s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_, cov3Ds_precomp,
             s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_, s.image_height_, s.image_width_, sh, s.sh_degree_,
             s.campos_, s.prefiltered_, s.raw_params_, s.sh_adam_)   # sh_adam_: lazy mode brings visible rows up to date first
+        ctx.set_materialize_grads(False)   # (no zero tensor for the unused gradient of `radii`)
         ctx.num_rendered = num_rendered
         ctx.raster_settings = s
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -59,6 +60,8 @@ class GaussianRasterizerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
+        if grad_out_color is None:   # the image took no part in the loss (set_materialize_grads(False)): no gradients
+            return (None,) * 9
         s = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
             ctx.saved_tensors

@@ -21,6 +21,8 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
 	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_, e.raw_params_,
 	                                e.sh_adam_ /* lazy mode: visible rows are brought up to date first */);
+	// (no zero tensor for the unused gradient of `radii`: autograd would otherwise fill P ints per backward)
+	ctx->set_materialize_grads(false);
 	ctx->saved_data["num_rendered"] = std::get<0>(r);
 	ctx->saved_data["scale_modifier"] = static_cast<double>(s.scale_modifier_);
 	ctx->saved_data["tanfovx"] = static_cast<double>(s.tanfovx_);
@@ -63,6 +65,10 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list grad_outputs,
                                            int n_extra)
 {
+	if (!grad_outputs[0].defined()) {   // the image took no part in the loss (set_materialize_grads(false)): no gradients
+		torch::autograd::tensor_list none(static_cast<size_t>(8 + n_extra));
+		return none;
+	}
 	const int num_rendered = static_cast<int>(ctx->saved_data["num_rendered"].toInt());
 	const float scale_modifier = static_cast<float>(ctx->saved_data["scale_modifier"].toDouble());
 	const float tanfovx = static_cast<float>(ctx->saved_data["tanfovx"].toDouble());
