@@ -50,6 +50,8 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	const int w = wave_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
 	const bool in_range = idx < p.P;
+	// lazy SH Adam: the row's step count is wanted right behind the geometry phase -- asked for now, it is there by then
+	const int row_step = (p.lazy.row_step != nullptr && in_range) ? p.lazy.row_step[idx] : 0;
 	uint32_t my_tiles = 0;
 	int radius_i = 0;
 	uint32_t depth_key = DEPTH_KEY_CULLED;
@@ -194,7 +196,7 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			// lazy SH Adam (gsr_sh_adam_lazy): a visible row that is behind (step - 1) takes its missed zero-gradient steps first
 			int lag = 0;
 			if (p.lazy.row_step != nullptr && vis) {
-				lag = p.lazy.step - 1 - p.lazy.row_step[idx];
+				lag = p.lazy.step - 1 - row_step;
 				lag = lag < 0 ? 0 : (lag >= p.lazy.window ? p.lazy.window - 1 : lag);
 			}
 			const bool lagging = wave_ballot(lag > 0) != 0;   // wave-uniform, false on nearly every wave of a steady view

@@ -24,7 +24,9 @@ def _run(exe, *args):
     out = subprocess.check_output([exe] + list(args), text=True, env=dict(os.environ, PYTEST_CURRENT_TEST="ref_link"))
     m = re.search(r"class_vs_free=([-\d.e+]+) present=(\d+) vis=(\d+)", out)
     assert m, out
-    assert float(m.group(1)) < 1e-6, out          # GaussianRasterizer / autograd == the free functions
+    # GaussianRasterizer / autograd == the free functions (two backward passes: on the GPU they differ by the order of the
+    # blend's LDS adds, one ulp of the compared sums)
+    assert float(m.group(1)) < 1e-5, out
     assert int(m.group(2)) == int(m.group(3)) == 5, out
     assert "reference_exception_text=1" in out, out
     return out
