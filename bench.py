@@ -493,12 +493,12 @@ def main():
                     traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
                     traffic_src = f
                     break
-        if dom == "blend_bwd" and fused_sh_adam and os.environ.get("GSR_SH_ADAM_SIDE_STREAM", "1") != "0":
-            # while blend_bwd runs, the library's second stream streams SH rows of culled Gaussians (gsr_backward): eagerly
-            # all of them (1152 B each), lazily this step's 1/window of them
-            side_bytes = 1152 * (P - V) // (lazy_window if lazy_window else 1)
-            stages[dom]["concurrent"] = {"kernel": ("sh_adam_lazy_kernel (side stream, 1152 B per culled Gaussian of this step's 1/%d of the row blocks)" % lazy_window)
-                                                   if lazy_window else "sh_adam_culled_kernel (side stream, 1152 B per culled Gaussian)",
+        if dom == "blend_bwd" and fused_sh_adam and not lazy_window and os.environ.get("GSR_SH_ADAM_SIDE_STREAM", "1") != "0":
+            # eager mode: while blend_bwd runs, the library's second stream streams the SH rows of ALL culled Gaussians
+            # (gsr_backward).  (Lazy mode: the slice kernel runs behind the blend, next to the preprocess_bwd stage, whose
+            # algorithmic bytes include it.)
+            side_bytes = 1152 * (P - V)
+            stages[dom]["concurrent"] = {"kernel": "sh_adam_culled_kernel (side stream, 1152 B per culled Gaussian)",
                                          "bytes": int(side_bytes),
                                          "combined_GBps_if_fully_overlapped": round((ab[dom] + side_bytes) / (stages[dom]["ms"] * 1e-3) / 1e9, 1)}
         if dom:
