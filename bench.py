@@ -262,7 +262,10 @@ def main():
         loss_ready[k].record()
         loss_state["n"] += 1
 
+    kf_now = [kf]   # (the changing-views leg swaps the keyframe between steps)
+
     def one_step():
+        kf = kf_now[0]
         if ops is not None:
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
@@ -388,6 +391,28 @@ def main():
                                   torch.empty(0, device=dev), kf.world_view_transform_, kf.full_proj_transform_,
                                   kf.tanfovx_, kf.tanfovy_, H, W, g.getFeatures().detach(), 3, kf.camera_center_, False)[0]
 
+    # ---- K steps that cycle through four keyframes of the scene's camera arc (same stationary parameters): the culled set
+    # changes from step to step, so rows of the lazily stepped SH tensor keep becoming visible and catch up in the forward pass
+    views_run = None
+    if stationary and not args.raster_only and not dp and ops is not None:
+        cams4 = scene.make_config(args.config, seed=0, n_views=4, P=args.points).cameras
+        kfs4 = [GaussianKeyframe.from_camera(c, dev) for c in cams4]
+        n4 = max(args.steps, 40)
+        for i in range(8):
+            kf_now[0] = kfs4[i % 4]
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n4):
+            kf_now[0] = kfs4[i % 4]
+            one_step()
+        barrier()
+        el4 = time.perf_counter() - t0
+        kf_now[0] = kf
+        views_run = {"steps": n4, "keyframes": 4, "ms_per_step": round(el4 / n4 * 1e3, 3), "iters_per_s": round(n4 / el4, 3),
+                     "note": "four keyframes on the scene's 1 m camera arc taken in turn (the ground-truth image stays the first "
+                             "keyframe's: the loss value is meaningless, the work is not)"}
+
     # ---- the same K steps with the training learning rates (the drifting synthetic workload), for the record
     train_run = None
     if stationary and not args.raster_only:
@@ -474,6 +499,8 @@ def main():
                                "source": "one HIP event per step on the compute stream of rank 0"}
             if args.dump_steps:
                 out["protocol"]["step_ms"] = [round(float(x), 3) for x in step_ms]
+        if views_run:
+            out["changing_views_run"] = views_run
         if train_run:
             out["training_lr_run"] = train_run
         if dp:

@@ -13,6 +13,10 @@ from photo_slam_amd.trainer import TrainStep
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+# third argument: lazy SH Adam window (32 = default of the hosts, 0 = eager); fourth: 0 = the four geometry tensors step in
+# separate passes
+window = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+fused_geom = (int(sys.argv[4]) if len(sys.argv) > 4 else 1) != 0
 dev = torch.device("cuda", 0)
 cl = scene.make_config(cfg, seed=0, n_views=4)
 g = GaussianModel.from_cloud(cl, device=dev)
@@ -27,7 +31,9 @@ with torch.no_grad():
     g.xyz_.add_(0.01 * torch.randn_like(g.xyz_))
     g.features_.add_(0.05 * torch.randn_like(g.features_))
 mask = torch.ones_like(gts[0])
-ts = TrainStep(g, opt, GaussianPipelineParams(), bg, cameras_extent=cl.extent, densify=True)
+torch.manual_seed(0)
+ts = TrainStep(g, opt, GaussianPipelineParams(), bg, cameras_extent=cl.extent, densify=True, lazy_sh_adam_window=window,
+               fused_geom_adam=fused_geom)
 t0 = time.time(); losses = []
 for it in range(iters):
     k = it % len(kfs)
@@ -42,4 +48,5 @@ for it in range(iters):
         assert torch.isfinite(g.xyz_).all() and torch.isfinite(g.features_).all()
         print(f"it {it:5d} loss {l:.5f} P {P}")
 torch.cuda.synchronize()
-print(f"soak ok: {iters} iterations in {time.time()-t0:.1f} s, loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+print(f"soak ok (lazy window {window}, fused geometry step {fused_geom}): {iters} iterations in {time.time()-t0:.1f} s, "
+      f"loss {losses[0]:.5f} -> {losses[-1]:.5f}, P {g.xyz_.shape[0]}, |features| {float(g.features_.abs().mean()):.6f}")
