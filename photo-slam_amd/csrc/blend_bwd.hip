@@ -99,7 +99,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 					const float4 q0 = p.rec[3 * (size_t)gid + 0];
 					const float4 q1 = p.rec[3 * (size_t)gid + 1];
 					const float4 q2 = p.rec[3 * (size_t)gid + 2];
-					keep = quad_keep(q0, q1, (float)qx0, (float)qy0);
+					// the forward blend's verdict for (quad, entry): a subset of the quad rejection test's survivors
+					keep = p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] != 0;
 					s_rec[quad][l][0] = prescale_q0(q0);
 					s_rec[quad][l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
 					s_rec[quad][l][2].x = q2.x;

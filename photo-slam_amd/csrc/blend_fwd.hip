@@ -58,6 +58,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 		unsigned long long m = wave_ballot(keep);
 		wave_fence();
 		bool wave_done = false;
+		unsigned long long contrib_m = 0ull;   // entries of this batch that some pixel of the quad blends (scalar)
 		while (m) {
 			const int bit = __ffsll((long long)m) - 1;
 			m &= m - 1ull;
@@ -71,6 +72,13 @@ blend_fwd_kernel(const BlendFwdParams p)
 			const float test_T = T * (1.f - alpha);
 			const unsigned long long below_m = wave_ballot(test_T < 0.0001f);
 			const unsigned long long upd_m = ok_m & ~below_m;
+#ifdef GSR_EMU
+			if (upd_m) contrib_m |= 1ull << bit;
+#else
+			// contrib_m |= upd_m ? 1 << bit : 0 in three scalar instructions (the compiler's select form takes five, and the
+			// loop is sensitive to scalar issue: +26 us per launch with those, tools/gpu_r2x.sh)
+			asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cbranch_scc0 1f\n\ts_bitset1_b64 %0, %2\n1:" : "+s"(contrib_m) : "s"(upd_m), "s"(bit) : "scc");
+#endif
 			done_m |= ok_m & below_m;
 			const float wgt = mask_select0_f32(upd_m, alpha * T);
 			Crg += (v2f){g1.z, g1.w} * (v2f){wgt, wgt};
@@ -82,6 +90,9 @@ blend_fwd_kernel(const BlendFwdParams p)
 				break;
 			}
 		}
+		// the backward pass walks the same batches: it visits only the entries flagged here (15 % of the entries that survive the
+		// quad rejection blend into no pixel -- alpha below 1/255 at every pixel centre, or every such pixel saturated)
+		if (have) p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] = (uint8_t)((contrib_m >> l) & 1ull);
 		if (wave_done) break;
 		wave_fence();  // all lanes have read this batch before the next one overwrites the slice
 	}

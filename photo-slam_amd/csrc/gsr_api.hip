@@ -278,6 +278,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	BlendFwdParams bp;
 	bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
 	bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.out_color = a->out_color;
+	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(7);
@@ -370,6 +371,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.dL_dpix = a->dL_dpix;
 		bp.partials = bs.partials;
 		bp.touched = bs.touched;
+		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
 	}

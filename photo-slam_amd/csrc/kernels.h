@@ -80,6 +80,8 @@ struct BlendFwdParams {
 	float* final_T;
 	uint32_t* n_contrib;
 	float* out_color;
+	uint8_t* contrib;       // [4][contrib_stride]: plane of quad q, byte per list entry (state.h)
+	size_t contrib_stride;
 	int W, H, grid_x, tiles;
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
@@ -94,6 +96,8 @@ struct BlendBwdParams {
 	const float* dL_dpix;   // [3,H,W]
 	float* partials;        // [R][12] per-instance gradient slots (blend.h); only slots flagged in `touched` are meaningful
 	uint8_t* touched;       // [R] zeroed by the caller; set to 1 for every slot written
+	const uint8_t* contrib; // [4][contrib_stride] the forward blend's per-quad contribution flags
+	size_t contrib_stride;
 	int W, H, grid_x, tiles;
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);

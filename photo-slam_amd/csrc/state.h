@@ -126,6 +126,8 @@ struct BinningState {
 	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
 	float*    partials;      // [12R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
 	uint8_t*  touched;       // [R] 1 where the backward blend wrote the slot (cleared per backward; the slots themselves are not)
+	uint8_t*  contrib;       // [4][R] per quad of the tile: 1 where the forward blend found a pixel of the quad that blends the
+	                         // list entry (written by blend_fwd for the batches it walks, read by blend_bwd: blend.h)
 
 	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
 	{
@@ -140,6 +142,7 @@ struct BinningState {
 		// readers fetch flags 16 bytes at a time (+ 64); the clear covers touched_clear_bytes(R): a multiple of 256 bytes, because
 		// the runtime splits a memset of any other size into two kernels (body + tail, 5 us each)
 		b.touched = c.take<uint8_t>(touched_clear_bytes(R));
+		b.contrib = c.take<uint8_t>(4 * R + 64);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}
