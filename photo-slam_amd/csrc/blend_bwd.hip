@@ -113,7 +113,11 @@ blend_bwd_kernel(const BlendBwdParams p)
 				wave_fence();
 				while (m) {
 					const int bit = 63 - __clzll((long long)m);
+#ifdef GSR_EMU
 					m &= ~(1ull << bit);
+#else
+					asm volatile("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));   // (one scalar instruction instead of shift + andn2)
+#endif
 					const uint32_t pos = (uint32_t)(base + bit);
 					const float4 g0 = s_rec[quad][bit][0];
 					const float4 g1 = s_rec[quad][bit][1];

@@ -57,11 +57,18 @@ blend_fwd_kernel(const BlendFwdParams p)
 		}
 		unsigned long long m = wave_ballot(keep);
 		wave_fence();
-		bool wave_done = false;
 		unsigned long long contrib_m = 0ull;   // entries of this batch that some pixel of the quad blends (scalar)
+		// The visit loop is bound by VALU issue AND sensitive to scalar issue (three more scalar instructions per visit cost
+		// 12 us per launch): its control flow is one scalar mask -- the surviving entries not yet visited, emptied when every
+		// pixel is saturated -- cleared bit by bit with s_bitset0_b64 (the compiler's m &= m - 1 is three instructions) and
+		// tested once per iteration.
 		while (m) {
 			const int bit = __ffsll((long long)m) - 1;
+#ifdef GSR_EMU
 			m &= m - 1ull;
+#else
+			asm volatile("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+#endif
 			const float4 g0 = s_rec[bit][0];
 			const float4 g1 = s_rec[bit][1];
 			const float gb = s_rec[bit][2].x;
@@ -75,8 +82,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 #ifdef GSR_EMU
 			if (upd_m) contrib_m |= 1ull << bit;
 #else
-			// contrib_m |= upd_m ? 1 << bit : 0 in three scalar instructions (the compiler's select form takes five, and the
-			// loop is sensitive to scalar issue: +26 us per launch with those, tools/gpu_r2x.sh)
+			// contrib_m |= upd_m ? 1 << bit : 0 in three scalar instructions (the compiler's select form takes five)
 			asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cbranch_scc0 1f\n\ts_bitset1_b64 %0, %2\n1:" : "+s"(contrib_m) : "s"(upd_m), "s"(bit) : "scc");
 #endif
 			done_m |= ok_m & below_m;
@@ -85,11 +91,14 @@ blend_fwd_kernel(const BlendFwdParams p)
 			Cb += gb * wgt;
 			T = mask_select_f32(upd_m, test_T, T);
 			last_contributor = mask_select_u32(upd_m, (uint32_t)(base + bit + 1), last_contributor);
-			if (~done_m == 0ull) {
-				wave_done = true;
-				break;
-			}
+			// every pixel saturated: the rest of the batch is not visited
+#ifdef GSR_EMU
+			m = (~done_m == 0ull) ? 0ull : m;
+#else
+			asm volatile("s_cmp_eq_u64 %1, -1\n\ts_cselect_b64 %0, 0, %0" : "+s"(m) : "s"(done_m) : "scc");
+#endif
 		}
+		const bool wave_done = ~done_m == 0ull;
 		// the backward pass walks the same batches: it visits only the entries flagged here (15 % of the entries that survive the
 		// quad rejection blend into no pixel -- alpha below 1/255 at every pixel centre, or every such pixel saturated)
 		if (have) p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] = (uint8_t)((contrib_m >> l) & 1ull);
