@@ -32,7 +32,11 @@ blend_fwd_kernel(const BlendFwdParams p)
 
 	float T = 1.0f;
 	typedef float v2f __attribute__((vector_size(8)));
-	v2f Crg = {0.f, 0.f};   // red and green ride in one v_pk_fma_f32
+#ifdef GSR_EMU
+	v2f Crg = {0.f, 0.f};
+#else
+	float Cr = 0.f, Cg = 0.f;
+#endif
 	float Cb = 0.f;
 	uint32_t last_contributor = 0;
 	// pixel state predicates live as 64-bit lane masks in SGPR pairs; their logic is scalar
@@ -58,10 +62,10 @@ blend_fwd_kernel(const BlendFwdParams p)
 		unsigned long long m = wave_ballot(keep);
 		wave_fence();
 		unsigned long long contrib_m = 0ull;   // entries of this batch that some pixel of the quad blends (scalar)
-		// The visit loop is bound by VALU issue AND sensitive to scalar issue (three more scalar instructions per visit cost
-		// 12 us per launch): its control flow is one scalar mask -- the surviving entries not yet visited, emptied when every
-		// pixel is saturated -- cleared bit by bit with s_bitset0_b64 (the compiler's m &= m - 1 is three instructions) and
-		// tested once per iteration.
+		// The visit loop is bound by VALU issue AND by scalar issue (one scalar unit serves the CU's four SIMDs: ~4 SIMD cycles
+		// per scalar instruction against ~75 of VALU issue per visit; three more scalar instructions per visit cost 12 us per
+		// launch): its control flow is one scalar mask, the surviving entries not yet visited, cleared bit by bit with
+		// s_bitset0_b64 (the compiler's m &= m - 1 is three instructions) and tested once per iteration.
 		while (m) {
 			const int bit = __ffsll((long long)m) - 1;
 #ifdef GSR_EMU
@@ -78,25 +82,47 @@ blend_fwd_kernel(const BlendFwdParams p)
 			const unsigned long long ok_m = wave_ballot(!(pw > 0.0f)) & wave_ballot(!(alpha < 1.0f / 255.0f)) & ~done_m;
 			const float test_T = T * (1.f - alpha);
 			const unsigned long long below_m = wave_ballot(test_T < 0.0001f);
-			const unsigned long long upd_m = ok_m & ~below_m;
 #ifdef GSR_EMU
+			const unsigned long long upd_m = ok_m & ~below_m;
 			if (upd_m) contrib_m |= 1ull << bit;
 #else
-			// contrib_m |= upd_m ? 1 << bit : 0 in three scalar instructions (the compiler's select form takes five)
-			asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cbranch_scc0 1f\n\ts_bitset1_b64 %0, %2\n1:" : "+s"(contrib_m) : "s"(upd_m), "s"(bit) : "scc");
+			// upd_m = ok_m & ~below_m, and contrib_m |= upd_m ? 1 << bit : 0 off the SCC that s_andn2_b64 leaves (three scalar
+			// instructions for both; the compiler's select form of the second alone takes five)
+			unsigned long long upd_m;
+			asm volatile("s_andn2_b64 %[upd], %[ok], %[below]\n\ts_cbranch_scc0 1f\n\ts_bitset1_b64 %[c], %[bit]\n1:"
+			             : [upd] "=&s"(upd_m), [c] "+s"(contrib_m) : [ok] "s"(ok_m), [below] "s"(below_m), [bit] "s"(bit) : "scc");
 #endif
 			done_m |= ok_m & below_m;
+#ifdef GSR_EMU
 			const float wgt = mask_select0_f32(upd_m, alpha * T);
 			Crg += (v2f){g1.z, g1.w} * (v2f){wgt, wgt};
 			Cb += gb * wgt;
 			T = mask_select_f32(upd_m, test_T, T);
 			last_contributor = mask_select_u32(upd_m, (uint32_t)(base + bit + 1), last_contributor);
-			// every pixel saturated: the rest of the batch is not visited
-#ifdef GSR_EMU
-			m = (~done_m == 0ull) ? 0ull : m;
 #else
-			asm volatile("s_cmp_eq_u64 %1, -1\n\ts_cselect_b64 %0, 0, %0" : "+s"(m) : "s"(done_m) : "scc");
+			// The state of the pixels that blend this entry is updated UNDER EXEC = upd_m: three v_fmac and two v_mov (17 issue
+			// cycles) instead of a multiply-by-select, a packed fma, and two selects each behind a v_mov (27 of the visit's 85);
+			// costs two scalar instructions.
+			{
+				const float wgt = alpha * T;
+				const uint32_t contributor = (uint32_t)(base + bit + 1);
+				unsigned long long saved_exec;
+				asm volatile("s_and_saveexec_b64 %[save], %[upd]\n\t"
+				             "v_fmac_f32 %[cr], %[gr], %[w]\n\t"
+				             "v_fmac_f32 %[cg], %[gg], %[w]\n\t"
+				             "v_fmac_f32 %[cb], %[gbv], %[w]\n\t"
+				             "v_mov_b32 %[t], %[tt]\n\t"
+				             "v_mov_b32 %[last], %[c]\n\t"
+				             "s_mov_b64 exec, %[save]"
+				             : [save] "=&s"(saved_exec), [cr] "+v"(Cr), [cg] "+v"(Cg), [cb] "+v"(Cb), [t] "+v"(T), [last] "+v"(last_contributor)
+				             : [upd] "s"(upd_m), [gr] "v"(g1.z), [gg] "v"(g1.w), [gbv] "v"(gb), [w] "v"(wgt), [tt] "v"(test_T), [c] "s"(contributor)
+				             : "scc");
+			}
 #endif
+			// (No test for "every pixel saturated" here: the rest of the batch then changes nothing -- ok_m excludes the saturated
+			// pixels -- and is at most a few dozen visits once per quad; the test cost every visit two scalar instructions.
+			// Tried and rejected: reading the NEXT entry's record from LDS while the current one is blended, unrolled by two so
+			// that the register sets alternate -- 22 instead of 15 scalar instructions per visit, 0.212 instead of 0.188 ms.)
 		}
 		const bool wave_done = ~done_m == 0ull;
 		// the backward pass walks the same batches: it visits only the entries flagged here (15 % of the entries that survive the
@@ -111,8 +137,11 @@ blend_fwd_kernel(const BlendFwdParams p)
 		const size_t plane = (size_t)p.H * p.W;
 		p.final_T[pix] = T;
 		p.n_contrib[pix] = last_contributor;
-		p.out_color[pix] = Crg[0] + T * p.bg[0];
-		p.out_color[plane + pix] = Crg[1] + T * p.bg[1];
+#ifdef GSR_EMU
+		const float Cr = Crg[0], Cg = Crg[1];
+#endif
+		p.out_color[pix] = Cr + T * p.bg[0];
+		p.out_color[plane + pix] = Cg + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];
 	}
 }
