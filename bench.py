@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--sh-adam-window", type=int, default=32,
                     help="lazy Adam steps for the SH rows of culled Gaussians, at most this many at a time (gsr_sh_adam_lazy; "
                          "0 = every row steps eagerly at every iteration)")
+    ap.add_argument("--scene-order", default="random", choices=["random", "morton"],
+                    help="index order of the synthetic Gaussians: 'random' (as generated: i.i.d. positions, so the ~47 %% a view sees are "
+                         "a random subset of every cache line of every per-Gaussian array -- the headline) or 'morton' (sorted along a "
+                         "Z-order curve: the index coherence of a map that grows keyframe by keyframe)")
     ap.add_argument("--no-fused-geom-adam", action="store_true",
                     help="xyz / opacity / scaling / rotation step in four separate Adam passes instead of inside the backward kernels")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
@@ -199,6 +203,17 @@ def main():
 
     cfg = scene.CONFIGS[args.config]
     cl = scene.make_config(args.config, seed=0, n_views=max(world, 1), P=args.points)
+    if args.scene_order == "morton":
+        # the same cloud, re-indexed along a Z-order curve (10 bits per axis)
+        q = ((cl.xyz - cl.xyz.min(0)) / (np.ptp(cl.xyz, axis=0) + 1e-9) * 1023.0).astype(np.uint64)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+        for name in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+            setattr(cl, name, np.ascontiguousarray(getattr(cl, name)[order]))
     cam = cl.cameras[rank % len(cl.cameras)]
     W, H, P = cam.W, cam.H, cl.xyz.shape[0]
     g = GaussianModel.from_cloud(cl, device=dev)
@@ -472,7 +487,7 @@ def main():
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "learning_rates": lr_note,
                        "sh_adam_fused_into_backward": fused_sh_adam,
-                       "sh_adam_lazy_window": lazy_window,
+                       "sh_adam_lazy_window": lazy_window, "scene_index_order": args.scene_order,
                        "geometry_adam_fused_into_backward": bool(fused_sh_adam and not args.no_fused_geom_adam),
                        "gaussians_after": int(g.xyz_.shape[0]) if ops is None else int(ops.trainer_params(handle)[0].shape[0]),
                        "host": "libtorch-c++ (photo-slam_amd/host)" if ops is not None else "python mirror"},
