@@ -27,7 +27,7 @@ constexpr int EMIT_SLOTS = 256;
 
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                      const uint16_t* __restrict__ rect, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                      const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                       float4* __restrict__ rec)
 {
 	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
@@ -57,7 +57,7 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 			if (s_off[w][j + step] <= slot) j += step;
 		const uint32_t k = slot - s_off[w][j];
 		const uint32_t g = order[r0 + j];
-		const uint2 r = reinterpret_cast<const uint2*>(rect)[g];
+		const uint2 r = rect_sorted[r0 + j];   // (in depth order: left there by the offset scan, sort.hip)
 		const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
 		const uint32_t wdt = maxx - minx;
 		const uint32_t yy = k / wdt;
@@ -93,7 +93,7 @@ int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint
 {
 	if (R <= 0) return GSR_OK;
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
-	           (const uint32_t*)g.offsets, (const uint16_t*)g.rect, grid_x, keys, vals, g.rec);
+	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -245,7 +245,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);
-	if ((st = launch_scan_u32(g.tiles_touched, g.order, g.offsets, P, false, g.scan_scratch, stream, g.visible)) != GSR_OK) return st;
+	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
+	                                 g.visible)) != GSR_OK)
+		return st;
 	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));

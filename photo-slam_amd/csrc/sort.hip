@@ -56,6 +56,33 @@ scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// The same first pass for the offsets of the instance emission: the element is the tile count of the rectangle of Gaussian
+// gather[i] -- ONE random gather serves the scan (the count) and the emission (the rectangle, left in rect_sorted in scan
+// order) where there used to be two, of tiles_touched here and of the rectangle there (60 MB of 64-byte lines each at C3).
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_reduce_rect_kernel(const uint2* __restrict__ rect, const uint32_t* __restrict__ gather, uint32_t* __restrict__ staged,
+                        uint2* __restrict__ rect_sorted, uint32_t* __restrict__ block_sums, int n, int items_per_block,
+                        const uint32_t* __restrict__ n_dev)
+{
+	__shared__ uint32_t s_wave[4];
+	const int base = blockIdx.x * items_per_block;
+	const int end_all = min(n, base + items_per_block);
+	const int end = n_dev ? min(end_all, (int)*n_dev) : end_all;
+	uint32_t acc = 0;
+	if (n_dev)
+		for (int i = max(base, end) + (int)threadIdx.x; i < end_all; i += SCAN_THREADS) staged[i] = 0u;
+	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) {
+		const uint2 r = rect[gather[i]];
+		const uint32_t v = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
+		rect_sorted[i] = r;
+		staged[i] = v;
+		acc += v;
+	}
+	uint32_t tot;
+	block_excl_scan_256(acc, &tot, s_wave);
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
 // Single workgroup: in-place exclusive scan of the block sums (nblocks <= 1024 * 4).
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_spine_kernel(uint32_t* __restrict__ block_sums, int nblocks)
@@ -88,6 +115,21 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 		if (i < end) out[i] = carry + ex + (inclusive ? v : 0u);
 		carry += tot;
 	}
+}
+
+int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
+                           hipStream_t stream, const uint32_t* n_dev)
+{
+	if (!rect || !gather || !out || !rect_sorted) return GSR_ERR_INVALID_ARG;
+	if (n <= 0) return GSR_OK;
+	const int ipb = scan_items_per_block(n);
+	const int nb = div_up(n, ipb);
+	GSR_LAUNCH(scan_reduce_rect_kernel, nb, SCAN_THREADS, stream, rect, gather, out, rect_sorted, scratch, n, ipb, n_dev);
+	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
+	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, (const uint32_t*)out, (const uint32_t*)nullptr, out,
+	           (const uint32_t*)scratch, n, ipb, 0);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
 }
 
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,

@@ -74,6 +74,8 @@ struct GeometryState {
 	uint32_t* sort_vals_b;    // [P]
 	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
+	uint2*    rect_sorted;    // [P] the tile rectangles in depth order (entry i belongs to order[i]): gathered once by the offset
+	                          // scan, read linearly by the instance emission
 	uint32_t* visible;        // [32] [0] number of visible Gaussians V, left by the first pass of the depth sort
 	// ids of the Gaussians that touch more than LONG_RUN tiles, in LONG_LISTS sub-lists (preprocess block b appends to
 	// sub-list b % LONG_LISTS, whose capacity long_list_capacity(P) covers all its blocks): one global counter would
@@ -100,6 +102,7 @@ struct GeometryState {
 		g.sort_vals_b = c.take<uint32_t>(P);
 		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
+		g.rect_sorted = c.take<uint2>(P);
 		g.visible = c.take<uint32_t>(32);
 		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
 		// the two arrays the forward pass has to find zeroed sit next to each other: ONE memset (zeroed_bytes())
@@ -185,6 +188,10 @@ static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((u
 
 // ---- device launchers (one per translation unit) ------------------------------------
 // n_dev (nullable, with gather only): a device word; elements from *n_dev on count as zeros (their gather indices are undefined)
+// exclusive scan of the tile counts of rect[gather[i]] ((maxx - minx) * (maxy - miny), packed as preprocess_fwd writes them) into
+// out, with the gathered rectangles left in rect_sorted; elements from *n_dev on count as zeros
+int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
+                           hipStream_t stream, const uint32_t* n_dev);
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
                     uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
