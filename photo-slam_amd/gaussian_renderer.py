@@ -35,7 +35,7 @@ class GaussianRenderer:
     @staticmethod
     def render(viewpoint_camera, image_height, image_width, pc, pipe, bg_color, override_color=None,
                scaling_modifier=1.0, use_override_color=False, fuse_activations=True, sh_grad_view=None, sh_adam=None, view_stats=None,
-               geom_adam=None):
+               geom_adam=None, training_outputs_only=False):
         """returns (render, viewspace_points, visibility_filter, radii)
 
         fuse_activations (extension; False = the reference data flow): hand the raw opacity / scaling / rotation
@@ -43,9 +43,11 @@ class GaussianRenderer:
         backward preprocess -- same result, ~13 fewer elementwise launches and 3 fewer [P,*] temporaries per step.
 
         sh_grad_view, sh_adam, view_stats, geom_adam (extensions; None = the reference data flow): see
-        GaussianRasterizationSettings."""
+        GaussianRasterizationSettings.  training_outputs_only: the viewspace gradient and dL_dcov3D are not computed (for a caller
+        whose densification statistics are fused: view_stats); implied by geom_adam."""
         # (with the fused geometry step nobody reads its gradient and the rasterizer never reads its values: no zero fill then)
-        screenspace_points = (torch.empty_like if geom_adam is not None else torch.zeros_like)(pc.getXYZ(), requires_grad=True)
+        slim = geom_adam is not None or training_outputs_only
+        screenspace_points = (torch.empty_like if slim else torch.zeros_like)(pc.getXYZ(), requires_grad=True)
         try:
             screenspace_points.retain_grad()
         except Exception:
@@ -58,7 +60,7 @@ class GaussianRenderer:
             viewpoint_camera.world_view_transform_, viewpoint_camera.full_proj_transform_, pc.active_sh_degree_,
             viewpoint_camera.camera_center_, False, raw,
             sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats,
-            geom_adam if raw == 7 else None, bool(geom_adam is not None and raw == 7))
+            geom_adam if raw == 7 else None, bool((geom_adam is not None or training_outputs_only) and raw == 7))
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points
@@ -87,4 +89,4 @@ class GaussianRenderer:
         rendered_image, radii = rasterizer(means3D, means2D, opacity, has_shs, has_color_precomp, has_sr, has_sr,
                                            pipe.compute_cov3D_, shs, colors_precomp, scales, rotations, cov3D_precomp)
         # (visibility_filter is one more launch: with the fused geometry step its consumers are fused too -- None then)
-        return rendered_image, screenspace_points, (None if geom_adam is not None else radii > 0), radii
+        return rendered_image, screenspace_points, (None if slim else radii > 0), radii

@@ -242,8 +242,9 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 			geom_adam.lr.push_back(grp.lr * g->lr_scale_);
 			geom_adam.step.push_back(grp.step);
 		}
-		geom_adam.training_outputs_only = true;   // the statistics are fused (or over): nobody reads the viewspace gradient
 	}
+	// the statistics are fused (or over) in every mode of this step: nobody reads the viewspace gradient or dL_dcov3D
+	geom_adam.training_outputs_only = true;
 	// the densification statistics of this view (:714-719) are added by the backward kernel that holds dL_dmean2D in
 	// registers
 	std::vector<torch::Tensor> view_stats;

@@ -244,7 +244,8 @@ class TrainStep:
         try:
             rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
                 viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats, geom_adam=geom_adam)
+                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats, geom_adam=geom_adam,
+                training_outputs_only=True)   # the statistics are fused (or over): nobody reads the viewspace gradient
         finally:
             g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
