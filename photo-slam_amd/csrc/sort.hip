@@ -326,9 +326,12 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 	}
 	const uint32_t* kin = keys_in;
 	const uint32_t* vin = vals_in;
+	// the key bits are spread evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): a pass scatters into 2^nbits streams,
+	// and with fewer streams a workgroup's runs per stream are longer, i.e. its writes better coalesced
+	const int bits_per_pass = div_up(end_bit - begin_bit, passes);
 	for (int p = 0; p < passes; p++) {
-		const int shift = begin_bit + p * RADIX_BITS;
-		const int nbits = min(RADIX_BITS, end_bit - shift);
+		const int shift = begin_bit + p * bits_per_pass;
+		const int nbits = min(bits_per_pass, end_bit - shift);
 		uint32_t* kout = (p % 2 == 0) ? keys_pong : keys_ping;
 		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
 		const uint32_t* n_dev = (compact_count && p > 0) ? compact_count : nullptr;
