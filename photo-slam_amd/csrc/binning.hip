@@ -28,13 +28,21 @@ constexpr int EMIT_SLOTS = 256;
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                      float4* __restrict__ rec)
+                      float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes)
 {
 	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
 	const int w = wave_id(), l = lane_id();
 	const uint32_t s0 = ((uint32_t)blockIdx.x * 4u + (uint32_t)w) * (uint32_t)EMIT_SLOTS;
 	if (s0 >= R) return;   // wave-uniform
 	const uint32_t n = (R - s0) < (uint32_t)EMIT_SLOTS ? (R - s0) : (uint32_t)EMIT_SLOTS;
+	// The slot flags of the backward blend (state.h: touched) start out cleared: this wave clears those of its slots (the wave
+	// that holds the last slot: up to the end of the padded array) -- the backward pass then needs no memset of its own in
+	// front of the blend (two 5 us fill kernels and the bubble behind them); it leaves the flags cleared again when it is done
+	// (sh_bwd_rows_kernel), so any number of backward passes may follow one forward pass.
+	{
+		const uint32_t c_end = (s0 + (uint32_t)EMIT_SLOTS >= R) ? touched_bytes : s0 + (uint32_t)EMIT_SLOTS;
+		for (uint32_t o = s0 + 4u * (uint32_t)l; o < c_end; o += 256u) *reinterpret_cast<uint32_t*>(touched + o) = 0u;
+	}
 	// r0 = last depth rank whose offset is <= s0 (offsets[0] == 0 keeps the invariant offsets[lo] <= s0)
 	uint32_t lo = 0, hi = (uint32_t)P;
 	while (hi - lo > 1u) {
@@ -89,11 +97,13 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 	if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream)
+int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
+                          hipStream_t stream)
 {
 	if (R <= 0) return GSR_OK;
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
-	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec);
+	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
+	           (uint32_t)touched_clear_bytes((size_t)R));
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

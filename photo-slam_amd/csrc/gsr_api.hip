@@ -262,7 +262,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// (im.ranges: zeroed by preprocess_fwd)
 	uint32_t* point_list = bs.vals_a;
 	if (R > 0) {
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, stream)) != GSR_OK) return st;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream)) != GSR_OK) return st;
 		PROF_FWD(4);
 		const int bits = (int)higher_msb((uint32_t)tiles);
 		uint32_t* tkeys = nullptr;
@@ -365,7 +365,10 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
 	// every API output is written exactly once by preprocess_bwd
 	// R bytes of flags instead of 48 R bytes of slots (+ the 64 pad bytes: the reader's byte->bit squeeze needs every byte 0/1)
-	if (R > 0) GSR_HIP(hipMemsetAsync(bs.touched, 0, touched_clear_bytes((size_t)R), stream));
+	// The forward pass hands the flags over cleared (emit_instances_kernel), and on the usual path -- aligned [P,16,3] SH rows:
+	// sh_bwd_rows_kernel runs last -- this pass leaves them cleared again; only the other paths clear them here.
+	const bool rows_path = sh_rows_path(a->shs, a->M, a->D, a->dL_dcolor_view != nullptr, a->sh_adam != nullptr, a->dL_dsh);
+	if (R > 0 && !rows_path) GSR_HIP(hipMemsetAsync(bs.touched, 0, touched_clear_bytes((size_t)R), stream));
 	PROF_BWD(1);
 	if (R > 0) {
 		BlendBwdParams bp;
@@ -404,6 +407,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.adam = AdamScalars{};
 	pb.adam_skip_culled = 0;
 	pb.lazy_row_step = nullptr; pb.lazy_step = 0;
+	pb.touched_clear = (R > 0 && rows_path) ? bs.touched : nullptr;
+	pb.touched_clear_bytes = (uint32_t)touched_clear_bytes((size_t)R);
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
 		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input

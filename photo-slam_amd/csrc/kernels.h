@@ -69,7 +69,8 @@ struct PreprocessParams {
 int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hipStream_t stream);
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
-int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, hipStream_t stream);
+int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
+                          hipStream_t stream);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
 
 struct BlendFwdParams {
@@ -160,10 +161,20 @@ struct PreprocessBwdParams {
 	int adam_skip_culled;     // the culled Gaussians' rows take this step elsewhere (gsr_backward: side stream) or later (lazy)
 	int* lazy_row_step;       // lazy mode: row_step[i] = lazy_step for the rows updated here (the visible ones); null = off
 	int lazy_step;
+	// the slot flags are left cleared for the next backward pass by sh_bwd_rows_kernel (null: the caller clears them itself)
+	uint8_t* touched_clear;
+	uint32_t touched_clear_bytes;
 	// optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_backward_args.geom_adam): their gradients are not written
 	GeomAdam geom;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
+// does the backward preprocess take the two-kernel path of the reference's SH layout (preprocess_bwd_kernel<true> +
+// sh_bwd_rows_kernel)?  (aligned 48-float rows, a row consumer: gradient rows out, the factored colour gradient, or the fused step)
+static inline bool sh_rows_path(const float* shs, int M, int D, bool factored, bool adam, const float* dL_dsh)
+{
+	return shs && 3 * M == 48 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0 && D >= 0 && D <= 3 &&
+	       (factored || adam || (dL_dsh && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0));
+}
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
 struct RowAdam;   // shrows.h: Adam state + scalars of the fused row update (null = write the gradient rows)
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,

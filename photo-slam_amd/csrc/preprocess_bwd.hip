@@ -77,6 +77,11 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
+	// the slot flags have been consumed by the kernels in front of this one: cleared here for the next backward pass (the
+	// forward pass hands them over cleared: emit_instances_kernel), 16 bytes per thread
+	if (p.touched_clear)
+		for (uint32_t o = 16u * (uint32_t)idx; o < p.touched_clear_bytes; o += 16u * (uint32_t)(gridDim.x * blockDim.x))
+			*reinterpret_cast<uint4*>(p.touched_clear + o) = make_uint4(0u, 0u, 0u, 0u);
 	const bool in_range = idx < p.P;
 	const bool vis = in_range && (p.radii[idx] > 0);
 	constexpr int ncoef = (DEG + 1) * (DEG + 1);
@@ -594,8 +599,7 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 	if (p.partials) GSR_LAUNCH(long_run_sums_kernel, LRS_BLOCKS, 256, stream, p);
 	const bool factored = p.dL_dcolor_view != nullptr;
 	const bool adam = p.adam_exp_avg != nullptr;
-	const bool rows_ok = p.shs && (3 * p.M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(p.shs) & 15) == 0) &&
-	                     (factored || adam || (p.dL_dsh && (reinterpret_cast<uintptr_t>(p.dL_dsh) & 15) == 0));
+	const bool rows_ok = sh_rows_path(p.shs, p.M, p.D, factored, adam, p.dL_dsh);   // (includes 0 <= D <= 3)
 	if (adam && (!rows_ok || factored || ((reinterpret_cast<uintptr_t>(p.adam_exp_avg) | reinterpret_cast<uintptr_t>(p.adam_exp_avg_sq)) & 15)))
 		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
 	if (p.geom.on && !(rows_ok && p.D >= 0 && p.D <= 3 && p.scales && p.rotations && p.dL_dmean3D))

@@ -484,3 +484,36 @@ def check_lazy_sh_adam(lib_path, dev, cl, cams, bg, steps=11, window=4, seed=0, 
                 assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (k, np.abs(a - b).max())
     finally:
         rp._LIB_OVERRIDE = None
+
+
+def check_backward_twice(lib_path, dev, cl, bg, seed=0):
+    """Two backward passes on the state of ONE forward pass (retain_graph) give the same gradients: the per-slot flags of the
+    gradient hand-off are handed over cleared by the forward pass and left cleared by every backward pass (no memset in
+    between: emit_instances_kernel / sh_bwd_rows_kernel)."""
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        rng = np.random.default_rng(seed)
+        cam = cl.cameras[0]
+        empty = torch.empty(0, device=dev)
+        t = lambda a: _t(a, dev)
+        args = dict(background=t(bg), means3D=t(cl.xyz), colors=empty, opacity=t(cl.get_opacity()), scales=t(cl.get_scaling()),
+                    rotations=t(cl.get_rotation()), scale_modifier=1.0, cov3D_precomp=empty, viewmatrix=t(cam.viewmatrix),
+                    projmatrix=t(cam.projmatrix), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, image_height=cam.H, image_width=cam.W,
+                    sh=t(_features(cl, None)), degree=3, campos=t(cam.campos), prefiltered=False)
+        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**args)
+        grads = []
+        for k in range(3):
+            # the second pass gets another image gradient, the third the first one again
+            dpix = t(np.random.default_rng(seed + (k % 2)).standard_normal((3, cam.H, cam.W)).astype(np.float32))
+            g = rp.RasterizeGaussiansBackwardCUDA(args["background"], args["means3D"], radii, empty, args["scales"], args["rotations"], 1.0,
+                                                  empty, args["viewmatrix"], args["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, args["sh"], 3,
+                                                  args["campos"], geom, R, binning, img)
+            grads.append([x.cpu().numpy().copy() for x in g])
+        assert any(np.abs(a - b).max() > 1e-6 for a, b in zip(grads[0], grads[1]))   # (the middle pass did differ)
+        for a, b in zip(grads[0], grads[2]):
+            if dev.type == "cpu":
+                assert np.array_equal(a, b)
+            else:
+                assert rel_l1(b, a) < 2e-5
+    finally:
+        rp._LIB_OVERRIDE = None

@@ -134,6 +134,10 @@ def test_fused_sh_adam(emu_lib_path, degree):
                                sh_degree=degree)
 
 
+def test_backward_may_follow_one_forward_more_than_once(emu_lib_path):
+    parity.check_backward_twice(emu_lib_path, CPU, _scene(P=400, seed=26), np.array([0.1, 0.2, 0.3], np.float32))
+
+
 def test_fused_geom_adam(emu_lib_path):
     parity.check_fused_geom_adam(emu_lib_path, CPU, _scene(P=330, seed=25), np.array([0.1, 0.2, 0.3], np.float32))
 

@@ -127,6 +127,12 @@ def test_fused_sh_adam(dev):
 
 
 @pytest.mark.gpu
+def test_backward_may_follow_one_forward_more_than_once(dev):
+    cl = scene.make_cloud(80_000, 640, 480, 400.0, 400.0, seed=16)
+    parity.check_backward_twice(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
+
+
+@pytest.mark.gpu
 def test_fused_geom_adam(dev):
     cl = scene.make_cloud(60_000, 320, 240, 250.0, 250.0, seed=12)
     parity.check_fused_geom_adam(None, dev, cl, np.array([0.1, 0.2, 0.3], np.float32))
