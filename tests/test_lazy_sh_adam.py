@@ -19,7 +19,7 @@ def _scene(P, W, H, seed):
     return cl, cams
 
 
-@pytest.mark.parametrize("window,steps", [(4, 9), (2, 5), (32, 7)])
+@pytest.mark.parametrize("window,steps", [(4, 9), (32, 7)])
 def test_lazy_sh_adam_equals_the_eager_update(emu_lib_path, window, steps):
     cl, cams = _scene(320, 48, 32, seed=11)
     parity.check_lazy_sh_adam(emu_lib_path, torch.device("cpu"), cl, cams, np.array([0.1, 0.2, 0.3], np.float32), steps=steps,
