@@ -1,7 +1,9 @@
 #!/bin/bash
+# SQ counters per gsr kernel (VALU / SALU / LDS instruction counts, cycles).  PMC_MODE=full: the fused train step (loss, optimizer
+# kernels) instead of the rasterizer alone -> gpurun_out/sq_counters_full.json
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python __graft_entry__.py > gpurun_out/build.log 2>&1
-rm -rf /tmp/sq; (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --raster-only --no-cpu-baseline --median-steps 0 > /tmp/sq.log 2>&1)
+rm -rf /tmp/sq; (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $( [ "$PMC_MODE" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 > /tmp/sq.log 2>&1)
 tail -2 /tmp/sq.log | cut -c1-160
 python - <<'PY'
 import csv, glob, collections
@@ -24,7 +26,8 @@ for k, d in out.items():
         # instruction mix (tools/isa_cost.py with profiles/r02_a_valu_rate.json: ~3.9 cycles for blend_fwd, ~4.5 for blend_bwd);
         # there is no single "cycles per VALU instruction" on gfx950 (2.5 ... 8.2 by class)
         d["simd_cycles_per_valu_inst"] = 1024 * d["kernel_cycles"] / d["SQ_INSTS_VALU"]
-json.dump(out, open("gpurun_out/sq_counters.json", "w"), indent=1)
-for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:8]:
+import os
+json.dump(out, open("gpurun_out/sq_counters_full.json" if os.environ.get("PMC_MODE") == "full" else "gpurun_out/sq_counters.json", "w"), indent=1)
+for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:14]:
     print(k, {c: f"{v:.3g}" for c, v in d.items()})
 PY
