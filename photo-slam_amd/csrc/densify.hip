@@ -63,8 +63,9 @@ __device__ __forceinline__ uint32_t densify_flags(const DensifySelect& p, int i)
 	const float s0 = expf(p.scaling[3 * (size_t)i + 0]), s1 = expf(p.scaling[3 * (size_t)i + 1]), s2 = expf(p.scaling[3 * (size_t)i + 2]);
 	const float smax = fmaxf(fmaxf(s0, s1), s2);
 	const bool big = smax > p.thr_dense;
-	// densifyAndClone (:768-773): frobenius_norm over the last dimension of [P,1] = sqrt(g*g); densifyAndSplit (:723-730): g itself
-	const bool clone_sel = (sqrtf(g * g) >= p.max_grad) && !big;
+	// densifyAndClone (:768-773): frobenius_norm over the last dimension of [P,1], i.e. |g| (ATen's norm kernel scales by the
+	// maximum: no overflow / underflow of g*g for |g| outside 1e-19 .. 1.8e19); densifyAndSplit (:723-730): g itself
+	const bool clone_sel = (fabsf(g) >= p.max_grad) && !big;
 	const bool split_sel = (g >= p.max_grad) && big;
 	// the final prune (:805-813) on the would-be rows
 	const float op = 1.0f / (1.0f + expf(-p.opacity[i]));

@@ -318,11 +318,50 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
 	t_prof.bwd_done = false;
+	// ---- the rest of the validation, BEFORE anything is enqueued: a call that is going to be refused must not have applied a
+	// part of an optimizer step already (the culled rows' update below is forked onto a second stream first thing)
+	const bool rows_path = sh_rows_path(a->shs, a->M, a->D, a->dL_dcolor_view != nullptr, a->sh_adam != nullptr, a->dL_dsh);
+	if (!a->dL_dcov3D && a->cov3D_precomp) return GSR_ERR_INVALID_ARG;
+	if (a->sh_adam) {
+		const gsr_sh_adam& o = *a->sh_adam;
+		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input
+		// the fused step exists for aligned [P,16,3] rows only (launch_preprocess_bwd)
+		if (!rows_path || ((reinterpret_cast<uintptr_t>(o.exp_avg) | reinterpret_cast<uintptr_t>(o.exp_avg_sq)) & 15))
+			return GSR_ERR_UNSUPPORTED;
+	}
+	GeomAdam geom{};
+	if (a->geom_adam) {
+		const gsr_geom_adam& o = *a->geom_adam;
+		const int all_raw = GSR_RAW_OPACITY | GSR_RAW_SCALING | GSR_RAW_ROTATION;
+		const gsr_adam_tensor* ts[4] = {&o.xyz, &o.opacity, &o.scaling, &o.rotation};
+		for (const gsr_adam_tensor* t : ts)
+			if (!t->param || !t->exp_avg || !t->exp_avg_sq || t->step < 1) return GSR_ERR_INVALID_ARG;
+		if ((a->raw_params & all_raw) != all_raw || a->cov3D_precomp || o.xyz.param != a->means3D || o.scaling.param != a->scales ||
+		    o.rotation.param != a->rotations || !a->dL_dmean3D || a->dL_dcolor_view)
+			return GSR_ERR_INVALID_ARG;
+		if ((reinterpret_cast<uintptr_t>(o.rotation.param) | reinterpret_cast<uintptr_t>(o.rotation.exp_avg) |
+		     reinterpret_cast<uintptr_t>(o.rotation.exp_avg_sq)) & 15)
+			return GSR_ERR_UNSUPPORTED;
+		// the fused geometry step lives in the two-kernel path of the reference's SH layout (launch_preprocess_bwd)
+		if (!(rows_path && a->scales && a->rotations)) return GSR_ERR_UNSUPPORTED;
+		auto fill = [&](const gsr_adam_tensor& t, GeomAdamTensor& gt) {
+			gt.param = t.param; gt.exp_avg = t.exp_avg; gt.exp_avg_sq = t.exp_avg_sq;
+			gt.s = adam_scalars(t.lr, t.lr, o.beta1, o.beta2, o.eps, t.step);
+		};
+		geom.on = 1;
+		fill(o.xyz, geom.xyz); fill(o.opacity, geom.opacity); fill(o.scaling, geom.scaling); fill(o.rotation, geom.rotation);
+	}
 	// Fused Adam step of the SH tensor: the rows of the CULLED Gaussians carry a zero gradient, i.e. their update does not
 	// depend on anything this pass computes.  It runs on a second stream from here on -- HBM-bound streaming (1152 B per culled
 	// Gaussian) next to the VALU-bound backward blend, which leaves HBM nearly idle -- and is joined at the end; the row kernel
 	// behind preprocess_bwd then updates the visible rows only.  (Only the radii of the forward pass are read.)
 	bool side_busy = false;
+	// an error exit taken while the second stream holds work of this call: join it first, so that nothing of this call is still
+	// writing the caller's tensors when the caller sees the status
+	auto fail = [&](int status) -> int {
+		if (side_busy) (void)hipStreamWaitEvent(stream, t_sync.join, 0);
+		return status;
+	};
 	const bool lazy = a->sh_adam && a->sh_adam->lazy;
 	LazyAdam la{};
 	if (lazy) {
@@ -341,25 +380,24 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		if (s2 != GSR_OK) return s2;
 		GSR_HIP(hipEventRecord(t_sync.fork, stream));
 		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
-		if ((s2 = launch_sh_adam_lazy(P, radii, la, t_sync.side)) != GSR_OK) return s2;
+		s2 = launch_sh_adam_lazy(P, radii, la, t_sync.side);
+		// (recorded even after a failed launch: whatever did reach the second stream is joined by fail())
 		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
 		side_busy = true;
-		return GSR_OK;
+		return s2;
 	};
 	if (lazy) {
 		// (launched behind the backward blend, below)
-	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled() &&
-	    !((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg) |
-	       reinterpret_cast<uintptr_t>(a->sh_adam->exp_avg_sq)) & 15)) {
+	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled()) {
 		const gsr_sh_adam& o = *a->sh_adam;
-		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;
 		if ((st = t_sync.init_side()) != GSR_OK) return st;
 		const RowAdam ra = {o.param, o.exp_avg, o.exp_avg_sq, adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step)};
 		GSR_HIP(hipEventRecord(t_sync.fork, stream));
 		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
-		if ((st = launch_sh_adam_culled(P, a->radii ? a->radii : g.radii, ra, t_sync.side)) != GSR_OK) return st;
+		st = launch_sh_adam_culled(P, a->radii ? a->radii : g.radii, ra, t_sync.side);
 		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
 		side_busy = true;
+		if (st != GSR_OK) return fail(st);
 	}
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
@@ -367,7 +405,6 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// R bytes of flags instead of 48 R bytes of slots (+ the 64 pad bytes: the reader's byte->bit squeeze needs every byte 0/1)
 	// The forward pass hands the flags over cleared (emit_instances_kernel), and on the usual path -- aligned [P,16,3] SH rows:
 	// sh_bwd_rows_kernel runs last -- this pass leaves them cleared again; only the other paths clear them here.
-	const bool rows_path = sh_rows_path(a->shs, a->M, a->D, a->dL_dcolor_view != nullptr, a->sh_adam != nullptr, a->dL_dsh);
 	if (R > 0 && !rows_path) GSR_HIP(hipMemsetAsync(bs.touched, 0, touched_clear_bytes((size_t)R), stream));
 	PROF_BWD(1);
 	if (R > 0) {
@@ -378,12 +415,12 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.touched = bs.touched;
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
-		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return st;
+		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);
 	// ... next to the HBM-bound per-Gaussian backward kernels that follow.  (Next to the VALU-bound blend it costs the same: the
 	// blend then takes 30 us longer and the kernels behind it 30 us less, tools/gpu_r2p.sh.)
-	if (lazy && (st = launch_lazy_slice()) != GSR_OK) return st;
+	if (lazy && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;
@@ -411,35 +448,14 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.touched_clear_bytes = (uint32_t)touched_clear_bytes((size_t)R);
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
-		if (o.param != a->shs || !o.param) return GSR_ERR_INVALID_ARG;   // the writable alias of the (const) SH input
 		pb.adam_param = o.param;
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
 		pb.adam = adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step);
 		pb.adam_skip_culled = (side_busy || lazy) ? 1 : 0;
 		if (lazy) { pb.lazy_row_step = la.row_step; pb.lazy_step = la.step; }
 	}
-	pb.geom = GeomAdam{};
-	if (a->geom_adam) {
-		const gsr_geom_adam& o = *a->geom_adam;
-		const int all_raw = GSR_RAW_OPACITY | GSR_RAW_SCALING | GSR_RAW_ROTATION;
-		const gsr_adam_tensor* ts[4] = {&o.xyz, &o.opacity, &o.scaling, &o.rotation};
-		for (const gsr_adam_tensor* t : ts)
-			if (!t->param || !t->exp_avg || !t->exp_avg_sq || t->step < 1) return GSR_ERR_INVALID_ARG;
-		if ((a->raw_params & all_raw) != all_raw || a->cov3D_precomp || o.xyz.param != a->means3D || o.scaling.param != a->scales ||
-		    o.rotation.param != a->rotations || !a->dL_dmean3D || a->dL_dcolor_view)
-			return GSR_ERR_INVALID_ARG;
-		if ((reinterpret_cast<uintptr_t>(o.rotation.param) | reinterpret_cast<uintptr_t>(o.rotation.exp_avg) |
-		     reinterpret_cast<uintptr_t>(o.rotation.exp_avg_sq)) & 15)
-			return GSR_ERR_UNSUPPORTED;
-		auto fill = [&](const gsr_adam_tensor& t, GeomAdamTensor& g) {
-			g.param = t.param; g.exp_avg = t.exp_avg; g.exp_avg_sq = t.exp_avg_sq;
-			g.s = adam_scalars(t.lr, t.lr, o.beta1, o.beta2, o.eps, t.step);
-		};
-		pb.geom.on = 1;
-		fill(o.xyz, pb.geom.xyz); fill(o.opacity, pb.geom.opacity); fill(o.scaling, pb.geom.scaling); fill(o.rotation, pb.geom.rotation);
-	}
-	if (!a->dL_dcov3D && a->cov3D_precomp) return GSR_ERR_INVALID_ARG;
-	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return st;
+	pb.geom = geom;
+	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return fail(st);
 	if (side_busy) GSR_HIP(hipStreamWaitEvent(stream, t_sync.join, 0));   // whatever follows on the caller's stream sees the whole update
 	PROF_BWD(3);
 	t_prof.bwd_done = t_prof.on != 0;

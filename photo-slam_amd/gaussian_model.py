@@ -195,7 +195,9 @@ class GaussianModel:
     def from_cloud(cls, cloud, device="cuda", sh_degree=3):
         """Load a scene.Cloud (raw parameters) -- stands in for createFromPcd/loadPly in benchmarks."""
         m = cls(sh_degree, device)
-        t = lambda a: torch.from_numpy(a).to(m.device_).contiguous().requires_grad_(True)
+        # (a copy also on the host: the fused optimizer steps update the leaves in place, and from_numpy() alone would alias
+        # the cloud's arrays there)
+        t = lambda a: torch.from_numpy(a).to(m.device_, copy=True).contiguous().requires_grad_(True)
         m.xyz_ = t(cloud.xyz)
         import numpy as _np
         m.features_ = t(_np.concatenate([cloud.features_dc, cloud.features_rest], axis=1))

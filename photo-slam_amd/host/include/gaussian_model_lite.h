@@ -23,6 +23,14 @@ struct GaussianOptimizationParams {  // include/gaussian_parameters.h:61-96 defa
 	float densify_grad_threshold_ = 0.0002f;
 };
 
+#ifndef GSR_HAVE_PIPELINE_PARAMS
+#define GSR_HAVE_PIPELINE_PARAMS
+struct GaussianPipelineParams {   // include/gaussian_parameters.h:41-49
+	bool convert_SHs_ = false;
+	bool compute_cov3D_ = false;
+};
+#endif
+
 struct GaussianKeyframe {
 	int image_height_ = 0, image_width_ = 0;
 	float FoVx_ = 0.f, FoVy_ = 0.f;
@@ -179,6 +187,9 @@ public:
 	// same iterations as fused_sh_adam_.  The viewspace gradient and dL_dcov3D are then not written either.
 	bool fused_geom_adam_ = true;
 	bool factored_exchange_ = false;
+	// pipeline flags of the render call (include/gaussian_parameters.h; every shipped config leaves both off).  The fused
+	// optimizer paths above are taken only when render() keeps the tensors they step inside the rasterizer.
+	GaussianPipelineParams pipe_;
 	torch::Tensor sh_send_;        // [P + 1, 3]: rows 0 .. P-1 = sh_grad_view_, row P = this view's camera centre (one all-gather)
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);

@@ -21,8 +21,9 @@
 #include "gaussian_keyframe.h"
 #include "gaussian_model.h"
 #include "gaussian_parameters.h"
-#else
-struct GaussianPipelineParams {
+#elif !defined(GSR_HAVE_PIPELINE_PARAMS)
+#define GSR_HAVE_PIPELINE_PARAMS
+struct GaussianPipelineParams {   // include/gaussian_parameters.h:41-49
 	bool convert_SHs_ = false;
 	bool compute_cov3D_ = false;
 };

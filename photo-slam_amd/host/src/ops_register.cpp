@@ -165,6 +165,8 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "fused_sh_adam") t->fused_sh_adam_ = v != 0.0;
 		else if (k == "lazy_sh_adam_window") t->lazy_sh_adam_window_ = (int)v;
 		else if (k == "fused_geom_adam") t->fused_geom_adam_ = v != 0.0;
+		else if (k == "convert_SHs") t->pipe_.convert_SHs_ = v != 0.0;
+		else if (k == "compute_cov3D") t->pipe_.compute_cov3D_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
 		else if (k == "lr_scale") t->gaussians_->lr_scale_ = v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;

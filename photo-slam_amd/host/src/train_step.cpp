@@ -188,7 +188,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	auto& g = gaussians_;
 	iteration_++;
 	g->updateLearningRate(iteration_);
-	GaussianPipelineParams pipe;
+	GaussianPipelineParams& pipe = pipe_;
 	torch::Tensor override_color;
 	if (factored_exchange_) {
 		const auto P = g->xyz_.size(0);
@@ -203,8 +203,12 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	const auto& o = g->opt_;
 	const bool rebuilds = densifyDue();
 	bool lazy = false;
+	// The fused optimizer steps advance their step counters HERE, so they are taken only when render() will really hand them
+	// to the rasterizer (gaussian_renderer.h: sh_in_rasterizer, raw_params_ == 7): with convert_SHs_ the rasterizer sees colours,
+	// not the SH tensor, and with compute_cov3D_ a covariance, not the raw scaling / rotation leaves -- autograd then leaves
+	// dense gradients and optimizerStepGroup() takes those groups' steps.
 	if (fused_sh_adam_ && !factored_exchange_ && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
-	    g->features_.size(1) == 16) {
+	    g->features_.size(1) == 16 && !pipe.convert_SHs_) {
 		auto& grp = g->groups_[1];
 		lazy = lazy_sh_adam_window_ >= 2 && g->features_.is_contiguous();
 		if (lazy && g->features_row_step_.defined() && g->features_lazy_window_ != lazy_sh_adam_window_) g->syncFeatures();
@@ -230,7 +234,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 	GeomAdamStep geom_adam;
-	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5) {
+	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5 && !pipe.compute_cov3D_) {
 		// xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (trainingSetup); their steps happen inside backward, and
 		// optimizerStepGroup() then finds no gradient on them
 		for (int gi : {0, 2, 3, 4}) {

@@ -226,10 +226,14 @@ class TrainStep:
         # optimizer step skips every group)
         rebuilds = bool(self.densify_ and it < opt.densify_until_iter_ and it > opt.densify_from_iter_ and
                         opt.densification_interval_ and it % opt.densification_interval_ == 0)
+        # The fused optimizer steps advance their step counters HERE, so they are taken only when render() will really hand
+        # them to the rasterizer: with convert_SHs_ the rasterizer sees colours, not the SH tensor (no SH step to fuse), and
+        # with compute_cov3D_ it sees a covariance, not the raw scaling / rotation leaves (no geometry step to fuse) --
+        # autograd then leaves dense gradients and the ordinary optimizer step below takes those groups.
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
-                g._features.size(1) == 16 and g.optimizer_ is not None:
+                g._features.size(1) == 16 and g.optimizer_ is not None and not self.pipe_.convert_SHs_:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)
-            if self.fused_geom_adam_ and len(g.optimizer_.param_groups) == 5:
+            if self.fused_geom_adam_ and len(g.optimizer_.param_groups) == 5 and not self.pipe_.compute_cov3D_:
                 # xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (GaussianModel.trainingSetup)
                 tensors = []
                 for gi in (0, 2, 3, 4):

@@ -336,6 +336,60 @@ def run_pipeline_flag_checks(ops, dev, lib_path):
         rp._LIB_OVERRIDE = None
 
 
+def run_pipeline_flag_train_checks(ops, dev, lib_path):
+    """A TRAIN step with convert_SHs_ / compute_cov3D_ set: render() then keeps the SH tensor resp. the raw scaling /
+    rotation leaves out of the rasterizer, so the fused optimizer paths must not be armed -- every group takes exactly ONE Adam
+    step per iteration, in both hosts, and the result equals the default data flow's (same maths) to a small fraction of a
+    learning-rate step."""
+    import math
+    cl, t = _scene(dev, P=400)
+    cam = cl.cameras[0]
+    torch.manual_seed(0)
+    gt = torch.rand(3, cam.H, cam.W).to(dev)
+    mask = torch.ones(3, cam.H, cam.W, device=dev)
+    bg = torch.zeros(3, device=dev)
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    kf = GaussianKeyframe.from_camera(cam, dev)
+    lrs = [0.00016 * cl.extent, 0.0025, 0.05, 0.005, 0.001]
+    n_it = 4
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        final = {}
+        for flags in ((False, False), (True, False), (False, True), (True, True)):
+            g = GaussianModel.from_cloud(cl, device=dev)
+            opt = GaussianOptimizationParams()
+            g.trainingSetup(opt)
+            h = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                                   g.rotation_.detach(), 3, float(cl.extent), bg)
+            ops.trainer_set_options(h, {"convert_SHs": float(flags[0]), "compute_cov3D": float(flags[1])})
+            ts = TrainStep(g, opt, GaussianPipelineParams(convert_SHs_=flags[0], compute_cov3D_=flags[1]), bg)
+            for it in range(n_it):
+                l_py = float(ts.trainForOneIteration(kf, gt, mask))
+                l_cpp = float(ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy,
+                                                              cam.H, cam.W, gt, mask))
+                ops.trainer_finish(h)
+                assert np.isclose(l_py, l_cpp, rtol=2e-5), (flags, it, l_py, l_cpp)
+            # one Adam step per group and iteration: nothing stepped twice, no phantom lazy steps
+            assert list(ops.trainer_steps(h)) == [n_it] * 5, (flags, list(ops.trainer_steps(h)))
+            assert [g.optimizer_.state[id(p)]["step"] for p in g.params()] == [n_it] * 5, flags
+            got = [p.detach().clone() for p in g.params()]
+            for a, b, lr in zip(ops.trainer_params(h), got, lrs):
+                err = (a - b).abs() / lr
+                assert float((err > 1e-2).float().mean()) < 2e-3, (flags, float(err.max()))
+            final[flags] = got
+            ops.trainer_destroy(h)
+        for flags, got in final.items():
+            for a, b, lr in zip(got, final[(False, False)], lrs):
+                err = (a - b).abs() / lr
+                assert float((err > 2e-2).float().mean()) < 5e-3, (flags, float(err.max()), float((err > 2e-2).float().mean()))
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def test_train_step_with_pipeline_flags_steps_every_group_once(emu_lib_path):
+    run_pipeline_flag_train_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
+
+
 def test_cpp_pipeline_flags_match_python_and_the_default_flow(emu_lib_path):
     run_pipeline_flag_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
 
@@ -365,6 +419,7 @@ def test_cpp_host_layer_on_gpu():
     run_trainer_checks(ops, torch.device("cuda:0"), None)
     run_map_maintenance_checks(ops, torch.device("cuda:0"), None)
     run_pipeline_flag_checks(ops, torch.device("cuda:0"), None)
+    run_pipeline_flag_train_checks(ops, torch.device("cuda:0"), None)
 
 
 def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
