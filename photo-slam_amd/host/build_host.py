@@ -33,6 +33,12 @@ def build(variant="hip", force=False):
     else:
         out = os.path.join(ROOT, "tests", "emu", "libphotoslam_host_emu.so")
         gsr_dir, gsr_name = os.path.join(ROOT, "tests", "emu"), "gsr_emu"
+        # a fresh checkout has no emulator library yet (it is git-ignored): build it before linking against it
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gsr_build_emu", os.path.join(gsr_dir, "build_emu.py"))
+        emu = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(emu)
+        emu.build()
         defs = ["-DGSR_HOST_NO_HIP=1"]
         extra_inc = []
         libs = ["-ltorch", "-ltorch_cpu", "-lc10"]
