@@ -89,11 +89,12 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-def cpu_train_step_baseline(scene, args, W, H, quick=False):
+def cpu_train_step_baseline(scene, args, W, H, quick=False, want_inputs=False):
     """The reference's CPU train step (oracle/cpu_trainer.py) on the box's host cores: C1 in full (>= 100 iterations after
     warm-up) and >= 3 measured iterations of the benchmarked configuration.  ~20-30 s of CPU work on the GPU box."""
     from oracle import cpu_trainer, oracle
     out = {}
+    keep = {}   # per config: the cloud, the ground truth and every loss of the CPU run (for the GPU loss check; not printed)
 
     def run(name, iterations, warmup, budget_s):
         cl = scene.make_config(name, seed=0)
@@ -107,6 +108,7 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False):
         t0 = time.perf_counter()
         r = cpu_trainer.train(cl, cam, gt, iterations, warmup=warmup, time_budget_s=budget_s)
         med = float(np.median(r["seconds"]))
+        keep[name] = dict(cloud=cl, gt=gt, losses=list(r["losses"]))
         return dict(config=name, gaussians=int(cl.xyz.shape[0]), width=cam.W, height=cam.H, iterations=len(r["seconds"]),
                     iterations_requested=iterations, time_budget_s=budget_s, warmup=warmup,
                     s_per_iteration_median=round(med, 4), iters_per_s=round(1.0 / med, 4),
@@ -118,6 +120,8 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False):
     main_cfg = args.config if args.config != "C1" else None
     if main_cfg:
         out[main_cfg] = run(main_cfg, 3, 1, 60.0)
+    if want_inputs:
+        return out, keep
     return out
 
 
@@ -149,6 +153,9 @@ def main():
                          "Z-order curve: the index coherence of a map that grows keyframe by keyframe)")
     ap.add_argument("--no-fused-geom-adam", action="store_true",
                     help="xyz / opacity / scaling / rotation step in four separate Adam passes instead of inside the backward kernels")
+    ap.add_argument("--densify-leg-steps", type=int, default=250,
+                    help="steps of the densify_run leg (densifyAndPrune every 100 steps, training learning rates; 0 = skip)")
+    ap.add_argument("--no-knn-leg", dest="knn_leg", action="store_false", help="skip the simple-knn leg (100 k and 1 M points)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -437,6 +444,87 @@ def main():
                      "iters_per_s": round(world * args.steps / el2, 3),
                      "note": "training learning rates from the same start: the synthetic scene inflates ~1 %/step (DESIGN.md section 7)"}
 
+    # ---- BASELINE config C3 as stated ("with densify/prune + simple-knn"): the same program with the training learning rates and
+    # densifyAndPrune every 100 steps (the reference's densification_interval_), on a fresh model; every step timed by its own
+    # HIP event so that the densifying steps can be read separately.  `value` stays the stationary leg above.
+    densify_run = None
+    if stationary and not args.raster_only and not dp and ops is not None and not args.densify_interval and args.densify_leg_steps > 0:
+        g2 = GaussianModel.from_cloud(cl, device=dev)
+        h2 = ops.trainer_create(g2.xyz_.detach(), g2.features_.detach(), g2.opacity_.detach(), g2.scaling_.detach(),
+                                g2.rotation_.detach(), 3, float(cl.extent), bg)
+        del g2
+        interval = 100
+        ops.trainer_set_options(h2, {"lazy_sh_adam_window": float(args.sh_adam_window), "densify": 1.0,
+                                     "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0,
+                                     "cameras_extent": float(cl.extent), "seed": 0.0, "densify_from_iter": 0.0,
+                                     "densification_interval": float(interval)})
+        n_d = args.densify_leg_steps
+        P_before = int(ops.trainer_params(h2)[0].shape[0])
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_d + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(n_d):
+            loss = ops.trainer_render_and_backward(h2, kf.world_view_transform_, kf.full_proj_transform_, kf.camera_center_, fovx,
+                                                   fovy, H, W, gt, mask)
+            ops.trainer_finish(h2)
+            read_loss_deferred(loss)
+            ev[i + 1].record()
+        barrier()
+        el_d = time.perf_counter() - t0
+        per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(n_d)])
+        calls = [i for i in range(n_d) if (i + 1) % interval == 0]
+        plain = np.array([per[i] for i in range(n_d) if i not in calls])
+        P_after = int(ops.trainer_params(h2)[0].shape[0])
+        last = [int(x) for x in ops.trainer_last_densify(h2)]
+        densify_run = {"steps": n_d, "densification_interval": interval, "learning_rates": "training",
+                       "ms_per_step": round(el_d / n_d * 1e3, 3), "iters_per_s": round(n_d / el_d, 3), "densify_calls": len(calls),
+                       "ms_per_densifying_step": [round(float(per[i]), 3) for i in calls],
+                       "ms_median_other_steps": round(float(np.median(plain)), 3),
+                       "ms_per_densify_call_over_a_plain_step": [round(float(per[i] - np.median(plain)), 3) for i in calls],
+                       "gaussians_before": P_before, "gaussians_after": P_after,
+                       "last_call": dict(zip(("cloned", "split", "pruned", "points"), last)),
+                       "note": "BASELINE config C3 as stated: densifyAndPrune (src/gaussian_model.cpp:716-815) every 100 steps inside the "
+                               "timed loop, training learning rates; a densifying step skips its optimizer update as the reference's does; "
+                               "the synthetic scene keeps splitting the same high-gradient Gaussians, so the work per step grows"}
+        ops.trainer_destroy(h2)
+        torch.cuda.empty_cache()
+
+    # ---- simple-knn (distCUDA2, third_party/simple-knn/simple_knn.cu:185-221): the other half of "with densify/prune + simple-knn"
+    knn_run = None
+    if rank == 0 and not args.raster_only and not dp and args.knn_leg:
+        from photo_slam_amd import rasterize_points as rp2
+        knn_run = {"bound_model": "120 B per point when box pruning is effective (SURVEY.md 8d): AABB 12 x 2 + Morton 16 + sort 64 + "
+                                  "neighbour scan 16", "runs": []}
+        rng_k = np.random.default_rng(7)
+        for n_pts in (100_000, 1_000_000):
+            pts_np = (rng_k.random((n_pts, 3), dtype=np.float32) * np.array([6, 3, 6], np.float32) - np.array([3, 1.5, 3], np.float32))
+            pts = torch.from_numpy(pts_np).to(dev)
+            for _ in range(2):
+                d = rp2.distCUDA2(pts)
+            reps = 5
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            e0[0].record()
+            for i in range(reps):
+                d = rp2.distCUDA2(pts)
+                e0[i + 1].record()
+            torch.cuda.synchronize()
+            ms = float(np.median([e0[i].elapsed_time(e0[i + 1]) for i in range(reps)]))
+            entry = {"points": n_pts, "ms": round(ms, 4), "algorithmic_GBps_at_120B_per_point": round(120.0 * n_pts / (ms * 1e-3) / 1e9, 2),
+                     "frac_of_hbm_peak": round(120.0 * n_pts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            if not args.no_cpu_baseline:
+                from oracle import oracle as orc
+                orc.build()
+                t0 = time.perf_counter()
+                d_cpu = orc.knn(pts_np)
+                entry["cpu_oracle_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                entry["cpu_oracle_threads"] = orc.get_threads()
+                entry["bit_identical_to_cpu_oracle"] = bool(np.array_equal(d.cpu().numpy(), d_cpu))
+            knn_run["runs"].append(entry)
+        knn_run["note"] = ("exact 3-NN search: the neighbour scan visits every 1024-point Morton box whose AABB can still hold a closer "
+                           "point and tests all its points -- VALU-bound in that scan (per-kernel split: profiles/r03_*_knn_kernel_stats.csv), "
+                           "far from the 120 B/point stream bound")
+
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
     fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank
@@ -518,6 +606,10 @@ def main():
             out["changing_views_run"] = views_run
         if train_run:
             out["training_lr_run"] = train_run
+        if densify_run:
+            out["densify_run"] = densify_run
+        if knn_run:
+            out["knn"] = knn_run
         if dp:
             out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                            "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
@@ -555,8 +647,39 @@ def main():
                                                      "duration inside the timed region",
                                "stages": stages}
         if world == 1 and not args.no_cpu_baseline:
-            base = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline)
+            base, kept = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline, want_inputs=True)
             main = base.get(args.config, base["C1"])
+            if ops is not None and "C1" in kept:
+                # the SAME sequence on the GPU: C1 cloud, the CPU run's ground truth, training learning rates, as many iterations
+                # as the CPU run took -- the fused program's losses next to the reference step's (tests/test_train_sequence_reference.py
+                # asserts the parameters as well, with a densification and an opacity reset in the sequence)
+                k1 = kept["C1"]
+                cl1 = k1["cloud"]
+                cam1 = cl1.cameras[0]
+                g1 = GaussianModel.from_cloud(cl1, device=dev)
+                h1 = ops.trainer_create(g1.xyz_.detach(), g1.features_.detach(), g1.opacity_.detach(), g1.scaling_.detach(),
+                                        g1.rotation_.detach(), 3, float(cl1.extent), bg)
+                ops.trainer_set_options(h1, {"lazy_sh_adam_window": float(args.sh_adam_window),
+                                             "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
+                kf1 = GaussianKeyframe.from_camera(cam1, dev)
+                gt1 = torch.from_numpy(k1["gt"]).to(dev)
+                mask1 = torch.ones(3, cam1.H, cam1.W, device=dev)
+                import math as _m
+                gl = []
+                for _ in range(len(k1["losses"])):
+                    l1_ = ops.trainer_render_and_backward(h1, kf1.world_view_transform_, kf1.full_proj_transform_, kf1.camera_center_,
+                                                          2 * _m.atan(cam1.tanfovx), 2 * _m.atan(cam1.tanfovy), cam1.H, cam1.W, gt1, mask1)
+                    ops.trainer_finish(h1)
+                    gl.append(l1_)
+                gl = [float(x) for x in torch.stack(gl).cpu()]
+                ops.trainer_destroy(h1)
+                cl_ = np.array(k1["losses"])
+                base["C1"]["gpu_fused_step_same_sequence"] = {
+                    "iterations": len(gl), "loss_first": round(gl[0], 5), "loss_last": round(gl[-1], 5),
+                    "cpu_loss_first": round(float(cl_[0]), 5), "cpu_loss_last": round(float(cl_[-1]), 5),
+                    "max_rel_diff_over_all_iterations": float(np.max(np.abs(np.array(gl) - cl_) / cl_)),
+                    "note": "C++ host, fused program (lazy SH Adam, geometry Adam in backward) on the MI355X vs the reference's step on the "
+                            "host cores: same cloud, same ground truth, same learning rates, every iteration's loss compared"}
             out["cpu_baseline"] = {
                 "value": main["iters_per_s"], "unit": "iters/s (full train step)", "cores": main["oracle_threads"],
                 "kind": "port",

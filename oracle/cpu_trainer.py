@@ -146,3 +146,125 @@ def train(cloud, cam, gt_image, iterations, warmup=0, lambda_dssim=0.2, threads=
     return dict(seconds=times, forward_seconds=raster_times, losses=losses, loss_ops=loss_kind, threads=threads,
                 oracle_threads=oracle.get_threads(), model=model,
                 phase_seconds_median=[round(float(np.median([p[k] for p in phases])), 4) for k in range(4)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same step over a SEQUENCE of keyframes with the map maintenance of the loop: densifyAndPrune every
+# densification_interval iterations after densify_from_iter, resetOpacity every opacity_reset_interval
+# (src/gaussian_trainer.cpp:108-127 = src/gaussian_mapper.cpp:711-735).  The two maintenance calls are the REFERENCE's OWN
+# member functions (oracle/_ref/libref_densify{,_cuda}.so: src/gaussian_model.cpp:556-565, 716-815 extracted verbatim,
+# oracle/ref_densify.cpp) on this model's tensors and Adam state -- nothing of them is restated here.
+
+
+def _adam_state(model):
+    """(exp_avg[6], exp_avg_sq[6], steps[6]) of the six leaves in the reference's group order; a leaf that never stepped
+    has zero moments and step 0."""
+    m, v, steps = [], [], []
+    for p in (model.xyz, model.features_dc, model.features_rest, model.opacity, model.scaling, model.rotation):
+        st = model.optimizer.state.get(p)
+        if st:
+            m.append(st["exp_avg"]), v.append(st["exp_avg_sq"]), steps.append(int(st["step"]))
+        else:
+            m.append(torch.zeros_like(p)), v.append(torch.zeros_like(p)), steps.append(0)
+    return m, v, steps
+
+
+def _reference_state(model, ref_model, dev):
+    m, v, steps = _adam_state(model)
+    to = lambda t: t.detach().to(dev)
+    leaves = (model.xyz, model.features_dc, model.features_rest, model.opacity, model.scaling, model.rotation)
+    P = model.xyz.shape[0]
+    exist = getattr(model, "exist_since_iter", None)
+    if exist is None:
+        exist = torch.zeros(P, dtype=torch.int32)
+    return ref_model.State([to(p) for p in leaves], [to(t) for t in m], [to(t) for t in v], steps, to(model.xyz_gradient_accum),
+                           to(model.denom), to(model.max_radii2D), to(exist))
+
+
+def _install_leaf(model, index, name, value, exp_avg, exp_avg_sq, step):
+    """Replace one leaf (and its Adam state) the way replaceTensorToOptimizer / densificationPostfix do: a fresh leaf without a
+    gradient, the given moments, the old step counter."""
+    old = getattr(model, name)
+    model.optimizer.state.pop(old, None)
+    leaf = value.detach().cpu().clone().requires_grad_(True)
+    setattr(model, name, leaf)
+    model.optimizer.param_groups[index]["params"][0] = leaf
+    if step >= 0:
+        model.optimizer.state[leaf] = dict(step=torch.tensor(float(step)), exp_avg=exp_avg.detach().cpu().clone(),
+                                           exp_avg_sq=exp_avg_sq.detach().cpu().clone())
+
+
+_LEAVES = ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation")
+
+
+def reference_densify_and_prune(model, max_grad, min_opacity, extent, max_screen_size, kind="cpu", percent_dense=0.01):
+    """GaussianModel::densifyAndPrune of the reference (src/gaussian_model.cpp:716-815) on this model.  kind "cuda": the HIP
+    build of the same code on the GPU box (at::normal then draws from the device generator the GPU hosts seed identically)."""
+    from . import ref_model
+    ops = ref_model.load(kind)
+    if ops is None:
+        raise RuntimeError("oracle/_ref/libref_densify*.so was never built")
+    dev = torch.device("cuda:0" if kind == "cuda" else "cpu")
+    new = ref_model.densify_and_prune(ops, _reference_state(model, ref_model, dev), percent_dense, max_grad, min_opacity, extent,
+                                      max_screen_size)
+    for i, name in enumerate(_LEAVES):
+        _install_leaf(model, i, name, new.params[i], new.exp_avg[i], new.exp_avg_sq[i], new.steps[i])
+    model.xyz_gradient_accum, model.denom = new.accum.cpu().clone(), new.denom.cpu().clone()
+    model.max_radii2D, model.exist_since_iter = new.max_radii2D.cpu().clone(), new.exist_since_iter.cpu().clone()
+    return model.xyz.shape[0]
+
+
+def reference_reset_opacity(model, kind="cpu"):
+    """GaussianModel::resetOpacity of the reference (:556-565): only the opacity leaf is replaced (no gradient: the
+    optimizer step that follows skips it, the other five groups step)."""
+    from . import ref_model
+    ops = ref_model.load(kind)
+    if ops is None:
+        raise RuntimeError("oracle/_ref/libref_densify*.so was never built")
+    dev = torch.device("cuda:0" if kind == "cuda" else "cpu")
+    new = ref_model.reset_opacity(ops, _reference_state(model, ref_model, dev))
+    _install_leaf(model, 3, "opacity", new.params[3], new.exp_avg[3], new.exp_avg_sq[3], new.steps[3])
+
+
+def train_sequence(cloud, cams, gt_images, iterations, densification_interval=0, densify_from_iter=0, opacity_reset_interval=0,
+                   densify_until_iter=15000, densify_grad_threshold=0.0002, min_opacity=0.005, lambda_dssim=0.2, seed=0,
+                   kind="cpu", threads=None, on_iteration=None):
+    """trainingOnce's loop (src/gaussian_trainer.cpp:45-133) over the keyframes cams[(it - 1) % len(cams)], it = 1..iterations,
+    with the reference's own densifyAndPrune / resetOpacity on the schedule of :108-127.  Returns dict(losses, points per
+    iteration, densified_at, reset_at, model).  The split samples come from the default generator of `kind`'s device,
+    seeded once with `seed` (the hosts under test seed a generator of their own identically)."""
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    oracle.build()
+    l1_loss, ssim, loss_kind = _loss_ops()
+    model = CpuModel(cloud, cloud.extent)
+    model.exist_since_iter = torch.zeros(model.xyz.shape[0], dtype=torch.int32)
+    gts = [torch.from_numpy(np.ascontiguousarray(g, np.float32)) for g in gt_images]
+    bg = np.zeros(3, np.float32)
+    (torch.cuda.manual_seed if kind == "cuda" else torch.manual_seed)(seed)
+    losses, points, densified_at, reset_at = [], [], [], []
+    for it in range(1, iterations + 1):
+        model.update_learning_rate(it)
+        k = (it - 1) % len(cams)
+        image, viewspace, visibility, radii = render(model, cams[k], bg)
+        loss = (1.0 - lambda_dssim) * l1_loss(image, gts[k]) + lambda_dssim * (1.0 - ssim(image, gts[k]))
+        loss.backward()
+        with torch.no_grad():
+            losses.append(float(loss))
+            if it < densify_until_iter:
+                model.max_radii2D[visibility] = torch.max(model.max_radii2D[visibility], radii[visibility].float())
+                model.xyz_gradient_accum[visibility] += torch.norm(viewspace.grad[visibility][:, :2], dim=-1, keepdim=True)
+                model.denom[visibility] += 1
+                if densification_interval and it > densify_from_iter and it % densification_interval == 0:
+                    size_threshold = 20 if (opacity_reset_interval and it > opacity_reset_interval) else 0     # :120
+                    reference_densify_and_prune(model, densify_grad_threshold, min_opacity, float(cloud.extent), size_threshold, kind)
+                    densified_at.append(it)
+                if opacity_reset_interval and it % opacity_reset_interval == 0:
+                    reference_reset_opacity(model, kind)
+                    reset_at.append(it)
+            model.optimizer.step()          # leaves without a gradient (fresh ones) are skipped, their step counters rest
+            model.optimizer.zero_grad(set_to_none=True)
+            points.append(int(model.xyz.shape[0]))
+        if on_iteration is not None:
+            on_iteration(it, model, losses[-1])
+    return dict(losses=losses, points=points, densified_at=densified_at, reset_at=reset_at, model=model, loss_ops=loss_kind)

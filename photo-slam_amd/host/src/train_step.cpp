@@ -234,7 +234,11 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 	GeomAdamStep geom_adam;
-	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5 && !pipe.compute_cov3D_) {
+	// (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then skips it -- no
+	// gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)
+	const bool resets = densify_ && iteration_ < o.densify_until_iter_ && o.opacity_reset_interval_ &&
+	                    iteration_ % o.opacity_reset_interval_ == 0;
+	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5 && !pipe.compute_cov3D_ && !resets) {
 		// xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (trainingSetup); their steps happen inside backward, and
 		// optimizerStepGroup() then finds no gradient on them
 		for (int gi : {0, 2, 3, 4}) {

@@ -233,7 +233,11 @@ class TrainStep:
         if self.world_size_ == 1 and self.fused_sh_adam_ and it < opt.iterations_ and not rebuilds and \
                 g._features.size(1) == 16 and g.optimizer_ is not None and not self.pipe_.convert_SHs_:
             sh_adam = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)
-            if self.fused_geom_adam_ and len(g.optimizer_.param_groups) == 5 and not self.pipe_.compute_cov3D_:
+            # (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then
+            # skips it -- no gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)
+            resets = bool(self.densify_ and it < opt.densify_until_iter_ and opt.opacity_reset_interval_ and
+                          it % opt.opacity_reset_interval_ == 0)
+            if self.fused_geom_adam_ and len(g.optimizer_.param_groups) == 5 and not self.pipe_.compute_cov3D_ and not resets:
                 # xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (GaussianModel.trainingSetup)
                 tensors = []
                 for gi in (0, 2, 3, 4):

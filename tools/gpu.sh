@@ -1,0 +1,127 @@
+#!/bin/bash
+# One parameterised GPU session script (replaces the per-session tools/gpu_r2?.sh of round 2).
+#   gpurun --timeout 1500 -- 'tools/gpu.sh TAG step [step ...]'
+# TAG names the output set gpurun_out/TAG/ (e.g. r03_a); copy what is to be judged into profiles/ as TAG_<file>.
+# Steps (run in the order given; each prints a one-line digest):
+#   build        python __graft_entry__.py
+#   tests        the whole -m gpu suite            tests:<expr>  only tests matching -k <expr>
+#   smoke        __graft_entry__.smoke()
+#   driver       the driver's command `bench.py --gpus 1 --steps 20 --warmup 5` (with the CPU baseline, timed)
+#   bench        `bench.py --no-cpu-baseline` (100 steps + median of 100)      bench:C2 | bench:C4 | bench:C5  other configs
+#   raster       `bench.py --raster-only --no-cpu-baseline`
+#   kstats       rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline) -> kernel_stats_bench_full_C3.csv
+#   knnstats     rocprofv3 --kernel-trace --stats of distCUDA2 at 100 k and 1 M points -> knn_kernel_stats_<points>.csv
+#   pmc          TCC traffic per launch, rasterizer only (two --pmc passes)      pmc:full  the fused train step
+#   sq           SQ counters (VALU / SALU / LDS issue, busy cycles), fused step  sq:raster  rasterizer only
+#   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
+#   dp:allreduce the same with the plain all-reduce
+#   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
+TAG=${1:-r03_x}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT; export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+
+kernel_stats() {  # $1 = output csv, rest = command
+  local out=$1; shift
+  rm -rf /tmp/kp; (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp -o kp -- "$@" > /tmp/kp.log 2>&1)
+  local f=$(find /tmp/kp -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then cp $f $out; head -14 $out | cut -c1-130; else echo "no kernel_stats.csv"; tail -5 /tmp/kp.log; fi
+}
+
+pmc_pass() {  # $1 = mode (raster|full) -> $OUT/pmc_traffic_<mode>.json
+  local mode=$1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
+        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg > /tmp/pmc_$c.log 2>&1)
+  done
+  python - "$OUT/pmc_traffic_$mode.json" <<'PY'
+import csv, glob, collections, json, sys
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        print("no counter file for", c); continue
+    acc = collections.defaultdict(list)
+    with open(fs[0]) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") == c and "gsr::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        out.setdefault(k, {})[c] = sum(v) / len(v)
+        out[k]["launches_" + c] = len(v)
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
+    f, w = v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0)
+    print(f"{k:36s} FETCH {f:11.1f} KB  WRITE {w:11.1f} KB  HBM bytes/launch (2F+W) = {(2*f + w)*1024/1e6:8.1f} MB")
+PY
+}
+
+sq_pass() {  # $1 = mode (raster|full) -> $OUT/sq_counters_<mode>.json
+  local mode=$1
+  local sets=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE")
+  local i=0
+  for set in "${sets[@]}"; do
+    rm -rf /tmp/sq_$i
+    (cd /tmp && timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$i -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
+        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg > /tmp/sq_$i.log 2>&1)
+    i=$((i+1))
+  done
+  python - "$OUT/sq_counters_$mode.json" <<'PY'
+import csv, glob, collections, json, sys
+out = {}
+for d in glob.glob("/tmp/sq_*"):
+    for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(fn) as f:
+            for r in csv.DictReader(f):
+                if "gsr::" in r["Kernel_Name"]:
+                    acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                out.setdefault(k, {})[c] = sum(v) / len(v)
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:12]:
+    print(f"{k:36s} " + "  ".join(f"{c.replace('SQ_', '')}={x:.3g}" for c, x in sorted(v.items())))
+PY
+}
+
+for step in "$@"; do
+  arg=${step#*:}; [ "$arg" = "$step" ] && arg=""
+  echo "=== $step"
+  case ${step%%:*} in
+    build)  python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }; tail -1 $OUT/build.log ;;
+    tests)  if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -q -m gpu -k "$arg" -s > $OUT/test_gpu.log 2>&1; else timeout 1200 python -m pytest tests -q -m gpu > $OUT/test_gpu.log 2>&1; fi
+            grep -v Warning $OUT/test_gpu.log | tail -6 | cut -c1-400 ;;
+    smoke)  timeout 300 python -c "import __graft_entry__ as e; e.smoke()" 2>&1 | tail -1 ;;
+    driver) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_driver_cmd_C3.log 2>&1
+            grep "^{\"metric\"" $OUT/bench_driver_cmd_C3.log > $OUT/bench_driver_cmd_C3.json; grep real $OUT/bench_driver_cmd_C3.log
+            python - $OUT/bench_driver_cmd_C3.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"]["kernel"], d["roofline"]["frac"], "raster frac", d["roofline"]["raster_fwd_bwd_frac"])
+print("stages", {k: v["ms"] for k, v in d["roofline"]["stages"].items()})
+for k in ("densify_run", "knn", "changing_views_run", "training_lr_run"):
+    if k in d: print(k, json.dumps(d[k])[:600])
+cb = d.get("cpu_baseline", {})
+print("cpu", cb.get("value"), json.dumps(cb.get("runs", {}).get("C1", {}).get("gpu_fused_step_same_sequence")))
+PY
+            ;;
+    bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg.json 2>$OUT/bench_err.log
+            python -c "
+import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
+    raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
+    kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg ;;
+    knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
+    pmc)    pmc_pass ${arg:-raster} ;;
+    sq)     sq_pass ${arg:-full} ;;
+    dp)     ex=${arg:-factored}
+            for cfg in C3 C4; do
+              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json 2>$OUT/dp_err.log
+              python -c "
+import json; d=json.load(open('$OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json')); print('$cfg dp 1 rank $ex', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'])" || tail -5 $OUT/dp_err.log
+            done ;;
+    py)     timeout 900 python tools/$arg > $OUT/${arg%.py}.log 2>&1; tail -30 $OUT/${arg%.py}.log | cut -c1-300 ;;
+    *)      echo "unknown step $step" ;;
+  esac
+done
