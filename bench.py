@@ -300,11 +300,13 @@ def main():
                                           [(i, t) for i, t in enumerate(grads) if i != FEATURES_GROUP], world)
                 ops.trainer_finish_begin(handle)
                 for first, (row0, centres, views) in enumerate(ex.gathered_parts()):
-                    # rebuild + Adam in one pass; reads xyz: before ITS Adam
+                    # rebuild + Adam in one pass over the rows SOME view lights (lazy rows, --sh-adam-window); reads xyz: before
+                    # ITS Adam
                     ops.trainer_features_step_from_views(handle, centres, views, row0, first == 0)
+                ops.trainer_features_finish_from_views(handle)   # this step's slice of the rotating catch-up
                 for i in ex.order():
-                    ex.wait(i)                # stream-side wait: the host keeps queueing
-                    ops.trainer_adam_group(handle, i)
+                    ex.wait(i)                # stream-side wait: the host keeps queueing (one collective for the four)
+                ops.trainer_geom_adam(handle)     # xyz / opacity / scaling / rotation: one Adam launch
                 ops.trainer_finish_end(handle)
             elif dp:
                 # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
@@ -354,7 +356,8 @@ def main():
     # lazy SH Adam (--sh-adam-window): the rotating catch-up of the culled rows reaches its steady state (every flushed row
     # `window` steps behind) after `window` steps -- the steps that the requested warm-up does not cover are run before it,
     # untimed, so that the timed region does a steady state's work per step
-    priming = max(0, (args.sh_adam_window if not (dp or args.raster_only) else 0) - args.warmup)
+    lazy_dp = dp and factored and ops is not None
+    priming = max(0, (args.sh_adam_window if (not (dp or args.raster_only) or lazy_dp) else 0) - args.warmup)
     for _ in range(priming + args.warmup):
         one_step()
     # Timed region: HIP events only around the backward blend, the dominant kernel (gsr_profile_enable(2)): every event

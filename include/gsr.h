@@ -240,6 +240,16 @@ int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3
 int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                            long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
                            float* shs, const gsr_sh_adam* sh_adam, void* stream);
+/* With sh_adam->lazy set (gsr_sh_adam_lazy) the data-parallel step is as lean as the single-GPU one: a row whose colour
+ * gradient is zero in EVERY gathered view would take a zero-gradient step -- it is left alone and steps later; a row some view
+ * lights first takes the zero-gradient steps it is behind (this rank's forward pass only caught up the rows ITS view sees),
+ * then this step, and row_step[i] = step.  1152 B of optimizer traffic per Gaussian some view of the batch sees instead of
+ * per Gaussian.  The call may cover a row range (pointers offset by the caller, row_step too).  After the last range of a
+ * step the caller runs gsr_sh_adam_lazy_slice over ALL rows: this step's 1/window of the row blocks catches up, so that no
+ * row ever lags by more than `window` steps.  Same contract as the single-GPU lazy mode otherwise (pass the struct to
+ * gsr_forward_args.sh_adam of the step; gsr_sh_adam_flush before anything else touches the tensor); results bit-identical to
+ * the eager update (tests/test_lazy_sh_adam.py). */
+int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, void* stream);
 
 /* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
  * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */
@@ -274,6 +284,20 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
  * (features_dc and features_rest live in one [P,16,3] buffer with learning rates lr and lr/20). */
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
                   double beta1, double beta2, double eps, int step, int period, int split, double lr_tail, void* stream);
+
+/* The same step for several tensors in ONE launch (the four small per-Gaussian tensors of a data-parallel step, whose
+ * gradients arrive together from one all-reduce): element arithmetic exactly as gsr_adam_step, one learning rate and step
+ * counter per tensor.  count <= 8; tensors with n == 0 are skipped. */
+typedef struct gsr_adam_multi_tensor {
+	float* param;            /* UPDATED IN PLACE */
+	const float* grad;
+	float* exp_avg;
+	float* exp_avg_sq;
+	long long n;             /* elements */
+	double lr;
+	int step;                /* >= 1: the step being taken */
+} gsr_adam_multi_tensor;
+int gsr_adam_step_multi(int count, const gsr_adam_multi_tensor* tensors, double beta1, double beta2, double eps, void* stream);
 
 /* Per-view densification statistics (src/gaussian_mapper.cpp:714-719, src/gaussian_model.cpp:817-831) for
  * vis = radii > 0:  max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmean2D.xy|; denom += 1.

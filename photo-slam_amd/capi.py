@@ -70,6 +70,12 @@ class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("step", C.c_int)]
 
 
+class AdamMultiTensor(C.Structure):
+    """gsr_adam_multi_tensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int)]
+
+
 class GeomAdam(C.Structure):
     """gsr_geom_adam: xyz, opacity, scaling, rotation"""
     _fields_ = [("xyz", AdamTensor), ("opacity", AdamTensor), ("scaling", AdamTensor), ("rotation", AdamTensor),
@@ -121,7 +127,7 @@ RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
 # every symbol include/gsr.h declares
 EXPORTED_SYMBOLS = [
     "gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_geometry_bytes", "gsr_binning_bytes",
-    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_sh_adam_flush", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
+    "gsr_image_bytes", "gsr_knn_scratch_bytes", "gsr_sh_grad_from_views", "gsr_sh_adam_from_views", "gsr_sh_adam_flush", "gsr_sh_adam_lazy_slice", "gsr_adam_step_multi", "gsr_strerror", "gsr_last_hip_error", "gsr_last_hip_error_string",
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
     "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_densify_scratch_bytes",
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
@@ -152,6 +158,10 @@ def load(path=None):
     L.gsr_sh_adam_from_views.argtypes = [i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.c_longlong, f32, vp, C.POINTER(ShAdam), vp]
     L.gsr_sh_adam_flush.restype = i32
     L.gsr_sh_adam_flush.argtypes = [i32, C.POINTER(ShAdam), vp]
+    L.gsr_sh_adam_lazy_slice.restype = i32
+    L.gsr_sh_adam_lazy_slice.argtypes = [i32, C.POINTER(ShAdam), vp]
+    L.gsr_adam_step_multi.restype = i32
+    L.gsr_adam_step_multi.argtypes = [i32, C.POINTER(AdamMultiTensor), C.c_double, C.c_double, C.c_double, vp]
     L.gsr_mark_visible.restype = i32
     L.gsr_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     L.gsr_knn_mean_dist2.restype = i32

@@ -495,8 +495,25 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 		return GSR_ERR_INVALID_ARG;
 	if (o->param && o->param != shs) return GSR_ERR_INVALID_ARG;
 	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, adam_scalars(o->lr, o->lr_tail, o->beta1, o->beta2, o->eps, o->step)};
+	LazyAdam la{};
+	if (o->lazy) {
+		gsr_sh_adam with_param = *o;
+		with_param.param = shs;
+		const int st = make_lazy_adam(with_param, shs, M, la);
+		if (st != GSR_OK) return st;
+	}
 	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
-	                                 nullptr, &ra, (hipStream_t)stream_);
+	                                 nullptr, &ra, (hipStream_t)stream_, o->lazy ? &la : nullptr);
+}
+
+int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, void* stream_)
+{
+	if (P < 0 || !adam || !adam->lazy) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	LazyAdam la{};
+	int st = make_lazy_adam(*adam, nullptr, 16, la);
+	if (st != GSR_OK) return st;
+	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_, /*slice_only=*/true);
 }
 
 int gsr_profile_enable(int on)

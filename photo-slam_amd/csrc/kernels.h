@@ -179,14 +179,15 @@ static inline bool sh_rows_path(const float* shs, int M, int D, bool factored, b
 struct RowAdam;   // shrows.h: Adam state + scalars of the fused row update (null = write the gradient rows)
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                               long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
-                              float* dL_dsh, const RowAdam* adam, hipStream_t stream);
+                              float* dL_dsh, const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy = nullptr);
 
 // this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
 int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream);
 
 // lazy mode: the zero-gradient steps the rows of this step's slice of row blocks are behind, up to and including a.step, for
 // the rows with radii <= 0 (radii == null: every row of EVERY block -- gsr_sh_adam_flush)
-int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream);
+// slice_only (with radii == null): this step's slice of the row blocks, every row that is behind (the data-parallel program)
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, bool slice_only = false);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

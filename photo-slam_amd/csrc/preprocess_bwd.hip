@@ -529,15 +529,16 @@ int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStrea
 
 // Lazy mode (shrows.h): one workgroup per row block of LAZY_BLOCK_ROWS rows, one thread per 16-byte vector of the block
 // (64 rows x 12 vectors = 768 threads: the `window` dependent steps per element are latency-bound, so the parallelism is spent
-// across elements).  The blocks of this step's slice (all blocks when radii == null: flush) bring their rows with radii <= 0
-// up to a.step -- the zero-gradient steps (row_step, a.step] in one read-modify-write of the row.  The workgroup owns its
+// across elements).  The blocks of this step's slice (all blocks: flush) bring their rows with radii <= 0 (radii == null: every
+// row that is behind -- the flush, and the slice of the data-parallel program, which runs BEHIND the kernel that stepped the
+// lit rows) up to a.step -- the zero-gradient steps (row_step, a.step] in one read-modify-write of the row.  The workgroup owns its
 // block: row_step is read by all threads before the barrier, written behind it.
 constexpr int LAZY_THREADS = LAZY_BLOCK_ROWS * ROW_F4;   // 768
 __global__ void __launch_bounds__(LAZY_THREADS)
-sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a)
+sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a, int all_blocks)
 {
-	const bool all = radii == nullptr;
-	const long long b = all ? (long long)blockIdx.x : (long long)(a.step % a.window) + (long long)blockIdx.x * a.window;
+	const bool all = radii == nullptr;   // no visibility filter: every row of the block that is behind a.step catches up
+	const long long b = all_blocks ? (long long)blockIdx.x : (long long)(a.step % a.window) + (long long)blockIdx.x * a.window;
 	const size_t row0 = (size_t)b * LAZY_BLOCK_ROWS;
 	const int item = (int)threadIdx.x;
 	const int rr = item / ROW_F4, col = item - rr * ROW_F4;
@@ -561,7 +562,7 @@ sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a)
 	if (mine && col == 0) a.row_step[row] = a.step;
 }
 
-int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream)
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, bool slice_only)
 {
 	if (P <= 0) return GSR_OK;
 	if (!a.row_step || a.window < 2 || a.window > LAZY_WINDOW_MAX || a.step < 1) return GSR_ERR_INVALID_ARG;
@@ -570,8 +571,9 @@ int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t 
 	const int nb = div_up(P, LAZY_BLOCK_ROWS);
 	// slice: the row blocks b with b % window == step % window
 	const int phase = a.step % a.window;
-	const int blocks = radii ? (nb > phase ? div_up(nb - phase, a.window) : 0) : nb;
-	if (blocks > 0) GSR_LAUNCH(sh_adam_lazy_kernel, blocks, LAZY_THREADS, stream, P, radii, a);
+	const bool slice = radii != nullptr || slice_only;
+	const int blocks = slice ? (nb > phase ? div_up(nb - phase, a.window) : 0) : nb;
+	if (blocks > 0) GSR_LAUNCH(sh_adam_lazy_kernel, blocks, LAZY_THREADS, stream, P, radii, a, slice ? 0 : 1);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
@@ -642,13 +644,19 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 // 192 B written per Gaussian, against 2 * 192 B sent per Gaussian by a ring all-reduce of the rows.
 // ADAM: the rows do not leave as a gradient -- this step's Adam update of the SH tensor is applied from LDS
 // (gsr_sh_adam_from_views; wave_adam_rows, shrows.h).
-template <int DEG, bool ADAM>
+// LAZY (gsr_sh_adam_from_views with sh_adam->lazy): a row whose colour gradient is zero in EVERY gathered view takes a
+// zero-gradient step -- exactly the case the lazy rows of the single-GPU program defer (shrows.h) -- so it is left alone here
+// (row_step keeps counting what it has taken); a row with a gradient first takes the zero-gradient steps it is behind (the
+// forward pass only caught up the rows THIS rank's view sees; another rank's view may light a row this rank culled), then this
+// step, and row_step[i] = step.  The dense 1152 B per Gaussian become 1152 B per Gaussian SOME view of the batch sees.
+template <int DEG, bool ADAM, bool LAZY>
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(4, 8)
 sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos,
                           long long campos_stride, const float* __restrict__ views, long long view_stride, float scale,
-                          float* __restrict__ dL_dsh, const RowAdam adam)
+                          float* __restrict__ dL_dsh, const RowAdam adam, const LazyAdam lz)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
+	__shared__ uint32_t s_lag[SHB_THREADS / 64][STAGE_ROWS];
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
@@ -663,6 +671,7 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 		my = means3D[3 * (size_t)idx + 1];
 		mz = means3D[3 * (size_t)idx + 2];
 	}
+	bool any = false;   // some view holds a colour gradient for this Gaussian
 #pragma unroll 1
 	for (int v = 0; v < n_views; v++) {
 		float r = 0.f, g = 0.f, b = 0.f;
@@ -672,6 +681,7 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 		}
 		// culled in this view (or every channel clamped): nothing to add, and most Gaussians are outside most views
 		if (r != 0.f || g != 0.f || b != 0.f) {
+			any = true;
 			const float* cp = campos + (size_t)v * (size_t)campos_stride;
 			const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
 			const float len = sqrtf(ox * ox + oy * oy + oz * oz);   // forward.cu:27-28
@@ -685,13 +695,20 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 			}
 		}
 	}
+	int lag = 0;
+	if (LAZY && any) {
+		lag = lz.step - 1 - lz.row_step[idx];
+		lag = lag < 0 ? 0 : (lag >= lz.window ? lz.window - 1 : lag);
+	}
 	// rows leave through LDS as contiguous 6 KiB bursts, half a wave at a time (shrows.h)
 #pragma unroll 1
 	for (int h = 0; h < 64 / STAGE_ROWS; h++) {
 		const size_t half_first = wave_first + (size_t)(h * STAGE_ROWS);
 		const long long left = (long long)P - (long long)half_first;
 		if (left <= 0) break;   // wave-uniform
-		if ((l / STAGE_ROWS) == h) {
+		const bool mine = (l / STAGE_ROWS) == h;
+		const unsigned long long m = LAZY ? wave_ballot(any && mine) : ~0ull;
+		if (mine && (!LAZY || any)) {
 			float4* row = s_rows[w][l % STAGE_ROWS];
 #pragma unroll
 			for (int i = 0; i < ROW_F4; i++) {
@@ -700,12 +717,17 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 				for (int c = 0; c < 4; c++) o[c] = (4 * i + c < 3 * ncoef) ? acc[(4 * i + c < 3 * ncoef) ? 4 * i + c : 0] * scale : 0.f;
 				row[i] = make_float4(o[0], o[1], o[2], o[3]);
 			}
+			if (LAZY) s_lag[w][l % STAGE_ROWS] = (uint32_t)lag;
 		}
-		if (ADAM)
+		if (ADAM && LAZY) {
+			if (m) wave_adam_rows<true>(adam, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w],
+			                            (uint32_t)(m >> (h * STAGE_ROWS)), &lz.t, s_lag[w]);
+		} else if (ADAM)
 			wave_adam_rows(adam, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 		else
 			wave_store_rows(reinterpret_cast<float4*>(dL_dsh), half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w]);
 	}
+	if (LAZY && any) lz.row_step[idx] = lz.step;   // this row has taken the step
 }
 
 // any other row length / alignment: one thread per Gaussian, scalar stores
@@ -749,7 +771,7 @@ sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float*
 
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                               long long campos_stride, const float* views, long long view_stride, float scale, float* dL_dsh,
-                              const RowAdam* adam, hipStream_t stream)
+                              const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy)
 {
 	if (P == 0) return GSR_OK;
 	if (campos_stride == 0) campos_stride = 3;
@@ -758,17 +780,22 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 	const bool rows_ok = (3 * M == ROW_F4 * 4) && ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
 	if (adam && (!rows_ok || ((reinterpret_cast<uintptr_t>(adam->exp_avg) | reinterpret_cast<uintptr_t>(adam->exp_avg_sq)) & 15)))
 		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
+	if (lazy && !adam) return GSR_ERR_INVALID_ARG;
 	if (rows_ok) {
 		const int g = div_up(P, SHB_THREADS);
 		const RowAdam ra = adam ? *adam : RowAdam{};
+		const LazyAdam lz = lazy ? *lazy : LazyAdam{};
 #define GSR_SHV(DEG)                                                                                                          \
 	do {                                                                                                                      \
-		if (adam)                                                                                                             \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos,          \
-			           campos_stride, views, view_stride, scale, dL_dsh, ra);                                                                                    \
+		if (adam && lazy)                                                                                                     \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos,    \
+			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
+		else if (adam)                                                                                                        \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,   \
+			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
 		else                                                                                                                  \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,         \
-			           campos_stride, views, view_stride, scale, dL_dsh, ra);                                                                                    \
+			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,  \
+			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
 	} while (0)
 		if (D == 3)
 			GSR_SHV(3);

@@ -95,9 +95,16 @@ struct RowAdam {
 	float* exp_avg_sq;
 	AdamScalars s;
 };
-// row_mask: bit r clear = row r of the stage is left alone (it took its step elsewhere: gsr_backward, side stream)
+// row_mask: bit r clear = row r of the stage is left alone (it took its step elsewhere: gsr_backward, side stream; or it takes
+// it later: lazy mode).
+// CATCH_UP (lazy mode of gsr_sh_adam_from_views): stage row r lags s_lag[r] steps behind (step - 1); the mover takes those
+// zero-gradient steps first -- parameter and moments are in its registers anyway -- and then this step with the gradient.
+__device__ __forceinline__ void lazy_zero_grad_steps(const LazyAdamTable& t, int k_hi, int k_lo, int col, float4& pv, float4& mv,
+                                                     float4& vv);
+template <bool CATCH_UP = false>
 __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD],
-                                               uint32_t row_mask = 0xFFFFFFFFu)
+                                               uint32_t row_mask = 0xFFFFFFFFu, const LazyAdamTable* t = nullptr,
+                                               const uint32_t* s_lag = nullptr)
 {
 	const int l = lane_id();
 	const int slot = l >> 4, col = l & 15;
@@ -115,6 +122,10 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
 			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
 			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+			if (CATCH_UP) {
+				const int lag = (int)s_lag[4 * k + slot];
+				if (lag > 0) lazy_zero_grad_steps(*t, lag, 1, col, pv, mv, vv);
+			}
 			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
 			for (int e = 0; e < 4; e++) {

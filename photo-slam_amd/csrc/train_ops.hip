@@ -471,14 +471,19 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 	// 16-byte staging: every row of every plane (inputs and the derivative maps in `scratch`) starts on a 16-byte boundary
 	p.vec = (width % 4 == 0) && !((reinterpret_cast<uintptr_t>(rendered) | reinterpret_cast<uintptr_t>(gt) |
 	                              reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(scratch)) & 15);
-	// gaussian(11, 1.5) normalised, include/loss_utils.h:49-62
-	float sum = 0.f;
+	// gaussian(11, 1.5) normalised, include/loss_utils.h:49-62.  The normaliser is torch's gauss.sum(): the correctly rounded
+	// sum of the eleven floats (a sequential float sum is one ulp lower: the weights then sum to 1 + 6e-8 instead of the
+	// reference's 1 - 1.6e-8, and sigma = E[x^2] - mu^2 -- a difference of two numbers ~0.25 that is itself ~1e-3 -- inherits
+	// mu^2 * 1.5e-7 with ONE sign over the whole image: a 2e-5 relative bias of the loss on a near-converged view, 150x the
+	// reference's own float error against float64; found by tests/test_train_sequence_reference.py)
+	double sum = 0.0;
 	for (int x = 0; x < 11; x++) {
 		const int t = x - 5;
 		p.g[x] = expf(-(float)(t * t) / (2.0f * 1.5f * 1.5f));
-		sum += p.g[x];
+		sum += (double)p.g[x];
 	}
-	for (int x = 0; x < 11; x++) p.g[x] /= sum;
+	const float fsum = (float)sum;
+	for (int x = 0; x < 11; x++) p.g[x] /= fsum;
 	const size_t plane = (size_t)width * height;
 	const int gx = div_up(width, LT), gy = div_up(height, LTY);
 	p.nblocks = gx * gy * 3;
@@ -505,6 +510,95 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 	if (blocks > 0x7FFFFFFFll) blocks = 0x7FFFFFFFll;
 	if (blocks < 1) blocks = 1;
 	GSR_LAUNCH(adam_kernel, (int)blocks, 256, stream, param, grad, exp_avg, exp_avg_sq, n, as, period, split);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// Several tensors in ONE launch (gsr_adam_step_multi): block b works on the tensor whose block range holds it, one float4 per
+// thread, the arithmetic of adam_kernel (uniform learning rate per tensor).
+constexpr int ADAM_MULTI_MAX = 8;
+struct AdamMultiParams {
+	float* param[ADAM_MULTI_MAX];
+	const float* grad[ADAM_MULTI_MAX];
+	float* exp_avg[ADAM_MULTI_MAX];
+	float* exp_avg_sq[ADAM_MULTI_MAX];
+	long long n[ADAM_MULTI_MAX];
+	int first_block[ADAM_MULTI_MAX + 1];
+	AdamScalars s[ADAM_MULTI_MAX];
+	int count;
+};
+}  // extern "C"
+namespace gsr {
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(const AdamMultiParams q)
+{
+	int t = 0;
+#pragma unroll
+	for (int k = 1; k < ADAM_MULTI_MAX; k++)
+		if (k < q.count && (int)blockIdx.x >= q.first_block[k]) t = k;
+	float* __restrict__ param = q.param[t];
+	const float* __restrict__ grad = q.grad[t];
+	float* __restrict__ exp_avg = q.exp_avg[t];
+	float* __restrict__ exp_avg_sq = q.exp_avg_sq[t];
+	const long long n = q.n[t];
+	const AdamScalars a = q.s[t];
+	const long long i = ((long long)((int)blockIdx.x - q.first_block[t]) * 256 + threadIdx.x) * 4;
+	if (i >= n) return;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+	                       reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+	if (i + 3 < n && aligned) {
+		float4 pv = load_stream_f4(reinterpret_cast<const float4*>(param + i));
+		const float4 gv = load_stream_f4(reinterpret_cast<const float4*>(grad + i));
+		float4 mv = load_stream_f4(reinterpret_cast<const float4*>(exp_avg + i));
+		float4 vv = load_stream_f4(reinterpret_cast<const float4*>(exp_avg_sq + i));
+		float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			mp[k] = a.b1 * mp[k] + a.omb1 * gp[k];
+			vp[k] = a.b2 * vp[k] + a.omb2 * gp[k] * gp[k];
+			pp[k] -= a.step_size * mp[k] / (sqrtf(vp[k]) * a.inv_sqrt_bc2 + a.eps);
+		}
+		store_stream_f4(reinterpret_cast<float4*>(param + i), pv);
+		store_stream_f4(reinterpret_cast<float4*>(exp_avg + i), mv);
+		store_stream_f4(reinterpret_cast<float4*>(exp_avg_sq + i), vv);
+	} else {
+		for (long long k = i; k < n && k < i + 4; k++) {
+			const float g = grad[k];
+			const float m = a.b1 * exp_avg[k] + a.omb1 * g;
+			const float v = a.b2 * exp_avg_sq[k] + a.omb2 * g * g;
+			exp_avg[k] = m;
+			exp_avg_sq[k] = v;
+			param[k] -= a.step_size * m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
+		}
+	}
+}
+}  // namespace gsr
+extern "C" {
+
+int gsr_adam_step_multi(int count, const gsr_adam_multi_tensor* tensors, double beta1, double beta2, double eps, void* stream_)
+{
+	if (count < 0 || count > ADAM_MULTI_MAX || (count && !tensors)) return GSR_ERR_INVALID_ARG;
+	AdamMultiParams q{};
+	long long blocks = 0;
+	int used = 0;
+	for (int k = 0; k < count; k++) {
+		const gsr_adam_multi_tensor& t = tensors[k];
+		if (t.n < 0 || t.step < 1) return GSR_ERR_INVALID_ARG;
+		if (t.n == 0) continue;
+		if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq) return GSR_ERR_INVALID_ARG;
+		q.param[used] = t.param; q.grad[used] = t.grad; q.exp_avg[used] = t.exp_avg; q.exp_avg_sq[used] = t.exp_avg_sq;
+		q.n[used] = t.n;
+		q.s[used] = adam_scalars(t.lr, t.lr, beta1, beta2, eps, t.step);
+		q.first_block[used] = (int)blocks;
+		blocks += (t.n + 1023) / 1024;
+		if (blocks > 0x7FFFFFFFll) return GSR_ERR_UNSUPPORTED;
+		used++;
+	}
+	if (!used) return GSR_OK;
+	q.first_block[used] = (int)blocks;
+	q.count = used;
+	hipStream_t stream = (hipStream_t)stream_;
+	GSR_LAUNCH(adam_multi_kernel, (int)blocks, 256, stream, q);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -58,6 +58,26 @@ class FusedAdam:
                                                   float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, rp._stream_ptr(p)),
                            "gsr_adam_step")
 
+    def step_groups(self, indices):
+        """step_group(i) for several single-tensor groups with uniform learning rates in ONE launch (gsr_adam_step_multi: the
+        four small per-Gaussian tensors of a data-parallel step, whose gradients arrive together from one all-reduce)."""
+        entries = []
+        with torch.no_grad():
+            for i in indices:
+                grp = self.param_groups[i]
+                (p,) = grp["params"]
+                if p.grad is None:
+                    continue
+                if grp.get("period", 0) or not p.is_contiguous() or not p.grad.is_contiguous():
+                    self.step_group(i)
+                    continue
+                st = self.state.get(id(p))
+                if st is None:
+                    st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
+                st["step"] += 1
+                entries.append((p.detach(), p.grad, st["exp_avg"], st["exp_avg_sq"], float(grp["lr"]) * self.lr_scale, st["step"]))
+            rp.adamStepMulti(entries, self.betas[0], self.betas[1], self.eps)
+
     def begin_fused_step(self, i, lazy_window=0):
         """Arguments of the fused update of single-tensor group i (GaussianRasterizationSettings.sh_adam_): advances the
         parameter's step counter -- the update itself happens inside the rasterizer's backward, and step_group(i) then finds
@@ -303,6 +323,11 @@ class GaussianModel:
 
     def params(self):
         return [self.xyz_, self.features_, self.opacity_, self.scaling_, self.rotation_]
+
+    def params_raw(self):
+        """The five leaves as they are (no catch-up of lazily stepped SH rows): for code that only needs the tensors' .grad or
+        shape inside a train step."""
+        return [self.xyz_, self._features, self.opacity_, self.scaling_, self.rotation_]
 
     # ---- optimizer, src/gaussian_model.cpp:477-510
     def trainingSetup(self, opt):

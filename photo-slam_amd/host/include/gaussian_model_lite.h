@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include "rasterize_points.h"   // ShAdamStep
+
 struct GaussianOptimizationParams {  // include/gaussian_parameters.h:61-96 defaults
 	int iterations_ = 30000;
 	float position_lr_init_ = 0.00016f, position_lr_final_ = 0.0000016f, position_lr_delay_mult_ = 0.01f;
@@ -92,6 +94,8 @@ public:
 		syncFeatures();
 		return {xyz_, features_, opacity_, scaling_, rotation_};
 	}
+	// the five leaves as they are (no catch-up of lazily stepped SH rows): for code that only needs their .grad() inside a step
+	std::vector<torch::Tensor> paramsRaw() { return {xyz_, features_, opacity_, scaling_, rotation_}; }
 
 	// Lazy Adam steps for the SH rows of culled Gaussians (gsr_sh_adam_lazy, include/gsr.h; TrainStep::lazy_sh_adam_window_).
 	// While features_row_step_ is defined, rows of features_ and of its two moment tensors may be up to `window` zero-gradient
@@ -199,6 +203,17 @@ public:
 	// part is applied as soon as ITS all-gather has landed, while the next one is still on the links; the Adam step counter
 	// advances with the first part only.
 	void stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views, int64_t row0 = 0, bool first_part = true);
+	// With lazy_sh_adam_window_ >= 2 the factored step is as lean as the single-GPU one: a row no gathered view lights takes a
+	// zero-gradient step, i.e. it may take it LATER (gsr_sh_adam_from_views with sh_adam->lazy) -- renderAndBackward() then
+	// advances the SH step counter itself and hands the lazy struct to the forward pass, stepFeaturesFromViews() steps only the
+	// lit rows, and finishFeaturesFromViews() -- after the last part -- runs this step's slice of the rotating catch-up and
+	// records the step's learning rates.  (finishEnd() calls it if the driver did not.)
+	void finishFeaturesFromViews();
+	// xyz / opacity / scaling / rotation in ONE Adam launch (gsr_adam_step_multi): the data-parallel step's four small
+	// gradients arrive together from one all-reduce.  Replaces finishAdamGroup(0 / 2 / 3 / 4).
+	void finishGeomAdam();
+	ShAdamStep views_adam_;
+	bool views_adam_pending_ = false;
 	std::shared_ptr<GaussianModel> gaussians_;
 	torch::Tensor background_;
 	int iteration_ = 0;

@@ -115,5 +115,16 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 // gsr_sh_adam_flush: lazy mode -- every row of `sh` takes the zero-gradient steps it is behind, up to sh_adam.step = the number
 // of Adam steps the tensor has taken (sh_adam.lr / lr_tail belong to that step)
 void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam);
+// gsr_sh_adam_lazy_slice: the data-parallel step's rotating catch-up -- after the last shAdamFromViews() range of a step with
+// lazy rows (sh_adam.row_step defined), this step's 1/window of the row blocks brings every row that is behind up to sh_adam.step
+void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam);
+
+// gsr_adam_step_multi: one Adam step (gsr_adam_step arithmetic) of several tensors in ONE launch
+struct AdamMultiEntry {
+	torch::Tensor param, grad, exp_avg, exp_avg_sq;   // contiguous float32, one size
+	double lr = 0.0;
+	int step = 0;
+};
+void adamStepMulti(const std::vector<AdamMultiEntry>& entries, double beta1, double beta2, double eps);
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);

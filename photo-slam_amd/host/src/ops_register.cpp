@@ -149,7 +149,7 @@ std::vector<torch::Tensor> trainer_grads(int64_t h)
 {
 	std::vector<torch::Tensor> g;
 	// (features_ has no gradient yet in the factored mode: an empty tensor keeps the positions)
-	for (auto& p : get(h)->gaussians_->params()) g.push_back(p.grad().defined() ? p.grad() : torch::empty({0}, p.options()));
+	for (auto& p : get(h)->gaussians_->paramsRaw()) g.push_back(p.grad().defined() ? p.grad() : torch::empty({0}, p.options()));
 	return g;
 }
 // densification: options of the schedule (names of GaussianOptimizationParams / GaussianMapper without the trailing
@@ -249,6 +249,8 @@ void trainer_features_step_from_views(int64_t h, torch::Tensor campos_views, tor
 {
 	get(h)->stepFeaturesFromViews(campos_views, views, row0, first_part);
 }
+void trainer_features_finish_from_views(int64_t h) { get(h)->finishFeaturesFromViews(); }
+void trainer_geom_adam(int64_t h) { get(h)->finishGeomAdam(); }
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
                                  int64_t M, double scale)
 {
@@ -305,6 +307,8 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_sh_send_buffer", &trainer_sh_send_buffer);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
 	m.def("trainer_features_step_from_views", &trainer_features_step_from_views);
+	m.def("trainer_features_finish_from_views", &trainer_features_finish_from_views);
+	m.def("trainer_geom_adam", &trainer_geom_adam);
 	m.def("sh_grad_from_views", &sh_grad_from_views);
 	m.def("trainer_destroy", &trainer_destroy);
 }

@@ -411,13 +411,11 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 		throw std::runtime_error("sh and its moments must be contiguous float32 (num_points, M, 3) tensors");
 	if (P == 0) return;
 	F32 m3(means3D);
+	// sh_adam.row_step (lazy mode, gsr_sh_adam_lazy): rows no view lights are left alone and step later; the caller runs
+	// shAdamLazySlice() after the last row range of the step
 	gsr_sh_adam adam{};
-	adam.param = sh.data_ptr<float>();
-	adam.exp_avg = sh_adam.exp_avg.data_ptr<float>();
-	adam.exp_avg_sq = sh_adam.exp_avg_sq.data_ptr<float>();
-	adam.lr = sh_adam.lr; adam.lr_tail = sh_adam.lr_tail;
-	adam.beta1 = sh_adam.beta1; adam.beta2 = sh_adam.beta2; adam.eps = sh_adam.eps;
-	adam.step = sh_adam.step;
+	gsr_sh_adam_lazy lazy{};
+	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
 	check(gsr_sh_adam_from_views(P, degree, static_cast<int>(sh.size(1)), va.n_views, m3.ptr, va.campos, va.campos_stride,
 	                             va.views, va.view_stride, scale, sh.data_ptr<float>(), &adam, current_stream(means3D)),
 	      "shAdamFromViews");
@@ -434,6 +432,39 @@ void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam)
 	gsr_sh_adam_lazy lazy{};
 	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
 	check(gsr_sh_adam_flush(static_cast<int>(sh.size(0)), &adam, current_stream(sh)), "shAdamFlush");
+}
+
+void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam)
+{
+	torch::NoGradGuard ng;
+	if (!sh_adam.row_step.defined() || !sh_adam.exp_avg.defined() || sh.dim() != 3 || sh.size(1) != 16 || !sh.is_contiguous() ||
+	    sh.scalar_type() != torch::kFloat32 || !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() ||
+	    sh_adam.exp_avg.sizes() != sh.sizes() || sh_adam.exp_avg_sq.sizes() != sh.sizes())
+		throw std::runtime_error("shAdamLazySlice needs a contiguous float32 [P,16,3] tensor, its moments and row_step");
+	gsr_sh_adam adam{};
+	gsr_sh_adam_lazy lazy{};
+	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
+	check(gsr_sh_adam_lazy_slice(static_cast<int>(sh.size(0)), &adam, current_stream(sh)), "shAdamLazySlice");
+}
+
+void adamStepMulti(const std::vector<AdamMultiEntry>& entries, double beta1, double beta2, double eps)
+{
+	torch::NoGradGuard ng;
+	if (entries.empty()) return;
+	std::vector<gsr_adam_multi_tensor> ts;
+	for (const auto& e : entries) {
+		for (const torch::Tensor* t : {&e.param, &e.grad, &e.exp_avg, &e.exp_avg_sq})
+			if (!t->defined() || t->scalar_type() != torch::kFloat32 || !t->is_contiguous() || t->numel() != e.param.numel() ||
+			    t->device() != e.param.device())
+				throw std::runtime_error("adamStepMulti needs contiguous float32 tensors of one size and device per entry");
+		gsr_adam_multi_tensor m{};
+		m.param = e.param.data_ptr<float>(); m.grad = e.grad.data_ptr<float>();
+		m.exp_avg = e.exp_avg.data_ptr<float>(); m.exp_avg_sq = e.exp_avg_sq.data_ptr<float>();
+		m.n = e.param.numel(); m.lr = e.lr; m.step = e.step;
+		ts.push_back(m);
+	}
+	check(gsr_adam_step_multi(static_cast<int>(ts.size()), ts.data(), beta1, beta2, eps, current_stream(entries[0].param)),
+	      "adamStepMulti");
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)

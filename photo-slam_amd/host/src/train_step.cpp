@@ -232,13 +232,43 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 			}
 		}
 	}
+	// Data-parallel step with the view-factored exchange: the SH rows step AFTER the exchange (stepFeaturesFromViews), and lazily
+	// there too -- a row no view of the batch lights takes a zero-gradient step, i.e. it may take it later.  The forward pass
+	// gets the same struct, so that the rows THIS view sees are up to date before they are evaluated; backward ignores it.
+	views_adam_ = ShAdamStep();
+	views_adam_pending_ = false;
+	if (factored_exchange_ && lazy_sh_adam_window_ >= 2 && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
+	    g->features_.size(1) == 16 && g->features_.is_contiguous() && !pipe.convert_SHs_) {
+		auto& grp = g->groups_[1];
+		lazy = true;
+		if (g->features_row_step_.defined() && g->features_lazy_window_ != lazy_sh_adam_window_) g->syncFeatures();
+		if (!g->features_row_step_.defined()) {   // every row has taken the grp.step steps so far
+			g->features_row_step_ = torch::full({g->features_.size(0)}, grp.step, g->features_.options().dtype(torch::kInt32).requires_grad(false));
+			g->features_lazy_window_ = lazy_sh_adam_window_;
+			g->features_lr_hist_.clear();
+		}
+		grp.step++;   // the step happens in stepFeaturesFromViews(); optimizerStepGroup(1) finds no gradient
+		sh_adam.exp_avg = grp.exp_avg;
+		sh_adam.exp_avg_sq = grp.exp_avg_sq;
+		sh_adam.lr = grp.lr * g->lr_scale_;
+		sh_adam.lr_tail = grp.lr_tail * g->lr_scale_;
+		sh_adam.step = grp.step;
+		sh_adam.row_step = g->features_row_step_;
+		sh_adam.window = g->features_lazy_window_;
+		for (const auto& h : g->features_lr_hist_) {
+			sh_adam.lr_past.push_back(h.first);
+			sh_adam.lr_tail_past.push_back(h.second);
+		}
+		views_adam_ = sh_adam;
+		views_adam_pending_ = true;
+	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 	GeomAdamStep geom_adam;
 	// (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then skips it -- no
 	// gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)
 	const bool resets = densify_ && iteration_ < o.densify_until_iter_ && o.opacity_reset_interval_ &&
 	                    iteration_ % o.opacity_reset_interval_ == 0;
-	if (fused_geom_adam_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5 && !pipe.compute_cov3D_ && !resets) {
+	if (fused_geom_adam_ && !factored_exchange_ && sh_adam.exp_avg.defined() && g->groups_.size() == 5 && !pipe.compute_cov3D_ && !resets) {
 		// xyz, opacity, scaling, rotation = groups 0, 2, 3, 4 (trainingSetup); their steps happen inside backward, and
 		// optimizerStepGroup() then finds no gradient on them
 		for (int gi : {0, 2, 3, 4}) {
@@ -269,7 +299,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	// the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward()
 	if (!root_grad_.defined() || root_grad_.device() != loss.device()) root_grad_ = torch::ones_like(loss).detach();
 	loss.backward(root_grad_);
-	if (lazy) {   // the step is taken: its learning rates join the history the later catch-ups need
+	if (lazy && !views_adam_pending_) {   // the step is taken: its learning rates join the history the later catch-ups need
 		auto& hist = g->features_lr_hist_;
 		hist.insert(hist.begin(), {sh_adam.lr, sh_adam.lr_tail});
 		if (static_cast<int>(hist.size()) > g->features_lazy_window_) hist.pop_back();
@@ -289,6 +319,13 @@ void TrainStep::setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tens
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
+	if (views_adam_pending_) {
+		// the dense route after all: the lazy step renderAndBackward() announced is withdrawn (its counter, not yet its learning
+		// rates, had been recorded) and every row catches up to the steps really taken
+		views_adam_pending_ = false;
+		views_adam_ = ShAdamStep();
+		g->groups_[1].step--;
+	}
 	g->syncFeatures();
 	g->features_.mutable_grad() =
 	    shGradFromViews(g->xyz_.detach(), campos_views, dL_dcolor_views, g->active_sh_degree_,
@@ -300,9 +337,20 @@ void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor 
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	if (iteration_ >= g->opt_.iterations_) return;
-	g->syncFeatures();
 	const int64_t P = g->xyz_.size(0), n = dL_dcolor_views.size(1);
 	if (row0 < 0 || row0 + n > P) throw std::runtime_error("stepFeaturesFromViews: the part exceeds the Gaussians");
+	if (views_adam_pending_) {
+		// lazy rows: renderAndBackward() advanced the step counter and prepared the struct; rows no view lights stay behind
+		ShAdamStep a = views_adam_;
+		a.exp_avg = views_adam_.exp_avg.narrow(0, row0, n);
+		a.exp_avg_sq = views_adam_.exp_avg_sq.narrow(0, row0, n);
+		a.row_step = views_adam_.row_step.narrow(0, row0, n);
+		auto sh = g->features_.detach().narrow(0, row0, n);
+		shAdamFromViews(g->xyz_.detach().narrow(0, row0, n), campos_views, dL_dcolor_views, g->active_sh_degree_,
+		                1.0f / static_cast<float>(dL_dcolor_views.size(0)), sh, a);
+		return;
+	}
+	g->syncFeatures();
 	if (g->features_.size(1) != 16 || g->groups_.size() < 2) {   // other layouts: gradient tensor + separate pass (whole batch only)
 		if (row0 != 0 || n != P) throw std::runtime_error("stepFeaturesFromViews: parts need the [P,16,3] SH layout");
 		setFeaturesGradFromViews(campos_views, dL_dcolor_views);
@@ -322,6 +370,47 @@ void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor 
 	                1.0f / static_cast<float>(dL_dcolor_views.size(0)), sh, a);
 }
 
+void TrainStep::finishFeaturesFromViews()
+{
+	if (!views_adam_pending_) return;
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	views_adam_pending_ = false;
+	if (iteration_ < g->opt_.iterations_) {
+		// this step's 1/window of the row blocks catches up, so that no row lags by more than `window` steps
+		auto sh = g->features_.detach();
+		shAdamLazySlice(sh, views_adam_);
+	}
+	auto& hist = g->features_lr_hist_;   // the step is taken: its learning rates join the history the later catch-ups need
+	hist.insert(hist.begin(), {views_adam_.lr, views_adam_.lr_tail});
+	if (static_cast<int>(hist.size()) > g->features_lazy_window_) hist.pop_back();
+	views_adam_ = ShAdamStep();
+}
+
+void TrainStep::finishGeomAdam()
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	if (iteration_ >= g->opt_.iterations_ || g->groups_.size() != 5) return;
+	std::vector<AdamMultiEntry> entries;
+	for (int gi : {0, 2, 3, 4}) {
+		auto& grp = g->groups_[static_cast<size_t>(gi)];
+		auto grad = grp.param.grad();
+		if (!grad.defined()) continue;   // (the iteration that rebuilt the tensors: no gradient, the step counter rests)
+		grp.step++;
+		AdamMultiEntry e;
+		e.param = grp.param.detach();
+		e.grad = grad.contiguous();
+		e.exp_avg = grp.exp_avg;
+		e.exp_avg_sq = grp.exp_avg_sq;
+		e.lr = grp.lr * g->lr_scale_;
+		e.step = grp.step;
+		entries.push_back(e);
+	}
+	adamStepMulti(entries, 0.9, 0.999, 1e-15);
+	for (int gi : {0, 2, 3, 4}) g->groups_[static_cast<size_t>(gi)].param.mutable_grad() = torch::Tensor();
+}
+
 void TrainStep::finishAdamGroup(int group)
 {
 	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->optimizerStepGroup(group);
@@ -329,6 +418,7 @@ void TrainStep::finishAdamGroup(int group)
 
 void TrainStep::finishEnd()
 {
+	finishFeaturesFromViews();   // (a driver that forgot the slice: the lazy state stays consistent)
 	if (iteration_ < gaussians_->opt_.iterations_) gaussians_->zeroGrad();
 }
 

@@ -267,10 +267,39 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
             raise RuntimeError("sh and its moments must be contiguous float32 (num_points, M, 3) tensors")
     if P != 0:
         k1, p1 = _ptr(means3D)
-        adam, adam_keep = capi.make_sh_adam(sh, {k: v for k, v in sh_adam.items() if k != "row_step"})
+        # sh_adam["row_step"] (lazy mode, gsr_sh_adam_lazy): rows no view lights are left alone and step later; the caller runs
+        # shAdamLazySlice() after the last row range of the step
+        adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
         st = lib.gsr_sh_adam_from_views(P, int(degree), int(sh.size(1)), n_views, p1, pc, sc, pv, sv, float(scale),
                                         C.c_void_p(sh.data_ptr()), C.byref(adam), _stream_ptr(means3D))
         capi.check(lib, st, "shAdamFromViews")
+
+
+def shAdamLazySlice(sh, sh_adam):
+    """gsr_sh_adam_lazy_slice (include/gsr.h): this step's 1/window of the row blocks of the lazily stepped [P,16,3] tensor
+    catches up (every row of the slice that is behind sh_adam["step"])."""
+    lib = _lib()
+    _check_device(lib, sh, sh_adam["exp_avg"], sh_adam["exp_avg_sq"], sh_adam["row_step"])
+    with torch.no_grad():
+        adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
+        capi.check(lib, lib.gsr_sh_adam_lazy_slice(int(sh.size(0)), C.byref(adam), _stream_ptr(sh)), "shAdamLazySlice")
+
+
+def adamStepMulti(tensors, beta1, beta2, eps):
+    """gsr_adam_step_multi (include/gsr.h): one Adam step of several tensors in ONE launch.
+    tensors: [(param, grad, exp_avg, exp_avg_sq, lr, step), ...] (contiguous float32, at most 8)."""
+    lib = _lib()
+    if not tensors:
+        return
+    arr = (capi.AdamMultiTensor * len(tensors))()
+    for k, (p, g, m, v, lr, step) in enumerate(tensors):
+        for t in (p, g, m, v):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+                raise RuntimeError("adamStepMulti needs contiguous float32 tensors of one size per entry")
+        arr[k] = capi.AdamMultiTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), int(step))
+    _check_device(lib, *[t for e in tensors for t in e[:4]])
+    capi.check(lib, lib.gsr_adam_step_multi(len(tensors), arr, float(beta1), float(beta2), float(eps), _stream_ptr(tensors[0][0])),
+               "adamStepMulti")
 
 
 def shAdamFlush(sh, sh_adam):

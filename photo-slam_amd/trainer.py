@@ -165,10 +165,17 @@ class ViewFactoredExchange:
         never reaches HBM.  sh_adam: FusedAdam.begin_fused_step(FEATURES_GROUP)."""
         from . import rasterize_points as rp
         m3, shd = means3D.detach(), sh.detach()
+        lazy = sh_adam.get("row_step") is not None
         for row0, centres, views in self.gathered_parts():
             n = views.size(1)
             part = dict(sh_adam, exp_avg=sh_adam["exp_avg"][row0:row0 + n], exp_avg_sq=sh_adam["exp_avg_sq"][row0:row0 + n])
+            if lazy:
+                part["row_step"] = sh_adam["row_step"][row0:row0 + n]
             rp.shAdamFromViews(m3[row0:row0 + n], centres, views, degree, 1.0 / self.world_size_, shd[row0:row0 + n], part)
+        if lazy:
+            # lazy rows (gsr_sh_adam_lazy): the rows no view of the batch lights were left alone above; this step's 1/window of
+            # the row blocks catches up, so that no row lags by more than `window` steps
+            rp.shAdamLazySlice(shd, sh_adam)
 
     def order(self):
         """parameter indices of the all-reduced tensors in completion order"""
@@ -219,7 +226,7 @@ class TrainStep:
         self.iteration_ += 1
         it = self.iteration_
         g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
-        sh_send = sh_view = sh_adam = geom_adam = None
+        sh_send = sh_view = sh_adam = geom_adam = sh_adam_views = None
         if self.world_size_ > 1 and self.factored_exchange_:
             sh_send, sh_view = ViewFactoredExchange.send_buffer(g.xyz_.size(0), g.xyz_.device)
         # this iteration densifies (src/gaussian_mapper.cpp:720-721; the fresh leaves have no gradient, so the reference's
@@ -244,15 +251,23 @@ class TrainStep:
                     d = g.optimizer_.begin_fused_step(gi)
                     tensors.append((g.optimizer_.param_groups[gi]["params"][0].detach(), d["exp_avg"], d["exp_avg_sq"], d["lr"], d["step"]))
                 geom_adam = dict(tensors=tensors, beta1=sh_adam["beta1"], beta2=sh_adam["beta2"], eps=sh_adam["eps"])
+        # Data-parallel step with the view-factored exchange: the SH rows step AFTER the exchange (gsr_sh_adam_from_views), and
+        # lazily there too -- a row no view of the batch lights takes a zero-gradient step, i.e. it may take it later; the
+        # forward pass gets the same struct so that the rows THIS view sees are up to date before they are evaluated.
+        if sh_view is not None and self.lazy_sh_adam_window_ >= 2 and it < opt.iterations_ and not rebuilds and \
+                g._features.size(1) == 16 and g.optimizer_ is not None and not self.pipe_.convert_SHs_ and \
+                g._features.is_contiguous():
+            sh_adam_views = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)
         # this view's densification statistics (:714-719) are added by the backward kernel that holds dL_dmean2D.  With
         # several ranks they accumulate PER RANK and are reduced only when densification consumes them (below): SUM and MAX
         # commute with the accumulation over iterations, so nothing crosses the links for them on the other 99 of 100 steps
         view_stats = (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_) if it < opt.densify_until_iter_ else None
-        g._in_lazy_step = sh_adam is not None and sh_adam.get("row_step") is not None
+        fwd_adam = sh_adam if sh_adam is not None else sh_adam_views
+        g._in_lazy_step = fwd_adam is not None and fwd_adam.get("row_step") is not None
         try:
             rendered_image, viewspace_point_tensor, visibility_filter, radii = GaussianRenderer.render(
                 viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
-                sh_grad_view=sh_view, sh_adam=sh_adam, view_stats=view_stats, geom_adam=geom_adam,
+                sh_grad_view=sh_view, sh_adam=fwd_adam, view_stats=view_stats, geom_adam=geom_adam,
                 training_outputs_only=True)   # the statistics are fused (or over): nobody reads the viewspace gradient
         finally:
             g._in_lazy_step = False
@@ -270,7 +285,7 @@ class TrainStep:
                 # keyframe-batch data parallelism: mean of the per-view gradients over RCCL, in flight from here on
                 if sh_view is not None:
                     reduction = ViewFactoredExchange(sh_send, viewpoint_cam.camera_center_,
-                                                     [(i, p.grad) for i, p in enumerate(g.params()) if i != FEATURES_GROUP],
+                                                     [(i, p.grad) for i, p in enumerate(g.params_raw()) if i != FEATURES_GROUP],
                                                      self.world_size_)
                 else:
                     reduction = GradientReduction([p.grad for p in g.params()], self.world_size_)
@@ -305,15 +320,29 @@ class TrainStep:
                     if sh_view is not None:
                         # the SH gradient is rebuilt from the gathered views (reads xyz_: before ITS update) and applied
                         # while the all-reduces of the other four tensors are on the links
-                        if g.features_.size(1) == 16:   # rebuild + Adam in one pass
+                        if sh_adam_views is not None:   # rebuild + Adam in one pass, lazy rows
+                            g._in_lazy_step = True
+                            try:
+                                reduction.sh_adam_step(g.xyz_, g.active_sh_degree_, g._features, sh_adam_views)
+                            finally:
+                                g._in_lazy_step = False
+                            g.optimizer_.end_fused_step(FEATURES_GROUP, sh_adam_views)
+                            sh_adam_views = None
+                        elif g.features_.size(1) == 16:   # rebuild + Adam in one pass
                             reduction.sh_adam_step(g.xyz_, g.active_sh_degree_, g.features_,
                                                    g.optimizer_.begin_fused_step(FEATURES_GROUP))
                         else:
                             g.features_.grad = reduction.sh_gradient(g.xyz_, g.active_sh_degree_, g.features_.size(1))
                             g.optimizer_.step_group(FEATURES_GROUP)
-                    for i in reduction.order():
-                        reduction.wait(i)
-                        g.optimizer_.step_group(i)
+                    small = [i for i in reduction.order() if i != FEATURES_GROUP]
+                    if sh_view is not None and len(small) == 4 and _one_buffer([g.params_raw()[i].grad for i in small]) is not None:
+                        # the four small gradients arrived in ONE all-reduce: one Adam launch for the four tensors
+                        reduction.wait(small[0])
+                        g.optimizer_.step_groups(small)
+                    else:
+                        for i in reduction.order():
+                            reduction.wait(i)
+                            g.optimizer_.step_group(i)
                 g.optimizer_.zero_grad(set_to_none=True)
             elif reduction is not None:
                 reduction.wait_all()

@@ -131,11 +131,19 @@ def run_trainer_checks(ops, dev, lib_path):
         if it == 1:   # the gradient tensor + the separate pass
             ops.trainer_features_grad_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0))
             ops.trainer_adam_group(h2, 1)
-        else:         # rebuild + Adam in one pass (what bench.py does)
+        elif it == 0:   # rebuild + Adam in one pass over two row ranges, lazy rows, then the slice (what bench.py does)
+            ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view[:148].unsqueeze(0), 0, True)
+            ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view[148:].unsqueeze(0), 148, False)
+            ops.trainer_features_finish_from_views(h2)
+        else:
             ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0), 0, True)
-        for i in (4, 0, 3, 2):
-            ops.trainer_adam_group(h2, i)
+        if it == 0:   # the four small tensors in one Adam launch (what bench.py does)
+            ops.trainer_geom_adam(h2)
+        else:
+            for i in (4, 0, 3, 2):
+                ops.trainer_adam_group(h2, i)
         ops.trainer_finish_end(h2)
+    assert list(ops.trainer_steps(h2)) == [3] * 5
     for a, b in zip(ops.trainer_params(h2), ops.trainer_params(h)):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
     for a, b in zip(ops.trainer_stats(h2), ops.trainer_stats(h)):

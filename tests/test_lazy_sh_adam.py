@@ -125,3 +125,100 @@ def test_both_hosts_train_the_same_with_lazy_rows_on_gpu():
         pytest.skip("no HIP device")
     from tests.test_cpp_host import load_host
     run_host_lazy_checks(load_host("hip"), torch.device("cuda:0"), None, P=20000, iterations=15)
+
+
+def run_lazy_from_views_checks(dev, lib_path, P=700, n_views=3, steps=11, window=4):
+    """gsr_sh_adam_from_views with lazy rows (the data-parallel step): rows no gathered view lights are left alone and catch up
+    later (in a later from-views call that lights them, in their slice, or in the flush) -- bit-identical to the dense update
+    that steps every row at every step.  Row ranges (two parts per step), learning rates that change per step, Gaussians that
+    are never lit, rows lit after a long pause."""
+    from photo_slam_amd import rasterize_points as rp
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)
+    xyz = (3.0 * r(P, 3)).to(dev)
+    sh0, m0, v0 = (0.3 * r(P, 16, 3)).to(dev), (0.01 * r(P, 16, 3)).to(dev), (1e-4 * torch.rand(P, 16, 3, generator=g)).to(dev)
+    never = torch.rand(P, generator=g) < 0.2
+    base = dict(beta1=0.9, beta2=0.999, eps=1e-15)
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        eager = [t.clone() for t in (sh0, m0, v0)]
+        lazy = [t.clone() for t in (sh0, m0, v0)]
+        row_step = torch.full((P,), 5, dtype=torch.int32, device=dev)    # the tensor has taken 5 steps so far
+        hist = []
+        half = (P // 2 // 4) * 4
+        for k in range(steps):
+            step = 6 + k
+            lr, lr_tail = 0.0025 * (1.0 + 0.1 * k), 0.000125 * (1.0 + 0.05 * k)
+            lit = (torch.rand(n_views, P, generator=g) < (0.05 if 3 <= k < 8 else 0.35)) & ~never     # (a long pause for most rows)
+            views = (r(n_views, P, 3) * lit.unsqueeze(-1)).to(dev)
+            centres = (2.0 * r(n_views, 3)).to(dev)
+            d = dict(base, lr=lr, lr_tail=lr_tail, step=step)
+            rp.shAdamFromViews(xyz, centres, views, 3, 1.0 / n_views, eager[0], dict(d, exp_avg=eager[1], exp_avg_sq=eager[2]))
+            dl = dict(d, window=window, lr_past=[a for a, _ in hist], lr_tail_past=[b for _, b in hist])
+            for a, b in ((0, half), (half, P)):
+                rp.shAdamFromViews(xyz[a:b], centres, views[:, a:b].contiguous(), 3, 1.0 / n_views, lazy[0][a:b],
+                                   dict(dl, exp_avg=lazy[1][a:b], exp_avg_sq=lazy[2][a:b], row_step=row_step[a:b]))
+            rp.shAdamLazySlice(lazy[0], dict(dl, exp_avg=lazy[1], exp_avg_sq=lazy[2], row_step=row_step))
+            hist.insert(0, (lr, lr_tail))
+            del hist[window:]
+            assert int(row_step.max()) == step and int(row_step.min()) >= step - window + 1
+            if k == 4:
+                assert int((row_step < step).sum()) > P // 10, "no row is behind: the case under test does not occur"
+        rp.shAdamFlush(lazy[0], dict(base, lr=hist[0][0], lr_tail=hist[0][1], step=step, exp_avg=lazy[1], exp_avg_sq=lazy[2],
+                                     row_step=row_step, window=window, lr_past=[a for a, _ in hist[1:]],
+                                     lr_tail_past=[b for _, b in hist[1:]]))
+        assert int(row_step.min()) == step
+        for a, b, name in zip(lazy, eager, ("sh", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(a, b), name
+        assert not torch.equal(eager[0], sh0)
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def run_adam_multi_checks(dev, lib_path, P=1237):
+    """gsr_adam_step_multi == one gsr_adam_step per tensor (the four small tensors of a data-parallel step in one launch)."""
+    from photo_slam_amd import capi, rasterize_points as rp
+    g = torch.Generator().manual_seed(9)
+    shapes = [(P, 4), (P, 3), (P, 3), (P, 1)]
+    mk = lambda s, k: (k * torch.randn(*s, generator=g)).to(dev)
+    params = [mk(s, 1.0) for s in shapes]
+    grads = torch.cat([mk(s, 1e-3).reshape(-1) for s in shapes])          # slices of one buffer, as the backward pass leaves them
+    gs, off = [], 0
+    for s in shapes:
+        n = s[0] * s[1]
+        gs.append(grads[off:off + n].view(s))
+        off += n
+    m = [mk(s, 1e-2) for s in shapes]
+    v = [(1e-4 * torch.rand(*s, generator=g)).to(dev) for s in shapes]
+    lrs, steps = [0.001, 0.00016 * 4.5, 0.005, 0.05], [7, 7, 9, 3]
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        lib = rp._lib()
+        one = [[t.clone() for t in ts] for ts in (params, m, v)]
+        for k in range(4):
+            capi.check(lib, lib.gsr_adam_step(one[0][k].data_ptr(), gs[k].data_ptr(), one[1][k].data_ptr(), one[2][k].data_ptr(),
+                                              one[0][k].numel(), lrs[k], 0.9, 0.999, 1e-15, steps[k], 0, 0, lrs[k], None), "gsr_adam_step")
+        multi = [[t.clone() for t in ts] for ts in (params, m, v)]
+        rp.adamStepMulti([(multi[0][k], gs[k], multi[1][k], multi[2][k], lrs[k], steps[k]) for k in range(4)], 0.9, 0.999, 1e-15)
+        for a, b in zip(one[0] + one[1] + one[2], multi[0] + multi[1] + multi[2]):
+            assert torch.equal(a, b)
+        assert not torch.equal(multi[0][0], params[0])
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def test_lazy_rows_in_the_from_views_step_equal_the_dense_update(emu_lib_path):
+    run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path)
+    run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path, P=333, n_views=1, steps=9, window=32)
+
+
+def test_adam_step_multi_equals_separate_steps(emu_lib_path):
+    run_adam_multi_checks(torch.device("cpu"), emu_lib_path)
+
+
+@pytest.mark.gpu
+def test_lazy_from_views_and_adam_multi_on_gpu():
+    dev = torch.device("cuda:0")
+    run_lazy_from_views_checks(dev, None, P=200_003, n_views=4, steps=13, window=4)
+    run_lazy_from_views_checks(dev, None, P=50_000, n_views=8, steps=40, window=32)
+    run_adam_multi_checks(dev, None, P=300_001)

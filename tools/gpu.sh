@@ -117,7 +117,8 @@ import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms
     sq)     sq_pass ${arg:-full} ;;
     dp)     ex=${arg:-factored}
             for cfg in C3 C4; do
-              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json 2>$OUT/dp_err.log
+              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
+              grep '^{"metric"' $OUT/dp_$cfg.log > $OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json   # (the RCCL banner precedes the JSON line)
               python -c "
 import json; d=json.load(open('$OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json')); print('$cfg dp 1 rank $ex', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'])" || tail -5 $OUT/dp_err.log
             done ;;
