@@ -155,6 +155,9 @@ def main():
                     help="xyz / opacity / scaling / rotation step in four separate Adam passes instead of inside the backward kernels")
     ap.add_argument("--densify-leg-steps", type=int, default=250,
                     help="steps of the densify_run leg (densifyAndPrune every 100 steps, training learning rates; 0 = skip)")
+    ap.add_argument("--insert-every", type=int, default=0,
+                    help="densify_run leg: GaussianModel::increasePcd of 5 k new points every N steps (0 = only the five timed calls "
+                         "after the leg)")
     ap.add_argument("--no-knn-leg", dest="knn_leg", action="store_false", help="skip the simple-knn leg (100 k and 1 M points)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
@@ -467,10 +470,17 @@ def main():
         barrier()
         t0 = time.perf_counter()
         ev[0].record()
+        new_pts = torch.from_numpy(np.random.default_rng(5).uniform([-3, -1.5, -3], [3, 1.5, 3], (5000, 3)).astype(np.float32)).to(dev)
+        new_cols = torch.rand(5000, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+        inserted_at = []
         for i in range(n_d):
             loss = ops.trainer_render_and_backward(h2, kf.world_view_transform_, kf.full_proj_transform_, kf.camera_center_, fovx,
                                                    fovy, H, W, gt, mask)
             ops.trainer_finish(h2)
+            if args.insert_every and (i + 1) % args.insert_every == 0:
+                # GaussianModel::increasePcd (src/gaussian_model.cpp:188-376): 5 k new map points, as a new keyframe brings them
+                ops.trainer_increase_pcd(h2, new_pts, new_cols, i + 1, False)
+                inserted_at.append(i)
             read_loss_deferred(loss)
             ev[i + 1].record()
         barrier()
@@ -490,6 +500,24 @@ def main():
                        "note": "BASELINE config C3 as stated: densifyAndPrune (src/gaussian_model.cpp:716-815) every 100 steps inside the "
                                "timed loop, training learning rates; a densifying step skips its optimizer update as the reference's does; "
                                "the synthetic scene keeps splitting the same high-gradient Gaussians, so the work per step grows"}
+        if inserted_at:
+            densify_run["insert_every"] = args.insert_every
+            densify_run["ms_per_inserting_step"] = [round(float(per[i]), 3) for i in inserted_at]
+        # increasePcd alone: 5 k points into the (by now ~2 M) model, five times in a row -- kNN among the new points + the
+        # append (in place while the arena has room; the reference re-cats all six tensors and their moments: 2 x 708 B x P)
+        ins = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        P0 = int(ops.trainer_params(h2)[0].shape[0])
+        torch.cuda.synchronize()
+        ins[0].record()
+        for k in range(5):
+            ops.trainer_increase_pcd(h2, new_pts, new_cols, n_d + k, False)
+            ins[k + 1].record()
+        torch.cuda.synchronize()
+        densify_run["increase_pcd"] = {"points_per_call": 5000, "calls": 5, "gaussians_before": P0,
+                                       "gaussians_after": int(ops.trainer_params(h2)[0].shape[0]),
+                                       "ms_per_call": [round(ins[k].elapsed_time(ins[k + 1]), 3) for k in range(5)],
+                                       "note": "GaussianModel::increasePcd (src/gaussian_model.cpp:188-376): distCUDA2 among the new "
+                                               "points + append with zero moments; the first call may grow the arena"}
         ops.trainer_destroy(h2)
         torch.cuda.empty_cache()
 

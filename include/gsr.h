@@ -354,6 +354,10 @@ typedef struct gsr_densify_gather_args {
 	 * at::normal(0, std) of the reference (:731-736) is randn * std.  NULL allowed when n_child == 0. */
 	const float* samples;
 	float* stats_out[3];              /* xyz_gradient_accum, denom, max_radii2D of the new set ([n_new] each): zero-filled; NULL = skip */
+	/* GaussianModel::exist_since_iter_ ([P] / [n_new] int32; both or neither): every row of the new set inherits its source's
+	 * value -- prunePoints (:636), clones (:782) and split children (:744) alike */
+	const int* exist_since_iter_in;
+	int* exist_since_iter_out;
 } gsr_densify_gather_args;
 int gsr_densify_gather(const gsr_densify_gather_args* args, const char* scratch, void* stream);
 

@@ -118,21 +118,23 @@ MODEL_OUT = {"cpu": os.path.join(OUT_DIR, "libref_densify.so"), "cuda": os.path.
 # the member functions of GaussianModel that oracle/ref_densify.cpp compiles, extracted verbatim by name
 MODEL_FUNCTIONS = ["getScalingActivation", "getXYZ", "getOpacityActivation", "trainingSetup", "resetOpacity",
                    "replaceTensorToOptimizer", "prunePoints", "densificationPostfix", "densifyAndSplit", "densifyAndClone",
-                   "densifyAndPrune", "addDensificationStats", "percentDense", "setPercentDense", "loadPly", "savePly"]
+                   "densifyAndPrune", "addDensificationStats", "percentDense", "setPercentDense", "loadPly", "savePly", "increasePcd"]
 ADAM_KEY = "c10::guts::to_string(param.unsafeGetTensorImpl())"   # LibTorch <= 2.1 state key (src/gaussian_model.cpp:571,598,670)
 
 
 def _member_function(text, name):
-    """`<return type> GaussianModel::name(...) {...}` of a .cpp file, verbatim."""
-    m = re.search(r"^[\w:<>&\* ]+\bGaussianModel::" + name + r"\s*\(", text, re.M)
-    if not m:
+    """`<return type> GaussianModel::name(...) {...}` of a .cpp file, verbatim -- every overload of the name."""
+    out = []
+    for m in re.finditer(r"^[\w:<>&\* ]+\bGaussianModel::" + name + r"\s*\(", text, re.M):
+        j = text.index("{", m.end())
+        depth, k = 1, j + 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(text[k], 0)
+            k += 1
+        out.append(text[m.start():k])
+    if not out:
         raise RuntimeError(f"GaussianModel::{name} not found in {MODEL_SRC}")
-    j = text.index("{", m.end())
-    depth, k = 1, j + 1
-    while depth:
-        depth += {"{": 1, "}": -1}.get(text[k], 0)
-        k += 1
-    return text[m.start():k]
+    return "\n\n".join(out)
 
 
 def build_densify(force=False):
@@ -152,6 +154,7 @@ def build_densify(force=False):
     text = open(MODEL_SRC).read()
     body = "\n\n".join(_member_function(text, n) for n in MODEL_FUNCTIONS)
     assert body.count(ADAM_KEY) == 6, "the Adam state key idiom changed in the reference"
+    assert body.count("GaussianModel::increasePcd(") == 2, "two overloads of increasePcd expected"
     body = body.replace(ADAM_KEY, "param.unsafeGetTensorImpl()")
     os.makedirs(GEN, exist_ok=True)
     with open(os.path.join(GEN, "ref_gaussian_model_functions.inc"), "w") as f:
@@ -165,7 +168,7 @@ def build_densify(force=False):
                                    "-w", "-I" + GEN, "-I" + os.path.join(REF, "include"), "-I" + REF] + ["-I" + i for i in inc] +
                                   (["-DREF_DENSIFY_DEVICE_CPU"] if kind == "cpu" else []) +
                                   [src, os.path.join(REF, "src", "gaussian_parameters.cpp"), "-o", out, "-L" + libdir, "-ltorch",
-                                   "-ltorch_cpu", "-lc10", "-Wl,-rpath," + libdir])
+                                   "-ltorch_cpu", "-lc10", "-ldl", "-Wl,-rpath," + libdir])
     finally:
         shutil.rmtree(GEN, ignore_errors=True)   # the extracted reference text does not outlive the compile
     return dict(MODEL_OUT)

@@ -2,8 +2,8 @@
  * ref_densify.cpp -- torch ops around the REFERENCE's own map-maintenance code: the member functions
  *   GaussianModel::{getXYZ, getScalingActivation, getOpacityActivation, trainingSetup, resetOpacity,
  *   replaceTensorToOptimizer, prunePoints, densificationPostfix, densifyAndSplit, densifyAndClone, densifyAndPrune,
- *   addDensificationStats, percentDense, setPercentDense, loadPly, savePly}
- *                                                      (src/gaussian_model.cpp:48-71, 477-510, 553-831, 838-1047, 1090-1100)
+ *   addDensificationStats, percentDense, setPercentDense, loadPly, savePly, increasePcd (both overloads)}
+ *                                                      (src/gaussian_model.cpp:48-71, 188-376, 477-510, 553-831, 838-1047, 1090-1100)
  * are extracted VERBATIM, by name, from /root/reference/src/gaussian_model.cpp by oracle/build_ref.py into a generated
  * include file (oracle/_ref/gen/ref_gaussian_model_functions.inc, deleted after the compile) and compiled here against
  * LibTorch.  The only rewrite is the Adam state key: `c10::guts::to_string(param.unsafeGetTensorImpl())` (LibTorch <= 2.1
@@ -45,6 +45,30 @@ inline void refEmptyCache() {}
 
 #include "general_utils.h"        /* the reference's own headers */
 #include "gaussian_parameters.h"
+#include "sh_utils.h"             /* RGB2SH for increasePcd */
+#include <dlfcn.h>
+
+/* third_party/simple-knn's distCUDA2 (spatial.h:14) for increasePcd (:238,325): OURS -- the reference's is CUDA.  It calls the
+ * CPU oracle's gsro_knn (oracle/libgsr_oracle.so, next to this library's directory), which tests/test_reference_pinning.py
+ * pins bit for bit to the reference's own simple_knn.cu compiled for the host. */
+static torch::Tensor distCUDA2(const torch::Tensor& points)
+{
+	using knn_fn = void (*)(int, const float*, float*);
+	static knn_fn fn = [] {
+		Dl_info info;
+		TORCH_CHECK(dladdr(reinterpret_cast<void*>(&distCUDA2), &info) && info.dli_fname, "dladdr failed");
+		std::string path = std::filesystem::path(info.dli_fname).parent_path().parent_path() / "libgsr_oracle.so";
+		void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+		TORCH_CHECK(h, "cannot load ", path, ": ", dlerror());
+		auto f = reinterpret_cast<knn_fn>(dlsym(h, "gsro_knn"));
+		TORCH_CHECK(f, "gsro_knn not found in ", path);
+		return f;
+	}();
+	auto host = points.detach().to(torch::kCPU).to(torch::kFloat32).contiguous();
+	auto out = torch::empty({host.size(0)}, host.options());
+	fn(static_cast<int>(host.size(0)), host.data_ptr<float>(), out.data_ptr<float>());
+	return out.to(points.device());
+}
 #define TINYPLY_IMPLEMENTATION    /* third_party/tinyply/tinyply.cpp does exactly this */
 #include "third_party/tinyply/tinyply.h"
 #include <cstring>
@@ -80,6 +104,9 @@ public:
 	void setPercentDense(const float percent_dense);
 	void loadPly(std::filesystem::path ply_path);
 	void savePly(std::filesystem::path result_path);
+	void increasePcd(std::vector<float> points, std::vector<float> colors, const int iteration);
+	void increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& new_colors, const int iteration);
+	torch::Tensor sparse_points_xyz_ = torch::empty({0, 3}), sparse_points_color_ = torch::empty({0, 3});
 	int active_sh_degree_ = 0;
 	int max_sh_degree_ = 3;
 
@@ -222,6 +249,25 @@ TensorList ref_prune_points(TensorList params, TensorList exp_avg, TensorList ex
 	return dump_model(*g);
 }
 
+/* increasePcd (src/gaussian_model.cpp:188-376): vector_overload selects (std::vector<float>, std::vector<float>, int), else
+ * (torch::Tensor&, torch::Tensor&, int) */
+TensorList ref_increase_pcd(TensorList params, TensorList exp_avg, TensorList exp_avg_sq, std::vector<int64_t> steps,
+                            torch::Tensor accum, torch::Tensor denom, torch::Tensor max_radii2D, torch::Tensor exist_since_iter,
+                            torch::Tensor points, torch::Tensor colors, int64_t iteration, bool vector_overload)
+{
+	torch::NoGradGuard ng;
+	auto g = make_model(params, exp_avg, exp_avg_sq, steps, accum, denom, max_radii2D, exist_since_iter, 0.01, 1.0);
+	if (vector_overload) {
+		auto p = points.detach().to(torch::kCPU).contiguous(), c = colors.detach().to(torch::kCPU).contiguous();
+		std::vector<float> pv(p.data_ptr<float>(), p.data_ptr<float>() + p.numel()), cv(c.data_ptr<float>(), c.data_ptr<float>() + c.numel());
+		g->increasePcd(pv, cv, (int)iteration);
+	} else {
+		auto p = points.detach().clone(), c = colors.detach().clone();
+		g->increasePcd(p, c, (int)iteration);
+	}
+	return dump_model(*g);
+}
+
 /* addDensificationStats (src/gaussian_model.cpp:817-831) on a viewspace tensor whose .grad() is `viewspace_grad` */
 TensorList ref_add_densification_stats(torch::Tensor accum, torch::Tensor denom, torch::Tensor viewspace_grad,
                                        torch::Tensor update_filter)
@@ -275,6 +321,7 @@ TensorList ref_load_ply(std::string path, int64_t max_sh_degree)
 	m.def("save_ply", &ref_save_ply);                                 \
 	m.def("load_ply", &ref_load_ply);                                 \
 	m.def("densify_and_prune", &ref_densify_and_prune);               \
+	m.def("increase_pcd", &ref_increase_pcd);                         \
 	m.def("reset_opacity", &ref_reset_opacity);                       \
 	m.def("prune_points", &ref_prune_points);                         \
 	m.def("add_densification_stats", &ref_add_densification_stats);   \

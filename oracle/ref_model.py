@@ -47,6 +47,12 @@ def densify_and_prune(ops, st, percent_dense, max_grad, min_opacity, extent, max
     return State.from_dump(ops.densify_and_prune(*st.args(), percent_dense, max_grad, min_opacity, extent, max_screen_size))
 
 
+def increase_pcd(ops, st, points, colors, iteration, vector_overload=False):
+    """the reference's GaussianModel::increasePcd (src/gaussian_model.cpp:188-376), either overload; distCUDA2 is the CPU
+    oracle's kNN (pinned to simple_knn.cu), see oracle/ref_densify.cpp"""
+    return State.from_dump(ops.increase_pcd(*st.args(), points, colors, int(iteration), bool(vector_overload)))
+
+
 def reset_opacity(ops, st):
     return State.from_dump(ops.reset_opacity(*st.args()))
 

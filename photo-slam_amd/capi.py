@@ -118,7 +118,8 @@ class DensifyGatherArgs(C.Structure):
                 ("n_split", C.c_int), ("features_row_floats", C.c_int),
                 ("param_in", C.c_void_p * 5), ("exp_avg_in", C.c_void_p * 5), ("exp_avg_sq_in", C.c_void_p * 5),
                 ("param_out", C.c_void_p * 5), ("exp_avg_out", C.c_void_p * 5), ("exp_avg_sq_out", C.c_void_p * 5),
-                ("samples", C.c_void_p), ("stats_out", C.c_void_p * 3)]
+                ("samples", C.c_void_p), ("stats_out", C.c_void_p * 3), ("exist_since_iter_in", C.c_void_p),
+                ("exist_since_iter_out", C.c_void_p)]
 
 
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h

@@ -196,7 +196,9 @@ struct DensifyGather {
 	const float* samples;         // [2k,3] standard normal draws (at::normal's randn before the scale), null if no children
 	GatherTensor t[5];            // xyz, features, opacity, scaling, rotation
 	float* stats[3];              // xyz_gradient_accum, denom, max_radii2D of the new set: zero-filled (may be null)
-	long long items_before[7];    // prefix sums of the work items: t[0..4], then the statistics, then the end
+	const int* exist_in;          // exist_since_iter_ [P] (nullable, with exist_out): every new row inherits its source's value
+	int* exist_out;               //   (prunePoints :636, densifyAndSplit :744, densifyAndClone :782)
+	long long items_before[7];    // prefix sums of the work items: t[0..4], then the statistics (+ exist_since_iter), then the end
 };
 
 __device__ __forceinline__ void quat_rotate(const float* q, float sx, float sy, float sz, float& ox, float& oy, float& oz)
@@ -220,7 +222,12 @@ densify_gather_kernel(const DensifyGather p)
 	if (item >= p.items_before[5]) {   // statistics of the new set start from zero (densificationPostfix :709-711)
 		const long long e = item - p.items_before[5];
 		const int a = (int)(e / p.n_new);
-		if (p.stats[a]) p.stats[a][e - (long long)a * p.n_new] = 0.f;
+		const long long row = e - (long long)a * p.n_new;
+		if (a == 3) {
+			if (p.exist_out) p.exist_out[row] = p.exist_in[p.src_of[row] & 0x3FFFFFFFu];
+		} else if (p.stats[a]) {
+			p.stats[a][row] = 0.f;
+		}
 		return;
 	}
 	int ti = 0;
@@ -344,7 +351,9 @@ int gsr_densify_gather(const gsr_densify_gather_args* a, const char* scratch, vo
 	}
 	p.items_before[5] = items;
 	for (int k = 0; k < 3; k++) p.stats[k] = a->stats_out[k];
-	items += 3ll * a->n_new;
+	if ((a->exist_since_iter_in == nullptr) != (a->exist_since_iter_out == nullptr)) return GSR_ERR_INVALID_ARG;
+	p.exist_in = a->exist_since_iter_in; p.exist_out = a->exist_since_iter_out;
+	items += 4ll * a->n_new;
 	p.items_before[6] = items;
 	const long long blocks = (items + 255) / 256;
 	if (blocks > 0x7FFFFFFFll) return GSR_ERR_UNSUPPORTED;

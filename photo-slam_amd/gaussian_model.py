@@ -192,6 +192,11 @@ class GaussianModel:
         self.optimizer_ = None
         self._features = None
         self._in_lazy_step = False   # set by the train step around its own render call
+        # include/gaussian_model.h:169,182-183: the iteration each Gaussian has existed since (read by the loop-closure
+        # transform, src/gaussian_model.cpp:433), and the sparse points handed to increasePcd so far (saveSparsePointsPly :1049)
+        self.exist_since_iter_ = None
+        self.sparse_points_xyz_ = None
+        self.sparse_points_color_ = None
 
     # features_: the [P,16,3] SH leaf.  With lazy Adam steps for the rows of culled Gaussians (FusedAdam.begin_fused_step,
     # gsr_sh_adam_lazy) rows of it may be behind between train steps: every read from outside the fused step brings them up
@@ -230,6 +235,7 @@ class GaussianModel:
         m.max_radii2D_ = torch.zeros(P, device=m.device_)
         m.xyz_gradient_accum_ = torch.zeros((P, 1), device=m.device_)
         m.denom_ = torch.zeros((P, 1), device=m.device_)
+        m.exist_since_iter_ = torch.zeros(P, dtype=torch.int32, device=m.device_)
         return m
 
     def createFromPcd(self, points, colors, spatial_lr_scale):
@@ -256,6 +262,81 @@ class GaussianModel:
         self.max_radii2D_ = torch.zeros(n, device=self.device_)
         self.xyz_gradient_accum_ = torch.zeros((n, 1), device=self.device_)
         self.denom_ = torch.zeros((n, 1), device=self.device_)
+        self.exist_since_iter_ = torch.zeros(n, dtype=torch.int32, device=self.device_)   # :167-169
+
+    def increasePcd(self, points, colors, iteration):
+        """src/gaussian_model.cpp:193-376, both overloads (std::vector<float> x 2 / torch::Tensor& x 2): new SLAM map points
+        join the model -- colours -> SH DC term, scales from the simple-knn distance AMONG THE NEW POINTS (distCUDA2 of the
+        new cloud alone, :238,325), identity rotations, opacity 0.1, exist_since_iter = iteration -- through
+        densificationPostfix (:644-712): appended behind the existing rows, zero Adam moments for the new rows, the step
+        counters carried, and -- as the reference does -- all three statistics arrays reset to zero.
+        Here the append is O(new points) while the arena has room (the reference re-cats every tensor and moment)."""
+        dev = self.xyz_.device
+        as_rows = lambda a: (a if torch.is_tensor(a) else torch.tensor(list(a), dtype=torch.float32)).to(dev, torch.float32).reshape(-1, 3)
+        pts, cols = as_rows(points), as_rows(colors)
+        assert pts.shape == cols.shape
+        n = pts.shape[0]
+        if n == 0:
+            return 0
+        with torch.no_grad():
+            self.sparse_points_xyz_ = pts if self.sparse_points_xyz_ is None else torch.cat([self.sparse_points_xyz_, pts], 0)
+            self.sparse_points_color_ = cols if self.sparse_points_color_ is None else torch.cat([self.sparse_points_color_, cols], 0)
+            C0 = 0.28209479177387814
+            M = (self.max_sh_degree_ + 1) ** 2
+            features = torch.zeros((n, M, 3), device=dev)
+            features[:, 0, :] = (cols - 0.5) / C0                                   # RGB2SH, include/sh_utils.h:138
+            dist2 = torch.clamp_min(rp.distCUDA2(pts.clone().contiguous()), 0.0000001)
+            scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3)
+            rots = torch.zeros((n, 4), device=dev)
+            rots[:, 0] = 1
+            opacities = inverse_sigmoid(0.1 * torch.ones((n, 1), device=dev))
+            self._append_rows(dict(xyz_=pts, features_=features, opacity_=opacities, scaling_=scales, rotation_=rots), int(iteration))
+        return n
+
+    def _append_rows(self, new_rows, iteration):
+        """densificationPostfix (:644-712) as an append into the arena of the rebuilds."""
+        _ = self.features_           # lazy SH Adam: every row up to date before the tensor is re-seated
+        P, n = self.xyz_.shape[0], new_rows["xyz_"].shape[0]
+        dev = self.xyz_.device
+        arena = getattr(self, "_arena", None)
+        live = arena is not None and arena["capacity"] >= P + n and all(
+            getattr(self, name).data_ptr() == arena["sets"][arena["cur"]]["params"][name][0].data_ptr() for name in self._PARAM_NAMES)
+        if self.exist_since_iter_ is None:
+            self.exist_since_iter_ = torch.zeros(P, dtype=torch.int32, device=dev)
+        old_exist = self.exist_since_iter_
+        if not live:
+            self.reserve(int((P + n) * 1.25) + 64)
+            arena = self._arena
+        cur = arena["sets"][arena["cur"]]
+        for name in self._PARAM_NAMES:
+            old = getattr(self, name)
+            have = self.optimizer_ is not None and id(old) in self.optimizer_.state
+            m, v = self.optimizer_.moments(old) if have else (None, None)
+            bufs = [b.narrow(0, 0, P + n) for b in cur["params"][name]]
+            if not live:
+                bufs[0][:P].copy_(old.detach())
+                if have:
+                    bufs[1][:P].copy_(m)
+                    bufs[2][:P].copy_(v)
+            bufs[0][P:].copy_(new_rows[name])
+            bufs[1][P:].zero_()
+            bufs[2][P:].zero_()
+            if not have:
+                bufs[1][:P].zero_()
+                bufs[2][:P].zero_()
+            new = bufs[0].detach().requires_grad_(True)
+            setattr(self, name, new)
+            if self.optimizer_ is not None:
+                self.optimizer_.replace_param(old, new, bufs[1], bufs[2])
+        exist = cur["exist"].narrow(0, 0, P + n)
+        if not live or old_exist.data_ptr() != exist.data_ptr():
+            exist[:P].copy_(old_exist)
+        exist[P:].fill_(iteration)
+        self.exist_since_iter_ = exist
+        stats = [b.narrow(0, 0, P + n) for b in cur["stats"]]
+        for t in stats:
+            t.zero_()                                                            # :709-711
+        self.xyz_gradient_accum_, self.denom_, self.max_radii2D_ = stats
 
     # ---- checkpoint interchange, src/gaussian_model.cpp:838-1047
     def savePly(self, path):
@@ -276,6 +357,7 @@ class GaussianModel:
         m.max_radii2D_ = torch.zeros(P, device=m.device_)
         m.xyz_gradient_accum_ = torch.zeros((P, 1), device=m.device_)
         m.denom_ = torch.zeros((P, 1), device=m.device_)
+        m.exist_since_iter_ = torch.zeros(P, dtype=torch.int32, device=m.device_)
         return m
 
     # ---- activations, src/gaussian_model.cpp:48-71
@@ -400,7 +482,8 @@ class GaussianModel:
         mk = lambda shape: torch.empty((capacity,) + shape, device=dev, dtype=torch.float32)
         self._arena = dict(capacity=capacity, cur=0,
                            sets=[dict(params={n: [mk(r), mk(r), mk(r)] for n, r in rows.items()},
-                                      stats=[mk((1,)), mk((1,)), mk(())]) for _ in range(2)])
+                                      stats=[mk((1,)), mk((1,)), mk(())],
+                                      exist=torch.empty((capacity,), device=dev, dtype=torch.int32)) for _ in range(2)])
 
     def _compact(self, select, generator=None):
         """select: fills a capi.DensifySelectArgs.  Returns the counts [kept, clones, child parents, split, clone-selected,
@@ -450,6 +533,11 @@ class GaussianModel:
             stats = [b.narrow(0, 0, n_new) for b in dst["stats"]]
             for k in range(3):
                 g.stats_out[k] = stats[k].data_ptr()
+            exist_old = self.exist_since_iter_
+            exist_new = dst["exist"].narrow(0, 0, n_new)
+            if exist_old is not None:   # every new row inherits its source's value (:636, :744, :782)
+                assert exist_old.is_contiguous() and exist_old.dtype == torch.int32 and exist_old.numel() == P
+                g.exist_since_iter_in, g.exist_since_iter_out = exist_old.data_ptr(), exist_new.data_ptr()
             if n_new:
                 capi.check(lib, lib.gsr_densify_gather(C.byref(g), scratch.data_ptr(), stream), "gsr_densify_gather")
         for name, (old, _, m, _), outs in zip(self._PARAM_NAMES, olds, news):
@@ -461,6 +549,8 @@ class GaussianModel:
                 else:
                     self.optimizer_.replace_param(old, new, outs[1].zero_(), outs[2].zero_())
         self.xyz_gradient_accum_, self.denom_, self.max_radii2D_ = stats
+        if exist_old is not None:
+            self.exist_since_iter_ = exist_new
         return n_keep, n_clone, n_child, n_split, n_clone_sel, n_new
 
     def prunePoints(self, mask):

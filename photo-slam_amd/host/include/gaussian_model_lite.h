@@ -55,6 +55,13 @@ public:
 
 	// map maintenance (src/gaussian_model_densify.cpp; include/gaussian_model.h:72-137 of the reference)
 	void createFromPcd(torch::Tensor points, torch::Tensor colors, float spatial_lr_scale);
+	// src/gaussian_model.cpp:188-376, both overloads: new SLAM map points join the model (colours -> SH DC term, scales from
+	// distCUDA2 AMONG THE NEW POINTS, identity rotations, opacity 0.1, exist_since_iter = iteration) through
+	// densificationPostfix (:644-712): appended behind the existing rows, zero Adam moments for the new rows, step counters
+	// carried, all three statistics arrays reset to zero.  The append is O(new points) while the arena has room (the reference
+	// re-cats every tensor and moment and then empties the allocator cache).
+	void increasePcd(std::vector<float> points, std::vector<float> colors, const int iteration);
+	void increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& new_colors, const int iteration);
 	void oneUpShDegree();
 	void resetOpacity();
 	bool intended_opacity_reset_ = false;   // see resetOpacity(): false = the reference as shipped
@@ -116,6 +123,10 @@ public:
 	double lr_scale_ = 1.0;
 	torch::Tensor xyz_, features_, opacity_, scaling_, rotation_;
 	torch::Tensor max_radii2D_, xyz_gradient_accum_, denom_;
+	// include/gaussian_model.h:169: the iteration each Gaussian has existed since ([P] int32; read by the loop-closure transform,
+	// src/gaussian_model.cpp:433); carried through prune / clone / split (:636, :744, :782) and set by increasePcd (:255)
+	torch::Tensor exist_since_iter_;
+	torch::Tensor sparse_points_xyz_, sparse_points_color_;   // :182-183: the points handed to increasePcd so far
 	GaussianOptimizationParams opt_;
 	std::vector<AdamGroup> groups_;
 
@@ -137,7 +148,19 @@ private:
 		int cur = 0;
 		std::array<std::array<torch::Tensor, 3>, 5> params[2];   // [set][tensor][parameter, exp_avg, exp_avg_sq]
 		std::array<torch::Tensor, 3> stats[2];
+		torch::Tensor exist[2];   // exist_since_iter_ ([capacity] int32)
 	} arena_;
+	void appendRows(const std::array<torch::Tensor, 5>& rows, int iteration);   // densificationPostfix as an append into the arena
+public:
+	// The arena keeps two sets of 1.25-1.5x (parameters + moments) resident (~2 kB per Gaussian) so that rebuilds allocate
+	// nothing.  LIFETIME CONTRACT: after a rebuild xyz_, features_, ..., the Adam moments and the statistics are narrow() views
+	// into one of the two sets; a tensor obtained BEFORE rebuild N (getXYZ(), a moment, xyz_gradient_accum_ held by a viewer or
+	// mapper thread) is overwritten by rebuild N + 2 -- clone() what has to outlive a rebuild (the reference hands out fresh
+	// tensors).  releaseArena(): the live tensors move into allocations of their own and both sets are freed (what the
+	// reference's emptyCache() after densification achieves, :814) -- call it when densification ends
+	// (iteration >= densify_until_iter_) or whenever stable tensors are needed; the next rebuild creates a new arena.
+	void releaseArena();
+private:
 	torch::Tensor densify_scratch_;
 };
 

@@ -53,7 +53,113 @@ void GaussianModel::createFromPcd(torch::Tensor points, torch::Tensor colors, fl
 	max_radii2D_ = torch::zeros({n}, o);
 	xyz_gradient_accum_ = torch::zeros({n, 1}, o);
 	denom_ = torch::zeros({n, 1}, o);
+	exist_since_iter_ = torch::zeros({n}, o.dtype(torch::kInt32));   // :167-169
 	groups_.clear();
+}
+
+// src/gaussian_model.cpp:193-290: the std::vector overload wraps the floats and proceeds as the tensor overload (:292-376)
+void GaussianModel::increasePcd(std::vector<float> points, std::vector<float> colors, const int iteration)
+{
+	if (points.size() != colors.size() || points.size() % 3 != 0) throw std::runtime_error("increasePcd: points / colors must hold 3 floats per point");
+	const int64_t n = static_cast<int64_t>(points.size() / 3);
+	if (n == 0) return;
+	const auto dev = xyz_.defined() ? xyz_.device() : device_;
+	auto p = torch::from_blob(points.data(), {n, 3}, torch::kFloat32).clone().to(dev);
+	auto c = torch::from_blob(colors.data(), {n, 3}, torch::kFloat32).clone().to(dev);
+	increasePcd(p, c, iteration);
+}
+
+void GaussianModel::increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& new_colors, const int iteration)
+{
+	torch::NoGradGuard ng;
+	const int64_t n = new_point_cloud.size(0);
+	if (n == 0) return;
+	const auto o = xyz_.options().requires_grad(false);
+	auto pts = new_point_cloud.to(o).contiguous(), cols = new_colors.to(o).contiguous();
+	if (!sparse_points_xyz_.defined() || sparse_points_xyz_.size(0) == 0) {   // :205-212
+		sparse_points_xyz_ = pts;
+		sparse_points_color_ = cols;
+	} else {
+		sparse_points_xyz_ = torch::cat({sparse_points_xyz_, pts}, 0);
+		sparse_points_color_ = torch::cat({sparse_points_color_, cols}, 0);
+	}
+	const double C0 = 0.28209479177387814;
+	const int64_t M = (max_sh_degree_ + 1) * (max_sh_degree_ + 1);
+	auto features = torch::zeros({n, M, 3}, o);
+	features.select(1, 0).copy_((cols - 0.5) / C0);   // RGB2SH, include/sh_utils.h:138
+	auto dist2 = torch::clamp_min(distCUDA2(pts.clone()), 0.0000001);
+	auto scales = torch::log(torch::sqrt(dist2)).unsqueeze(1).repeat({1, 3});
+	auto rots = torch::zeros({n, 4}, o);
+	rots.select(1, 0).fill_(1.0);
+	auto opacities = inverse_sigmoid(0.1 * torch::ones({n, 1}, o));
+	appendRows({pts, features, opacities, scales, rots}, iteration);
+}
+
+// densificationPostfix (src/gaussian_model.cpp:644-712) as an append: while the arena has room and the live tensors are its
+// views, only the new rows are written.
+void GaussianModel::appendRows(const std::array<torch::Tensor, 5>& rows, int iteration)
+{
+	torch::NoGradGuard ng;
+	syncFeatures();   // the SH tensor is re-seated: no row may be behind (lazy SH Adam)
+	const int64_t P = xyz_.size(0), n = rows[0].size(0);
+	const bool have_state = groups_.size() == 5;
+	bool live = arena_.capacity >= P + n && arena_.params[0][0][0].defined() && arena_.params[0][0][0].device() == xyz_.device();
+	for (int i = 0; live && i < 5; i++) live = paramByIndex(i).data_ptr() == arena_.params[arena_.cur][i][0].data_ptr();
+	if (!exist_since_iter_.defined()) exist_since_iter_ = torch::zeros({P}, xyz_.options().dtype(torch::kInt32).requires_grad(false));
+	auto old_exist = exist_since_iter_;
+	std::array<torch::Tensor, 5> old_param;
+	std::array<std::array<torch::Tensor, 2>, 5> old_mom;
+	for (int i = 0; i < 5; i++) {
+		old_param[i] = paramByIndex(i).detach();
+		if (have_state) old_mom[i] = {groups_[i].exp_avg, groups_[i].exp_avg_sq};
+	}
+	if (!live) {
+		reserve(static_cast<int64_t>((P + n) * 1.25) + 64);   // (cur = 0; the old tensors stay alive through old_param / old_mom)
+	}
+	auto& cur = arena_.params[arena_.cur];
+	for (int i = 0; i < 5; i++) {
+		std::array<torch::Tensor, 3> b;
+		for (int k = 0; k < 3; k++) b[k] = cur[i][k].narrow(0, 0, P + n);
+		if (!live) {
+			b[0].narrow(0, 0, P).copy_(old_param[i]);
+			if (have_state) {
+				b[1].narrow(0, 0, P).copy_(old_mom[i][0]);
+				b[2].narrow(0, 0, P).copy_(old_mom[i][1]);
+			}
+		}
+		b[0].narrow(0, P, n).copy_(rows[i].reshape(b[0].narrow(0, P, n).sizes()));
+		b[1].narrow(0, P, n).zero_();
+		b[2].narrow(0, P, n).zero_();
+		if (have_state) replaceParam(i, b[0], b[1], b[2]);
+		else replaceParam(i, b[0], torch::Tensor(), torch::Tensor());
+	}
+	auto exist = arena_.exist[arena_.cur].narrow(0, 0, P + n);
+	if (old_exist.data_ptr() != exist.data_ptr()) exist.narrow(0, 0, P).copy_(old_exist);
+	exist.narrow(0, P, n).fill_(iteration);
+	exist_since_iter_ = exist;
+	std::array<torch::Tensor, 3> stats;
+	for (int k = 0; k < 3; k++) stats[k] = arena_.stats[arena_.cur][k].narrow(0, 0, P + n).zero_();   // :709-711
+	xyz_gradient_accum_ = stats[0];
+	denom_ = stats[1];
+	max_radii2D_ = stats[2];
+}
+
+void GaussianModel::releaseArena()
+{
+	torch::NoGradGuard ng;
+	syncFeatures();
+	const bool have_state = groups_.size() == 5;
+	for (int i = 0; i < 5; i++) {
+		auto fresh = paramByIndex(i).detach().clone();
+		if (have_state) replaceParam(i, fresh, groups_[i].exp_avg.clone(), groups_[i].exp_avg_sq.clone());
+		else replaceParam(i, fresh, torch::Tensor(), torch::Tensor());
+	}
+	if (xyz_gradient_accum_.defined()) xyz_gradient_accum_ = xyz_gradient_accum_.clone();
+	if (denom_.defined()) denom_ = denom_.clone();
+	if (max_radii2D_.defined()) max_radii2D_ = max_radii2D_.clone();
+	if (exist_since_iter_.defined()) exist_since_iter_ = exist_since_iter_.clone();
+	arena_ = Arena();
+	densify_scratch_ = torch::Tensor();
 }
 
 void GaussianModel::oneUpShDegree()   // :72 / src/gaussian_model.cpp:98-102
@@ -121,6 +227,7 @@ void GaussianModel::reserve(int64_t capacity)
 		arena_.stats[s][0] = torch::empty({capacity, 1}, o);
 		arena_.stats[s][1] = torch::empty({capacity, 1}, o);
 		arena_.stats[s][2] = torch::empty({capacity}, o);
+		arena_.exist[s] = torch::empty({capacity}, o.dtype(torch::kInt32));
 	}
 	arena_.capacity = capacity;
 	arena_.cur = 0;
@@ -190,7 +297,16 @@ std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10:
 		stats[k] = arena_.stats[arena_.cur][k].narrow(0, 0, n_new);
 		g.stats_out[k] = stats[k].data_ptr<float>();
 	}
+	// exist_since_iter_: every row of the new set inherits its source's value (:636, :744, :782)
+	torch::Tensor exist_old, exist_new;
+	if (exist_since_iter_.defined() && exist_since_iter_.numel() == P) {
+		exist_old = exist_since_iter_.contiguous();
+		exist_new = arena_.exist[arena_.cur].narrow(0, 0, n_new);
+		g.exist_since_iter_in = exist_old.data_ptr<int>();
+		g.exist_since_iter_out = exist_new.data_ptr<int>();
+	}
 	if (n_new) check_gsr(gsr_densify_gather(&g, reinterpret_cast<const char*>(densify_scratch_.data_ptr<uint8_t>()), stream), "gsr_densify_gather");
+	if (exist_new.defined()) exist_since_iter_ = exist_new;
 	for (int i = 0; i < 5; i++) {
 		if (have_state) replaceParam(i, out[i][0], out[i][1], out[i][2]);
 		else replaceParam(i, out[i][0], torch::Tensor(), torch::Tensor());

@@ -249,6 +249,25 @@ void trainer_features_step_from_views(int64_t h, torch::Tensor campos_views, tor
 {
 	get(h)->stepFeaturesFromViews(campos_views, views, row0, first_part);
 }
+// GaussianModel::increasePcd (src/gaussian_model.cpp:188-376): the tensor overload, or -- vector_overload -- the std::vector one
+void trainer_increase_pcd(int64_t h, torch::Tensor points, torch::Tensor colors, int64_t iteration, bool vector_overload)
+{
+	auto g = get(h)->gaussians_;
+	if (vector_overload) {
+		auto p = points.detach().to(torch::kCPU).to(torch::kFloat32).contiguous(), c = colors.detach().to(torch::kCPU).to(torch::kFloat32).contiguous();
+		std::vector<float> pv(p.data_ptr<float>(), p.data_ptr<float>() + p.numel()), cv(c.data_ptr<float>(), c.data_ptr<float>() + c.numel());
+		g->increasePcd(pv, cv, (int)iteration);
+	} else {
+		g->increasePcd(points, colors, (int)iteration);
+	}
+}
+torch::Tensor trainer_exist_since_iter(int64_t h) { return get(h)->gaussians_->exist_since_iter_; }
+void trainer_set_exist_since_iter(int64_t h, torch::Tensor v)
+{
+	auto g = get(h)->gaussians_;
+	g->exist_since_iter_ = v.to(g->xyz_.device()).to(torch::kInt32).contiguous().clone();
+}
+void trainer_release_arena(int64_t h) { get(h)->gaussians_->releaseArena(); }
 void trainer_features_finish_from_views(int64_t h) { get(h)->finishFeaturesFromViews(); }
 void trainer_geom_adam(int64_t h) { get(h)->finishGeomAdam(); }
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
@@ -307,6 +326,10 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_sh_send_buffer", &trainer_sh_send_buffer);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
 	m.def("trainer_features_step_from_views", &trainer_features_step_from_views);
+	m.def("trainer_increase_pcd", &trainer_increase_pcd);
+	m.def("trainer_exist_since_iter", &trainer_exist_since_iter);
+	m.def("trainer_set_exist_since_iter", &trainer_set_exist_since_iter);
+	m.def("trainer_release_arena", &trainer_release_arena);
 	m.def("trainer_features_finish_from_views", &trainer_features_finish_from_views);
 	m.def("trainer_geom_adam", &trainer_geom_adam);
 	m.def("sh_grad_from_views", &sh_grad_from_views);

@@ -70,6 +70,7 @@ GaussianModel::GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor fea
 	max_radii2D_ = torch::zeros({P}, xyz_.options());
 	xyz_gradient_accum_ = torch::zeros({P, 1}, xyz_.options());
 	denom_ = torch::zeros({P, 1}, xyz_.options());
+	exist_since_iter_ = torch::zeros({P}, xyz_.options().dtype(torch::kInt32).requires_grad(false));
 }
 
 // src/gaussian_model.cpp:73-96: Sigma = (R S)(R S)^T with R = build_rotation(rotation_) (include/general_utils.h:33-57: the

@@ -46,7 +46,7 @@ def make_state(ref_model, P, seed, dev, scale_split=0.5):
     accum[denom == 0] = 0
     max_radii = torch.rand(P, generator=g) * 40
     st = ref_model.State([t.to(dev) for t in params], [t.to(dev) for t in m], [t.to(dev) for t in v], [7] * 6, accum.to(dev),
-                         denom.to(dev), max_radii.to(dev), torch.zeros(P, dtype=torch.int32, device=dev))
+                         denom.to(dev), max_radii.to(dev), torch.randint(0, 900, (P,), generator=g, dtype=torch.int32).to(dev))
     return st
 
 
@@ -57,6 +57,7 @@ def python_host(st, dev):
     g.scaling_, g.rotation_ = leaf(st.params[4]), leaf(st.params[5])
     g.active_sh_degree_ = 3
     g.xyz_gradient_accum_, g.denom_, g.max_radii2D_ = st.accum.clone(), st.denom.clone(), st.max_radii2D.clone()
+    g.exist_since_iter_ = st.exist_since_iter.clone()
     g.trainingSetup(GaussianOptimizationParams())
     cat = lambda l: torch.cat([l[1], l[2]], 1)
     for name, m, v in zip(NAMES, (st.exp_avg[0], cat(st.exp_avg), st.exp_avg[3], st.exp_avg[4], st.exp_avg[5]),
@@ -69,7 +70,7 @@ def python_state(g):
     params = [getattr(g, n).detach() for n in NAMES]
     mom = [g.optimizer_.moments(getattr(g, n)) for n in NAMES]
     steps = [g.optimizer_.state[id(getattr(g, n))]["step"] for n in NAMES]
-    return params, [m for m, _ in mom], [v for _, v in mom], steps, (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_)
+    return params, [m for m, _ in mom], [v for _, v in mom], steps, (g.xyz_gradient_accum_, g.denom_, g.max_radii2D_), g.exist_since_iter_
 
 
 def cpp_host(ops, st, dev):
@@ -84,17 +85,20 @@ def cpp_host(ops, st, dev):
         mom[i].copy_(m)
         mom[5 + i].copy_(v)
     ops.trainer_set_steps(h, [st.steps[0]] * 5)
+    ops.trainer_set_exist_since_iter(h, st.exist_since_iter)
     return h
 
 
 def cpp_state(ops, h):
     mom = ops.trainer_moments(h)
-    return list(ops.trainer_params(h)), list(mom[:5]), list(mom[5:]), list(ops.trainer_steps(h)), tuple(ops.trainer_stats(h))
+    return (list(ops.trainer_params(h)), list(mom[:5]), list(mom[5:]), list(ops.trainer_steps(h)), tuple(ops.trainer_stats(h)),
+            ops.trainer_exist_since_iter(h))
 
 
 def compare(ref, got, n_children, what):
     """ref: ref_model.State after the reference's call; got: (params[5], m[5], v[5], steps[5], stats) of one of our hosts."""
-    params, m, v, steps, stats = got
+    params, m, v, steps, stats, exist = got
+    assert exist.dtype == torch.int32 and torch.equal(exist, ref.exist_since_iter), (what, "exist_since_iter_")
     cat = lambda l: torch.cat([l[1], l[2]], 1)
     want_p = (ref.params[0], cat(ref.params), ref.params[3], ref.params[4], ref.params[5])
     want_m = (ref.exp_avg[0], cat(ref.exp_avg), ref.exp_avg[3], ref.exp_avg[4], ref.exp_avg[5])
@@ -236,7 +240,7 @@ def run_adam(kind, dev, lib_path, P=300):
             for n, gr in zip(NAMES, (grads6[0], torch.cat([grads6[1], grads6[2]], 1), grads6[3], grads6[4], grads6[5])):
                 getattr(g, n).grad = gr.clone()
             g.optimizer_.step()
-            params, mm, vv, steps, _ = python_state(g)
+            params, mm, vv, steps, _, _ = python_state(g)
             cat = lambda l: torch.cat([l[1], l[2]], 1)
             for a, b in zip(params, (cur.params[0], cat(cur.params), cur.params[3], cur.params[4], cur.params[5])):
                 assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), it          # <= 1 ulp of the parameter (measured)
@@ -245,6 +249,59 @@ def run_adam(kind, dev, lib_path, P=300):
             for a, b in zip(vv, (cur.exp_avg_sq[0], cat(cur.exp_avg_sq), cur.exp_avg_sq[3], cur.exp_avg_sq[4], cur.exp_avg_sq[5])):
                 assert torch.allclose(a, b, rtol=1e-6, atol=2e-11), it
             assert steps == [cur.steps[0]] * 5 == [8 + it] * 5
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def run_increase_pcd(kind, dev, host_ops, lib_path, P=600, n_new=(157, 40)):
+    """GaussianModel::increasePcd (src/gaussian_model.cpp:188-376), both overloads, against both hosts: the new rows (colours ->
+    SH DC, kNN scales among the NEW points, identity rotations, opacity 0.1), the carried rows and moments, the zeroed
+    statistics, exist_since_iter -- everything bit-equal (the hosts run the same ATen expressions on the same kNN distances; the
+    reference's distCUDA2 is the CPU oracle, pinned to simple_knn.cu).  Two insertions in a row (the second one appends in place
+    inside the hosts' arena), then a densifyAndPrune that has to carry exist_since_iter through clones and split children."""
+    ref_model, ops = _ref_ops(kind)
+    st = make_state(ref_model, P, 17, dev, 0.7)
+    gen = torch.Generator().manual_seed(23)
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        g = python_host(st, dev)
+        h = cpp_host(host_ops, st, dev)
+        ref = st
+        for k, n in enumerate(n_new):
+            pts = (2.0 * torch.randn(n, 3, generator=gen)).to(dev)
+            cols = torch.rand(n, 3, generator=gen).to(dev)
+            vector_overload = k == 0
+            ref = ref_model.increase_pcd(ops, ref, pts, cols, 700 + k, vector_overload)
+            assert ref.params[0].shape[0] == P + sum(n_new[:k + 1])
+            if vector_overload:
+                assert g.increasePcd(pts.cpu().reshape(-1).tolist(), cols.cpu().reshape(-1).tolist(), 700 + k) == n
+            else:
+                g.increasePcd(pts, cols, 700 + k)
+            compare(ref, python_state(g), 0, f"increasePcd {k}/python")
+            host_ops.trainer_increase_pcd(h, pts, cols, 700 + k, vector_overload)
+            compare(ref, cpp_state(host_ops, h), 0, f"increasePcd {k}/c++")
+            assert not ref.accum.any() and not ref.max_radii2D.any()       # densificationPostfix resets the statistics (:709-711)
+            assert int(ref.exist_since_iter[-1]) == 700 + k
+        # ... and a rebuild on top: the new rows' exist_since_iter_ travels through clone / split / prune
+        Pn = ref.params[0].shape[0]
+        grads = torch.rand(Pn, 1, generator=gen) * 4e-4
+        for obj in (ref,):
+            obj.accum, obj.denom = grads.to(dev), torch.ones(Pn, 1, device=dev)
+        g.xyz_gradient_accum_, g.denom_ = grads.to(dev).clone(), torch.ones(Pn, 1, device=dev)
+        for dst, src in zip(host_ops.trainer_stats(h)[:2], (grads.to(dev), torch.ones(Pn, 1, device=dev))):
+            dst.copy_(src)
+        extent = float(torch.exp(ref.params[4]).max(dim=1).values.median()) / 0.01
+        (torch.cuda.manual_seed if dev.type == "cuda" else torch.manual_seed)(31)
+        ref2 = ref_model.densify_and_prune(ops, ref, 0.01, 2e-4, 0.005, extent, 0)
+        info = g.densifyAndPrune(2e-4, 0.005, extent, 0, generator=torch.Generator(device=dev).manual_seed(31))
+        assert info["cloned"] > 0 and info["split"] > 0
+        compare(ref2, python_state(g), info["children_kept"], "increasePcd + densify/python")
+        assert list(host_ops.trainer_densify_and_prune(h, 2e-4, 0.005, extent, 0, 31))[3] == ref2.params[0].shape[0]
+        compare(ref2, cpp_state(host_ops, h), info["children_kept"], "increasePcd + densify/c++")
+        # the arena released: the same values in stable allocations
+        host_ops.trainer_release_arena(h)
+        compare(ref2, cpp_state(host_ops, h), info["children_kept"], "released arena/c++")
+        host_ops.trainer_destroy(h)
     finally:
         rp._LIB_OVERRIDE = None
 
@@ -268,6 +325,10 @@ def test_reset_prune_stats_match_reference(emu_lib_path):
     run_reset_prune_stats("cpu", torch.device("cpu"), _host("emu"), emu_lib_path)
 
 
+def test_increase_pcd_matches_reference(emu_lib_path):
+    run_increase_pcd("cpu", torch.device("cpu"), _host("emu"), emu_lib_path)
+
+
 def test_adam_matches_reference_optimizer(emu_lib_path):
     run_adam("cpu", torch.device("cpu"), emu_lib_path)
 
@@ -284,3 +345,8 @@ def test_densify_and_prune_matches_reference_on_gpu(name):
 def test_reset_prune_stats_adam_match_reference_on_gpu():
     run_reset_prune_stats("cuda", torch.device("cuda:0"), _host("hip"), None, P=20000)
     run_adam("cuda", torch.device("cuda:0"), None, P=20000)
+
+
+@pytest.mark.gpu
+def test_increase_pcd_matches_reference_on_gpu():
+    run_increase_pcd("cuda", torch.device("cuda:0"), _host("hip"), None, P=20000, n_new=(5000, 1200))
