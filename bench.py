@@ -140,7 +140,7 @@ def main():
                     help="host layer driving the step: the LibTorch C++ one (photo-slam_amd/host, default) or its Python mirror")
     ap.add_argument("--densify-interval", type=int, default=0,
                     help="run densifyAndPrune every N steps inside the timed region (0 = off; reference: 100); with several "
-                         "ranks the Python host drives it (it reduces the per-view statistics over the ranks)")
+                         "ranks the host reduces the per-rank statistics over the ranks right before")
     ap.add_argument("--training-lr", action="store_true",
                     help="time the main leg with the training learning rates (drifting synthetic workload) instead of the "
                          "stationary one")
@@ -170,8 +170,6 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("GSR_BENCH_FORCE_DP") != "1":
         self_launch(args)
-    if args.densify_interval and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        args.host = "py"
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
@@ -256,9 +254,14 @@ def main():
         fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
         ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window),
                                          "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
+        # GSR_BENCH_PY_EXCHANGE=1: the collectives issued from Python around the C++ pieces (the round-2 arrangement, kept for
+        # comparison); default: the C++ host drives the exchange itself on the c10d process group (keyframe_batch_exchange.cpp)
+        py_exchange = os.environ.get("GSR_BENCH_PY_EXCHANGE") == "1" or (dp and backend != "nccl")
         if dp:
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
-        if dp and factored:
+        if dp and not py_exchange:
+            ops.trainer_set_process_group(handle, dist.group.WORLD.group_name, factored)
+        elif dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
         if args.densify_interval:
             ops.trainer_set_options(handle, {"densify": 1.0, "cameras_extent": float(cl.extent), "seed": 0.0,
@@ -291,7 +294,12 @@ def main():
 
     def one_step():
         kf = kf_now[0]
-        if ops is not None:
+        if ops is not None and dp and not py_exchange:
+            # one call: render + backward, the exchange (RCCL, issued by the C++ host), the optimizer
+            loss = ops.trainer_train_one_iteration(handle, kf.world_view_transform_, kf.full_proj_transform_, kf.camera_center_,
+                                                   fovx, fovy, H, W, gt, mask)
+            read_loss_deferred(loss)
+        elif ops is not None:
             loss = ops.trainer_render_and_backward(handle, kf.world_view_transform_, kf.full_proj_transform_,
                                                    kf.camera_center_, fovx, fovy, H, W, gt, mask)
             if dp and factored:
@@ -643,6 +651,8 @@ def main():
             out["knn"] = knn_run
         if dp:
             out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                           "collectives_issued_by": "python (trainer.py classes)" if (ops is None or py_exchange) else
+                                                    "the C++ host (host/src/keyframe_batch_exchange.cpp on c10d::ProcessGroup)",
                            "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
                            "exchange": "view-factored" if factored else "all-reduce"}
         traffic = traffic_src = None

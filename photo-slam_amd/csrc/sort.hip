@@ -183,7 +183,8 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 		if (i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY)) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
 	}
 	__syncthreads();
-	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
+	// (rows beyond the pass's digits -- 128 of the 256 in a 7-bit pass of the tile sort -- are never read: not written either)
+	if ((int)threadIdx.x < (1 << nbits)) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
 }
 
 // One workgroup per digit: exclusive scan of that digit's row hist[d][0..nblocks) in place, row total to
@@ -263,12 +264,13 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const uint32_t tot = c0 + c1 + c2 + c3;
 		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
 		uint32_t all;
-		const uint32_t digit_base = block_excl_scan_256(totals[tid], &all, s_wave);   // elements with a smaller digit
+		const bool used = tid < (1 << nbits);   // (the rows of the digits this pass does not have are neither written nor scanned)
+		const uint32_t digit_base = block_excl_scan_256(used ? totals[tid] : 0u, &all, s_wave);   // elements with a smaller digit
 		s_whist[0][tid] = lstart;
 		s_whist[1][tid] = lstart + c0;
 		s_whist[2][tid] = lstart + c0 + c1;
 		s_whist[3][tid] = lstart + c0 + c1 + c2;
-		s_gbase[tid] = digit_base + hist_rows[(size_t)tid * nblocks + blockIdx.x] - lstart;
+		s_gbase[tid] = digit_base + (used ? hist_rows[(size_t)tid * nblocks + blockIdx.x] : 0u) - lstart;
 		if (count_out && blockIdx.x == 0 && tid == 0) *count_out = all;   // the elements that exist: later passes run over them only
 	}
 	__syncthreads();
@@ -337,7 +339,7 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		const uint32_t* n_dev = (compact_count && p > 0) ? compact_count : nullptr;
 		const int skip = (compact_count && p == 0) ? 1 : 0;
 		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip);
-		GSR_LAUNCH(radix_row_prefix_kernel, RADIX_BINS, SCAN_THREADS, stream, hist, totals, nb);
+		GSR_LAUNCH(radix_row_prefix_kernel, 1 << nbits, SCAN_THREADS, stream, hist, totals, nb);
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
 		           (const uint32_t*)hist, (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr);
 		kin = kout;

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SRCS = ["rasterize_points.cpp", "gaussian_rasterizer.cpp", "train_step.cpp", "gaussian_model_densify.cpp", "ply_io.cpp", "operate_points.cpp",
-        "ops_register.cpp"]
+        "keyframe_batch_exchange.cpp", "ops_register.cpp"]
 
 
 def _torch_paths():

@@ -5,11 +5,14 @@
 // same code for both.
 #pragma once
 #include <torch/torch.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
 #include <array>
 #include <cmath>
+#include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "rasterize_points.h"   // ShAdamStep
@@ -184,10 +187,21 @@ public:
 	bool densifyDue() const;
 	torch::Tensor trainForOneIteration(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
 	{
+		if (process_group_) return trainForOneIterationDataParallel(kf, gt_image, mask);
 		auto loss = renderAndBackward(kf, gt_image, mask);
 		finishOneIteration();
 		return loss;
 	}
+	// Keyframe batches, one keyframe per rank: with a process group set, trainForOneIteration() is the
+	// data-parallel step -- render + backward of THIS rank's keyframe, the gradient exchange over c10d (RCCL on the GPU boxes:
+	// ViewFactoredExchange by default, the plain GradientReduction otherwise; host/include/keyframe_batch_exchange.h), the
+	// optimizer on the batch-mean gradient, and before a densification the SUM / MAX of the per-rank statistics.  Every rank
+	// holds a replica; replicas stay bit-identical (identical Adam on identical gradients, identically seeded split samples).
+	// No collective is issued from anywhere but here.  A C++ mapper creates c10d::TCPStore + ProcessGroupNCCL and hands the
+	// group over; under Python the default group is resolved by name (ops_register.cpp: trainer_set_process_group).
+	void setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool factored = true);
+	torch::Tensor trainForOneIterationDataParallel(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask);
+	c10::intrusive_ptr<c10d::ProcessGroup> process_group_;
 	// Data-parallel keyframe batches with the view-factored exchange (include/gsr.h, gsr_sh_grad_from_views): backward
 	// then leaves the clamp-masked colour gradient of this view in sh_grad_view_ and no gradient on features_; after the
 	// driver has gathered the views of all ranks, setFeaturesGradFromViews() installs the batch-mean SH gradient.  It reads
@@ -242,6 +256,7 @@ public:
 	int iteration_ = 0;
 	torch::Tensor last_viewspace_, last_visibility_ /* undefined when the step fused its consumers: last_radii_ > 0 */, last_radii_;
 	torch::Tensor root_grad_;   // the constant 1 handed to loss.backward()
+	std::map<std::tuple<uintptr_t, int64_t, int64_t>, bool> mask_is_ones_;   // masks seen so far: all ones? (renderAndBackward)
 };
 
 // loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)

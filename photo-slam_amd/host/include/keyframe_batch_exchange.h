@@ -1,0 +1,76 @@
+// keyframe_batch_exchange.h -- the gradient exchange of a keyframe batch, one keyframe per rank (DESIGN.md
+// section 6), on c10d::ProcessGroup: RCCL (ProcessGroupNCCL on ROCm) over xGMI on the GPU boxes, gloo in the host tests.
+//
+// The reference trains on one keyframe per step on one GPU (src/gaussian_mapper.cpp:620,677) and has no collective anywhere;
+// this is the data-parallel extension of its train step, in the reference's host language.  The Python classes of the same
+// names (photo-slam_amd/trainer.py: ViewFactoredExchange, GradientReduction) are mirrors for the tests.
+//
+//   ViewFactoredExchange   81 % of the gradient is the [P,16,3] SH tensor, and ONE view's SH gradient is rank one per
+//                          Gaussian: basis(dir) x dL_dcolor with dir known to every rank.  So the ranks ALL-GATHER the 3-float
+//                          colour gradients (in PARTS row ranges) and the camera centres, each rebuilds the batch-mean SH
+//                          gradient locally and applies it (TrainStep::stepFeaturesFromViews), and only the other four
+//                          tensors (11 floats per Gaussian, ONE buffer) are all-reduced.
+//   GradientReduction      the plain mean of every leaf gradient, largest first, each tensor's Adam as soon as ITS reduction
+//                          has landed.
+//
+// Work handles are waited on the compute stream (Work::wait() of ProcessGroupNCCL blocks the current stream, not the host):
+// the host keeps queueing.  The process group comes from the caller: a C++ mapper builds c10d::TCPStore + ProcessGroupNCCL
+// itself; under Python it is the default group, resolved by name (c10d::resolve_process_group).
+#pragma once
+#include <torch/torch.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+#include <vector>
+
+// a flat view over the storage the given contiguous fp32 tensors tile exactly and without gaps, or an undefined tensor
+torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors);
+
+class GradientReduction {
+public:
+	// tensors: gradients, averaged in place over the ranks; members of one buffer (oneBuffer) share ONE collective
+	GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors);
+	const std::vector<int>& order() const { return order_; }   // indices by decreasing size: the order the collectives were issued in
+	void wait(int i);                                           // tensor i is reduced (stream-side on RCCL)
+	void waitAll();
+	int collectives() const { return static_cast<int>(groups_.size()); }
+
+private:
+	struct Group {
+		torch::Tensor flat;
+		c10::intrusive_ptr<c10d::Work> work;
+		bool scaled = false;
+	};
+	c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+	std::vector<torch::Tensor> tensors_;
+	std::vector<int> order_, group_of_;
+	std::vector<Group> groups_;
+	bool avg_ = false;   // the backend averages inside the collective (ncclAvg); gloo sums and wait() scales
+};
+
+class ViewFactoredExchange {
+public:
+	static constexpr int PARTS = 2;   // the colour gradients travel in this many all-gathers (by rows): the rebuild + Adam of one
+	                                  // part runs while the next one is still on the links
+	// send: [P + 1, 3] (rows 0 .. P-1 = this view's colour gradients; row P is a spare), camera_center [3], others = the
+	// gradients of xyz / opacity / scaling / rotation.  After construction everything is in flight.
+	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
+	                     std::vector<torch::Tensor> others);
+	struct Part {
+		int64_t row0 = 0;
+		torch::Tensor views;   // [N, rows, 3]
+		c10::intrusive_ptr<c10d::Work> work;
+	};
+	int parts() const { return static_cast<int>(parts_.size()); }
+	// part k once ITS all-gather has landed (stream-side wait): (first row, camera centres [N,3], colour gradients [N,rows,3])
+	const Part& part(int k);
+	torch::Tensor centres();
+	GradientReduction& reduction() { return *reduction_; }
+	void waitAll();
+
+private:
+	c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+	torch::Tensor centres_;
+	c10::intrusive_ptr<c10d::Work> centre_work_;
+	std::vector<Part> parts_;
+	std::unique_ptr<GradientReduction> reduction_;
+};

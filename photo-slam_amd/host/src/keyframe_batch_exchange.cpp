@@ -1,0 +1,223 @@
+// keyframe_batch_exchange.cpp -- see keyframe_batch_exchange.h; the data-parallel half of TrainStep lives here too.
+#include "keyframe_batch_exchange.h"
+
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+
+#include "gaussian_model_lite.h"
+
+torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
+{
+	if (tensors.size() < 2) return torch::Tensor();
+	for (const auto& t : tensors)
+		if (!t.defined() || !t.is_contiguous() || t.scalar_type() != torch::kFloat32) return torch::Tensor();
+	const auto& storage = tensors[0].storage();
+	for (const auto& t : tensors)
+		if (t.storage().data() != storage.data()) return torch::Tensor();
+	std::vector<std::pair<int64_t, int64_t>> spans;
+	for (const auto& t : tensors) spans.emplace_back(t.storage_offset(), t.numel());
+	std::sort(spans.begin(), spans.end());
+	int64_t end = spans[0].first;
+	for (const auto& s : spans) {
+		if (s.first != end) return torch::Tensor();
+		end = s.first + s.second;
+	}
+	if (spans[0].first != 0 || static_cast<size_t>(end) * 4 != storage.nbytes()) return torch::Tensor();
+	auto flat = torch::empty({0}, tensors[0].options().requires_grad(false));
+	flat.set_(storage, 0, {end}, {1});
+	return flat;
+}
+
+GradientReduction::GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors)
+    : pg_(std::move(pg)), tensors_(std::move(tensors))
+{
+	avg_ = pg_->getBackendName() == "nccl";
+	const int n = static_cast<int>(tensors_.size());
+	order_.resize(n);
+	for (int i = 0; i < n; i++) order_[i] = i;
+	std::stable_sort(order_.begin(), order_.end(), [&](int a, int b) { return tensors_[a].numel() > tensors_[b].numel(); });
+	group_of_.assign(n, -1);
+	// members of one buffer share a single collective
+	std::map<const void*, std::vector<int>> by_storage;
+	std::vector<const void*> keys;
+	for (int i : order_) {
+		const void* k = tensors_[i].storage().data();
+		if (!by_storage.count(k)) keys.push_back(k);
+		by_storage[k].push_back(i);
+	}
+	for (const void* k : keys) {
+		const auto& members = by_storage[k];
+		std::vector<torch::Tensor> ts;
+		for (int i : members) ts.push_back(tensors_[i]);
+		auto flat = oneBuffer(ts);
+		if (flat.defined()) {
+			for (int i : members) group_of_[i] = static_cast<int>(groups_.size());
+			groups_.push_back({flat, nullptr, false});
+		}
+	}
+	for (int i : order_)
+		if (group_of_[i] < 0) {
+			group_of_[i] = static_cast<int>(groups_.size());
+			groups_.push_back({tensors_[i], nullptr, false});
+		}
+	c10d::AllreduceOptions opts;
+	opts.reduceOp = avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+	for (int i : order_) {   // issue in size order; a shared buffer goes out when its first member comes up
+		auto& grp = groups_[static_cast<size_t>(group_of_[i])];
+		if (grp.work) continue;
+		std::vector<at::Tensor> v{grp.flat};
+		grp.work = pg_->allreduce(v, opts);
+	}
+}
+
+void GradientReduction::wait(int i)
+{
+	auto& grp = groups_.at(static_cast<size_t>(group_of_.at(static_cast<size_t>(i))));
+	grp.work->wait();
+	if (!avg_ && !grp.scaled) {
+		grp.flat.mul_(1.0 / pg_->getSize());
+		grp.scaled = true;
+	}
+}
+
+void GradientReduction::waitAll()
+{
+	for (int i : order_) wait(i);
+}
+
+ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
+                                           std::vector<torch::Tensor> others)
+    : pg_(std::move(pg))
+{
+	const int64_t N = pg_->getSize(), P = send.size(0) - 1;
+	const auto o = send.options().requires_grad(false);
+	if (pg_->getBackendName() == "gloo" && send.is_cuda())
+		throw std::runtime_error("ViewFactoredExchange: gloo moves host tensors; use the RCCL backend for device tensors");
+	// the camera centres: 12 bytes per rank, their own (first) collective -- every part's rebuild needs all of them
+	centres_ = torch::empty({N, 3}, o);
+	auto centre = camera_center.detach().reshape({1, 3}).to(o).contiguous();
+	centre_work_ = pg_->_allgather_base(centres_, centre);
+	const int n_parts = P >= 4 * PARTS ? PARTS : 1;
+	std::vector<int64_t> bounds;
+	for (int k = 0; k <= n_parts; k++) bounds.push_back(k == 0 ? 0 : (k == n_parts ? P : ((P * k / n_parts) / 4) * 4));
+	for (int k = 0; k < n_parts; k++) {
+		Part p;
+		p.row0 = bounds[k];
+		const int64_t rows = bounds[k + 1] - bounds[k];
+		p.views = torch::empty({N, rows, 3}, o);
+		auto in = send.narrow(0, p.row0, rows).unsqueeze(0);   // ([1, rows, 3]: gloo checks the input against a 1/N chunk of the output)
+		p.work = pg_->_allgather_base(p.views, in);
+		parts_.push_back(p);
+	}
+	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others));
+}
+
+torch::Tensor ViewFactoredExchange::centres()
+{
+	if (centre_work_) {
+		centre_work_->wait();
+		centre_work_ = nullptr;
+	}
+	return centres_;
+}
+
+const ViewFactoredExchange::Part& ViewFactoredExchange::part(int k)
+{
+	centres();
+	auto& p = parts_.at(static_cast<size_t>(k));
+	if (p.work) {
+		p.work->wait();
+		p.work = nullptr;
+	}
+	return p;
+}
+
+void ViewFactoredExchange::waitAll()
+{
+	for (int k = 0; k < parts(); k++) part(k);
+	reduction_->waitAll();
+}
+
+// ---- TrainStep: the data-parallel step --------------------------------------------------------------------------------------
+
+void TrainStep::setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool factored)
+{
+	process_group_ = std::move(pg);
+	factored_exchange_ = process_group_ && factored;
+	if (process_group_) fused_sh_adam_ = false;   // the optimizer follows the gradient exchange
+}
+
+torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
+{
+	if (!process_group_) throw std::runtime_error("trainForOneIterationDataParallel: setProcessGroup() first");
+	auto loss = renderAndBackward(kf, gt_image, mask);
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	const auto& o = g->opt_;
+	auto params = g->paramsRaw();
+	// keyframe-batch data parallelism: mean of the per-view gradients over the ranks, in flight from here on
+	std::unique_ptr<ViewFactoredExchange> vf;
+	std::unique_ptr<GradientReduction> red;
+	if (factored_exchange_) {
+		std::vector<torch::Tensor> others;
+		for (int i : {0, 2, 3, 4}) others.push_back(params[static_cast<size_t>(i)].grad());
+		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others);
+	} else {
+		std::vector<torch::Tensor> grads;
+		for (auto& p : params) grads.push_back(p.grad());
+		red = std::make_unique<GradientReduction>(process_group_, grads);
+	}
+	auto wait_all = [&]() {
+		if (vf) vf->waitAll();
+		else red->waitAll();
+	};
+	if (densifyDue()) {
+		// every tensor is about to be rebuilt and this step's update is skipped: the exchange only has to finish.  The
+		// statistics accumulated PER RANK since the last densification (SUM and MAX commute with the accumulation over
+		// iterations): norm sums and counts SUM, radii MAX -- every rank then takes the same decisions with the same samples.
+		wait_all();
+		c10d::AllreduceOptions sum, mx;
+		sum.reduceOp = c10d::ReduceOp::SUM;
+		mx.reduceOp = c10d::ReduceOp::MAX;
+		std::vector<at::Tensor> a{g->xyz_gradient_accum_}, d{g->denom_}, r{g->max_radii2D_};
+		auto w1 = process_group_->allreduce(a, sum), w2 = process_group_->allreduce(d, sum), w3 = process_group_->allreduce(r, mx);
+		w1->wait();
+		w2->wait();
+		w3->wait();
+		finishBegin();   // densifies (and drops the gradients: the fresh leaves have none)
+		finishEnd();
+		return loss;
+	}
+	finishBegin();   // (an opacity reset alone replaces ONE leaf: the others keep their gradients and step below)
+	if (iteration_ < o.iterations_) {
+		if (vf) {
+			if (g->features_.size(1) == 16 && g->groups_.size() > 1) {
+				// the SH gradient is rebuilt from the gathered views (reads xyz_: before ITS update) and applied part by part as
+				// each all-gather lands, while the all-reduce of the other four tensors is on the links
+				for (int k = 0; k < vf->parts(); k++) {
+					const auto& p = vf->part(k);
+					stepFeaturesFromViews(vf->centres(), p.views, p.row0, k == 0);
+				}
+				finishFeaturesFromViews();
+			} else {   // other SH layouts: gradient tensor + separate pass (whole batch)
+				std::vector<torch::Tensor> views;
+				for (int k = 0; k < vf->parts(); k++) views.push_back(vf->part(k).views);
+				setFeaturesGradFromViews(vf->centres(), views.size() == 1 ? views[0] : torch::cat(views, 1));
+				finishAdamGroup(1);
+			}
+			vf->reduction().waitAll();   // ONE collective for the four small tensors ...
+			finishGeomAdam();            // ... and one Adam launch
+		} else {
+			// each tensor is updated as soon as ITS reduction has landed (largest first)
+			for (int i : red->order()) {
+				red->wait(i);
+				finishAdamGroup(i);
+			}
+		}
+	} else {
+		wait_all();
+	}
+	finishEnd();
+	return loss;
+}

@@ -8,6 +8,7 @@
 
 #include "gaussian_model_lite.h"
 #include "gaussian_renderer.h"
+#include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
 #include "operate_points.h"
 #include "spatial.h"
 #include "stereo_vision.h"
@@ -268,6 +269,18 @@ void trainer_set_exist_since_iter(int64_t h, torch::Tensor v)
 	g->exist_since_iter_ = v.to(g->xyz_.device()).to(torch::kInt32).contiguous().clone();
 }
 void trainer_release_arena(int64_t h) { get(h)->gaussians_->releaseArena(); }
+// Data-parallel keyframe batches driven from C++: the process group Python created (torch.distributed's default group, or any
+// other) is resolved by its registered name; from then on trainer_train_one_iteration() issues every collective itself.
+void trainer_set_process_group(int64_t h, std::string group_name, bool factored)
+{
+	if (group_name.empty()) get(h)->setProcessGroup(nullptr, factored);
+	else get(h)->setProcessGroup(c10d::resolve_process_group(group_name), factored);
+}
+torch::Tensor trainer_train_one_iteration(int64_t h, torch::Tensor view, torch::Tensor proj, torch::Tensor campos, double fovx, double fovy,
+                                          int64_t height, int64_t width, torch::Tensor gt, torch::Tensor mask)
+{
+	return get(h)->trainForOneIteration(make_kf(view, proj, campos, fovx, fovy, height, width), gt, mask).detach();
+}
 void trainer_features_finish_from_views(int64_t h) { get(h)->finishFeaturesFromViews(); }
 void trainer_geom_adam(int64_t h) { get(h)->finishGeomAdam(); }
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
@@ -330,6 +343,8 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_exist_since_iter", &trainer_exist_since_iter);
 	m.def("trainer_set_exist_since_iter", &trainer_set_exist_since_iter);
 	m.def("trainer_release_arena", &trainer_release_arena);
+	m.def("trainer_set_process_group", &trainer_set_process_group);
+	m.def("trainer_train_one_iteration", &trainer_train_one_iteration);
 	m.def("trainer_features_finish_from_views", &trainer_features_finish_from_views);
 	m.def("trainer_geom_adam", &trainer_geom_adam);
 	m.def("sh_grad_from_views", &sh_grad_from_views);

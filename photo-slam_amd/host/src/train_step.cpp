@@ -296,7 +296,22 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);
 	last_radii_ = std::get<3>(pkg);
-	auto loss = fusedL1SSIMLoss(rendered, gt_image, mask, g->opt_.lambda_dssim_, /*is_root=*/true);
+	// rendered * mask with a mask of ones is the identity (src/gaussian_mapper.cpp:692-693; most keyframes carry a full mask):
+	// recognised ONCE per mask tensor (one reduction + host read when a keyframe's mask is first seen, remembered by storage
+	// pointer and version counter); the loss kernels then skip its 2 x 25 MB of reads at 1080p
+	torch::Tensor eff_mask = mask;
+	if (mask.defined() && mask.numel()) {
+		const auto key = std::make_tuple(reinterpret_cast<uintptr_t>(mask.data_ptr()), static_cast<int64_t>(mask.numel()),
+		                                 static_cast<int64_t>(mask._version()));
+		auto it = mask_is_ones_.find(key);
+		if (it == mask_is_ones_.end()) {
+			if (mask_is_ones_.size() >= 64) mask_is_ones_.clear();
+			torch::NoGradGuard ng;
+			it = mask_is_ones_.emplace(key, (mask == 1).all().item<bool>()).first;
+		}
+		if (it->second) eff_mask = torch::empty({0}, mask.options());   // (an empty mask = none: FusedL1SSIMFunction::forward)
+	}
+	auto loss = fusedL1SSIMLoss(rendered, gt_image, eff_mask, g->opt_.lambda_dssim_, /*is_root=*/true);
 	// the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward()
 	if (!root_grad_.defined() || root_grad_.device() != loss.device()) root_grad_ = torch::ones_like(loss).detach();
 	loss.backward(root_grad_);

@@ -221,6 +221,21 @@ class TrainStep:
         self.fused_geom_adam_ = fused_geom_adam
         self.ema_loss_for_log_ = 0.0
 
+    def _effective_mask(self, mask):
+        """rendered * mask with a mask of ones is the identity (src/gaussian_mapper.cpp:692-693; most keyframes carry a full
+        mask): such a mask is recognised ONCE per mask tensor (one reduction + host read when a keyframe's mask is first seen,
+        remembered by storage pointer and version counter) and the loss kernels then skip its 2 x 25 MB of reads at 1080p."""
+        if mask is None:
+            return None
+        key = (mask.data_ptr(), mask.numel(), mask._version)
+        cache = self.__dict__.setdefault("_mask_is_ones", {})
+        if key not in cache:
+            if len(cache) >= 64:
+                cache.clear()
+            with torch.no_grad():
+                cache[key] = bool((mask == 1).all().item())
+        return None if cache[key] else mask
+
     def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
         g, opt = self.gaussians_, self.opt_
         self.iteration_ += 1
@@ -272,7 +287,7 @@ class TrainStep:
         finally:
             g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)
-        loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, mask, opt.lambda_dssim_, is_root=True)
+        loss = loss_utils.fused_l1_ssim_loss(rendered_image, gt_image, self._effective_mask(mask), opt.lambda_dssim_, is_root=True)
         # :699 (the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward())
         if getattr(self, "_root_grad", None) is None or self._root_grad.device != loss.device:
             self._root_grad = torch.ones_like(loss).detach()

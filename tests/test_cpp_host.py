@@ -355,6 +355,7 @@ def run_pipeline_flag_train_checks(ops, dev, lib_path):
     torch.manual_seed(0)
     gt = torch.rand(3, cam.H, cam.W).to(dev)
     mask = torch.ones(3, cam.H, cam.W, device=dev)
+    mask[:, :6, :] = 0.0   # a real mask (the train steps recognise an all-ones mask and skip it: this one takes the masked path)
     bg = torch.zeros(3, device=dev)
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
     kf = GaussianKeyframe.from_camera(cam, dev)

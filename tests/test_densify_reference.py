@@ -110,8 +110,11 @@ def compare(ref, got, n_children, what):
             assert torch.equal(a[:n - n_children], b[:n - n_children]), (what, name, "copied rows")
             tol = dict(rtol=1e-6, atol=1e-6) if name == "xyz_" else dict(rtol=1e-6, atol=2e-7)
             assert torch.allclose(a[n - n_children:], b[n - n_children:], **tol), (what, name, "split children")
-        else:
-            assert torch.equal(a, b), (what, name)
+        elif not torch.equal(a, b):   # (say where: the first differing row and the size of the difference)
+            d = (a - b).abs().reshape(a.shape[0], -1).max(dim=1).values
+            row = int(torch.nonzero(d > 0)[0])
+            raise AssertionError((what, name, "rows differing", int((d > 0).sum()), "of", a.shape[0], "first", row,
+                                  "max abs diff", float(d.max()), a[row].flatten()[:6].tolist(), b[row].flatten()[:6].tolist()))
     for name, a, b in zip(NAMES, m, want_m):
         assert torch.equal(a, b), (what, name, "exp_avg")
     for name, a, b in zip(NAMES, v, want_v):

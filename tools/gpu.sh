@@ -14,7 +14,8 @@
 #   pmc          TCC traffic per launch, rasterizer only (two --pmc passes)      pmc:full  the fused train step
 #   sq           SQ counters (VALU / SALU / LDS issue, busy cycles), fused step  sq:raster  rasterizer only
 #   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
-#   dp:allreduce the same with the plain all-reduce
+#   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
+#   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
 TAG=${1:-r03_x}; shift
 OUT=gpurun_out/$TAG
@@ -115,13 +116,16 @@ import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
     pmc)    pmc_pass ${arg:-raster} ;;
     sq)     sq_pass ${arg:-full} ;;
-    dp)     ex=${arg:-factored}
+    dp)     # dp | dp:allreduce | dp:py (view-factored, collectives issued from Python as in round 2)
+            ex=factored; pyx=0; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
             for cfg in C3 C4; do
-              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
-              grep '^{"metric"' $OUT/dp_$cfg.log > $OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json   # (the RCCL banner precedes the JSON line)
+              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex GSR_BENCH_PY_EXCHANGE=$pyx timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
+              f=$OUT/bench_${cfg}_dp_path_1rank_rccl_${arg:-factored}.json
+              grep '^{"metric"' $OUT/dp_$cfg.log > $f   # (the RCCL banner precedes the JSON line)
               python -c "
-import json; d=json.load(open('$OUT/bench_${cfg}_dp_path_1rank_rccl_$ex.json')); print('$cfg dp 1 rank $ex', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'])" || tail -5 $OUT/dp_err.log
+import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
             done ;;
+    dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
     py)     timeout 900 python tools/$arg > $OUT/${arg%.py}.log 2>&1; tail -30 $OUT/${arg%.py}.log | cut -c1-300 ;;
     *)      echo "unknown step $step" ;;
   esac
