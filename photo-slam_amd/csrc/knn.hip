@@ -10,9 +10,15 @@
 //   * no host round trips (the reference blocks on two D2H copies of the AABB and calls
 //     cudaMalloc/thrust allocations per invocation): the AABB stays in HBM and scratch
 //     comes from the caller;
-//   * the sorted points are gathered once into a contiguous array so box scans are coalesced;
-//     a workgroup shares each visited box through LDS instead of every thread gathering the
-//     same 1024 points via the index array;
+//   * the sorted points are gathered once into a contiguous array so box scans read consecutive
+//     addresses (the reference gathers every candidate through the index array);
+//   * a three-level hierarchy of bounding boxes over the Morton order -- 32 points, the reference's
+//     1024 points, 32768 points -- prunes the scan: the reference tests every 1024-box against the
+//     query (P/1024 tests per point) and scans all 1024 points of a box that can still hold a
+//     closer one; here a super box that cannot is skipped with its 32 boxes, and inside a surviving
+//     box only the 32-point runs that can are scanned.  The result is the same set of three
+//     smallest distances: a box is skipped only if its (float, monotone) lower bound exceeds the
+//     current third-best, exactly the reference's test (:165-166) applied at finer grain;
 //   * compiled with -ffp-contract=off so distances are bit-identical to the CPU oracle.
 #include "state.h"
 #include "wave64.h"
@@ -23,6 +29,9 @@
 namespace gsr {
 
 constexpr int KNN_BOX = 1024;      // BOX_SIZE, simple_knn.cu:10
+constexpr int KNN_SUB = 32;        // points per sub-box (Morton-consecutive: a compact cell)
+constexpr int KNN_FAN = 32;        // sub-boxes per box, boxes per super box
+static_assert(KNN_SUB * KNN_FAN == KNN_BOX, "a box is KNN_FAN sub-boxes");
 constexpr int KNN_THREADS = 256;
 
 struct KnnState {
@@ -35,6 +44,8 @@ struct KnnState {
 	uint32_t* vals_b;     // [P]
 	float* sorted_pts;    // [3P]
 	float* boxes;         // [nbox][6]
+	float* subs;          // [nsub][6]  bounding boxes of the runs of KNN_SUB points
+	float* supers;        // [nsup][6]  bounding boxes of KNN_FAN consecutive boxes
 	uint32_t* sort_scratch;
 	static KnnState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -51,6 +62,8 @@ struct KnnState {
 		k.vals_b = c.take<uint32_t>(P);
 		k.sorted_pts = c.take<float>(3 * P);
 		k.boxes = c.take<float>(6 * nbox);
+		k.subs = c.take<float>(6 * ((P + KNN_SUB - 1) / KNN_SUB + 1));
+		k.supers = c.take<float>(6 * ((nbox + KNN_FAN - 1) / KNN_FAN + 1));
 		k.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return k;
@@ -208,13 +221,70 @@ __device__ __forceinline__ void update3(float px, float py, float pz, float qx, 
 	}
 }
 
-// boxMeanDist, simple_knn.cu:147-183.  Thread = one point (in Morton order).  Every thread walks the boxes in
-// order (the box AABBs are wave-uniform loads) and scans a box only if its AABB distance can still improve the
-// point's 3rd-best; the 64 lanes of a wave are Morton neighbours, so they mostly scan the same boxes and the
-// contiguous, pre-gathered points of a box are fetched once per wave (same-address loads).  No barriers, no LDS.
+// Bounding boxes of the runs of KNN_SUB Morton-consecutive points (thread per run: 384 contiguous bytes).
+__global__ void __launch_bounds__(KNN_THREADS)
+knn_sub_boxes_kernel(int P, const float* __restrict__ spts, float* __restrict__ subs)
+{
+	const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int first = c * KNN_SUB;
+	if (first >= P) return;
+	float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	for (int i = first; i < min(P, first + KNN_SUB); i++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const float v = spts[3 * (size_t)i + k];
+			mn[k] = fminf(mn[k], v);
+			mx[k] = fmaxf(mx[k], v);
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		subs[6 * (size_t)c + k] = mn[k];
+		subs[6 * (size_t)c + 3 + k] = mx[k];
+	}
+}
+// ... and of KNN_FAN consecutive boxes (thread per super box)
+__global__ void __launch_bounds__(KNN_THREADS)
+knn_super_boxes_kernel(int nbox, const float* __restrict__ boxes, float* __restrict__ supers)
+{
+	const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int first = s * KNN_FAN;
+	if (first >= nbox) return;
+	float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	for (int b = first; b < min(nbox, first + KNN_FAN); b++) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			mn[k] = fminf(mn[k], boxes[6 * (size_t)b + k]);
+			mx[k] = fmaxf(mx[k], boxes[6 * (size_t)b + 3 + k]);
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		supers[6 * (size_t)s + k] = mn[k];
+		supers[6 * (size_t)s + 3 + k] = mx[k];
+	}
+}
+
+// distBoxPoint, simple_knn.cu:119-129: a lower bound of the squared distance from p to any point inside the box -- also in
+// float arithmetic: every operation is monotone and it is the expression of the point distance (dx dx + dy dy + dz dz, no
+// contraction in this translation unit) with |d| replaced by something not larger
+__device__ __forceinline__ float box_dist(const float* __restrict__ b, float px, float py, float pz)
+{
+	float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+	if (px < b[0] || px > b[3]) ddx = fminf(fabsf(px - b[0]), fabsf(px - b[3]));
+	if (py < b[1] || py > b[4]) ddy = fminf(fabsf(py - b[1]), fabsf(py - b[4]));
+	if (pz < b[2] || pz > b[5]) ddz = fminf(fabsf(pz - b[2]), fabsf(pz - b[5]));
+	return ddx * ddx + ddy * ddy + ddz * ddz;
+}
+
+// boxMeanDist, simple_knn.cu:147-183.  Thread = one point (in Morton order).  Every thread walks the hierarchy in index order
+// and descends only where the bound can still improve its 3rd-best (the reference's test `dist > reject || dist > best[2]`,
+// :165-166, at three grains); the 64 lanes of a wave are Morton neighbours, so they mostly descend into the same boxes and the
+// contiguous, pre-gathered points of a run are fetched once per wave (same-address loads).  No barriers, no LDS.
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_mean_dist_kernel(int P, const float* __restrict__ spts, const uint32_t* __restrict__ indices,
-                     const float* __restrict__ boxes, int nbox, float* __restrict__ dists)
+                     const float* __restrict__ boxes, int nbox, const float* __restrict__ subs, const float* __restrict__ supers,
+                     float* __restrict__ dists)
 {
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (idx >= P) return;
@@ -228,21 +298,24 @@ knn_mean_dist_kernel(int P, const float* __restrict__ spts, const uint32_t* __re
 	best[0] = FLT_MAX;
 	best[1] = FLT_MAX;
 	best[2] = FLT_MAX;
-	for (int b = 0; b < nbox; b++) {
-		// distBoxPoint, simple_knn.cu:119-129
-		const float bnx = boxes[6 * (size_t)b], bny = boxes[6 * (size_t)b + 1], bnz = boxes[6 * (size_t)b + 2];
-		const float bxx = boxes[6 * (size_t)b + 3], bxy = boxes[6 * (size_t)b + 4], bxz = boxes[6 * (size_t)b + 5];
-		float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-		if (px < bnx || px > bxx) ddx = fminf(fabsf(px - bnx), fabsf(px - bxx));
-		if (py < bny || py > bxy) ddy = fminf(fabsf(py - bny), fabsf(py - bxy));
-		if (pz < bnz || pz > bxz) ddz = fminf(fabsf(pz - bnz), fabsf(pz - bxz));
-		const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
-		if (dist > reject || dist > best[2]) continue;
-		const int bbase = b * KNN_BOX;
-		const int cnt = min(KNN_BOX, P - bbase);
-		for (int i = 0; i < cnt; i++) {
-			if (bbase + i == idx) continue;
-			update3(px, py, pz, spts[3 * (size_t)(bbase + i)], spts[3 * (size_t)(bbase + i) + 1], spts[3 * (size_t)(bbase + i) + 2], best);
+	const int nsup = (nbox + KNN_FAN - 1) / KNN_FAN, nsub = (P + KNN_SUB - 1) / KNN_SUB;
+	for (int s = 0; s < nsup; s++) {
+		const float ds = box_dist(supers + 6 * (size_t)s, px, py, pz);
+		if (ds > reject || ds > best[2]) continue;
+		const int b_end = min(nbox, (s + 1) * KNN_FAN);
+		for (int b = s * KNN_FAN; b < b_end; b++) {
+			const float db = box_dist(boxes + 6 * (size_t)b, px, py, pz);
+			if (db > reject || db > best[2]) continue;
+			const int c_end = min(nsub, (b + 1) * KNN_FAN);
+			for (int c = b * KNN_FAN; c < c_end; c++) {
+				const float dc = box_dist(subs + 6 * (size_t)c, px, py, pz);
+				if (dc > reject || dc > best[2]) continue;
+				const int i_end = min(P, (c + 1) * KNN_SUB);
+				for (int i = c * KNN_SUB; i < i_end; i++) {
+					if (i == idx) continue;
+					update3(px, py, pz, spts[3 * (size_t)i], spts[3 * (size_t)i + 1], spts[3 * (size_t)i + 2], best);
+				}
+			}
 		}
 	}
 	dists[indices[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
@@ -261,8 +334,10 @@ int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipS
 	                           &kres, &vres);
 	if (st != GSR_OK) return st;
 	GSR_LAUNCH(knn_gather_boxes_kernel, nbox, KNN_THREADS, stream, P, points, (const uint32_t*)vres, k.sorted_pts, k.boxes);
+	GSR_LAUNCH(knn_sub_boxes_kernel, div_up(div_up(P, KNN_SUB), KNN_THREADS), KNN_THREADS, stream, P, (const float*)k.sorted_pts, k.subs);
+	GSR_LAUNCH(knn_super_boxes_kernel, div_up(div_up(nbox, KNN_FAN), KNN_THREADS), KNN_THREADS, stream, nbox, (const float*)k.boxes, k.supers);
 	GSR_LAUNCH(knn_mean_dist_kernel, div_up(P, KNN_THREADS), KNN_THREADS, stream, P, (const float*)k.sorted_pts,
-	           (const uint32_t*)vres, (const float*)k.boxes, nbox, meanDists);
+	           (const uint32_t*)vres, (const float*)k.boxes, nbox, (const float*)k.subs, (const float*)k.supers, meanDists);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

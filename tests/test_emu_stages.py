@@ -65,6 +65,18 @@ def test_knn_matches_oracle_and_bruteforce(emu_lib_path, oracle, P):
     assert np.array_equal(got, want)
 
 
+def test_knn_box_hierarchy_across_super_boxes(emu_lib_path, oracle):
+    """40 000 points = 40 boxes of 1024 in 2 super boxes of the three-level hierarchy (csrc/knn.hip), with a dense clump whose
+    distances are 1/20 of the rest and duplicates: bit-identical to the oracle's scan of whole 1024-boxes (simple_knn.cu:147-183)."""
+    rng = np.random.default_rng(3)
+    P = 40000
+    pts = (rng.random((P, 3), dtype=np.float32) * np.array([6, 3, 6], np.float32)).astype(np.float32)
+    pts[:5000] *= 0.05
+    pts[7000:7010] = pts[6999]
+    got = stages.knn(emu_lib_path, CPU, pts)
+    assert np.array_equal(got, oracle.knn(pts))
+
+
 def test_mark_visible(emu_lib_path, oracle):
     cl = scene.make_cloud(3000, 64, 48, 50.0, 50.0, seed=5)
     cam = cl.cameras[0]
