@@ -180,7 +180,9 @@ typedef struct gsr_backward_args {
 	int raw_params;
 	/* Extension for keyframe-batch data parallelism (NULL = the reference contract).  [P,3]: when set, dL_dsh is NOT
 	 * written (and may be NULL); instead the gradient w.r.t. the SH colour BEFORE the clamp -- dL_dcolor with the
-	 * clamped channels zeroed (backward.cu:41-48), zeros for culled Gaussians -- is written here.  dL_dsh of one view is
+	 * clamped channels zeroed (backward.cu:41-48), zeros for culled Gaussians -- is written here (a VISIBLE Gaussian whose masked
+	 * gradient is all zero carries -0.0f in channel 0: numerically nothing, a visibility marker for the lazy rows of
+	 * gsr_sh_adam_from_views).  dL_dsh of one view is
 	 * basis(dir) x this vector; gsr_sh_grad_from_views rebuilds it for all views after the exchange.  The SH term of
 	 * dL_dmean3D is computed as usual. */
 	float* dL_dcolor_view;
@@ -191,7 +193,11 @@ typedef struct gsr_backward_args {
 	 * the Gaussians this view culls do not depend on the backward pass at all (zero gradient): gsr_backward updates them on
 	 * a second HIP stream it owns, concurrently with the VALU-bound backward blend that leaves HBM nearly idle, and joins
 	 * that stream before it returns (environment GSR_SH_ADAM_SIDE_STREAM=0: everything on the caller's stream).  Only for
-	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise); mutually exclusive with dL_dcolor_view. */
+	 * 16-byte aligned [P,16,3] tensors (GSR_ERR_UNSUPPORTED otherwise).  Together with dL_dcolor_view only in the lazy form
+	 * (sh_adam->lazy, window >= 3), and then with another meaning: no step is fused (it follows the exchange:
+	 * gsr_sh_adam_from_views); backward runs, on its second stream next to the blend kernel, the rotating catch-up that
+	 * bounds the lag of the rows no view lights -- the row blocks b with b % (window - 1) == step % (window - 1) take the
+	 * zero-gradient steps they are behind up to step - 1 (what happens AT step is decided by the exchange). */
 	const gsr_sh_adam* sh_adam;
 	/* Extension (all three or none; NULL = the reference contract): the densification statistics of this view, updated by
 	 * the kernel that holds dL_dmean2D in registers instead of a separate pass (gsr_densify_stats, same arithmetic): for
@@ -244,12 +250,17 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
  * gradient is zero in EVERY gathered view would take a zero-gradient step -- it is left alone and steps later; a row some view
  * lights first takes the zero-gradient steps it is behind (this rank's forward pass only caught up the rows ITS view sees),
  * then this step, and row_step[i] = step.  1152 B of optimizer traffic per Gaussian some view of the batch sees instead of
- * per Gaussian.  The call may cover a row range (pointers offset by the caller, row_step too).  After the last range of a
- * step the caller runs gsr_sh_adam_lazy_slice over ALL rows: this step's 1/window of the row blocks catches up, so that no
- * row ever lags by more than `window` steps.  Same contract as the single-GPU lazy mode otherwise (pass the struct to
+ * per Gaussian.  The call may cover a row range (pointers offset by the caller, row_step too).  The lag of the rows nobody
+ * lights is bounded either by gsr_backward (sh_adam together with dL_dcolor_view: the catch-up runs ahead of the exchange,
+ * next to the blend kernel -- what both hosts do) or by gsr_sh_adam_lazy_slice over ALL rows after the last range of the
+ * step (this step's 1/window of the row blocks catches up to `step`).  Same contract as the single-GPU lazy mode otherwise (pass the struct to
  * gsr_forward_args.sh_adam of the step; gsr_sh_adam_flush before anything else touches the tensor); results bit-identical to
  * the eager update (tests/test_lazy_sh_adam.py). */
-int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, void* stream);
+/* ahead == 0: after the last gsr_sh_adam_from_views range of the step -- row blocks b with b % window == step % window, every
+ * row that is behind catches up to `step`.  ahead != 0 (window >= 3): BEFORE the step's gsr_sh_adam_from_views calls (what
+ * gsr_backward does on its second stream in the view-factored mode) -- row blocks b with b % (window - 1) == step % (window - 1)
+ * catch up to step - 1.  A step uses one of the two. */
+int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, int ahead, void* stream);
 
 /* Rasterizer::markVisible, cuda_rasterizer/rasterizer_impl.cu:141-153:
  * present[i] = (view-space z of means3D[i] > 0.2).  present is [P] bytes (bool). */

@@ -160,7 +160,7 @@ def load(path=None):
     L.gsr_sh_adam_flush.restype = i32
     L.gsr_sh_adam_flush.argtypes = [i32, C.POINTER(ShAdam), vp]
     L.gsr_sh_adam_lazy_slice.restype = i32
-    L.gsr_sh_adam_lazy_slice.argtypes = [i32, C.POINTER(ShAdam), vp]
+    L.gsr_sh_adam_lazy_slice.argtypes = [i32, C.POINTER(ShAdam), i32, vp]
     L.gsr_adam_step_multi.restype = i32
     L.gsr_adam_step_multi.argtypes = [i32, C.POINTER(AdamMultiTensor), C.c_double, C.c_double, C.c_double, vp]
     L.gsr_mark_visible.restype = i32

@@ -303,7 +303,10 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	if (a->shs && !a->dL_dsh && !a->dL_dcolor_view && !a->sh_adam) return GSR_ERR_INVALID_ARG;
 	if ((a->stat_grad_accum != nullptr) != (a->stat_denom != nullptr) || (a->stat_denom != nullptr) != (a->stat_max_radii != nullptr))
 		return GSR_ERR_INVALID_ARG;
-	if (a->sh_adam && (!a->shs || a->dL_dcolor_view || !a->sh_adam->exp_avg || !a->sh_adam->exp_avg_sq || a->sh_adam->step < 1))
+	// (sh_adam together with dL_dcolor_view: only its lazy form, which then means "catch up this step's slice ahead of the
+	// exchange", see gsr.h)
+	if (a->sh_adam && (!a->shs || (a->dL_dcolor_view && !a->sh_adam->lazy) || !a->sh_adam->exp_avg || !a->sh_adam->exp_avg_sq ||
+	                   a->sh_adam->step < 1))
 		return GSR_ERR_INVALID_ARG;
 	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
 	if (a->scales && (!a->dL_dscale || !a->dL_drot) && !a->geom_adam) return GSR_ERR_INVALID_ARG;
@@ -320,7 +323,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	t_prof.bwd_done = false;
 	// ---- the rest of the validation, BEFORE anything is enqueued: a call that is going to be refused must not have applied a
 	// part of an optimizer step already (the culled rows' update below is forked onto a second stream first thing)
-	const bool rows_path = sh_rows_path(a->shs, a->M, a->D, a->dL_dcolor_view != nullptr, a->sh_adam != nullptr, a->dL_dsh);
+	const bool pre_slice = a->sh_adam && a->dL_dcolor_view;   // factored mode: no fused step, only the lazy rows' catch-up
+	const bool rows_path = sh_rows_path(a->shs, a->M, a->D, a->dL_dcolor_view != nullptr, a->sh_adam != nullptr && !pre_slice, a->dL_dsh);
 	if (!a->dL_dcov3D && a->cov3D_precomp) return GSR_ERR_INVALID_ARG;
 	if (a->sh_adam) {
 		const gsr_sh_adam& o = *a->sh_adam;
@@ -367,20 +371,22 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	if (lazy) {
 		// lazy mode (gsr_sh_adam_lazy): the culled rows do NOT take this step now; a rotating 1/window of the row blocks catches
 		// up instead (launched behind the backward blend, below)
-		if (a->dL_dcolor_view || !a->shs) return GSR_ERR_INVALID_ARG;
+		if (!a->shs) return GSR_ERR_INVALID_ARG;
 		if ((st = make_lazy_adam(*a->sh_adam, a->shs, a->M, la)) != GSR_OK) return st;
+		if (pre_slice && la.window < 3) return GSR_ERR_INVALID_ARG;
 	}
 	// This step's slice of the lazy rows: 1/window of the culled rows, each taking `window` zero-gradient steps in registers --
 	// little traffic (72 MB at C3), mostly arithmetic -- on the second stream if there is one; its rows are disjoint from the
 	// visible ones the per-Gaussian backward kernels update.
 	auto launch_lazy_slice = [&]() -> int {
-		const int* radii = a->radii ? a->radii : g.radii;
-		if (!side_stream_enabled()) return launch_sh_adam_lazy(P, radii, la, stream);
+		const int* radii = pre_slice ? nullptr : (a->radii ? a->radii : g.radii);
+		const int mode = pre_slice ? 3 : 0;
+		if (!side_stream_enabled()) return launch_sh_adam_lazy(P, radii, la, stream, mode);
 		int s2 = t_sync.init_side();
 		if (s2 != GSR_OK) return s2;
 		GSR_HIP(hipEventRecord(t_sync.fork, stream));
 		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
-		s2 = launch_sh_adam_lazy(P, radii, la, t_sync.side);
+		s2 = launch_sh_adam_lazy(P, radii, la, t_sync.side, mode);
 		// (recorded even after a failed launch: whatever did reach the second stream is joined by fail())
 		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
 		side_busy = true;
@@ -446,7 +452,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.lazy_row_step = nullptr; pb.lazy_step = 0;
 	pb.touched_clear = (R > 0 && rows_path) ? bs.touched : nullptr;
 	pb.touched_clear_bytes = (uint32_t)touched_clear_bytes((size_t)R);
-	if (a->sh_adam) {
+	if (a->sh_adam && !pre_slice) {
 		const gsr_sh_adam& o = *a->sh_adam;   // the same scalars gsr_adam_step derives (kernels.h: adam_scalars)
 		pb.adam_param = o.param;
 		pb.adam_exp_avg = o.exp_avg; pb.adam_exp_avg_sq = o.exp_avg_sq;
@@ -469,7 +475,7 @@ int gsr_sh_adam_flush(int P, const gsr_sh_adam* adam, void* stream_)
 	LazyAdam la{};
 	int st = make_lazy_adam(*adam, nullptr, 16, la);
 	if (st != GSR_OK) return st;
-	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_);
+	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_, 1);
 }
 
 int gsr_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
@@ -506,14 +512,14 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 	                                 nullptr, &ra, (hipStream_t)stream_, o->lazy ? &la : nullptr);
 }
 
-int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, void* stream_)
+int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, int ahead, void* stream_)
 {
 	if (P < 0 || !adam || !adam->lazy) return GSR_ERR_INVALID_ARG;
 	if (P == 0) return GSR_OK;
 	LazyAdam la{};
 	int st = make_lazy_adam(*adam, nullptr, 16, la);
 	if (st != GSR_OK) return st;
-	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_, /*slice_only=*/true);
+	return launch_sh_adam_lazy(P, nullptr, la, (hipStream_t)stream_, ahead ? 3 : 2);
 }
 
 int gsr_profile_enable(int on)

@@ -184,10 +184,11 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 // this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
 int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream);
 
-// lazy mode: the zero-gradient steps the rows of this step's slice of row blocks are behind, up to and including a.step, for
-// the rows with radii <= 0 (radii == null: every row of EVERY block -- gsr_sh_adam_flush)
-// slice_only (with radii == null): this step's slice of the row blocks, every row that is behind (the data-parallel program)
-int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, bool slice_only = false);
+// lazy mode: the zero-gradient steps rows are behind (preprocess_bwd.hip: sh_adam_lazy_kernel).  mode 0: this step's slice,
+// rows with radii <= 0, up to a.step (the fused backward); 1: every row of every block (gsr_sh_adam_flush); 2: this step's slice,
+// every row (gsr_sh_adam_lazy_slice); 3: the slice of period window - 1, every row, up to a.step - 1 (the data-parallel step,
+// next to the backward blend).  radii: mode 0 only.
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, int mode);
 
 // simple-knn
 size_t knn_scratch_bytes(int P);

@@ -99,6 +99,10 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		dRGB[2] = p.dL_dcolor[3 * (size_t)idx + 2] * ((cl & 4) ? 0.f : 1.f);
 	}
 	if (FACTORED && in_range) {
+		// a VISIBLE Gaussian whose masked colour gradient is all zero (drawn, but blended into no pixel that matters) leaves -0.0f
+		// in channel 0: numerically nothing, but it tells the lazy rows of gsr_sh_adam_from_views that some view SEES this
+		// Gaussian -- its row steps now (with a zero gradient) instead of being caught up by the next forward pass of this view
+		if (vis && dRGB[0] == 0.f && dRGB[1] == 0.f && dRGB[2] == 0.f) dRGB[0] = -0.0f;
 		p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
 		p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
 		p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
@@ -296,6 +300,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 				shz = (-ox * oz * dLx - oy * oz * dLy + (sum2 - oz * oz) * dLz) * invsum32;
 			}
 			if (p.dL_dcolor_view && in_range) {
+				if (vis && dRGB[0] == 0.f && dRGB[1] == 0.f && dRGB[2] == 0.f) dRGB[0] = -0.0f;   // (visibility marker: sh_bwd_rows_kernel)
 				p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
 				p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
 				p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
@@ -534,46 +539,63 @@ int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStrea
 // lit rows) up to a.step -- the zero-gradient steps (row_step, a.step] in one read-modify-write of the row.  The workgroup owns its
 // block: row_step is read by all threads before the barrier, written behind it.
 constexpr int LAZY_THREADS = LAZY_BLOCK_ROWS * ROW_F4;   // 768
+// mode 0: this step's slice (row blocks b with b % window == step % window), rows with radii <= 0, up to a.step (the fused
+//         backward: the visible rows step in sh_bwd_rows_kernel at the same time);
+// mode 1: every block, every row that is behind, up to a.step (gsr_sh_adam_flush; radii == null);
+// mode 2: this step's slice, every row that is behind, up to a.step (gsr_sh_adam_lazy_slice: BEHIND the kernel that stepped
+//         the lit rows of a data-parallel step);
+// mode 3: the slice of period window - 1, every row that is behind, up to a.step - 1 only (the data-parallel step's catch-up
+//         run AHEAD of the exchange, next to the backward blend: what happens at a.step is not known yet -- a row some view
+//         lights takes a real step, the others none -- so a row visited here lags by at most window - 1 steps afterwards).
 __global__ void __launch_bounds__(LAZY_THREADS)
-sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a, int all_blocks)
+sh_adam_lazy_kernel(int P, const int* __restrict__ radii, const LazyAdam a, int mode)
 {
-	const bool all = radii == nullptr;   // no visibility filter: every row of the block that is behind a.step catches up
-	const long long b = all_blocks ? (long long)blockIdx.x : (long long)(a.step % a.window) + (long long)blockIdx.x * a.window;
+	const int period = mode == 3 ? a.window - 1 : a.window;
+	const long long b = mode == 1 ? (long long)blockIdx.x : (long long)(a.step % period) + (long long)blockIdx.x * period;
 	const size_t row0 = (size_t)b * LAZY_BLOCK_ROWS;
 	const int item = (int)threadIdx.x;
 	const int rr = item / ROW_F4, col = item - rr * ROW_F4;
 	const size_t row = row0 + (size_t)rr;
-	const bool mine = row < (size_t)P && (all || radii[row] <= 0);
+	const bool mine = row < (size_t)P && (radii == nullptr || radii[row] <= 0);
+	const int k_lo = mode == 3 ? 1 : 0;
+	bool moved = false;
 	if (mine) {
 		int k_hi = a.step - 1 - a.row_step[row];
 		k_hi = k_hi >= a.window ? a.window - 1 : k_hi;
-		if (k_hi >= 0) {
+		if (k_hi >= k_lo) {
+			moved = true;
 			const size_t i = row * ROW_F4 + col;
 			float4 pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
 			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
 			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
-			lazy_zero_grad_steps(a.t, k_hi, 0, col, pv, mv, vv);
+			lazy_zero_grad_steps(a.t, k_hi, k_lo, col, pv, mv, vv);
 			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
 			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
 			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
 		}
 	}
 	__syncthreads();
-	if (mine && col == 0) a.row_step[row] = a.step;
+	if (mode == 3) {
+		if (moved && col == 0) a.row_step[row] = a.step - 1;
+	} else if (mine && col == 0) {
+		a.row_step[row] = a.step;
+	}
 }
 
-int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, bool slice_only)
+int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t stream, int mode)
 {
 	if (P <= 0) return GSR_OK;
 	if (!a.row_step || a.window < 2 || a.window > LAZY_WINDOW_MAX || a.step < 1) return GSR_ERR_INVALID_ARG;
+	if (mode == 3 && a.window < 3) return GSR_ERR_INVALID_ARG;
+	if ((radii != nullptr) != (mode == 0)) return GSR_ERR_INVALID_ARG;
 	if ((reinterpret_cast<uintptr_t>(a.param) | reinterpret_cast<uintptr_t>(a.exp_avg) | reinterpret_cast<uintptr_t>(a.exp_avg_sq)) & 15)
 		return GSR_ERR_UNSUPPORTED;
 	const int nb = div_up(P, LAZY_BLOCK_ROWS);
-	// slice: the row blocks b with b % window == step % window
-	const int phase = a.step % a.window;
-	const bool slice = radii != nullptr || slice_only;
-	const int blocks = slice ? (nb > phase ? div_up(nb - phase, a.window) : 0) : nb;
-	if (blocks > 0) GSR_LAUNCH(sh_adam_lazy_kernel, blocks, LAZY_THREADS, stream, P, radii, a, slice ? 0 : 1);
+	// slice: the row blocks b with b % period == step % period
+	const int period = mode == 3 ? a.window - 1 : a.window;
+	const int phase = a.step % period;
+	const int blocks = mode == 1 ? nb : (nb > phase ? div_up(nb - phase, period) : 0);
+	if (blocks > 0) GSR_LAUNCH(sh_adam_lazy_kernel, blocks, LAZY_THREADS, stream, P, radii, a, mode);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
@@ -679,9 +701,10 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 			const float* c = views + (size_t)v * (size_t)view_stride + (size_t)idx * 3;
 			r = c[0]; g = c[1]; b = c[2];
 		}
+		// some view SEES this Gaussian (a visible one with an all-zero gradient carries -0.0f: sh_bwd_rows_kernel)
+		any = any || (__float_as_uint(r) | __float_as_uint(g) | __float_as_uint(b)) != 0u;
 		// culled in this view (or every channel clamped): nothing to add, and most Gaussians are outside most views
 		if (r != 0.f || g != 0.f || b != 0.f) {
-			any = true;
 			const float* cp = campos + (size_t)v * (size_t)campos_stride;
 			const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
 			const float len = sqrtf(ox * ox + oy * oy + oz * oz);   // forward.cu:27-28

@@ -243,8 +243,10 @@ class GaussianModel:
         self.spatial_lr_scale_ = spatial_lr_scale
         pts = points.to(self.device_).float().contiguous()
         n = pts.shape[0]
-        C0 = 0.28209479177387814
-        fused_color = (colors.to(self.device_).float() - 0.5) / C0  # RGB2SH, include/sh_utils.h:138
+        # RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT C0 -- a device scalar as divisor, so that the HIP kernel
+        # divides (a host scalar makes ATen multiply by the reciprocal there: one ulp off the reference's values on the GPU)
+        C0 = torch.tensor(0.28209479177387814, dtype=torch.float32, device=self.device_)
+        fused_color = (colors.to(self.device_).float() - 0.5) / C0
         M = (self.max_sh_degree_ + 1) ** 2
         features = torch.zeros((n, 3, M), device=self.device_)
         features[:, :3, 0] = fused_color
@@ -281,7 +283,7 @@ class GaussianModel:
         with torch.no_grad():
             self.sparse_points_xyz_ = pts if self.sparse_points_xyz_ is None else torch.cat([self.sparse_points_xyz_, pts], 0)
             self.sparse_points_color_ = cols if self.sparse_points_color_ is None else torch.cat([self.sparse_points_color_, cols], 0)
-            C0 = 0.28209479177387814
+            C0 = torch.tensor(0.28209479177387814, dtype=torch.float32, device=dev)   # (a device scalar: see createFromPcd)
             M = (self.max_sh_degree_ + 1) ** 2
             features = torch.zeros((n, M, 3), device=dev)
             features[:, 0, :] = (cols - 0.5) / C0                                   # RGB2SH, include/sh_utils.h:138
@@ -484,6 +486,27 @@ class GaussianModel:
                            sets=[dict(params={n: [mk(r), mk(r), mk(r)] for n, r in rows.items()},
                                       stats=[mk((1,)), mk((1,)), mk(())],
                                       exist=torch.empty((capacity,), device=dev, dtype=torch.int32)) for _ in range(2)])
+
+    def release_arena(self):
+        """The live tensors move into allocations of their own and both arena sets are freed (GaussianModel::releaseArena of the
+        C++ host; what the reference's emptyCache() after densification achieves, src/gaussian_model.cpp:814).  LIFETIME
+        CONTRACT of the arena: after a rebuild xyz_, features_, ..., the Adam moments, the statistics and exist_since_iter_ are
+        narrow() views into one of two persistent sets -- a tensor obtained BEFORE rebuild N is overwritten by rebuild N + 2;
+        clone() what has to outlive a rebuild, or call this when densification ends."""
+        with torch.no_grad():
+            for name in self._PARAM_NAMES:
+                old = getattr(self, name)      # (features_: brings lazily stepped rows up to date first)
+                new = old.detach().clone().requires_grad_(True)
+                setattr(self, name, new)
+                if self.optimizer_ is not None:
+                    m, v = self.optimizer_.moments(old)
+                    self.optimizer_.replace_param(old, new, m.clone(), v.clone())
+            self.xyz_gradient_accum_, self.denom_ = self.xyz_gradient_accum_.clone(), self.denom_.clone()
+            self.max_radii2D_ = self.max_radii2D_.clone()
+            if self.exist_since_iter_ is not None:
+                self.exist_since_iter_ = self.exist_since_iter_.clone()
+        self._arena = None
+        self._densify_scratch = None
 
     def _compact(self, select, generator=None):
         """select: fills a capi.DensifySelectArgs.  Returns the counts [kept, clones, child parents, split, clone-selected,

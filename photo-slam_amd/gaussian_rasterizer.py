@@ -70,9 +70,10 @@ class GaussianRasterizerFunction(torch.autograd.Function):
             s.bg_, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier_, cov3Ds_precomp, s.viewmatrix_,
             s.projmatrix_, s.tanfovx_, s.tanfovy_, grad_out_color, sh, s.sh_degree_, s.campos_, geomBuffer,
             ctx.num_rendered, binningBuffer, imgBuffer, s.raw_params_, s.sh_grad_view_,
-            # view-factored mode: the SH step follows the exchange (gsr_sh_adam_from_views); sh_adam_ then served the forward
-            # pass only (lazy rows of visible Gaussians caught up)
-            None if s.sh_grad_view_ is not None else s.sh_adam_, s.view_stats_,
+            # view-factored mode: the SH step follows the exchange (gsr_sh_adam_from_views); sh_adam_ -- its lazy form -- served
+            # the forward pass (rows this view sees caught up) and lets backward run this step's slice of the rotating
+            # catch-up next to the blend kernel
+            s.sh_adam_ if (s.sh_grad_view_ is None or (s.sh_adam_ or {}).get("row_step") is not None) else None, s.view_stats_,
             s.geom_adam_, s.training_outputs_only_)
         # order of src/gaussian_rasterizer.cpp:159-179
         def g(t, like):   # (None where an extension took the gradient's place)

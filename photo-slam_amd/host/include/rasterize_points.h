@@ -115,9 +115,10 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 // gsr_sh_adam_flush: lazy mode -- every row of `sh` takes the zero-gradient steps it is behind, up to sh_adam.step = the number
 // of Adam steps the tensor has taken (sh_adam.lr / lr_tail belong to that step)
 void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam);
-// gsr_sh_adam_lazy_slice: the data-parallel step's rotating catch-up -- after the last shAdamFromViews() range of a step with
-// lazy rows (sh_adam.row_step defined), this step's 1/window of the row blocks brings every row that is behind up to sh_adam.step
-void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam);
+// gsr_sh_adam_lazy_slice: the data-parallel step's rotating catch-up of the rows no view lights -- after the last
+// shAdamFromViews() range of the step (up to sh_adam.step), or `ahead` of them (up to step - 1: what the rasterizer's backward
+// does by itself in the view-factored mode, so TrainStep never calls this)
+void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam, bool ahead = false);
 
 // gsr_adam_step_multi: one Adam step (gsr_adam_step arithmetic) of several tensors in ONE launch
 struct AdamMultiEntry {

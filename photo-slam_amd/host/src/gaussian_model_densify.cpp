@@ -32,8 +32,10 @@ void GaussianModel::createFromPcd(torch::Tensor points, torch::Tensor colors, fl
 	auto pts = points.to(torch::kFloat32).contiguous();
 	const auto n = pts.size(0);
 	const auto o = pts.options();
-	const double C0 = 0.28209479177387814;
-	auto fused_color = (colors.to(o) - 0.5) / C0;
+	// RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT C0 -- a device scalar as divisor, so that the HIP kernel
+	// divides (a host scalar makes ATen multiply by the reciprocal there: one ulp off the reference's values on the GPU)
+	const auto C0 = torch::full({}, 0.28209479177387814f, o);
+	auto fused_color = (colors.to(o) - 0.5f) / C0;
 	const int64_t M = (max_sh_degree_ + 1) * (max_sh_degree_ + 1);
 	auto features = torch::zeros({n, M, 3}, o);   // the reference's [n,3,M] transposed: one [n,M,3] leaf
 	features.select(1, 0).copy_(fused_color);
@@ -83,10 +85,10 @@ void GaussianModel::increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& n
 		sparse_points_xyz_ = torch::cat({sparse_points_xyz_, pts}, 0);
 		sparse_points_color_ = torch::cat({sparse_points_color_, cols}, 0);
 	}
-	const double C0 = 0.28209479177387814;
+	const auto C0 = torch::full({}, 0.28209479177387814f, o);   // (a device scalar: see createFromPcd)
 	const int64_t M = (max_sh_degree_ + 1) * (max_sh_degree_ + 1);
 	auto features = torch::zeros({n, M, 3}, o);
-	features.select(1, 0).copy_((cols - 0.5) / C0);   // RGB2SH, include/sh_utils.h:138
+	features.select(1, 0).copy_((cols - 0.5f) / C0);   // RGB2SH, include/sh_utils.h:138
 	auto dist2 = torch::clamp_min(distCUDA2(pts.clone()), 0.0000001);
 	auto scales = torch::log(torch::sqrt(dist2)).unsqueeze(1).repeat({1, 3});
 	auto rots = torch::zeros({n, 4}, o);

@@ -112,8 +112,10 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 	                                        sh_degree, v[3] /*campos*/, v[11], num_rendered, v[12], v[13], raw_params,
 	                                        sh_grad_view,
 	                                        // view-factored mode: the SH step follows the exchange (gsr_sh_adam_from_views);
-	                                        // sh_adam_ then served the forward pass only (lazy rows of visible Gaussians)
-	                                        sh_grad_view.defined() ? ShAdamStep() : sh_adam, view_stats, geom_adam);
+	                                        // sh_adam_ -- its lazy form -- served the forward pass (rows this view sees caught up)
+	                                        // and lets backward run this step's slice of the rotating catch-up
+	                                        (sh_grad_view.defined() && !sh_adam.row_step.defined()) ? ShAdamStep() : sh_adam, view_stats,
+	                                        geom_adam);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();

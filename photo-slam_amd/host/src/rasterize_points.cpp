@@ -267,7 +267,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 	                 dL_dcolor_view.device() != means3D.device()))
 		throw std::runtime_error("dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor on the device of means3D, with SHs");
 	const bool fused_adam = sh_adam.exp_avg.defined();
-	if (fused_adam && (factored || !has_sh || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 ||
+	// (sh_adam together with dL_dcolor_view only in its lazy form: backward then runs this step's slice of the rows' catch-up)
+	if (fused_adam && ((factored && !sh_adam.row_step.defined()) || !has_sh || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 ||
 	                   !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() ||
 	                   sh_adam.exp_avg.sizes() != sh.sizes() || sh_adam.exp_avg_sq.sizes() != sh.sizes() || sh_adam.step < 1))
 		throw std::runtime_error("sh_adam needs contiguous float32 sh and moments of one shape, step >= 1, and no dL_dcolor_view");
@@ -434,7 +435,7 @@ void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam)
 	check(gsr_sh_adam_flush(static_cast<int>(sh.size(0)), &adam, current_stream(sh)), "shAdamFlush");
 }
 
-void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam)
+void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam, bool ahead)
 {
 	torch::NoGradGuard ng;
 	if (!sh_adam.row_step.defined() || !sh_adam.exp_avg.defined() || sh.dim() != 3 || sh.size(1) != 16 || !sh.is_contiguous() ||
@@ -444,7 +445,7 @@ void shAdamLazySlice(torch::Tensor& sh, const ShAdamStep& sh_adam)
 	gsr_sh_adam adam{};
 	gsr_sh_adam_lazy lazy{};
 	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
-	check(gsr_sh_adam_lazy_slice(static_cast<int>(sh.size(0)), &adam, current_stream(sh)), "shAdamLazySlice");
+	check(gsr_sh_adam_lazy_slice(static_cast<int>(sh.size(0)), &adam, ahead ? 1 : 0, current_stream(sh)), "shAdamLazySlice");
 }
 
 void adamStepMulti(const std::vector<AdamMultiEntry>& entries, double beta1, double beta2, double eps)

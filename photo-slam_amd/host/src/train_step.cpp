@@ -238,7 +238,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	// gets the same struct, so that the rows THIS view sees are up to date before they are evaluated; backward ignores it.
 	views_adam_ = ShAdamStep();
 	views_adam_pending_ = false;
-	if (factored_exchange_ && lazy_sh_adam_window_ >= 2 && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
+	if (factored_exchange_ && lazy_sh_adam_window_ >= 3 && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
 	    g->features_.size(1) == 16 && g->features_.is_contiguous() && !pipe.convert_SHs_) {
 		auto& grp = g->groups_[1];
 		lazy = true;
@@ -392,11 +392,8 @@ void TrainStep::finishFeaturesFromViews()
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
 	views_adam_pending_ = false;
-	if (iteration_ < g->opt_.iterations_) {
-		// this step's 1/window of the row blocks catches up, so that no row lags by more than `window` steps
-		auto sh = g->features_.detach();
-		shAdamLazySlice(sh, views_adam_);
-	}
+	// (the rotating catch-up that bounds the lag of the rows no view lights ran inside the rasterizer's backward, next to the
+	// blend kernel: gsr_backward_args.sh_adam together with dL_dcolor_view)
 	auto& hist = g->features_lr_hist_;   // the step is taken: its learning rates join the history the later catch-ups need
 	hist.insert(hist.begin(), {views_adam_.lr, views_adam_.lr_tail});
 	if (static_cast<int>(hist.size()) > g->features_lazy_window_) hist.pop_back();

@@ -155,7 +155,8 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     dL_dcov3D = torch.empty((P, 6), **opts)
     factored = dL_dcolor_view is not None
     if sh_adam is not None:
-        if factored:
+        if factored and sh_adam.get("row_step") is None:
+            # (together only in the lazy form: backward then runs this step's slice of the rows' rotating catch-up, gsr.h)
             raise RuntimeError("sh_adam and dL_dcolor_view are mutually exclusive")
         for t in (sh_adam["exp_avg"], sh_adam["exp_avg_sq"]):
             if t.shape != sh.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
@@ -275,14 +276,15 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
         capi.check(lib, st, "shAdamFromViews")
 
 
-def shAdamLazySlice(sh, sh_adam):
-    """gsr_sh_adam_lazy_slice (include/gsr.h): this step's 1/window of the row blocks of the lazily stepped [P,16,3] tensor
-    catches up (every row of the slice that is behind sh_adam["step"])."""
+def shAdamLazySlice(sh, sh_adam, ahead=False):
+    """gsr_sh_adam_lazy_slice (include/gsr.h): this step's slice of the row blocks of the lazily stepped [P,16,3] tensor catches
+    up -- after the step's shAdamFromViews calls to sh_adam["step"], or (ahead) before them to step - 1 (what the rasterizer's
+    backward does by itself in the view-factored mode)."""
     lib = _lib()
     _check_device(lib, sh, sh_adam["exp_avg"], sh_adam["exp_avg_sq"], sh_adam["row_step"])
     with torch.no_grad():
         adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
-        capi.check(lib, lib.gsr_sh_adam_lazy_slice(int(sh.size(0)), C.byref(adam), _stream_ptr(sh)), "shAdamLazySlice")
+        capi.check(lib, lib.gsr_sh_adam_lazy_slice(int(sh.size(0)), C.byref(adam), int(bool(ahead)), _stream_ptr(sh)), "shAdamLazySlice")
 
 
 def adamStepMulti(tensors, beta1, beta2, eps):

@@ -166,16 +166,17 @@ class ViewFactoredExchange:
         from . import rasterize_points as rp
         m3, shd = means3D.detach(), sh.detach()
         lazy = sh_adam.get("row_step") is not None
+        if lazy and int(sh_adam["window"]) < 3:
+            raise RuntimeError("lazy rows in the view-factored step need a window of at least 3")
         for row0, centres, views in self.gathered_parts():
             n = views.size(1)
             part = dict(sh_adam, exp_avg=sh_adam["exp_avg"][row0:row0 + n], exp_avg_sq=sh_adam["exp_avg_sq"][row0:row0 + n])
             if lazy:
                 part["row_step"] = sh_adam["row_step"][row0:row0 + n]
             rp.shAdamFromViews(m3[row0:row0 + n], centres, views, degree, 1.0 / self.world_size_, shd[row0:row0 + n], part)
-        if lazy:
-            # lazy rows (gsr_sh_adam_lazy): the rows no view of the batch lights were left alone above; this step's 1/window of
-            # the row blocks catches up, so that no row lags by more than `window` steps
-            rp.shAdamLazySlice(shd, sh_adam)
+        # (lazy rows, gsr_sh_adam_lazy: the rows no view of the batch lights were left alone above; the rotating catch-up that
+        # bounds their lag ran inside the rasterizer's backward, next to the blend kernel -- gsr_backward_args.sh_adam together
+        # with dL_dcolor_view)
 
     def order(self):
         """parameter indices of the all-reduced tensors in completion order"""
@@ -269,7 +270,7 @@ class TrainStep:
         # Data-parallel step with the view-factored exchange: the SH rows step AFTER the exchange (gsr_sh_adam_from_views), and
         # lazily there too -- a row no view of the batch lights takes a zero-gradient step, i.e. it may take it later; the
         # forward pass gets the same struct so that the rows THIS view sees are up to date before they are evaluated.
-        if sh_view is not None and self.lazy_sh_adam_window_ >= 2 and it < opt.iterations_ and not rebuilds and \
+        if sh_view is not None and self.lazy_sh_adam_window_ >= 3 and it < opt.iterations_ and not rebuilds and \
                 g._features.size(1) == 16 and g.optimizer_ is not None and not self.pipe_.convert_SHs_ and \
                 g._features.is_contiguous():
             sh_adam_views = g.optimizer_.begin_fused_step(FEATURES_GROUP, self.lazy_sh_adam_window_)

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# the end-to-end tests alternate between two OpenMP consumers (the CPU oracle and ATen): with spinning worker threads each
+# starves the other on a many-core host (the GPU boxes have 256 hardware threads: minutes instead of seconds) -- sleep instead
+# (must be set before libgomp loads; bench.py does the same for its CPU baseline leg)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -350,7 +350,7 @@ def run_pipeline_flag_train_checks(ops, dev, lib_path):
     step per iteration, in both hosts, and the result equals the default data flow's (same maths) to a small fraction of a
     learning-rate step."""
     import math
-    cl, t = _scene(dev, P=400)
+    cl, t = _scene(dev, P=240 if dev.type == "cpu" else 400)
     cam = cl.cameras[0]
     torch.manual_seed(0)
     gt = torch.rand(3, cam.H, cam.W).to(dev)
@@ -360,7 +360,7 @@ def run_pipeline_flag_train_checks(ops, dev, lib_path):
     fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
     kf = GaussianKeyframe.from_camera(cam, dev)
     lrs = [0.00016 * cl.extent, 0.0025, 0.05, 0.005, 0.001]
-    n_it = 4
+    n_it = 3 if dev.type == "cpu" else 4
     rp._LIB_OVERRIDE = lib_path
     try:
         final = {}

@@ -304,6 +304,8 @@ def run_increase_pcd(kind, dev, host_ops, lib_path, P=600, n_new=(157, 40)):
         # the arena released: the same values in stable allocations
         host_ops.trainer_release_arena(h)
         compare(ref2, cpp_state(host_ops, h), info["children_kept"], "released arena/c++")
+        g.release_arena()
+        compare(ref2, python_state(g), info["children_kept"], "released arena/python")
         host_ops.trainer_destroy(h)
     finally:
         rp._LIB_OVERRIDE = None

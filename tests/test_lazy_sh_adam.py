@@ -116,7 +116,7 @@ def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
 
 def test_both_hosts_train_the_same_with_lazy_rows(emu_lib_path):
     from tests.test_cpp_host import load_host
-    run_host_lazy_checks(load_host("emu"), torch.device("cpu"), emu_lib_path)
+    run_host_lazy_checks(load_host("emu"), torch.device("cpu"), emu_lib_path, P=200)
 
 
 @pytest.mark.gpu
@@ -127,7 +127,7 @@ def test_both_hosts_train_the_same_with_lazy_rows_on_gpu():
     run_host_lazy_checks(load_host("hip"), torch.device("cuda:0"), None, P=20000, iterations=15)
 
 
-def run_lazy_from_views_checks(dev, lib_path, P=700, n_views=3, steps=11, window=4):
+def run_lazy_from_views_checks(dev, lib_path, P=700, n_views=3, steps=11, window=4, ahead=False):
     """gsr_sh_adam_from_views with lazy rows (the data-parallel step): rows no gathered view lights are left alone and catch up
     later (in a later from-views call that lights them, in their slice, or in the flush) -- bit-identical to the dense update
     that steps every row at every step.  Row ranges (two parts per step), learning rates that change per step, Gaussians that
@@ -150,18 +150,26 @@ def run_lazy_from_views_checks(dev, lib_path, P=700, n_views=3, steps=11, window
             step = 6 + k
             lr, lr_tail = 0.0025 * (1.0 + 0.1 * k), 0.000125 * (1.0 + 0.05 * k)
             lit = (torch.rand(n_views, P, generator=g) < (0.05 if 3 <= k < 8 else 0.35)) & ~never     # (a long pause for most rows)
-            views = (r(n_views, P, 3) * lit.unsqueeze(-1)).to(dev)
+            # (+0.0 where a view does not see the Gaussian: a negative zero is the "visible, zero gradient" marker of the
+            # factored backward and would count as lit)
+            views = torch.where(lit.unsqueeze(-1), r(n_views, P, 3), torch.zeros(())).to(dev)
+            if k % 3 == 1:
+                views[0, ::7, 0] = torch.where(never[::7].to(dev), views[0, ::7, 0], torch.full((), -0.0, device=dev))   # seen, zero gradient
+                views[0, ::7, 1:] = torch.where(never[::7].to(dev).unsqueeze(-1), views[0, ::7, 1:], torch.zeros((), device=dev))
             centres = (2.0 * r(n_views, 3)).to(dev)
             d = dict(base, lr=lr, lr_tail=lr_tail, step=step)
             rp.shAdamFromViews(xyz, centres, views, 3, 1.0 / n_views, eager[0], dict(d, exp_avg=eager[1], exp_avg_sq=eager[2]))
             dl = dict(d, window=window, lr_past=[a for a, _ in hist], lr_tail_past=[b for _, b in hist])
+            if ahead:   # the rotating catch-up AHEAD of the step's from-views calls (what gsr_backward does in the factored mode)
+                rp.shAdamLazySlice(lazy[0], dict(dl, exp_avg=lazy[1], exp_avg_sq=lazy[2], row_step=row_step), ahead=True)
             for a, b in ((0, half), (half, P)):
                 rp.shAdamFromViews(xyz[a:b], centres, views[:, a:b].contiguous(), 3, 1.0 / n_views, lazy[0][a:b],
                                    dict(dl, exp_avg=lazy[1][a:b], exp_avg_sq=lazy[2][a:b], row_step=row_step[a:b]))
-            rp.shAdamLazySlice(lazy[0], dict(dl, exp_avg=lazy[1], exp_avg_sq=lazy[2], row_step=row_step))
+            if not ahead:
+                rp.shAdamLazySlice(lazy[0], dict(dl, exp_avg=lazy[1], exp_avg_sq=lazy[2], row_step=row_step))
             hist.insert(0, (lr, lr_tail))
             del hist[window:]
-            assert int(row_step.max()) == step and int(row_step.min()) >= step - window + 1
+            assert int(row_step.max()) == step and int(row_step.min()) >= step - window + (0 if ahead else 1)
             if k == 4:
                 assert int((row_step < step).sum()) > P // 10, "no row is behind: the case under test does not occur"
         rp.shAdamFlush(lazy[0], dict(base, lr=hist[0][0], lr_tail=hist[0][1], step=step, exp_avg=lazy[1], exp_avg_sq=lazy[2],
@@ -210,6 +218,8 @@ def run_adam_multi_checks(dev, lib_path, P=1237):
 def test_lazy_rows_in_the_from_views_step_equal_the_dense_update(emu_lib_path):
     run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path)
     run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path, P=333, n_views=1, steps=9, window=32)
+    run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path, steps=14, window=4, ahead=True)
+    run_lazy_from_views_checks(torch.device("cpu"), emu_lib_path, P=450, n_views=2, steps=9, window=3, ahead=True)
 
 
 def test_adam_step_multi_equals_separate_steps(emu_lib_path):
@@ -221,4 +231,5 @@ def test_lazy_from_views_and_adam_multi_on_gpu():
     dev = torch.device("cuda:0")
     run_lazy_from_views_checks(dev, None, P=200_003, n_views=4, steps=13, window=4)
     run_lazy_from_views_checks(dev, None, P=50_000, n_views=8, steps=40, window=32)
+    run_lazy_from_views_checks(dev, None, P=120_000, n_views=4, steps=21, window=5, ahead=True)
     run_adam_multi_checks(dev, None, P=300_001)

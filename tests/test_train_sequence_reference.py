@@ -91,14 +91,17 @@ def _compare(name, losses, points, params, stats, ref, cl, grad_threshold):
 def run_sequence(dev, lib_path, host_variant, cl, kind, P_note=""):
     from oracle import cpu_trainer, oracle
     n_views = 3
+    threads = min(os.cpu_count() or 1, 32)   # (a 50 k-Gaussian step does not feed 256 hardware threads)
+    oracle.set_threads(threads)
     gts = _ground_truth(oracle, cl, n_views)
     # the threshold that clones / splits a few per cent of the Gaussians at the fifth iteration of THIS scene
-    probe = cpu_trainer.train_sequence(cl, cl.cameras[:n_views], gts, SCHEDULE["densification_interval"], seed=SEED, kind=kind)
+    probe = cpu_trainer.train_sequence(cl, cl.cameras[:n_views], gts, SCHEDULE["densification_interval"], seed=SEED, kind=kind,
+                                       threads=threads)
     pm = probe["model"]
     g = (pm.xyz_gradient_accum / pm.denom).nan_to_num(0.0).squeeze(1)
     thr = float(torch.quantile(g[g > 0], 0.93))
     ref = cpu_trainer.train_sequence(cl, cl.cameras[:n_views], gts, ITERATIONS, densify_grad_threshold=thr, seed=SEED, kind=kind,
-                                     **SCHEDULE)
+                                     threads=threads, **SCHEDULE)
     assert ref["densified_at"] == [5] and ref["reset_at"] == [7]
     assert ref["points"][4] != ref["points"][3], "the densification changed nothing: the sequence would not test it"
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -159,7 +162,7 @@ def _need_reference_ops(kind):
 
 def test_fused_train_sequence_equals_the_reference_loop_on_the_emulator(emu_lib_path):
     _need_reference_ops("cpu")
-    cl = scene.make_cloud(500, 64, 48, 50.0, 50.0, seed=3, scale_k=0.35, n_views=3)
+    cl = scene.make_cloud(320, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=3)
     run_sequence(torch.device("cpu"), emu_lib_path, "emu", cl, "cpu")
 
 

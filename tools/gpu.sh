@@ -92,8 +92,8 @@ for step in "$@"; do
   echo "=== $step"
   case ${step%%:*} in
     build)  python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }; tail -1 $OUT/build.log ;;
-    tests)  if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -q -m gpu -k "$arg" -s > $OUT/test_gpu.log 2>&1; else timeout 1200 python -m pytest tests -q -m gpu > $OUT/test_gpu.log 2>&1; fi
-            grep -v Warning $OUT/test_gpu.log | tail -6 | cut -c1-400 ;;
+    tests)  if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -q -m gpu -k "$arg" -s --durations=8 > $OUT/test_gpu.log 2>&1; else timeout 1200 python -m pytest tests -q -m gpu --durations=8 > $OUT/test_gpu.log 2>&1; fi
+            grep -v Warning $OUT/test_gpu.log | tail -18 | cut -c1-300 ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as e; e.smoke()" 2>&1 | tail -1 ;;
     driver) ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_driver_cmd_C3.log 2>&1
             grep "^{\"metric\"" $OUT/bench_driver_cmd_C3.log > $OUT/bench_driver_cmd_C3.json; grep real $OUT/bench_driver_cmd_C3.log
