@@ -243,9 +243,10 @@ class GaussianModel:
         self.spatial_lr_scale_ = spatial_lr_scale
         pts = points.to(self.device_).float().contiguous()
         n = pts.shape[0]
-        # RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT C0 -- a device scalar as divisor, so that the HIP kernel
-        # divides (a host scalar makes ATen multiply by the reciprocal there: one ulp off the reference's values on the GPU)
-        C0 = torch.tensor(0.28209479177387814, dtype=torch.float32, device=self.device_)
+        # RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT constant C0 as a host scalar, exactly the reference's
+        # expression: ATen divides on the host and multiplies by the reciprocal of THAT float on the GPU (the double
+        # 0.28209479177387814 has another reciprocal in float: one ulp off in nearly every row, found on the GPU box)
+        C0 = float(torch.tensor(0.28209479177387814, dtype=torch.float32))
         fused_color = (colors.to(self.device_).float() - 0.5) / C0
         M = (self.max_sh_degree_ + 1) ** 2
         features = torch.zeros((n, 3, M), device=self.device_)
@@ -283,7 +284,7 @@ class GaussianModel:
         with torch.no_grad():
             self.sparse_points_xyz_ = pts if self.sparse_points_xyz_ is None else torch.cat([self.sparse_points_xyz_, pts], 0)
             self.sparse_points_color_ = cols if self.sparse_points_color_ is None else torch.cat([self.sparse_points_color_, cols], 0)
-            C0 = torch.tensor(0.28209479177387814, dtype=torch.float32, device=dev)   # (a device scalar: see createFromPcd)
+            C0 = float(torch.tensor(0.28209479177387814, dtype=torch.float32))   # (the FLOAT constant: see createFromPcd)
             M = (self.max_sh_degree_ + 1) ** 2
             features = torch.zeros((n, M, 3), device=dev)
             features[:, 0, :] = (cols - 0.5) / C0                                   # RGB2SH, include/sh_utils.h:138

@@ -7,9 +7,9 @@
 //
 //   ViewFactoredExchange   81 % of the gradient is the [P,16,3] SH tensor, and ONE view's SH gradient is rank one per
 //                          Gaussian: basis(dir) x dL_dcolor with dir known to every rank.  So the ranks ALL-GATHER the 3-float
-//                          colour gradients (in PARTS row ranges) and the camera centres, each rebuilds the batch-mean SH
-//                          gradient locally and applies it (TrainStep::stepFeaturesFromViews), and only the other four
-//                          tensors (11 floats per Gaussian, ONE buffer) are all-reduced.
+//                          colour gradients with the camera centre as one more row (ONE collective), each rebuilds the
+//                          batch-mean SH gradient locally and applies it (TrainStep::stepFeaturesFromViews), and only the
+//                          other four tensors (11 floats per Gaussian, ONE buffer, one more collective) are all-reduced.
 //   GradientReduction      the plain mean of every leaf gradient, largest first, each tensor's Adam as soon as ITS reduction
 //                          has landed.
 //
@@ -49,10 +49,9 @@ private:
 
 class ViewFactoredExchange {
 public:
-	static constexpr int PARTS = 2;   // the colour gradients travel in this many all-gathers (by rows): the rebuild + Adam of one
-	                                  // part runs while the next one is still on the links
-	// send: [P + 1, 3] (rows 0 .. P-1 = this view's colour gradients; row P is a spare), camera_center [3], others = the
-	// gradients of xyz / opacity / scaling / rotation.  After construction everything is in flight.
+	// send: [P + 1, 3] (rows 0 .. P-1 = this view's colour gradients; row P receives the camera centre), camera_center [3],
+	// others = the gradients of xyz / opacity / scaling / rotation.  After construction everything is in flight (two
+	// collectives; round 2 sent the centres and two row ranges separately: four).
 	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
 	                     std::vector<torch::Tensor> others);
 	struct Part {
@@ -69,8 +68,7 @@ public:
 
 private:
 	c10::intrusive_ptr<c10d::ProcessGroup> pg_;
-	torch::Tensor centres_;
-	c10::intrusive_ptr<c10d::Work> centre_work_;
+	torch::Tensor gathered_, centres_;
 	std::vector<Part> parts_;
 	std::unique_ptr<GradientReduction> reduction_;
 };

@@ -32,9 +32,10 @@ void GaussianModel::createFromPcd(torch::Tensor points, torch::Tensor colors, fl
 	auto pts = points.to(torch::kFloat32).contiguous();
 	const auto n = pts.size(0);
 	const auto o = pts.options();
-	// RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT C0 -- a device scalar as divisor, so that the HIP kernel
-	// divides (a host scalar makes ATen multiply by the reciprocal there: one ulp off the reference's values on the GPU)
-	const auto C0 = torch::full({}, 0.28209479177387814f, o);
+	// RGB2SH, include/sh_utils.h:138: (rgb - 0.5f) / C0 with the FLOAT constant as a host scalar, exactly the reference's
+	// expression: ATen divides on the host and multiplies by the reciprocal of THAT float on the GPU (the double
+	// 0.28209479177387814 has another reciprocal in float: one ulp off in nearly every row, found on the GPU box)
+	const float C0 = 0.28209479177387814f;
 	auto fused_color = (colors.to(o) - 0.5f) / C0;
 	const int64_t M = (max_sh_degree_ + 1) * (max_sh_degree_ + 1);
 	auto features = torch::zeros({n, M, 3}, o);   // the reference's [n,3,M] transposed: one [n,M,3] leaf
@@ -85,7 +86,7 @@ void GaussianModel::increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& n
 		sparse_points_xyz_ = torch::cat({sparse_points_xyz_, pts}, 0);
 		sparse_points_color_ = torch::cat({sparse_points_color_, cols}, 0);
 	}
-	const auto C0 = torch::full({}, 0.28209479177387814f, o);   // (a device scalar: see createFromPcd)
+	const float C0 = 0.28209479177387814f;   // (the FLOAT constant: see createFromPcd)
 	const int64_t M = (max_sh_degree_ + 1) * (max_sh_degree_ + 1);
 	auto features = torch::zeros({n, M, 3}, o);
 	features.select(1, 0).copy_((cols - 0.5f) / C0);   // RGB2SH, include/sh_utils.h:138

@@ -94,37 +94,29 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	const auto o = send.options().requires_grad(false);
 	if (pg_->getBackendName() == "gloo" && send.is_cuda())
 		throw std::runtime_error("ViewFactoredExchange: gloo moves host tensors; use the RCCL backend for device tensors");
-	// the camera centres: 12 bytes per rank, their own (first) collective -- every part's rebuild needs all of them
-	centres_ = torch::empty({N, 3}, o);
-	auto centre = camera_center.detach().reshape({1, 3}).to(o).contiguous();
-	centre_work_ = pg_->_allgather_base(centres_, centre);
-	const int n_parts = P >= 4 * PARTS ? PARTS : 1;
-	std::vector<int64_t> bounds;
-	for (int k = 0; k <= n_parts; k++) bounds.push_back(k == 0 ? 0 : (k == n_parts ? P : ((P * k / n_parts) / 4) * 4));
-	for (int k = 0; k < n_parts; k++) {
-		Part p;
-		p.row0 = bounds[k];
-		const int64_t rows = bounds[k + 1] - bounds[k];
-		p.views = torch::empty({N, rows, 3}, o);
-		auto in = send.narrow(0, p.row0, rows).unsqueeze(0);   // ([1, rows, 3]: gloo checks the input against a 1/N chunk of the output)
-		p.work = pg_->_allgather_base(p.views, in);
-		parts_.push_back(p);
-	}
+	// ONE all-gather: rows 0 .. P-1 of `send` are this view's colour gradients, row P its camera centre -- every collective
+	// costs a launch on RCCL's stream and two cross-stream hand-offs (measured at one rank: four collectives per step cost
+	// ~0.1 ms more than two), which is more than the overlap of a second row range's rebuild with its gather could win back
+	send.select(0, P).copy_(camera_center.detach().reshape({3}).to(o));
+	gathered_ = torch::empty({N, P + 1, 3}, o);
+	auto in = send.unsqueeze(0);   // ([1, P + 1, 3]: gloo checks the input against a 1/N chunk of the output)
+	Part p;
+	p.row0 = 0;
+	p.views = gathered_.narrow(1, 0, P);      // [N, P, 3], view stride (P + 1) * 3
+	p.work = pg_->_allgather_base(gathered_, in);
+	parts_.push_back(p);
+	centres_ = gathered_.select(1, P);       // [N, 3], stride (P + 1) * 3
 	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others));
 }
 
 torch::Tensor ViewFactoredExchange::centres()
 {
-	if (centre_work_) {
-		centre_work_->wait();
-		centre_work_ = nullptr;
-	}
+	part(0);   // (the centres travel with the colour gradients)
 	return centres_;
 }
 
 const ViewFactoredExchange::Part& ViewFactoredExchange::part(int k)
 {
-	centres();
 	auto& p = parts_.at(static_cast<size_t>(k));
 	if (p.work) {
 		p.work->wait();

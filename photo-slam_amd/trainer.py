@@ -93,7 +93,7 @@ class ViewFactoredExchange:
     (11 floats per Gaussian) are all-reduced.  Per Gaussian a rank sends (N-1) * 12 + 2 (N-1)/N * 44 B instead of 2 (N-1)/N * 236 B.
 
     Usage: send, color_view = ViewFactoredExchange.send_buffer(P, device) before the render; color_view ([P,3], rows 0..P-1 of
-    send) is handed to the backward (row P is a spare from the single-gather layout); others =
+    send) is handed to the backward (row P receives the camera centre: one gather carries both); others =
     [(index, grad), ...] of the remaining parameters (one all-reduce when they share a buffer, GradientReduction); after
     construction everything is in flight.  sh_gradient() / sh_adam_step() wait for the gather; they read means3D, so call
     them BEFORE Adam moves the positions."""
@@ -103,8 +103,8 @@ class ViewFactoredExchange:
         send = torch.empty((P + 1, 3), dtype=torch.float32, device=device)
         return send, send[:P]
 
-    PARTS = 2   # the colour gradients travel in this many all-gathers (by rows): the SH rebuild + Adam of one part runs while
-                # the next part is still on the links
+    PARTS = 1   # ONE all-gather: the colour gradients with the camera centre as row P (every collective costs a launch on
+                # RCCL's stream and two cross-stream hand-offs: at one rank four collectives per step cost ~0.1 ms more than two)
 
     def __init__(self, send, camera_center, others, world_size):
         self.world_size_ = world_size
@@ -112,29 +112,19 @@ class ViewFactoredExchange:
         dev = send.device
         self.P_ = P
         self.nccl_ = dist.get_backend() == "nccl"
-        # the camera centres: 12 bytes per rank, their own (first) collective -- every part's rebuild needs all of them
-        self.centres_ = torch.empty((world_size, 3), dtype=torch.float32, device=dev)
-        centre = camera_center.detach().reshape(1, 3).to(torch.float32).contiguous()
-        n_parts = self.PARTS if P >= 4 * self.PARTS else 1
-        bounds = [((P * k // n_parts) // 4) * 4 if 0 < k < n_parts else (0 if k == 0 else P) for k in range(n_parts + 1)]
-        self.parts_ = []     # [row0, gathered [N, rows, 3], work or None]
+        send[P].copy_(camera_center.detach().reshape(3).to(torch.float32))
+        gathered = torch.empty((world_size, P + 1, 3), dtype=torch.float32, device=dev)
         if self.nccl_:
-            self.centre_work_ = dist.all_gather_into_tensor(self.centres_, centre, async_op=True)
-            for a, b in zip(bounds[:-1], bounds[1:]):
-                out = torch.empty((world_size, b - a, 3), dtype=torch.float32, device=dev)
-                self.parts_.append([a, out, dist.all_gather_into_tensor(out, send[a:b].unsqueeze(0), async_op=True)])
+            work = dist.all_gather_into_tensor(gathered, send.unsqueeze(0), async_op=True)
         else:
             # gloo (the CPU test path) gathers host tensors
-            self.centre_work_ = None
-            host = self.centres_.cpu()
-            dist.all_gather_into_tensor(host, centre.cpu())
-            self.centres_.copy_(host)
-            for a, b in zip(bounds[:-1], bounds[1:]):
-                out = torch.empty((world_size, b - a, 3), dtype=torch.float32, device=dev)
-                host = out.cpu()
-                dist.all_gather_into_tensor(host, send[a:b].unsqueeze(0).cpu().contiguous())
-                out.copy_(host)
-                self.parts_.append([a, out, None])
+            host = gathered.cpu()
+            dist.all_gather_into_tensor(host, send.unsqueeze(0).cpu().contiguous())
+            gathered.copy_(host)
+            work = None
+        self.centre_work_ = None
+        self.centres_ = gathered[:, P]            # [N, 3], stride (P + 1) * 3
+        self.parts_ = [[0, gathered[:, :P], work]]   # [row0, views [N, P, 3] (strided over the views), work or None]
         self.indices_ = [i for i, _ in others]
         self.reduction_ = GradientReduction([t for _, t in others], world_size)
 
