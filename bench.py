@@ -317,7 +317,7 @@ def main():
                 ops.trainer_features_finish_from_views(handle)   # this step's slice of the rotating catch-up
                 for i in ex.order():
                     ex.wait(i)                # stream-side wait: the host keeps queueing (one collective for the four)
-                ops.trainer_geom_adam(handle)     # xyz / opacity / scaling / rotation: one Adam launch
+                ops.trainer_geom_adam(handle, ex.reduction_.grad_scale())   # xyz / opacity / scaling / rotation: one Adam launch (+ the 1/N)
                 ops.trainer_finish_end(handle)
             elif dp:
                 # reductions in flight from here (largest first); each tensor's Adam follows ITS reduction, so the
@@ -560,9 +560,10 @@ def main():
                 entry["cpu_oracle_threads"] = orc.get_threads()
                 entry["bit_identical_to_cpu_oracle"] = bool(np.array_equal(d.cpu().numpy(), d_cpu))
             knn_run["runs"].append(entry)
-        knn_run["note"] = ("exact 3-NN search: the neighbour scan visits every 1024-point Morton box whose AABB can still hold a closer "
-                           "point and tests all its points -- VALU-bound in that scan (per-kernel split: profiles/r03_*_knn_kernel_stats.csv), "
-                           "far from the 120 B/point stream bound")
+        knn_run["note"] = ("exact 3-NN search over a three-level box hierarchy of the Morton order (32 / 1024 / 32768 points, csrc/knn.hip): "
+                           "compute-bound in the neighbour scan (sub-box tests + candidate distances; per-kernel split: "
+                           "profiles/r03_*_knn_kernel_stats_*.csv), far from the 120 B/point stream bound of SURVEY.md 8(d); round 2's "
+                           "scan of whole 1024-point boxes took 4.4 ms / 11.2 ms at these sizes")
 
     T = ((W + 15) // 16) * ((H + 15) // 16)
     tile_bits = int(np.ceil(np.log2(max(T, 2))))

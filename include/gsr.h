@@ -307,6 +307,8 @@ typedef struct gsr_adam_multi_tensor {
 	long long n;             /* elements */
 	double lr;
 	int step;                /* >= 1: the step being taken */
+	float grad_scale;        /* the gradient is multiplied by this as it is read (1 = as it is): the 1/N of a batch mean whose
+	                            all-reduce SUMMED -- one pass over the gradients less than averaging first */
 } gsr_adam_multi_tensor;
 int gsr_adam_step_multi(int count, const gsr_adam_multi_tensor* tensors, double beta1, double beta2, double eps, void* stream);
 

@@ -73,7 +73,7 @@ class AdamTensor(C.Structure):
 class AdamMultiTensor(C.Structure):
     """gsr_adam_multi_tensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int)]
+                ("n", C.c_longlong), ("lr", C.c_double), ("step", C.c_int), ("grad_scale", C.c_float)]
 
 
 class GeomAdam(C.Structure):

@@ -525,6 +525,7 @@ struct AdamMultiParams {
 	long long n[ADAM_MULTI_MAX];
 	int first_block[ADAM_MULTI_MAX + 1];
 	AdamScalars s[ADAM_MULTI_MAX];
+	float grad_scale[ADAM_MULTI_MAX];
 	int count;
 };
 }  // extern "C"
@@ -542,6 +543,7 @@ adam_multi_kernel(const AdamMultiParams q)
 	float* __restrict__ exp_avg_sq = q.exp_avg_sq[t];
 	const long long n = q.n[t];
 	const AdamScalars a = q.s[t];
+	const float gs = q.grad_scale[t];
 	const long long i = ((long long)((int)blockIdx.x - q.first_block[t]) * 256 + threadIdx.x) * 4;
 	if (i >= n) return;
 	const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
@@ -554,8 +556,9 @@ adam_multi_kernel(const AdamMultiParams q)
 		float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
-			mp[k] = a.b1 * mp[k] + a.omb1 * gp[k];
-			vp[k] = a.b2 * vp[k] + a.omb2 * gp[k] * gp[k];
+			const float g = gs == 1.0f ? gp[k] : gp[k] * gs;
+			mp[k] = a.b1 * mp[k] + a.omb1 * g;
+			vp[k] = a.b2 * vp[k] + a.omb2 * g * g;
 			pp[k] -= a.step_size * mp[k] / (sqrtf(vp[k]) * a.inv_sqrt_bc2 + a.eps);
 		}
 		store_stream_f4(reinterpret_cast<float4*>(param + i), pv);
@@ -563,7 +566,7 @@ adam_multi_kernel(const AdamMultiParams q)
 		store_stream_f4(reinterpret_cast<float4*>(exp_avg_sq + i), vv);
 	} else {
 		for (long long k = i; k < n && k < i + 4; k++) {
-			const float g = grad[k];
+			const float g = gs == 1.0f ? grad[k] : grad[k] * gs;
 			const float m = a.b1 * exp_avg[k] + a.omb1 * g;
 			const float v = a.b2 * exp_avg_sq[k] + a.omb2 * g * g;
 			exp_avg[k] = m;
@@ -589,6 +592,7 @@ int gsr_adam_step_multi(int count, const gsr_adam_multi_tensor* tensors, double 
 		q.param[used] = t.param; q.grad[used] = t.grad; q.exp_avg[used] = t.exp_avg; q.exp_avg_sq[used] = t.exp_avg_sq;
 		q.n[used] = t.n;
 		q.s[used] = adam_scalars(t.lr, t.lr, beta1, beta2, eps, t.step);
+		q.grad_scale[used] = t.grad_scale;
 		q.first_block[used] = (int)blocks;
 		blocks += (t.n + 1023) / 1024;
 		if (blocks > 0x7FFFFFFFll) return GSR_ERR_UNSUPPORTED;

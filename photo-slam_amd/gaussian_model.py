@@ -58,9 +58,10 @@ class FusedAdam:
                                                   float(grp.get("lr_tail", grp["lr"])) * self.lr_scale, rp._stream_ptr(p)),
                            "gsr_adam_step")
 
-    def step_groups(self, indices):
+    def step_groups(self, indices, grad_scale=1.0):
         """step_group(i) for several single-tensor groups with uniform learning rates in ONE launch (gsr_adam_step_multi: the
-        four small per-Gaussian tensors of a data-parallel step, whose gradients arrive together from one all-reduce)."""
+        four small per-Gaussian tensors of a data-parallel step, whose gradients arrive together from one all-reduce).
+        grad_scale: the gradients are multiplied by it as they are read (1/N of a batch mean whose all-reduce summed)."""
         entries = []
         with torch.no_grad():
             for i in indices:
@@ -69,6 +70,8 @@ class FusedAdam:
                 if p.grad is None:
                     continue
                 if grp.get("period", 0) or not p.is_contiguous() or not p.grad.is_contiguous():
+                    if grad_scale != 1.0:
+                        p.grad.mul_(grad_scale)
                     self.step_group(i)
                     continue
                 st = self.state.get(id(p))
@@ -76,7 +79,7 @@ class FusedAdam:
                     st = self.state[id(p)] = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p), step=0)
                 st["step"] += 1
                 entries.append((p.detach(), p.grad, st["exp_avg"], st["exp_avg_sq"], float(grp["lr"]) * self.lr_scale, st["step"]))
-            rp.adamStepMulti(entries, self.betas[0], self.betas[1], self.eps)
+            rp.adamStepMulti(entries, self.betas[0], self.betas[1], self.eps, grad_scale)
 
     def begin_fused_step(self, i, lazy_window=0):
         """Arguments of the fused update of single-tensor group i (GaussianRasterizationSettings.sh_adam_): advances the

@@ -247,8 +247,9 @@ public:
 	// records the step's learning rates.  (finishEnd() calls it if the driver did not.)
 	void finishFeaturesFromViews();
 	// xyz / opacity / scaling / rotation in ONE Adam launch (gsr_adam_step_multi): the data-parallel step's four small
-	// gradients arrive together from one all-reduce.  Replaces finishAdamGroup(0 / 2 / 3 / 4).
-	void finishGeomAdam();
+	// gradients arrive together from one all-reduce.  Replaces finishAdamGroup(0 / 2 / 3 / 4).  grad_scale: the gradients are
+	// multiplied by it as they are read (the 1/N of a batch mean whose all-reduce summed).
+	void finishGeomAdam(float grad_scale = 1.0f);
 	ShAdamStep views_adam_;
 	bool views_adam_pending_ = false;
 	std::shared_ptr<GaussianModel> gaussians_;

@@ -27,8 +27,12 @@ torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors);
 
 class GradientReduction {
 public:
-	// tensors: gradients, averaged in place over the ranks; members of one buffer (oneBuffer) share ONE collective
-	GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors);
+	// tensors: gradients, averaged in place over the ranks; members of one buffer (oneBuffer) share ONE collective.
+	// sum_only: the collective SUMS and nothing scales -- the consumer multiplies by gradScale() = 1/N as it reads the
+	// gradient (gsr_adam_multi_tensor.grad_scale): no averaging pass over the buffer, on RCCL (ncclAvg = pre-multiply +
+	// sum; with ONE rank a whole extra kernel) as on gloo
+	GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors, bool sum_only = false);
+	float gradScale() const { return sum_only_ ? 1.0f / static_cast<float>(pg_->getSize()) : 1.0f; }
 	const std::vector<int>& order() const { return order_; }   // indices by decreasing size: the order the collectives were issued in
 	void wait(int i);                                           // tensor i is reduced (stream-side on RCCL)
 	void waitAll();
@@ -45,6 +49,7 @@ private:
 	std::vector<int> order_, group_of_;
 	std::vector<Group> groups_;
 	bool avg_ = false;   // the backend averages inside the collective (ncclAvg); gloo sums and wait() scales
+	bool sum_only_ = false;
 };
 
 class ViewFactoredExchange {

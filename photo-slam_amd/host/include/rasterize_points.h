@@ -125,6 +125,7 @@ struct AdamMultiEntry {
 	torch::Tensor param, grad, exp_avg, exp_avg_sq;   // contiguous float32, one size
 	double lr = 0.0;
 	int step = 0;
+	float grad_scale = 1.0f;   // multiplies the gradient as it is read
 };
 void adamStepMulti(const std::vector<AdamMultiEntry>& entries, double beta1, double beta2, double eps);
 

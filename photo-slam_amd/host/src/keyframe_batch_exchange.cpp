@@ -29,10 +29,10 @@ torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
 	return flat;
 }
 
-GradientReduction::GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors)
-    : pg_(std::move(pg)), tensors_(std::move(tensors))
+GradientReduction::GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors, bool sum_only)
+    : pg_(std::move(pg)), tensors_(std::move(tensors)), sum_only_(sum_only)
 {
-	avg_ = pg_->getBackendName() == "nccl";
+	avg_ = !sum_only_ && pg_->getBackendName() == "nccl";
 	const int n = static_cast<int>(tensors_.size());
 	order_.resize(n);
 	for (int i = 0; i < n; i++) order_[i] = i;
@@ -75,7 +75,7 @@ void GradientReduction::wait(int i)
 {
 	auto& grp = groups_.at(static_cast<size_t>(group_of_.at(static_cast<size_t>(i))));
 	grp.work->wait();
-	if (!avg_ && !grp.scaled) {
+	if (!avg_ && !sum_only_ && !grp.scaled) {
 		grp.flat.mul_(1.0 / pg_->getSize());
 		grp.scaled = true;
 	}
@@ -106,7 +106,8 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	p.work = pg_->_allgather_base(gathered_, in);
 	parts_.push_back(p);
 	centres_ = gathered_.select(1, P);       // [N, 3], stride (P + 1) * 3
-	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others));
+	// (summed, not averaged: finishGeomAdam() multiplies by 1/N as it reads the gradients)
+	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others), /*sum_only=*/true);
 }
 
 torch::Tensor ViewFactoredExchange::centres()
@@ -198,8 +199,8 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 				setFeaturesGradFromViews(vf->centres(), views.size() == 1 ? views[0] : torch::cat(views, 1));
 				finishAdamGroup(1);
 			}
-			vf->reduction().waitAll();   // ONE collective for the four small tensors ...
-			finishGeomAdam();            // ... and one Adam launch
+			vf->reduction().waitAll();                    // ONE collective for the four small tensors (a SUM) ...
+			finishGeomAdam(vf->reduction().gradScale());   // ... and one Adam launch that applies the 1/N
 		} else {
 			// each tensor is updated as soon as ITS reduction has landed (largest first)
 			for (int i : red->order()) {

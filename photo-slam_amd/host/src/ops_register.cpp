@@ -282,7 +282,7 @@ torch::Tensor trainer_train_one_iteration(int64_t h, torch::Tensor view, torch::
 	return get(h)->trainForOneIteration(make_kf(view, proj, campos, fovx, fovy, height, width), gt, mask).detach();
 }
 void trainer_features_finish_from_views(int64_t h) { get(h)->finishFeaturesFromViews(); }
-void trainer_geom_adam(int64_t h) { get(h)->finishGeomAdam(); }
+void trainer_geom_adam(int64_t h, double grad_scale) { get(h)->finishGeomAdam((float)grad_scale); }
 torch::Tensor sh_grad_from_views(torch::Tensor means3D, torch::Tensor campos_views, torch::Tensor views, int64_t degree,
                                  int64_t M, double scale)
 {

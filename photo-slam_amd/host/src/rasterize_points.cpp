@@ -461,7 +461,7 @@ void adamStepMulti(const std::vector<AdamMultiEntry>& entries, double beta1, dou
 		gsr_adam_multi_tensor m{};
 		m.param = e.param.data_ptr<float>(); m.grad = e.grad.data_ptr<float>();
 		m.exp_avg = e.exp_avg.data_ptr<float>(); m.exp_avg_sq = e.exp_avg_sq.data_ptr<float>();
-		m.n = e.param.numel(); m.lr = e.lr; m.step = e.step;
+		m.n = e.param.numel(); m.lr = e.lr; m.step = e.step; m.grad_scale = e.grad_scale;
 		ts.push_back(m);
 	}
 	check(gsr_adam_step_multi(static_cast<int>(ts.size()), ts.data(), beta1, beta2, eps, current_stream(entries[0].param)),

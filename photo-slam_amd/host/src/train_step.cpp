@@ -400,7 +400,7 @@ void TrainStep::finishFeaturesFromViews()
 	views_adam_ = ShAdamStep();
 }
 
-void TrainStep::finishGeomAdam()
+void TrainStep::finishGeomAdam(float grad_scale)
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
@@ -418,6 +418,7 @@ void TrainStep::finishGeomAdam()
 		e.exp_avg_sq = grp.exp_avg_sq;
 		e.lr = grp.lr * g->lr_scale_;
 		e.step = grp.step;
+		e.grad_scale = grad_scale;
 		entries.push_back(e);
 	}
 	adamStepMulti(entries, 0.9, 0.999, 1e-15);

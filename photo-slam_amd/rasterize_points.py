@@ -287,9 +287,10 @@ def shAdamLazySlice(sh, sh_adam, ahead=False):
         capi.check(lib, lib.gsr_sh_adam_lazy_slice(int(sh.size(0)), C.byref(adam), int(bool(ahead)), _stream_ptr(sh)), "shAdamLazySlice")
 
 
-def adamStepMulti(tensors, beta1, beta2, eps):
+def adamStepMulti(tensors, beta1, beta2, eps, grad_scale=1.0):
     """gsr_adam_step_multi (include/gsr.h): one Adam step of several tensors in ONE launch.
-    tensors: [(param, grad, exp_avg, exp_avg_sq, lr, step), ...] (contiguous float32, at most 8)."""
+    tensors: [(param, grad, exp_avg, exp_avg_sq, lr, step), ...] (contiguous float32, at most 8); grad_scale multiplies every
+    gradient as it is read (the 1/N of a batch mean whose all-reduce summed)."""
     lib = _lib()
     if not tensors:
         return
@@ -298,7 +299,8 @@ def adamStepMulti(tensors, beta1, beta2, eps):
         for t in (p, g, m, v):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
                 raise RuntimeError("adamStepMulti needs contiguous float32 tensors of one size per entry")
-        arr[k] = capi.AdamMultiTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), int(step))
+        arr[k] = capi.AdamMultiTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), int(step),
+                                      float(grad_scale))
     _check_device(lib, *[t for e in tensors for t in e[:4]])
     capi.check(lib, lib.gsr_adam_step_multi(len(tensors), arr, float(beta1), float(beta2), float(eps), _stream_ptr(tensors[0][0])),
                "adamStepMulti")

@@ -40,9 +40,13 @@ class GradientReduction:
     collective.  RCCL averages inside the collective (ncclAvg); gloo (the CPU test path) has no AVG: it sums, and wait()
     scales."""
 
-    def __init__(self, tensors, world_size):
+    def __init__(self, tensors, world_size, sum_only=False):
+        """sum_only: the collective SUMS and nothing scales -- the consumer multiplies by grad_scale() = 1/N as it reads the
+        gradient (FusedAdam.step_groups): no averaging pass over the buffer (ncclAvg = pre-multiply + sum: with ONE rank a
+        whole extra kernel)"""
         self.tensors_, self.world_size_ = tensors, world_size
-        self.avg_ = dist.get_backend() == "nccl"
+        self.sum_only_ = sum_only
+        self.avg_ = not sum_only and dist.get_backend() == "nccl"
         op = dist.ReduceOp.AVG if self.avg_ else dist.ReduceOp.SUM
         self.order_ = sorted(range(len(tensors)), key=lambda i: -tensors[i].numel())
         # members of one buffer share a single collective: group -> [tensor to reduce, work, scaled?]
@@ -76,9 +80,22 @@ class GradientReduction:
     def wait(self, i):
         grp = self.groups_[self.group_of_[i]]
         grp[1].wait()
-        if not self.avg_ and not grp[2]:
+        if not self.avg_ and not self.sum_only_ and not grp[2]:
             grp[0].mul_(1.0 / self.world_size_)
             grp[2] = True
+
+    def grad_scale(self):
+        return 1.0 / self.world_size_ if self.sum_only_ else 1.0
+
+    def scale_now(self):
+        """sum_only mode after all: average in place (a consumer that cannot apply the scale itself)"""
+        if self.sum_only_:
+            self.wait_all()
+            for grp in self.groups_:
+                if not grp[2]:
+                    grp[0].mul_(1.0 / self.world_size_)
+                    grp[2] = True
+            self.sum_only_ = False
 
     def wait_all(self):
         for i in self.order_:
@@ -126,7 +143,8 @@ class ViewFactoredExchange:
         self.centres_ = gathered[:, P]            # [N, 3], stride (P + 1) * 3
         self.parts_ = [[0, gathered[:, :P], work]]   # [row0, views [N, P, 3] (strided over the views), work or None]
         self.indices_ = [i for i, _ in others]
-        self.reduction_ = GradientReduction([t for _, t in others], world_size)
+        # (summed, not averaged: the Adam launch of the four small tensors multiplies by 1/N as it reads the gradients)
+        self.reduction_ = GradientReduction([t for _, t in others], world_size, sum_only=True)
 
     def gathered_parts(self):
         """Yields (first row, camera centres [N,3], colour gradients [N,rows,3]) part by part, each once ITS all-gather has
@@ -341,10 +359,12 @@ class TrainStep:
                             g.features_.grad = reduction.sh_gradient(g.xyz_, g.active_sh_degree_, g.features_.size(1))
                             g.optimizer_.step_group(FEATURES_GROUP)
                     small = [i for i in reduction.order() if i != FEATURES_GROUP]
-                    if sh_view is not None and len(small) == 4 and _one_buffer([g.params_raw()[i].grad for i in small]) is not None:
-                        # the four small gradients arrived in ONE all-reduce: one Adam launch for the four tensors
-                        reduction.wait(small[0])
-                        g.optimizer_.step_groups(small)
+                    if sh_view is not None:
+                        # the small gradients arrived SUMMED (in ONE all-reduce when they share a buffer): one Adam launch for
+                        # the four tensors, which applies the 1/N as it reads them
+                        for i in small:
+                            reduction.wait(i)
+                        g.optimizer_.step_groups(small, reduction.reduction_.grad_scale())
                     else:
                         for i in reduction.order():
                             reduction.wait(i)

@@ -138,7 +138,7 @@ def run_trainer_checks(ops, dev, lib_path):
         else:
             ops.trainer_features_step_from_views(h2, t(cam.campos).reshape(1, 3), view.unsqueeze(0), 0, True)
         if it == 0:   # the four small tensors in one Adam launch (what bench.py does)
-            ops.trainer_geom_adam(h2)
+            ops.trainer_geom_adam(h2, 1.0)
         else:
             for i in (4, 0, 3, 2):
                 ops.trainer_adam_group(h2, i)

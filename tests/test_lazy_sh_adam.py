@@ -211,6 +211,21 @@ def run_adam_multi_checks(dev, lib_path, P=1237):
         for a, b in zip(one[0] + one[1] + one[2], multi[0] + multi[1] + multi[2]):
             assert torch.equal(a, b)
         assert not torch.equal(multi[0][0], params[0])
+        # grad_scale: the gradient multiplied as it is read == a pre-scaled gradient
+        scaled = [[t.clone() for t in ts] for ts in (params, m, v)]
+        rp.adamStepMulti([(scaled[0][k], gs[k], scaled[1][k], scaled[2][k], lrs[k], steps[k]) for k in range(4)], 0.9, 0.999, 1e-15,
+                         grad_scale=0.125)
+        pre = [[t.clone() for t in ts] for ts in (params, m, v)]
+        gpre = grads * 0.125
+        off = 0
+        ent = []
+        for k, sh in enumerate(shapes):
+            n = sh[0] * sh[1]
+            ent.append((pre[0][k], gpre[off:off + n].view(sh), pre[1][k], pre[2][k], lrs[k], steps[k]))
+            off += n
+        rp.adamStepMulti(ent, 0.9, 0.999, 1e-15)
+        for a, b in zip(scaled[0] + scaled[1] + scaled[2], pre[0] + pre[1] + pre[2]):
+            assert torch.equal(a, b)
     finally:
         rp._LIB_OVERRIDE = None
 
