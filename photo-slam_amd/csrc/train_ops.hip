@@ -373,6 +373,18 @@ loss_bwd_kernel(const LossParams p)
 // ------------------------------------------------------------------ Adam
 // torch.optim.Adam / torch::optim::Adam step (no amsgrad, no weight decay):
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// One element of the step.  Contraction is switched off inside: the two kernels below must produce the same bits from the same
+// inputs (tests compare them with torch.equal), and with -ffp-contract=fast the compiler forms different FMAs in different
+// surroundings (found on the GPU when adam_multi_kernel gained its gradient scale).
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float omb1, float b2, float omb2,
+                                            float step_size, float inv_sqrt_bc2, float eps)
+{
+#pragma clang fp contract(off)
+	m = b1 * m + omb1 * g;
+	v = b2 * v + omb2 * g * g;
+	p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
             float* __restrict__ exp_avg_sq, long long n, const AdamScalars a, int period, int split)
@@ -403,9 +415,7 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 				uint32_t rk = r + (uint32_t)k;
 				if (rk >= per) rk -= per;
 				const float ss = (per && rk >= (uint32_t)split) ? step_size_tail : step_size;
-				mp[k] = b1 * mp[k] + omb1 * gp[k];
-				vp[k] = b2 * vp[k] + omb2 * gp[k] * gp[k];
-				pp[k] -= ss * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
+				adam_update(pp[k], mp[k], vp[k], gp[k], b1, omb1, b2, omb2, ss, inv_sqrt_bc2, eps);
 			}
 			store_stream_f4(reinterpret_cast<float4*>(param + i), pv);
 			store_stream_f4(reinterpret_cast<float4*>(exp_avg + i), mv);
@@ -415,12 +425,11 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 				uint32_t rk = r + (uint32_t)(k - i);
 				if (rk >= per) rk -= per;
 				const float ss = (per && rk >= (uint32_t)split) ? step_size_tail : step_size;
-				const float g = grad[k];
-				const float m = b1 * exp_avg[k] + omb1 * g;
-				const float v = b2 * exp_avg_sq[k] + omb2 * g * g;
-				exp_avg[k] = m;
-				exp_avg_sq[k] = v;
-				param[k] -= ss * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+				float pk = param[k], mk = exp_avg[k], vk = exp_avg_sq[k];
+				adam_update(pk, mk, vk, grad[k], b1, omb1, b2, omb2, ss, inv_sqrt_bc2, eps);
+				exp_avg[k] = mk;
+				exp_avg_sq[k] = vk;
+				param[k] = pk;
 			}
 		}
 		r += dr;
@@ -557,9 +566,7 @@ adam_multi_kernel(const AdamMultiParams q)
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const float g = gs == 1.0f ? gp[k] : gp[k] * gs;
-			mp[k] = a.b1 * mp[k] + a.omb1 * g;
-			vp[k] = a.b2 * vp[k] + a.omb2 * g * g;
-			pp[k] -= a.step_size * mp[k] / (sqrtf(vp[k]) * a.inv_sqrt_bc2 + a.eps);
+			adam_update(pp[k], mp[k], vp[k], g, a.b1, a.omb1, a.b2, a.omb2, a.step_size, a.inv_sqrt_bc2, a.eps);
 		}
 		store_stream_f4(reinterpret_cast<float4*>(param + i), pv);
 		store_stream_f4(reinterpret_cast<float4*>(exp_avg + i), mv);
@@ -567,11 +574,11 @@ adam_multi_kernel(const AdamMultiParams q)
 	} else {
 		for (long long k = i; k < n && k < i + 4; k++) {
 			const float g = gs == 1.0f ? grad[k] : grad[k] * gs;
-			const float m = a.b1 * exp_avg[k] + a.omb1 * g;
-			const float v = a.b2 * exp_avg_sq[k] + a.omb2 * g * g;
-			exp_avg[k] = m;
-			exp_avg_sq[k] = v;
-			param[k] -= a.step_size * m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
+			float pk = param[k], mk = exp_avg[k], vk = exp_avg_sq[k];
+			adam_update(pk, mk, vk, g, a.b1, a.omb1, a.b2, a.omb2, a.step_size, a.inv_sqrt_bc2, a.eps);
+			exp_avg[k] = mk;
+			exp_avg_sq[k] = vk;
+			param[k] = pk;
 		}
 	}
 }
