@@ -27,6 +27,41 @@ kernel_stats() {  # $1 = output csv, rest = command
   rm -rf /tmp/kp; (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp -o kp -- "$@" > /tmp/kp.log 2>&1)
   local f=$(find /tmp/kp -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $out; head -14 $out | cut -c1-130; else echo "no kernel_stats.csv"; tail -5 /tmp/kp.log; fi
+  # idle time of the device between consecutive kernels of a step, from the same trace (${out%.csv}_gaps.json): the host
+  # wait in the middle of the forward pass (the instance count sizes the binning buffer) and everything else
+  local t=$(find /tmp/kp -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python - "$t" "${out%.csv}_gaps.json" <<'PY'
+import csv, json, sys, statistics as st
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+# a step = from one preprocess_fwd to the next
+starts = [i for i, r in enumerate(rows) if "preprocess_fwd_kernel" in r[2]]
+steps = []
+for a, b in zip(starts[:-1], starts[1:]):
+    ks = rows[a:b]
+    span = ks[-1][1] - ks[0][0]
+    busy_end, idle, sync_gap = ks[0][1], 0, None
+    for i in range(1, len(ks)):
+        gap = ks[i][0] - busy_end
+        if gap > 0:
+            idle += gap
+            if "emit_instances" in ks[i][2]:
+                sync_gap = gap
+        busy_end = max(busy_end, ks[i][1])
+    steps.append((span, idle, sync_gap, len(ks)))
+steps = steps[len(steps) // 3:]   # (the warm-up third of the run is dropped)
+if steps:
+    med = lambda k: st.median(s[k] for s in steps if s[k] is not None) / 1e3
+    out = {"steps": len(steps), "kernels_per_step_median": st.median(s[3] for s in steps),
+           "step_span_us_median": round(med(0), 1), "device_idle_us_per_step_median": round(med(1), 1),
+           "idle_before_emit_instances_us_median (the mid-forward host wait)": round(med(2), 1),
+           "note": "from rocprofv3 --kernel-trace timestamps of the same run; concurrent kernels (second stream) count as busy"}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out))
+PY
 }
 
 pmc_pass() {  # $1 = mode (raster|full) -> $OUT/pmc_traffic_<mode>.json
