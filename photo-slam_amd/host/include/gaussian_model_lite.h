@@ -257,7 +257,12 @@ public:
 	int iteration_ = 0;
 	torch::Tensor last_viewspace_, last_visibility_ /* undefined when the step fused its consumers: last_radii_ > 0 */, last_radii_;
 	torch::Tensor root_grad_;   // the constant 1 handed to loss.backward()
-	std::map<std::tuple<uintptr_t, int64_t, int64_t>, bool> mask_is_ones_;   // masks seen so far: all ones? (renderAndBackward)
+	struct MaskEntry {
+		c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl> self{c10::intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>()};
+		int64_t version = 0;
+		bool ones = false;
+	};
+	std::map<const void*, MaskEntry> mask_is_ones_;   // masks seen so far: all ones? (renderAndBackward)
 };
 
 // loss = (1-lambda) L1 + lambda (1-SSIM) with its gradient in two HIP kernels (gsr_l1_ssim_loss)

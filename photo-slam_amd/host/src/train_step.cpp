@@ -235,7 +235,8 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	}
 	// Data-parallel step with the view-factored exchange: the SH rows step AFTER the exchange (stepFeaturesFromViews), and lazily
 	// there too -- a row no view of the batch lights takes a zero-gradient step, i.e. it may take it later.  The forward pass
-	// gets the same struct, so that the rows THIS view sees are up to date before they are evaluated; backward ignores it.
+	// gets the same struct, so that the rows THIS view sees are up to date before they are evaluated; backward (factored mode)
+	// uses it only to run this step's slice of the rows' rotating catch-up next to the blend kernel.
 	views_adam_ = ShAdamStep();
 	views_adam_pending_ = false;
 	if (factored_exchange_ && lazy_sh_adam_window_ >= 3 && !rebuilds && iteration_ < o.iterations_ && g->groups_.size() > 1 &&
@@ -301,15 +302,21 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	// pointer and version counter); the loss kernels then skip its 2 x 25 MB of reads at 1080p
 	torch::Tensor eff_mask = mask;
 	if (mask.defined() && mask.numel()) {
-		const auto key = std::make_tuple(reinterpret_cast<uintptr_t>(mask.data_ptr()), static_cast<int64_t>(mask.numel()),
-		                                 static_cast<int64_t>(mask._version()));
-		auto it = mask_is_ones_.find(key);
-		if (it == mask_is_ones_.end()) {
+		// remembered per TensorImpl through a weak pointer (it keeps the object's address from being reused by another tensor
+		// after this one is freed) together with the version counter (in-place writes invalidate the entry)
+		auto* impl = mask.unsafeGetTensorImpl();
+		const int64_t version = static_cast<int64_t>(mask._version());
+		auto it = mask_is_ones_.find(impl);
+		if (it == mask_is_ones_.end() || it->second.self.expired() || it->second.version != version) {
 			if (mask_is_ones_.size() >= 64) mask_is_ones_.clear();
 			torch::NoGradGuard ng;
-			it = mask_is_ones_.emplace(key, (mask == 1).all().item<bool>()).first;
+			MaskEntry e;
+			e.self = c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>(mask.getIntrusivePtr());
+			e.version = version;
+			e.ones = (mask == 1).all().item<bool>();
+			it = mask_is_ones_.insert_or_assign(impl, std::move(e)).first;
 		}
-		if (it->second) eff_mask = torch::empty({0}, mask.options());   // (an empty mask = none: FusedL1SSIMFunction::forward)
+		if (it->second.ones) eff_mask = torch::empty({0}, mask.options());   // (an empty mask = none: FusedL1SSIMFunction::forward)
 	}
 	auto loss = fusedL1SSIMLoss(rendered, gt_image, eff_mask, g->opt_.lambda_dssim_, /*is_root=*/true);
 	// the root gradient: a cached 1 instead of the ones_like fill autograd launches per backward()

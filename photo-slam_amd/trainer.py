@@ -232,18 +232,21 @@ class TrainStep:
 
     def _effective_mask(self, mask):
         """rendered * mask with a mask of ones is the identity (src/gaussian_mapper.cpp:692-693; most keyframes carry a full
-        mask): such a mask is recognised ONCE per mask tensor (one reduction + host read when a keyframe's mask is first seen,
-        remembered by storage pointer and version counter) and the loss kernels then skip its 2 x 25 MB of reads at 1080p."""
+        mask): such a mask is recognised ONCE per mask tensor (one reduction + host read when a keyframe's mask is first seen)
+        and the loss kernels then skip its 2 x 25 MB of reads at 1080p.  Remembered per tensor OBJECT through a weak reference
+        (an address or id alone could be reused by another tensor after this one is freed) together with its version counter
+        (in-place writes invalidate the entry)."""
         if mask is None:
             return None
-        key = (mask.data_ptr(), mask.numel(), mask._version)
+        import weakref
         cache = self.__dict__.setdefault("_mask_is_ones", {})
-        if key not in cache:
+        entry = cache.get(id(mask))
+        if entry is None or entry[0]() is not mask or entry[1] != mask._version:
             if len(cache) >= 64:
                 cache.clear()
             with torch.no_grad():
-                cache[key] = bool((mask == 1).all().item())
-        return None if cache[key] else mask
+                entry = cache[id(mask)] = (weakref.ref(mask), mask._version, bool((mask == 1).all().item()))
+        return None if entry[2] else mask
 
     def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
         g, opt = self.gaussians_, self.opt_

@@ -6,6 +6,37 @@
 
 #include <vector>
 
+// Context switch.  glibc's swapcontext / getcontext save and restore the signal mask with one rt_sigprocmask system call
+// each: three system calls per emulated GPU thread, which was 40 % of the CPU test-suite's time (sys 4m51 of 11m30).  On
+// x86-64 the switch below keeps the callee-saved registers on the fiber's own stack and exchanges stack pointers -- no system
+// call; other hosts keep the ucontext path.
+#if defined(__x86_64__) && !defined(HIPEMU_USE_UCONTEXT)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* const* load_sp);
+asm(R"(
+	.text
+	.globl hipemu_switch
+	.type hipemu_switch,@function
+hipemu_switch:
+	pushq %rbp
+	pushq %rbx
+	pushq %r12
+	pushq %r13
+	pushq %r14
+	pushq %r15
+	movq %rsp, (%rdi)
+	movq (%rsi), %rsp
+	popq %r15
+	popq %r14
+	popq %r13
+	popq %r12
+	popq %rbx
+	popq %rbp
+	ret
+	.size hipemu_switch, .-hipemu_switch
+)");
+#endif
+
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace hipemu {
@@ -14,20 +45,32 @@ constexpr size_t STACK_BYTES = 256 * 1024;
 constexpr int MAX_THREADS = 1024;
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
 struct Fiber {
+#ifdef HIPEMU_FAST_SWITCH
+	void* sp = nullptr;
+#else
 	ucontext_t ctx;
+#endif
 	char* stack = nullptr;
 	State state = DONE;
 	unsigned gen = 0;  // generation waited on
 };
 Fiber g_f[MAX_THREADS];
+#ifdef HIPEMU_FAST_SWITCH
+void* g_sched_sp = nullptr;
+#else
 ucontext_t g_sched;
+#endif
 int g_cur = -1, g_nthreads = 0, g_alive = 0;
 unsigned g_bar_count = 0, g_bar_gen = 0;
 unsigned g_wcount[MAX_THREADS / 64], g_wgen[MAX_THREADS / 64], g_walive[MAX_THREADS / 64];
 uint64_t g_slots[MAX_THREADS / 64][64];
 const std::function<void()>* g_body = nullptr;
 
+#ifdef HIPEMU_FAST_SWITCH
+void yield_to_sched() { hipemu_switch(&g_f[g_cur].sp, &g_sched_sp); }
+#else
 void yield_to_sched() { swapcontext(&g_f[g_cur].ctx, &g_sched); }
+#endif
 
 void release_checks_after_exit(int w)
 {
@@ -50,7 +93,21 @@ void fiber_entry()
 	g_walive[w]--;
 	release_checks_after_exit(w);
 	yield_to_sched();
+	abort();   // (a finished fiber is never resumed)
 }
+#ifdef HIPEMU_FAST_SWITCH
+// a fresh fiber: six zeroed callee-saved registers under the address hipemu_switch's `ret` jumps to, and above it one slot so
+// that fiber_entry starts with the stack alignment of a called function (rsp = 16 k + 8)
+void prepare_fiber(Fiber& f)
+{
+	uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + STACK_BYTES) & ~uintptr_t(15);
+	void** sp = reinterpret_cast<void**>(top);
+	*--sp = nullptr;                                   // (the return address fiber_entry never uses)
+	*--sp = reinterpret_cast<void*>(&fiber_entry);     // popped by `ret`
+	for (int k = 0; k < 6; k++) *--sp = nullptr;       // rbp rbx r12 r13 r14 r15
+	f.sp = sp;
+}
+#endif
 }  // namespace
 
 int lane() { return g_cur & 63; }
@@ -121,11 +178,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 				for (int l = 0; l < 64; l++) g_slots[w][l] = 0;  // lanes beyond the block read as zero
 			}
 			for (int i = 0; i < nthreads; i++) {
+#ifdef HIPEMU_FAST_SWITCH
+				prepare_fiber(g_f[i]);
+#else
 				getcontext(&g_f[i].ctx);
 				g_f[i].ctx.uc_stack.ss_sp = g_f[i].stack;
 				g_f[i].ctx.uc_stack.ss_size = STACK_BYTES;
 				g_f[i].ctx.uc_link = nullptr;
 				makecontext(&g_f[i].ctx, fiber_entry, 0);
+#endif
 				g_f[i].state = RUNNABLE;
 			}
 			while (g_alive > 0) {
@@ -138,7 +199,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 					f.state = RUNNABLE;
 					g_cur = i;
 					threadIdx = dim3((unsigned)i, 0, 0);
+#ifdef HIPEMU_FAST_SWITCH
+					hipemu_switch(&g_sched_sp, &f.sp);
+#else
 					swapcontext(&g_sched, &f.ctx);
+#endif
 					progress = true;
 				}
 				if (!progress && g_alive > 0) {
