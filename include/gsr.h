@@ -213,6 +213,12 @@ typedef struct gsr_backward_args {
 	 * cov3D_precomp) and the 16-byte aligned [P,16,3] SH layout (GSR_ERR_UNSUPPORTED otherwise); every Gaussian steps, culled
 	 * ones with a zero gradient as a dense optimizer does. */
 	const gsr_geom_adam* geom_adam;
+	/* Extension for the view-factored exchange (NULL = off; a hipStream_t, consulted only with dL_dcolor_view): dL_dcolor_view is
+	 * complete before the last kernel of the backward pass (which only READS it, for the view-direction term of dL_dmean3D).
+	 * gsr_backward makes this stream wait for exactly that point, so that a gather the caller issues on it -- the RCCL
+	 * all-gather of the exchange -- overlaps that last kernel instead of following the whole pass.  The stream must not be the
+	 * one gsr_backward is called with. */
+	void* color_view_ready_stream;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.

@@ -105,7 +105,7 @@ class BackwardArgs(C.Structure):
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int),
                 ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam)),
                 ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p),
-                ("geom_adam", C.POINTER(GeomAdam))]
+                ("geom_adam", C.POINTER(GeomAdam)), ("color_view_ready_stream", C.c_void_p)]
 
 class DensifySelectArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("scaling", C.c_void_p),

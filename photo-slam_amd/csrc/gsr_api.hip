@@ -35,6 +35,12 @@ struct HostSync {
 	// events that fork it from and join it to the caller's stream
 	hipStream_t side = nullptr;
 	hipEvent_t fork = nullptr, join = nullptr;
+	hipEvent_t notify = nullptr;   // gsr_backward_args.color_view_ready_stream: "dL_dcolor_view is complete"
+	int init_notify()
+	{
+		if (!notify) GSR_HIP(hipEventCreateWithFlags(&notify, hipEventDisableTiming));
+		return GSR_OK;
+	}
 	int init_side()
 	{
 		if (!side) {
@@ -461,6 +467,13 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		if (lazy) { pb.lazy_row_step = la.row_step; pb.lazy_step = la.step; }
 	}
 	pb.geom = geom;
+	pb.notify_stream = nullptr; pb.notify_event = nullptr;
+	if (a->color_view_ready_stream && a->dL_dcolor_view) {
+		if (a->color_view_ready_stream == stream_) return fail(GSR_ERR_INVALID_ARG);
+		if ((st = t_sync.init_notify()) != GSR_OK) return fail(st);
+		pb.notify_stream = a->color_view_ready_stream;
+		pb.notify_event = (void*)t_sync.notify;
+	}
 	if ((st = launch_preprocess_bwd(pb, stream)) != GSR_OK) return fail(st);
 	if (side_busy) GSR_HIP(hipStreamWaitEvent(stream, t_sync.join, 0));   // whatever follows on the caller's stream sees the whole update
 	PROF_BWD(3);

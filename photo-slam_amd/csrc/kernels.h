@@ -166,6 +166,11 @@ struct PreprocessBwdParams {
 	uint32_t touched_clear_bytes;
 	// optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_backward_args.geom_adam): their gradients are not written
 	GeomAdam geom;
+	// view-factored mode (gsr_backward_args.color_view_ready_stream): dL_dcolor_view is complete when preprocess_bwd_kernel has
+	// run -- notify_stream is made to wait for exactly that point (notify_event recorded between the two kernels), so that a
+	// gather issued on it overlaps sh_bwd_rows_kernel.  Host-side only; null = off.
+	void* notify_stream;
+	void* notify_event;
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // does the backward preprocess take the two-kernel path of the reference's SH layout (preprocess_bwd_kernel<true> +

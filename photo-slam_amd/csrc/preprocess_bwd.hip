@@ -93,19 +93,19 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 		ox = p.means3D[3 * (size_t)idx] - p.campos[0];
 		oy = p.means3D[3 * (size_t)idx + 1] - p.campos[1];
 		oz = p.means3D[3 * (size_t)idx + 2] - p.campos[2];
-		const uint8_t cl = p.clamped[idx];   // dL_dcolor: written by preprocess_bwd_kernel, which runs first
-		dRGB[0] = p.dL_dcolor[3 * (size_t)idx + 0] * ((cl & 1) ? 0.f : 1.f);
-		dRGB[1] = p.dL_dcolor[3 * (size_t)idx + 1] * ((cl & 2) ? 0.f : 1.f);
-		dRGB[2] = p.dL_dcolor[3 * (size_t)idx + 2] * ((cl & 4) ? 0.f : 1.f);
-	}
-	if (FACTORED && in_range) {
-		// a VISIBLE Gaussian whose masked colour gradient is all zero (drawn, but blended into no pixel that matters) leaves -0.0f
-		// in channel 0: numerically nothing, but it tells the lazy rows of gsr_sh_adam_from_views that some view SEES this
-		// Gaussian -- its row steps now (with a zero gradient) instead of being caught up by the next forward pass of this view
-		if (vis && dRGB[0] == 0.f && dRGB[1] == 0.f && dRGB[2] == 0.f) dRGB[0] = -0.0f;
-		p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
-		p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
-		p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
+		if (FACTORED) {
+			// the clamp-masked colour gradient was written by preprocess_bwd_kernel, which runs first -- it is the quantity the
+			// exchange gathers, complete one kernel earlier than this one (a visible Gaussian with an all-zero gradient carries
+			// -0.0f in channel 0 there: numerically nothing)
+			dRGB[0] = p.dL_dcolor_view[3 * (size_t)idx + 0];
+			dRGB[1] = p.dL_dcolor_view[3 * (size_t)idx + 1];
+			dRGB[2] = p.dL_dcolor_view[3 * (size_t)idx + 2];
+		} else {
+			const uint8_t cl = p.clamped[idx];   // dL_dcolor: written by preprocess_bwd_kernel, which runs first
+			dRGB[0] = p.dL_dcolor[3 * (size_t)idx + 0] * ((cl & 1) ? 0.f : 1.f);
+			dRGB[1] = p.dL_dcolor[3 * (size_t)idx + 1] * ((cl & 2) ? 0.f : 1.f);
+			dRGB[2] = p.dL_dcolor[3 * (size_t)idx + 2] * ((cl & 4) ? 0.f : 1.f);
+		}
 	}
 	// The wave handles its 64 rows in two halves of STAGE_ROWS: the SH rows of the half's visible lanes are fetched
 	// by the whole wave into LDS, each owner turns its row into the gradient row IN PLACE (zeros for culled
@@ -241,6 +241,24 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 		p.dL_dcolor[3 * (size_t)idx + 0] = ga0.x;
 		p.dL_dcolor[3 * (size_t)idx + 1] = ga0.y;
 		p.dL_dcolor[3 * (size_t)idx + 2] = ga0.z;
+		if (rows_ok && p.dL_dcolor_view) {
+			// view-factored mode: the clamp-masked colour gradient (backward.cu:41-48) leaves HERE, one kernel before the SH
+			// backward that consumes it too -- the exchange's gather can start while sh_bwd_rows_kernel runs.  A VISIBLE Gaussian
+			// whose masked gradient is all zero (drawn, but blended into no pixel that matters) leaves -0.0f in channel 0:
+			// numerically nothing, but it tells the lazy rows of gsr_sh_adam_from_views that some view SEES this Gaussian -- its
+			// row steps now (with a zero gradient) instead of being caught up by the next forward pass of this view
+			float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+			if (vis) {
+				const uint8_t cl = p.clamped[idx];
+				v0 = ga0.x * ((cl & 1) ? 0.f : 1.f);
+				v1 = ga0.y * ((cl & 2) ? 0.f : 1.f);
+				v2 = ga0.z * ((cl & 4) ? 0.f : 1.f);
+				if (v0 == 0.f && v1 == 0.f && v2 == 0.f) v0 = -0.0f;
+			}
+			p.dL_dcolor_view[3 * (size_t)idx + 0] = v0;
+			p.dL_dcolor_view[3 * (size_t)idx + 1] = v1;
+			p.dL_dcolor_view[3 * (size_t)idx + 2] = v2;
+		}
 		if (p.geom.on) {
 			const float go[1] = {g_opacity};
 			geom_adam_row<1>(p.geom.opacity, (size_t)idx, go);
@@ -632,6 +650,10 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
 		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
 		GSR_CHECK_LAUNCH();
+		if (p.notify_stream && p.notify_event) {   // dL_dcolor_view is complete: whoever gathers it need not wait for the SH kernel
+			GSR_HIP(hipEventRecord((hipEvent_t)p.notify_event, stream));
+			GSR_HIP(hipStreamWaitEvent((hipStream_t)p.notify_stream, (hipEvent_t)p.notify_event, 0));
+		}
 		const int g = div_up(p.P, SHB_THREADS);
 #define GSR_SHB(DEG)                                                                  \
 	do {                                                                              \
@@ -653,6 +675,10 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 #undef GSR_SHB
 	} else {
 		GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
+		if (p.notify_stream && p.notify_event) {
+			GSR_HIP(hipEventRecord((hipEvent_t)p.notify_event, stream));
+			GSR_HIP(hipStreamWaitEvent((hipStream_t)p.notify_stream, (hipEvent_t)p.notify_event, 0));
+		}
 	}
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;

@@ -202,6 +202,10 @@ public:
 	void setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool factored = true);
 	torch::Tensor trainForOneIterationDataParallel(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask);
 	c10::intrusive_ptr<c10d::ProcessGroup> process_group_;
+	// The all-gather of the view-factored exchange is issued on a stream of its own that waits only for the point inside
+	// backward at which the colour gradients are complete (gsr_backward_args.color_view_ready_stream): it overlaps the SH
+	// backward kernel instead of following it.  A hipStream_t from LibTorch's pool, created on first use; null on the host.
+	void* gather_stream_ = nullptr;
 	// Data-parallel keyframe batches with the view-factored exchange (include/gsr.h, gsr_sh_grad_from_views): backward
 	// then leaves the clamp-masked colour gradient of this view in sh_grad_view_ and no gradient on features_; after the
 	// driver has gathered the views of all ranks, setFeaturesGradFromViews() installs the batch-mean SH gradient.  It reads

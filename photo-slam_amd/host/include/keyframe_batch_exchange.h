@@ -57,8 +57,11 @@ public:
 	// send: [P + 1, 3] (rows 0 .. P-1 = this view's colour gradients; row P receives the camera centre), camera_center [3],
 	// others = the gradients of xyz / opacity / scaling / rotation.  After construction everything is in flight (two
 	// collectives; round 2 sent the centres and two row ranges separately: four).
+	// gather_stream (a hipStream_t; null = the current stream): the all-gather is issued with THAT stream current, so it waits
+	// for whatever the stream waits for -- TrainStep hands over the stream gsr_backward made wait for "dL_dcolor_view is
+	// complete", and the gather overlaps the last kernel of the backward pass.
 	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
-	                     std::vector<torch::Tensor> others);
+	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr);
 	struct Part {
 		int64_t row0 = 0;
 		torch::Tensor views;   // [N, rows, 3]

@@ -22,6 +22,10 @@ struct ShAdamStep {
 	torch::Tensor row_step;              // lazy mode: [P] int32, the Adam steps each row has taken; undefined = eager
 	int window = 0;                      // lazy mode: 2 .. GSR_SH_LAZY_WINDOW
 	std::vector<double> lr_past, lr_tail_past;   // lazy mode: [k-1] = the learning rates of step (step - k)
+	// view-factored mode only (gsr_backward_args.color_view_ready_stream; consulted by backward, with or without the fields
+	// above): a hipStream_t that is made to wait for the point inside backward at which dL_dcolor_view is complete -- the
+	// exchange issues its all-gather there and overlaps the last kernel of the pass
+	void* color_view_ready_stream = nullptr;
 };
 
 // (num_rendered, out_color[3,H,W], radii[P] i32, geomBuffer u8, binningBuffer u8, imgBuffer u8)

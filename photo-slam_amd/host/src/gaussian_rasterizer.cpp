@@ -30,6 +30,8 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 	ctx->saved_data["sh_degree"] = s.sh_degree_;
 	ctx->saved_data["raw_params"] = e.raw_params_;
 	if (e.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = e.sh_grad_view_;
+	if (e.sh_adam_.color_view_ready_stream)
+		ctx->saved_data["color_view_ready_stream"] = static_cast<int64_t>(reinterpret_cast<intptr_t>(e.sh_adam_.color_view_ready_stream));
 	if (!e.view_stats_.empty()) ctx->saved_data["view_stats"] = e.view_stats_;
 	if (e.sh_adam_.exp_avg.defined()) {
 		ctx->saved_data["sh_adam_m"] = e.sh_adam_.exp_avg;
@@ -105,6 +107,9 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 		geom_adam.beta1 = h[0]; geom_adam.beta2 = h[1]; geom_adam.eps = h[2];
 		geom_adam.training_outputs_only = h[3] != 0.0;
 	}
+	ShAdamStep bwd_adam = (sh_grad_view.defined() && !sh_adam.row_step.defined()) ? ShAdamStep() : sh_adam;
+	if (ctx->saved_data.count("color_view_ready_stream"))
+		bwd_adam.color_view_ready_stream = reinterpret_cast<void*>(static_cast<intptr_t>(ctx->saved_data["color_view_ready_stream"].toInt()));
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,
@@ -114,8 +119,7 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 	                                        // view-factored mode: the SH step follows the exchange (gsr_sh_adam_from_views);
 	                                        // sh_adam_ -- its lazy form -- served the forward pass (rows this view sees caught up)
 	                                        // and lets backward run this step's slice of the rotating catch-up
-	                                        (sh_grad_view.defined() && !sh_adam.row_step.defined()) ? ShAdamStep() : sh_adam, view_stats,
-	                                        geom_adam);
+	                                        bwd_adam, view_stats, geom_adam);
 	// gradient order of the forward inputs (src/gaussian_rasterizer.cpp:159-179); absent optionals get none
 	auto opt = [](const torch::Tensor& grad, const torch::Tensor& input) {
 		return (input.defined() && input.numel() != 0 && grad.defined()) ? grad : torch::Tensor();

@@ -7,6 +7,10 @@
 
 #include "gaussian_model_lite.h"
 
+#ifndef GSR_HOST_NO_HIP
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#endif
+
 torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
 {
 	if (tensors.size() < 2) return torch::Tensor();
@@ -87,7 +91,7 @@ void GradientReduction::waitAll()
 }
 
 ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
-                                           std::vector<torch::Tensor> others)
+                                           std::vector<torch::Tensor> others, void* gather_stream)
     : pg_(std::move(pg))
 {
 	const int64_t N = pg_->getSize(), P = send.size(0) - 1;
@@ -97,13 +101,30 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	// ONE all-gather: rows 0 .. P-1 of `send` are this view's colour gradients, row P its camera centre -- every collective
 	// costs a launch on RCCL's stream and two cross-stream hand-offs (measured at one rank: four collectives per step cost
 	// ~0.1 ms more than two), which is more than the overlap of a second row range's rebuild with its gather could win back
-	send.select(0, P).copy_(camera_center.detach().reshape({3}).to(o));
+	// (row P: the camera centre.  TrainStep::renderAndBackward wrote it BEFORE backward -- a gather that does not wait for the
+	// end of the backward pass must not depend on a copy queued behind it; other callers get it written here)
+	if (!gather_stream) send.select(0, P).copy_(camera_center.detach().reshape({3}).to(o));
 	gathered_ = torch::empty({N, P + 1, 3}, o);
 	auto in = send.unsqueeze(0);   // ([1, P + 1, 3]: gloo checks the input against a 1/N chunk of the output)
 	Part p;
 	p.row0 = 0;
 	p.views = gathered_.narrow(1, 0, P);      // [N, P, 3], view stride (P + 1) * 3
-	p.work = pg_->_allgather_base(gathered_, in);
+#ifndef GSR_HOST_NO_HIP
+	if (gather_stream && send.is_cuda()) {
+		// issue the gather with the side stream current: ProcessGroupNCCL orders the collective behind the CURRENT stream, and
+		// this one waits only for "dL_dcolor_view is complete" (gsr_backward), not for the kernels queued behind that point.
+		// Both buffers were allocated on the compute stream: the caching allocator is told that the side stream uses them.
+		const auto idx = send.device().index();
+		auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream), idx);
+		send.record_stream(side.unwrap());
+		gathered_.record_stream(side.unwrap());
+		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+		p.work = pg_->_allgather_base(gathered_, in);
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
+	} else
+#endif
+		p.work = pg_->_allgather_base(gathered_, in);
 	parts_.push_back(p);
 	centres_ = gathered_.select(1, P);       // [N, 3], stride (P + 1) * 3
 	// (summed, not averaged: finishGeomAdam() multiplies by 1/N as it reads the gradients)
@@ -155,7 +176,7 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 	if (factored_exchange_) {
 		std::vector<torch::Tensor> others;
 		for (int i : {0, 2, 3, 4}) others.push_back(params[static_cast<size_t>(i)].grad());
-		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others);
+		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others, gather_stream_);
 	} else {
 		std::vector<torch::Tensor> grads;
 		for (auto& p : params) grads.push_back(p.grad());

@@ -333,6 +333,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 			a.sh_adam = &adam;
 		}
 		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
+		a.color_view_ready_stream = factored ? sh_adam.color_view_ready_stream : nullptr;
 		a.dL_dscale = (has_scales && !geom) ? dL_dscales.data_ptr<float>() : nullptr;
 		a.dL_drot = (has_scales && !geom) ? dL_drotations.data_ptr<float>() : nullptr;
 		a.raw_params = raw_params;

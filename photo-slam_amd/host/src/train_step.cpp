@@ -265,6 +265,13 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		views_adam_pending_ = true;
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
+#ifndef GSR_HOST_NO_HIP
+	if (factored_exchange_ && process_group_ && g->xyz_.is_cuda()) {
+		// the exchange's gather waits for the colour gradients only, not for the whole backward pass (keyframe_batch_exchange.cpp)
+		if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, g->xyz_.device().index()).stream();
+		sh_adam.color_view_ready_stream = gather_stream_;
+	}
+#endif
 	GeomAdamStep geom_adam;
 	// (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then skips it -- no
 	// gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)

@@ -431,6 +431,60 @@ def test_cpp_host_layer_on_gpu():
     run_pipeline_flag_train_checks(ops, torch.device("cuda:0"), None)
 
 
+@pytest.mark.gpu
+def test_cpp_data_parallel_step_over_rccl_with_one_rank_on_gpu():
+    """The C++ host's data-parallel step on the MI355X with a ONE-rank RCCL process group (what `GSR_BENCH_FORCE_DP=1 bench.py`
+    times): render + backward in the factored mode with the lazy rows' catch-up inside, the all-gather issued on the side stream
+    that waits only for the colour gradients, the all-reduce (SUM), the SH step for the lit rows, the four small tensors in one
+    Adam launch -- against the fused single-GPU program from the same start, and against the plain all-reduce exchange."""
+    import math
+    import torch.distributed as dist
+    ops = load_host("hip")
+    dev = torch.device("cuda:0")
+    cl, t = _scene(dev, P=20000, W=320, H=240)
+    cam = cl.cameras[0]
+    torch.manual_seed(0)
+    gt = torch.rand(3, cam.H, cam.W).to(dev)
+    mask = torch.ones(3, cam.H, cam.W, device=dev)
+    bg = torch.zeros(3, device=dev)
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    g = GaussianModel.from_cloud(cl, device=dev)
+    make = lambda: ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
+                                      g.rotation_.detach(), 3, float(cl.extent), bg)
+    step = lambda h: float(ops.trainer_train_one_iteration(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), fovx, fovy, cam.H,
+                                                           cam.W, gt, mask))
+    n_it = 6
+    h_fused = make()
+    ops.trainer_set_options(h_fused, {"lazy_sh_adam_window": 4.0})
+    l_fused = [step(h_fused) for _ in range(n_it)]
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=dev)
+    try:
+        results = {}
+        for factored in (True, False):
+            h = make()
+            ops.trainer_set_options(h, {"lazy_sh_adam_window": 4.0})   # (window 4: rows fall behind and catch up within six steps)
+            ops.trainer_set_process_group(h, dist.group.WORLD.group_name, factored)
+            losses = [step(h) for _ in range(n_it)]
+            results[factored] = (losses, [p.detach().clone() for p in ops.trainer_params(h)], list(ops.trainer_steps(h)))
+            ops.trainer_destroy(h)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    want = ops.trainer_params(h_fused)
+    lrs = [0.00016 * cl.extent, 0.0025 / 20.0, 0.05, 0.005, 0.001]
+    for factored, (losses, params, steps) in results.items():
+        assert steps == [n_it] * 5, (factored, steps)
+        assert np.allclose(losses, l_fused, rtol=2e-5), (factored, losses, l_fused)
+        for a, b, lr in zip(params, want, lrs):
+            # (the fused program forms its update terms with v_rcp / v_sqrt, the separate Adam launches with exact division: in units
+            # of a learning-rate step, as everywhere the two are compared)
+            err = (a - b).abs() / lr
+            assert float((err > 1e-2).float().mean()) < 2e-3, (factored, float(err.max()))
+    ops.trainer_destroy(h_fused)
+
+
 def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
     ops = load_host("emu")
     from photo_slam_amd import operate_points as op
