@@ -1,4 +1,5 @@
 // train_step.cpp -- LibTorch host code of the measured train step (see gaussian_model_lite.h).
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -266,7 +267,9 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 #ifndef GSR_HOST_NO_HIP
-	if (factored_exchange_ && process_group_ && g->xyz_.is_cuda()) {
+	// GSR_EARLY_GATHER=0: the gather is issued on the compute stream behind the whole backward pass (A/B timing)
+	static const bool early_gather = [] { const char* e = getenv("GSR_EARLY_GATHER"); return !e || atoi(e) != 0; }();
+	if (early_gather && factored_exchange_ && process_group_ && g->xyz_.is_cuda()) {
 		// the exchange's gather waits for the colour gradients only, not for the whole backward pass (keyframe_batch_exchange.cpp)
 		if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, g->xyz_.device().index()).stream();
 		sh_adam.color_view_ready_stream = gather_stream_;

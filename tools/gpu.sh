@@ -151,8 +151,9 @@ import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
     pmc)    pmc_pass ${arg:-raster} ;;
     sq)     sq_pass ${arg:-full} ;;
-    dp)     # dp | dp:allreduce | dp:py (view-factored, collectives issued from Python as in round 2)
+    dp)     # dp | dp:allreduce | dp:py (view-factored, collectives issued from Python as in round 2) | dp:late (GSR_EARLY_GATHER=0)
             ex=factored; pyx=0; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
+            [ "$arg" = late ] && export GSR_EARLY_GATHER=0 || unset GSR_EARLY_GATHER
             for cfg in C3 C4; do
               GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex GSR_BENCH_PY_EXCHANGE=$pyx timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
               f=$OUT/bench_${cfg}_dp_path_1rank_rccl_${arg:-factored}.json
