@@ -17,6 +17,7 @@
 #   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
 #   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
+#   env:VAR=VAL  export VAR=VAL for the steps behind it (A/B runs; bench outputs get a _VAR_VAL suffix)
 TAG=${1:-r03_x}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT; export TMPDIR=/tmp
@@ -143,9 +144,9 @@ cb = d.get("cpu_baseline", {})
 print("cpu", cb.get("value"), json.dumps(cb.get("runs", {}).get("C1", {}).get("gpu_fused_step_same_sequence")))
 PY
             ;;
-    bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg.json 2>$OUT/bench_err.log
+    bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg$SUF.json 2>$OUT/bench_err.log
             python -c "
-import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
+import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
     kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
@@ -162,6 +163,7 @@ import json; d=json.load(open('$OUT/bench_full_$cfg.json')); print('$cfg', d['ms
 import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
             done ;;
     dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
+    env)    export "$arg"; SUF="_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; echo "exported $arg" ;;   # env:VAR=VALUE for the steps behind it (A/B runs)
     py)     timeout 900 python tools/$arg > $OUT/${arg%.py}.log 2>&1; tail -30 $OUT/${arg%.py}.log | cut -c1-300 ;;
     *)      echo "unknown step $step" ;;
   esac
