@@ -608,9 +608,9 @@ def main():
                        "visible": V, "instances": R, "instances_per_visible": round(R / max(V, 1), 2),
                        "keyframes_per_step": world, "sh_degree": 3,
                        "parallelism": "single GPU" if not dp else
-                                      (f"dp{world} (one keyframe per GPU; camera centres + two all-gathers of 3 floats/Gaussian "
-                                       "+ one all-reduce of 11 floats/Gaussian, SH gradient rebuilt per rank; densification "
-                                       "statistics accumulate per rank)") if factored else
+                                      (f"dp{world} (one keyframe per GPU; ONE all-gather of 3 floats/Gaussian + the camera centre, issued "
+                                       "behind preprocess_bwd on a second stream, + ONE all-reduce (sum) of 11 floats/Gaussian; SH "
+                                       "gradient rebuilt and stepped lazily per rank; densification statistics accumulate per rank)") if factored else
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "learning_rates": lr_note,
