@@ -147,6 +147,9 @@ PY
     bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg$SUF.json 2>$OUT/bench_err.log
             python -c "
 import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
+    benchq) cfg=${arg:-C3}; timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/benchq_$cfg$SUF.json 2>$OUT/bench_err.log   # quick A/B form: no densify leg
+            python -c "
+import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
     kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
@@ -163,7 +166,7 @@ import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF
 import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
             done ;;
     dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
-    env)    export "$arg"; SUF="_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; echo "exported $arg" ;;   # env:VAR=VALUE for the steps behind it (A/B runs)
+    env)    export "$arg"; SUF="${SUF}_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; echo "exported $arg" ;;   # env:VAR=VALUE for the steps behind it (A/B runs)
     py)     timeout 900 python tools/$arg > $OUT/${arg%.py}.log 2>&1; tail -30 $OUT/${arg%.py}.log | cut -c1-300 ;;
     *)      echo "unknown step $step" ;;
   esac
