@@ -40,7 +40,27 @@ struct LossParams {
 	float* grad;            // [3,H,W] dL/d rendered
 	float* loss;            // [1]
 	int nblocks;
+	int gx, gy;             // tile grid per channel: nblocks = 3 gx gy
 };
+
+// Workgroup -> (channel, tile) with the same XCD banding as the blend kernels (blend.h: tile_assignment): workgroup b runs on
+// XCD b % 8, and every XCD gets a contiguous run of the row-major tile order, so that the 5-pixel halo a tile shares with its
+// neighbours (1.72x the tile's own pixels at 32 x 32) is found in THAT XCD's L2 instead of being fetched once per XCD.  The
+// launch is 1-D, padded to a multiple of 8; returns false for a padding workgroup.
+__device__ __forceinline__ bool loss_tile(const LossParams& p, int& t, int& ch, int& x0, int& y0)
+{
+	const int per = (p.nblocks + 7) >> 3;
+	const int b = (int)blockIdx.x, in_xcd = b >> 3;
+	t = (b & 7) * per + in_xcd;
+	if (in_xcd >= per || t >= p.nblocks) return false;
+	const int per_ch = p.gx * p.gy;
+	ch = t / per_ch;
+	const int r = t - ch * per_ch, ty = r / p.gx;
+	x0 = (r - ty * p.gx) * LT;
+	y0 = ty * LTY;
+	return true;
+}
+static inline int loss_grid(int nblocks) { return ((nblocks + 7) >> 3) * 8; }
 
 __device__ __forceinline__ float block_sum_256(float v, float* s4)
 {
@@ -141,8 +161,8 @@ loss_fwd_kernel(const LossParams p)
 	__shared__ float4 s_mem[5 * LRY * HP4];
 	static_assert(5 * LRY * HP4 >= 2 * LRY * SP4, "the filtered maps cover the staged tile");
 	__shared__ float s_red[4];
-	const int ch = (int)blockIdx.z;
-	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
+	int t, ch, x0, y0;
+	if (!loss_tile(p, t, ch, x0, y0)) return;   // (workgroup-uniform)
 	const size_t plane = (size_t)p.W * p.H;
 	const int tid = (int)threadIdx.x;
 	{
@@ -256,9 +276,8 @@ loss_fwd_kernel(const LossParams p)
 	const float t1 = block_sum_256(l1_sum, s_red);
 	const float t2 = block_sum_256(ssim_sum, s_red);
 	if (tid == 0) {
-		const int b = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
-		p.partial[b] = t1;
-		p.partial[p.nblocks + b] = t2;
+		p.partial[t] = t1;   // (indexed by tile: the final sum's order does not depend on the workgroup mapping)
+		p.partial[p.nblocks + t] = t2;
 	}
 }
 
@@ -286,8 +305,8 @@ loss_bwd_kernel(const LossParams p)
 	// staged derivative maps: 3 x 42 x 13 float4; then their filtered rows: 3 x 42 x 9 float4 in the same memory
 	__shared__ float4 s_mem[3 * LRY * SP4];
 	__shared__ float s_red[4];
-	const int ch = (int)blockIdx.z;
-	const int x0 = (int)blockIdx.x * LT, y0 = (int)blockIdx.y * LTY;
+	int t, ch, x0, y0;
+	if (!loss_tile(p, t, ch, x0, y0)) return;   // (workgroup-uniform)
 	const size_t plane = (size_t)p.W * p.H;
 	const int tid = (int)threadIdx.x;
 	{
@@ -367,7 +386,7 @@ loss_bwd_kernel(const LossParams p)
 			}
 		}
 	}
-	if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0) loss_finalize(p, s_red);
+	if (t == 0) loss_finalize(p, s_red);
 }
 
 // ------------------------------------------------------------------ Adam
@@ -496,12 +515,13 @@ int gsr_l1_ssim_loss(const float* rendered, const float* gt, const float* mask, 
 	const size_t plane = (size_t)width * height;
 	const int gx = div_up(width, LT), gy = div_up(height, LTY);
 	p.nblocks = gx * gy * 3;
+	p.gx = gx; p.gy = gy;
 	p.dmaps = reinterpret_cast<float*>(scratch);
 	p.partial = p.dmaps + 9 * plane;
 	p.grad = grad_rendered;
 	p.loss = loss;
-	GSR_LAUNCH(loss_fwd_kernel, dim3(gx, gy, 3), 256, stream, p);
-	GSR_LAUNCH(loss_bwd_kernel, dim3(gx, gy, 3), 256, stream, p);
+	GSR_LAUNCH(loss_fwd_kernel, loss_grid(p.nblocks), 256, stream, p);
+	GSR_LAUNCH(loss_bwd_kernel, loss_grid(p.nblocks), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
