@@ -74,6 +74,8 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_list[SHB_THREADS / 64][STAGE_ROWS];
+	// fused step (MODE 2): the stage keeps the PARAMETER rows; basis values + colour gradient of each row (shrows.h: rank one)
+	__shared__ float s_aux[SHB_THREADS / 64][MODE == 2 ? STAGE_ROWS : 1][AUX_PITCH];
 	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	const int w = wave_id(), l = lane_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
@@ -112,7 +114,7 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 	// Gaussians) while accumulating dRGB/d(direction), and the half leaves as one contiguous 6 KiB burst.
 	{
 		{
-			const int nf4 = (3 * ncoef + 3) >> 2;
+			const int nf4 = MODE == 2 ? ROW_F4 : (3 * ncoef + 3) >> 2;   // (fused step: the movers need the whole parameter row)
 #pragma unroll 1
 			for (int h = 0; h < 64 / STAGE_ROWS; h++) {
 				const size_t half_first = wave_first + (size_t)(h * STAGE_ROWS);
@@ -134,8 +136,16 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 						GSR_OPAQUE_F32(uz);
 						const float len = sqrtf(ux * ux + uy * uy + uz * uz);
 						const ShDir d = sh_dir(ux / len, uy / len, uz / len);
-						sh_row_backward<!FACTORED>(row, ncoef, d, dRGB, ddx, ddy, ddz);
-					} else if (!FACTORED) {
+						sh_row_backward<MODE == 0>(row, ncoef, d, dRGB, ddx, ddy, ddz);
+						if (MODE == 2) {
+							float* ax = s_aux[w][l % STAGE_ROWS];
+#pragma unroll
+							for (int k = 0; k < 16; k++) ax[k] = k < ncoef ? sh_basis(k, d) : 0.f;
+							ax[16] = dRGB[0];
+							ax[17] = dRGB[1];
+							ax[18] = dRGB[2];
+						}
+					} else if (MODE == 0) {
 #pragma unroll
 						for (int i = 0; i < ROW_F4; i++) row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 					}
@@ -146,8 +156,9 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 					const RowAdam ra = {p.adam_param, p.adam_exp_avg, p.adam_exp_avg_sq, p.adam};
 					// the rows of this half that step here: all of them, or only the visible ones when the culled Gaussians
 					// took the step in gsr_forward (their rows then are neither read nor written)
-					const uint32_t rows = p.adam_skip_culled ? (uint32_t)(m >> (h * STAGE_ROWS)) : 0xFFFFFFFFu;
-					wave_adam_rows(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w], rows);
+					const uint32_t lit = (uint32_t)(m >> (h * STAGE_ROWS));
+					const uint32_t rows = p.adam_skip_culled ? lit : 0xFFFFFFFFu;
+					wave_adam_rows_rank1(ra, half_first, (int)(left > STAGE_ROWS ? STAGE_ROWS : left), s_rows[w], s_aux[w], rows, lit);
 				} else {
 					wave_fence();   // the next pass refills the slice
 				}

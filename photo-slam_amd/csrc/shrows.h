@@ -142,6 +142,61 @@ __device__ __forceinline__ void wave_adam_rows(const RowAdam& a, size_t first_ro
 	wave_fence();
 }
 
+// The fused step of sh_bwd_rows_kernel: the gradient row of a visible Gaussian is rank one, dL_dsh[k][ch] = basis_k(dir) *
+// dRGB[ch] (backward.cu:41-127), and the row's PARAMETER is in the stage already (the SH backward needs the coefficients for the
+// view-direction term).  So the stage keeps the parameter, the owner leaves the 16 basis values and the 3 colour gradients in
+// s_aux (19 floats instead of a 48-float gradient row written over the parameter), and the movers form their four gradient
+// elements as the same products -- the parameter is not read from HBM a second time (192 B per visible Gaussian).
+// vis_mask: rows whose parameter and s_aux entry are staged; the other rows of row_mask step with a zero gradient and read
+// their parameter from HBM as wave_adam_rows does.
+constexpr int AUX_PITCH = 21;   // 16 basis values + 3 colour gradients, odd pitch: conflict-free owner writes
+__device__ __forceinline__ void wave_adam_rows_rank1(const RowAdam& a, size_t first_row, int nrows, float4 (*s_rows)[ROW_F4_PAD],
+                                                     const float (*s_aux)[AUX_PITCH], uint32_t row_mask, uint32_t vis_mask)
+{
+	const int l = lane_id();
+	const int slot = l >> 4, col = l & 15;
+	wave_fence();
+	const size_t base = (first_row + slot) * ROW_F4 + col;
+	const float ss_first = col == 0 ? a.s.step_size : a.s.step_size_tail;
+	int kc[4], cc[4];   // element e = 4 col + c of the row is coefficient e / 3, channel e % 3
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		const int e = (4 * col + c) % (4 * ROW_F4);   // (lanes with col >= ROW_F4 do nothing below)
+		kc[c] = e / 3;
+		cc[c] = 16 + e - 3 * kc[c];
+	}
+#pragma unroll GSR_ADAM_UNROLL
+	for (int k = 0; k < STAGE_ROWS / 4; k++) {
+		const int r = 4 * k + slot;
+		if (col < ROW_F4 && r < nrows && ((row_mask >> r) & 1u)) {
+			const size_t i = base + (size_t)(4 * k * ROW_F4);
+			float4 mv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg) + i);
+			float4 vv = load_stream_f4(reinterpret_cast<const float4*>(a.exp_avg_sq) + i);
+			float4 pv, gv;
+			if ((vis_mask >> r) & 1u) {
+				pv = s_rows[r][col];
+				const float* ax = s_aux[r];
+				gv = make_float4(ax[kc[0]] * ax[cc[0]], ax[kc[1]] * ax[cc[1]], ax[kc[2]] * ax[cc[2]], ax[kc[3]] * ax[cc[3]]);
+			} else {
+				pv = load_stream_f4(reinterpret_cast<const float4*>(a.param) + i);
+				gv = make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+			float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				const float ss = e < 3 ? ss_first : a.s.step_size_tail;
+				mp[e] = a.s.b1 * mp[e] + a.s.omb1 * gp[e];
+				vp[e] = a.s.b2 * vp[e] + a.s.omb2 * gp[e] * gp[e];
+				pp[e] -= ss * adam_ratio(mp[e], vp[e], a.s.inv_sqrt_bc2, a.s.eps);
+			}
+			store_stream_f4(reinterpret_cast<float4*>(a.param) + i, pv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg) + i, mv);
+			store_stream_f4(reinterpret_cast<float4*>(a.exp_avg_sq) + i, vv);
+		}
+	}
+	wave_fence();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Lazy Adam for rows whose gradient is zero (gsr_sh_adam_lazy, include/gsr.h).  A Gaussian the view culls gets a zero SH
 // gradient, and a zero-gradient Adam step of a row depends on nothing but the row itself and the step's scalars:
