@@ -66,14 +66,36 @@ __device__ __forceinline__ void wave_sum_long_run(uint32_t first, uint32_t cnt, 
 	for (int c = 0; c < 9; c++) v[c] = 0.f;
 	const float4* src = part4 + 3 * (size_t)first;
 	bool any = false;
-	for (uint32_t i = (uint32_t)l; i < cnt; i += 64u) {
-		if (!touched[first + i]) continue;
-		any = true;
-		const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
-		const float z = src[3 * (size_t)i + 2].x;
-		v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-		v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
-		v[8] += z;
+	// four slots per lane and trip: the flags first, then the touched slots' loads together, then the sums in slot order -- the
+	// kernel's time is the longest run's chain of dependent (flag, slot) round trips
+	constexpr int U = 4;
+	for (uint32_t i0 = (uint32_t)l; i0 < cnt; i0 += 64u * U) {
+		bool t[U];
+		float4 x[U], y[U];
+		float z[U];
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const uint32_t i = i0 + 64u * (uint32_t)j;
+			t[j] = i < cnt && touched[first + i] != 0;
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			const size_t i = (size_t)i0 + 64u * (size_t)j;
+			if (t[j]) {
+				x[j] = src[3 * i];
+				y[j] = src[3 * i + 1];
+				z[j] = src[3 * i + 2].x;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			if (t[j]) {
+				any = true;
+				v[0] += x[j].x; v[1] += x[j].y; v[2] += x[j].z; v[3] += x[j].w;
+				v[4] += y[j].x; v[5] += y[j].y; v[6] += y[j].z; v[7] += y[j].w;
+				v[8] += z[j];
+			}
+		}
 	}
 	const bool some = wave_ballot(any) != 0ull;
 	wave_reduce9_f32(v);  // totals in lane 63; every lane has read its slots by now (the reduction is a rendezvous)
