@@ -376,7 +376,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	LazyAdam la{};
 	if (lazy) {
 		// lazy mode (gsr_sh_adam_lazy): the culled rows do NOT take this step now; a rotating 1/window of the row blocks catches
-		// up instead (launched behind the backward blend, below)
+		// up instead (forked next to the backward blend, below)
 		if (!a->shs) return GSR_ERR_INVALID_ARG;
 		if ((st = make_lazy_adam(*a->sh_adam, a->shs, a->M, la)) != GSR_OK) return st;
 		if (pre_slice && la.window < 3) return GSR_ERR_INVALID_ARG;
@@ -399,7 +399,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		return s2;
 	};
 	if (lazy) {
-		// (launched behind the backward blend, below)
+		// (forked next to the backward blend, below)
 	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled()) {
 		const gsr_sh_adam& o = *a->sh_adam;
 		if ((st = t_sync.init_side()) != GSR_OK) return st;
@@ -411,6 +411,13 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		side_busy = true;
 		if (st != GSR_OK) return fail(st);
 	}
+	// The lazy rows' slice is forked HERE, next to the backward blend (GSR_LAZY_SLICE_EARLY=0: behind the blend, next to the
+	// per-Gaussian kernels, as until r03_r).  Round 2 measured the two placements equal; since the fused SH step keeps its
+	// parameter rows in LDS (16 instead of 24 waves per CU) it is the one that suffers from a neighbour: same box, C3 1.660 ->
+	// 1.637 ms, a C5 view 1.768 -> 1.738 (the blend pays 5-13 us, the per-Gaussian stage gains 30-40).
+	const char* slice_env = getenv("GSR_LAZY_SLICE_EARLY");
+	const bool slice_early = !(slice_env && slice_env[0] == '0');
+	if (lazy && slice_early && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
 	// every API output is written exactly once by preprocess_bwd
@@ -430,9 +437,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);
-	// ... next to the HBM-bound per-Gaussian backward kernels that follow.  (Next to the VALU-bound blend it costs the same: the
-	// blend then takes 30 us longer and the kernels behind it 30 us less, tools/gpu_r2p.sh.)
-	if (lazy && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
+	if (lazy && !slice_early && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
 
 	PreprocessBwdParams pb;
 	pb.P = P; pb.D = a->D; pb.M = a->M;

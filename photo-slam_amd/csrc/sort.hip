@@ -83,22 +83,6 @@ scan_reduce_rect_kernel(const uint2* __restrict__ rect, const uint32_t* __restri
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// Single workgroup: in-place exclusive scan of the block sums (nblocks <= 1024 * 4).
-__global__ void __launch_bounds__(SCAN_THREADS)
-scan_spine_kernel(uint32_t* __restrict__ block_sums, int nblocks)
-{
-	__shared__ uint32_t s_wave[4];
-	uint32_t carry = 0;
-	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
-		const int i = base + (int)threadIdx.x;
-		const uint32_t v = i < nblocks ? block_sums[i] : 0u;
-		uint32_t tot;
-		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
-		if (i < nblocks) block_sums[i] = carry + ex;
-		carry += tot;
-	}
-}
-
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint32_t* out,   // in may alias out (staged input)
                   const uint32_t* __restrict__ block_sums, int n, int items_per_block, int inclusive)
@@ -106,7 +90,14 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 	__shared__ uint32_t s_wave[4];
 	const int base = blockIdx.x * items_per_block;
 	const int end = min(n, base + items_per_block);
-	uint32_t carry = block_sums[blockIdx.x];
+	// the block's carry = the sum of the block sums in front of it, formed HERE (a few hundred words, one block reduction)
+	// instead of by a single-workgroup launch between the two passes: one launch and its bubble less per scan
+	uint32_t carry;
+	{
+		uint32_t part = 0;
+		for (int j = (int)threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) part += block_sums[j];
+		(void)block_excl_scan_256(part, &carry, s_wave);
+	}
 	for (int b = base; b < end; b += SCAN_THREADS) {
 		const int i = b + (int)threadIdx.x;
 		const uint32_t v = i < end ? (gather ? in[gather[i]] : in[i]) : 0u;
@@ -125,7 +116,6 @@ int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* 
 	const int ipb = scan_items_per_block(n);
 	const int nb = div_up(n, ipb);
 	GSR_LAUNCH(scan_reduce_rect_kernel, nb, SCAN_THREADS, stream, rect, gather, out, rect_sorted, scratch, n, ipb, n_dev);
-	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, (const uint32_t*)out, (const uint32_t*)nullptr, out,
 	           (const uint32_t*)scratch, n, ipb, 0);
 	GSR_CHECK_LAUNCH();
@@ -142,7 +132,6 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 	const int nb = div_up(n, ipb);
 	uint32_t* staged = gather ? out : nullptr;
 	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, staged, scratch, n, ipb, n_dev);
-	GSR_LAUNCH(scan_spine_kernel, 1, SCAN_THREADS, stream, scratch, nb);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, gather ? (const uint32_t*)out : in, (const uint32_t*)nullptr, out,
 	           (const uint32_t*)scratch, n, ipb, inclusive ? 1 : 0);
 	GSR_CHECK_LAUNCH();
