@@ -26,7 +26,10 @@ namespace gsr {
 
 constexpr int ROW_F4 = 12;        // 48 floats
 constexpr int ROW_F4_PAD = 13;    // LDS row pitch in float4
-constexpr int STAGE_ROWS = 32;    // rows staged per pass
+#ifndef GSR_STAGE_ROWS
+#define GSR_STAGE_ROWS 32
+#endif
+constexpr int STAGE_ROWS = GSR_STAGE_ROWS;    // rows staged per pass (16 or 32: the movers take four rows per instruction)
 
 // Both movers give 16 lanes to a row (12 of them active at degree 3): four rows per wave instruction, and every index
 // is a shift or a compile-time offset -- the 5-rows-per-instruction packing needed divisions by 12 whose results
