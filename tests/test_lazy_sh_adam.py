@@ -40,6 +40,11 @@ def test_lazy_sh_adam_equals_the_eager_update_on_gpu():
     parity.check_lazy_sh_adam(None, dev, cl, cams, np.array([0.1, 0.2, 0.3], np.float32), steps=13, window=4, zero_gradient=True)
     parity.check_lazy_sh_adam(None, dev, cl, cams, np.zeros(3, np.float32), steps=40, window=32, seed=3, zero_gradient=True)
     parity.check_lazy_sh_adam(None, dev, cl, cams, np.array([0.1, 0.2, 0.3], np.float32), steps=13, window=4, exact=False)
+    # lower active degrees: the fused row kernel's other instantiations (whole parameter rows staged, basis values beyond the
+    # active coefficients zero: shrows.h, wave_adam_rows_rank1)
+    for degree in (0, 1, 2):
+        parity.check_lazy_sh_adam(None, dev, cl, cams, np.zeros(3, np.float32), steps=7, window=3, sh_degree=degree, zero_gradient=True)
+    parity.check_lazy_sh_adam(None, dev, cl, cams, np.array([0.1, 0.2, 0.3], np.float32), steps=7, window=3, sh_degree=1, exact=False)
 
 
 def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
