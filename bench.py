@@ -614,6 +614,7 @@ def main():
                                       f"dp{world} (one keyframe per GPU, all-reduce of 59 floats/Gaussian)",
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "learning_rates": lr_note,
+                       "cull_empty_tiles": os.environ.get("GSR_CULL_EMPTY_TILES", "0") == "1",   # (include/gsr.h: same image and gradients)
                        "sh_adam_fused_into_backward": fused_sh_adam,
                        "sh_adam_lazy_window": lazy_window, "scene_index_order": args.scene_order,
                        "geometry_adam_fused_into_backward": bool(fused_sh_adam and not args.no_fused_geom_adam),

@@ -12,6 +12,7 @@
 #include "state.h"
 #include "wave64.h"
 #include "kernels.h"
+#include "blend.h"
 
 namespace gsr {
 
@@ -28,7 +29,7 @@ constexpr int EMIT_SLOTS = 256;
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                      float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes)
+                      float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull)
 {
 	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
 	const int w = wave_id(), l = lane_id();
@@ -70,7 +71,12 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		const uint32_t wdt = maxx - minx;
 		const uint32_t yy = k / wdt;
 		const uint32_t xx = k - yy * wdt;
-		keys[slot] = (miny + yy) * (uint32_t)grid_x + (minx + xx);
+		uint32_t key = (miny + yy) * (uint32_t)grid_x + (minx + xx);
+		// GSR_CULL_EMPTY_TILES: the instance of a tile in which no pixel can blend this Gaussian (the blend kernels' own
+		// conservative test, on the tile's 16 x 16 rectangle) gets the key that the tile sort's first pass drops
+		if (cull && !rect_keep(rec[3 * (size_t)g], rec[3 * (size_t)g + 1], (float)((minx + xx) * TILE), (float)((miny + yy) * TILE), (float)(TILE - 1)))
+			key = RADIX_INVALID_KEY;
+		keys[slot] = key;
 		vals[slot] = g;
 		// slot of the Gaussian's first instance = its emission offset (the backward blend writes its per-tile gradient
 		// partials there, preprocess_bwd sums the contiguous run)
@@ -80,8 +86,9 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 
 // identifyTileRanges, rasterizer_impl.cu:116-138, on 32-bit tile keys.
 __global__ void __launch_bounds__(256)
-tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges)
+tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev)
 {
+	if (n_dev) R = min(R, (int)*n_dev);   // (the list was compacted by the tile sort: GSR_CULL_EMPTY_TILES)
 	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i >= R) return;
 	const uint32_t cur = tile_keys[i];
@@ -98,20 +105,20 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          hipStream_t stream)
+                          hipStream_t stream, int cull)
 {
 	if (R <= 0) return GSR_OK;
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
 	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
-	           (uint32_t)touched_clear_bytes((size_t)R));
+	           (uint32_t)touched_clear_bytes((size_t)R), cull);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
 
-int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream)
+int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream, const uint32_t* n_dev)
 {
 	if (R <= 0) return GSR_OK;
-	GSR_LAUNCH(tile_ranges_kernel, div_up(R, 256), 256, stream, R, tile_keys, ranges);
+	GSR_LAUNCH(tile_ranges_kernel, div_up(R, 256), 256, stream, R, tile_keys, ranges, n_dev);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -51,16 +51,18 @@ static inline int quad_grid(int tiles) { return ((tiles + 7) >> 3) * 8 * QUADS_P
 // exceeds the threshold (plus a rounding margin) no pixel of the quad can blend this
 // Gaussian and the whole wave skips it -- the skipped pairs are exactly pairs the
 // reference `continue`s over, so results are unchanged.
-// (x0, y0) = pixel coordinates of the quad's first pixel.
-__device__ __forceinline__ bool quad_keep(const float4 q0, const float4 q1, float x0, float y0)
+// (x0, y0) = pixel coordinates of the rectangle's first pixel, ext = its width and height - 1 (7: a quad; 15: a whole tile --
+// the instance emission's test under GSR_CULL_EMPTY_TILES: a tile's rectangle contains its four quads', and its margin is the
+// larger one, so an instance it rejects is one quad_keep rejects in all four quads).
+__device__ __forceinline__ bool rect_keep(const float4 q0, const float4 q1, float x0, float y0, float ext)
 {
 	const float mx = q0.x, my = q0.y, A = q0.z, B = q0.w, C = q1.x, o = q1.y;
 	if (o < 1.0f / 255.0f) return false;          // alpha <= o < 1/255 everywhere (NaN opacity falls through: keep)
 	const float det = A * C - B * B;
 	if (!(A > 0.f && C > 0.f && det > 0.f)) return true;  // not positive definite (or NaN): no bound, keep
 	const float thr = __logf(255.0f * o);
-	const float u0 = x0 - mx, u1 = u0 + 7.0f;
-	const float v0 = y0 - my, v1 = v0 + 7.0f;
+	const float u0 = x0 - mx, u1 = u0 + ext;
+	const float v0 = y0 - my, v1 = v0 + ext;
 	float qmin;
 	if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) {
 		qmin = 0.f;
@@ -86,6 +88,7 @@ __device__ __forceinline__ bool quad_keep(const float4 q0, const float4 q1, floa
 	const float margin = 0.01f + 1e-4f * thr + 2e-5f * mag;
 	return !(qmin > thr + margin);
 }
+__device__ __forceinline__ bool quad_keep(const float4 q0, const float4 q1, float x0, float y0) { return rect_keep(q0, q1, x0, y0, 7.0f); }
 
 // Gradient hand-off without global atomics.  Every (tile, Gaussian) instance owns one 48-byte slot
 //   [0..2] dL_dcolor  [3..4] sum w*dx, sum w*dy  [5..7] sum w*dx*dx, w*dx*dy, w*dy*dy  [8] sum w  [9..11] unused

@@ -268,15 +268,20 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// (im.ranges: zeroed by preprocess_fwd)
 	uint32_t* point_list = bs.vals_a;
 	if (R > 0) {
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream)) != GSR_OK) return st;
-		PROF_FWD(4);
 		const int bits = (int)higher_msb((uint32_t)tiles);
+		// GSR_CULL_EMPTY_TILES: instances of tiles in which no pixel can blend the Gaussian leave the list in the tile sort's
+		// first pass (78 % of the rectangle instances at C3 blend into no pixel); the count that remains lives on the device
+		// (a sort of zero passes -- a one-tile image -- cannot drop anything: the flag is ignored there)
+		const bool cull = (a->raw_params & GSR_CULL_EMPTY_TILES) != 0 && bits > 0;
+		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0)) != GSR_OK) return st;
+		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
-		                            bs.sort_scratch, stream, &tkeys, &point_list)) != GSR_OK)
+		                            bs.sort_scratch, stream, &tkeys, &point_list, listed)) != GSR_OK)
 			return st;
 		PROF_FWD(5);
-		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream)) != GSR_OK) return st;
+		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream, listed)) != GSR_OK) return st;
 	} else {
 		PROF_FWD(4);
 		PROF_FWD(5);

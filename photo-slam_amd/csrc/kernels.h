@@ -70,8 +70,8 @@ int launch_preprocess_fwd(const PreprocessParams& p, const GeometryState& g, hip
 int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t stream);
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          hipStream_t stream);
-int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream);
+                          hipStream_t stream, int cull = 0);
+int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream, const uint32_t* n_dev = nullptr);
 
 struct BlendFwdParams {
 	const uint2* ranges;

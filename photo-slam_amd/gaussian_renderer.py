@@ -1,4 +1,5 @@
 """GaussianRenderer::render (include/gaussian_renderer.h:29-42, src/gaussian_renderer.cpp:23-149)."""
+import os
 from dataclasses import dataclass
 
 import torch
@@ -60,7 +61,8 @@ class GaussianRenderer:
             viewpoint_camera.world_view_transform_, viewpoint_camera.full_proj_transform_, pc.active_sh_degree_,
             viewpoint_camera.camera_center_, False, raw,
             sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats,
-            geom_adam if raw == 7 else None, bool((geom_adam is not None or training_outputs_only) and raw == 7))
+            geom_adam if raw == 7 else None, bool((geom_adam is not None or training_outputs_only) and raw == 7),
+            cull_empty_tiles_=os.environ.get("GSR_CULL_EMPTY_TILES", "0") == "1")   # opt-in: measured a wash
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points

@@ -84,6 +84,9 @@ struct GaussianRasterizationExtensions {
 	// optimizer-in-backward for xyz / opacity / scaling / rotation (rasterize_points.h): fill param to enable; those four then
 	// get no gradient from autograd
 	GeomAdamStep geom_adam_;
+	// GSR_CULL_EMPTY_TILES (include/gsr.h): instances of tiles in which no pixel can blend the Gaussian are dropped in front of
+	// the tile sort -- the same image and the same gradients from shorter internal lists
+	bool cull_empty_tiles_ = false;
 };
 
 class GaussianRasterizerFunctionEx : public torch::autograd::Function<GaussianRasterizerFunctionEx> {

@@ -11,6 +11,7 @@
 #include <torch/torch.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <tuple>
 
@@ -65,6 +66,9 @@ public:
 		if (sh_in_rasterizer) ext.sh_grad_view_ = sh_grad_view;
 		if (sh_in_rasterizer) ext.sh_adam_ = sh_adam;
 		ext.view_stats_ = view_stats;
+		// (the same image and gradients either way; opt-in with GSR_CULL_EMPTY_TILES=1: measured a wash)
+		static const bool cull_empty_tiles = [] { const char* e = std::getenv("GSR_CULL_EMPTY_TILES"); return e && e[0] == '1'; }();
+		ext.cull_empty_tiles_ = cull_empty_tiles;
 		// the fused geometry step needs the raw leaves in the rasterizer (it steps opacity_ / scaling_ / rotation_ themselves)
 		if (ext.raw_params_ == 7 && !pipe.compute_cov3D_) ext.geom_adam_ = geom_adam;
 		GaussianRasterizerEx rasterizer(raster_settings, ext);

@@ -53,8 +53,9 @@ def _features(cl, sh_coeffs):
 
 
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None, view_stats=None):
-    """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  factored: backward in the
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None, view_stats=None, flags=0):
+    """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  flags: extension bits of raw_params
+    that do not concern the inputs (GSR_CULL_EMPTY_TILES = 8).  factored: backward in the
     view-factored mode (dL_dcolor_view instead of dL_dsh, include/gsr.h)."""
     rp._LIB_OVERRIDE = lib_path
     try:
@@ -70,7 +71,7 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                  projmatrix=_t(cam.projmatrix, dev), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, image_height=cam.H,
                  image_width=cam.W, sh=empty if use_colors_precomp else _t(_features(cl, sh_coeffs), dev), degree=sh_degree,
                  campos=_t(cam.campos, dev), prefiltered=False)
-        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a)
+        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a, raw_params=flags)
         r = BackendResult()
         r.R, r.out_color, r.radii = R, color.cpu().numpy(), radii.cpu().numpy()
         if P:
@@ -517,3 +518,40 @@ def check_backward_twice(lib_path, dev, cl, bg, seed=0):
                 assert rel_l1(b, a) < 2e-5
     finally:
         rp._LIB_OVERRIDE = None
+
+
+def check_cull_empty_tiles(lib_path, dev, cl, cam, bg, sh_degree=3, seed=0, exact=True):
+    """GSR_CULL_EMPTY_TILES (include/gsr.h): the instances of tiles in which no pixel can blend the Gaussian are dropped in
+    front of the tile sort.  The image, final_T and every gradient must be those of the reference's lists -- bit for bit where
+    two runs of the same program are (emulator; on the GPU the order of the four quad-waves' LDS adds in the backward blend
+    differs from run to run: exact=False compares the gradients to 1e-6 of their range) -- while the instance list gets
+    shorter: every tile's range is a sub-sequence of the reference's, in the same order."""
+    rng = np.random.default_rng(seed)
+    dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
+    ref = run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix)
+    cut = run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix, flags=8)
+    assert cut.R == ref.R                      # num_rendered sizes the buffers: still the rectangles
+    assert np.array_equal(cut.radii, ref.radii)
+    assert np.array_equal(cut.out_color, ref.out_color), float(np.abs(cut.out_color - ref.out_color).max())
+    assert np.array_equal(cut.final_T, ref.final_T)
+    kept = int((cut.ranges[:, 1] - cut.ranges[:, 0]).sum())
+    listed = int((ref.ranges[:, 1] - ref.ranges[:, 0]).sum())
+    assert listed == ref.R and kept <= listed
+    # every tile's list is a sub-sequence of the reference's (same Gaussians, same order)
+    for t in np.flatnonzero(ref.ranges[:, 1] > ref.ranges[:, 0])[:: max(1, len(ref.ranges) // 64)]:
+        full = ref.point_list[ref.ranges[t, 0]:ref.ranges[t, 1]]
+        part = cut.point_list[cut.ranges[t, 0]:cut.ranges[t, 1]]
+        pos = {int(g): i for i, g in enumerate(full)}
+        idx = [pos[int(g)] for g in part]
+        assert idx == sorted(idx) and len(set(idx)) == len(idx), t
+    # the gradients: the SAME per-pixel terms; the four quad-waves of a tile merge their sums of a list entry in LDS in an order
+    # that depends on how the waves interleave (on the GPU it differs from run to run of one program) -- a sum of four floats in
+    # another order: compared to 5e-6 of the tensor's range (1.7e-6 seen at C3 on the GPU)
+    worst = {}
+    for n, g in ref.grads.items():
+        c = cut.grads[n]
+        scale = float(np.abs(g).max() + 1e-30)
+        worst[n] = float(np.abs(c - g).max()) / scale
+        assert worst[n] <= 5e-6, (n, worst[n])
+    print("cull_empty_tiles: worst |difference| / range per gradient", {n: f"{v:.1e}" for n, v in worst.items()})
+    return kept, listed

@@ -27,3 +27,13 @@ def test_forward_backward_matches_oracle(emu_lib_path, oracle, P, W, H, seed):
     r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix)
     rep = parity.compare(r, ores, ocolor, oradii, ograds, cam)
     print(rep)
+
+
+@pytest.mark.parametrize("P,W,H,seed,scale_k", [(600, 64, 48, 1, 0.35), (1500, 80, 70, 2, 0.35), (300, 96, 64, 5, 1.5), (40, 16, 16, 7, 0.35)])
+def test_cull_empty_tiles_keeps_image_and_gradients(emu_lib_path, P, W, H, seed, scale_k):
+    """GSR_CULL_EMPTY_TILES: shorter instance lists, the same image and the same gradients bit for bit (the last case is a
+    one-tile image: a tile sort of zero passes, where the flag must be ignored)."""
+    cl = small_scene(P, W, H, seed, scale_k=scale_k)
+    kept, listed = parity.check_cull_empty_tiles(emu_lib_path, CPU, cl, cl.cameras[0], np.array([0.2, 0.5, 0.1], np.float32), seed=seed)
+    print(f"instances listed {listed} -> {kept}")
+    assert kept < listed or W * H <= 256
