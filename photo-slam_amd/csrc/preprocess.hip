@@ -113,8 +113,6 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 				c3[3] = M10 * M10 + M11 * M11 + M12 * M12;
 				c3[4] = M20 * M10 + M21 * M11 + M22 * M12;
 				c3[5] = M20 * M20 + M21 * M21 + M22 * M22;
-#pragma unroll
-				for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c3[i];
 			}
 
 			// computeCov2D, forward.cu:74-113
@@ -165,6 +163,12 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			const int rmaxy = min(p.grid_y, max(0, f2i((piy + mr + TILE - 1) / TILE)));
 			const uint32_t tiles = (uint32_t)(rmaxy - rminy) * (uint32_t)(rmaxx - rminx);
 			if (tiles == 0) break;
+			// (written only now: the backward pass reads the covariance of VISIBLE Gaussians only, and a third of the Gaussians in
+			// front of the camera end here with no tile -- 24 bytes each that nobody would read)
+			if (p.cov3D_precomp == nullptr) {
+#pragma unroll
+				for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c3[i];
+			}
 			depth_key = __float_as_uint(vz);
 			radius_i = mr;
 			my_tiles = tiles;
