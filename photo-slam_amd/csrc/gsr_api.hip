@@ -420,8 +420,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// per-Gaussian kernels, as until r03_r).  Round 2 measured the two placements equal; since the fused SH step keeps its
 	// parameter rows in LDS (16 instead of 24 waves per CU) it is the one that suffers from a neighbour: same box, C3 1.660 ->
 	// 1.637 ms, a C5 view 1.768 -> 1.738 (the blend pays 5-13 us, the per-Gaussian stage gains 30-40).
-	const char* slice_env = getenv("GSR_LAZY_SLICE_EARLY");
-	const bool slice_early = !(slice_env && slice_env[0] == '0');
+	static const bool slice_early = [] { const char* e = getenv("GSR_LAZY_SLICE_EARLY"); return !(e && e[0] == '0'); }();
 	if (lazy && slice_early && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
