@@ -193,8 +193,11 @@ def build_link_consumer(force=False):
     sys.path.insert(0, os.path.join(root, "photo-slam_amd", "host"))
     import build_host
     src = os.path.join(root, "tests", "ref_link", "consumer.cpp")
-    libs = {"emu": build_host.build("emu"), "hip": build_host.build("hip")}
-    deps = [src, hdr, os.path.join(REF, "include", "rasterize_points.h"), __file__] + list(libs.values())
+    build_host.build("emu")
+    build_host.build("hip")
+    # the boundary libraries (the reference's `cuda_rasterizer` / `simple_knn` by name) + this repository's GaussianRasterizer
+    libs = {k: list(build_host.outputs(k).values()) for k in ("emu", "hip")}
+    deps = [src, hdr, os.path.join(REF, "include", "rasterize_points.h"), __file__] + libs["emu"] + libs["hip"]
     if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in LINK_OUT.values()):
         return have
     text = open(hdr).read()
@@ -207,17 +210,123 @@ def build_link_consumer(force=False):
     libdir = os.path.join(base, "lib")
     try:
         for kind, out in LINK_OUT.items():
-            lib = libs[kind]
             extra = ["-ltorch_hip", "-lc10_hip"] if kind == "hip" else []
+            dirs = sorted({os.path.dirname(l) for l in libs[kind]})
             # GEN first: "gaussian_rasterizer.h" resolves to the generated copy, "rasterize_points.h" to the reference's own file
             subprocess.check_call(["g++", "-std=c++17", "-O1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
                                    "-I" + GEN, "-I" + os.path.join(REF, "include")] + ["-I" + i for i in inc] +
-                                  [src, "-o", out, "-L" + os.path.dirname(lib), "-l" + os.path.basename(lib)[3:-3], "-L" + libdir,
-                                   "-ltorch", "-ltorch_cpu", "-lc10"] + extra +
-                                  ["-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--no-as-needed"])
+                                  [src, "-o", out] + ["-L" + d for d in dirs] + ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
+                                  ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + extra +
+                                  ["-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in dirs] + ["-Wl,--no-as-needed"])
     finally:
         shutil.rmtree(GEN, ignore_errors=True)
     return dict(LINK_OUT)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's HOST code, unchanged, on this repository's kernels.
+
+HOST_OUT = {"emu": os.path.join(OUT_DIR, "libref_host_emu.so"), "hip": os.path.join(OUT_DIR, "libref_host_hip.so")}
+# compiled VERBATIM (the files themselves, through a tree of symbolic links -- no copy, no rewrite)
+HOST_SOURCES = ["gaussian_rasterizer.cpp", "gaussian_renderer.cpp", "gaussian_trainer.cpp", "gaussian_parameters.cpp"]
+HOST_HEADERS_REF = ["gaussian_renderer.h", "gaussian_rasterizer.h", "rasterize_points.h", "operate_points.h", "loss_utils.h",
+                    "sh_utils.h", "general_utils.h", "gaussian_parameters.h", "types.h"]
+# OUR stand-ins for the four headers that need Sophus / Eigen / OpenCV / ORB-SLAM3 (oracle/ref_host/)
+HOST_HEADERS_STANDIN = ["gaussian_model.h", "gaussian_keyframe.h", "gaussian_scene.h", "gaussian_trainer.h"]
+# every member function oracle/ref_host/gaussian_model.h declares, extracted verbatim by name from src/gaussian_model.cpp
+HOST_MODEL_FUNCTIONS = ["getScalingActivation", "getRotationActivation", "getXYZ", "getFeatures", "getOpacityActivation",
+                        "getCovarianceActivation", "oneUpShDegree", "setShDegree", "increasePcd", "scaledTransformationPostfix",
+                        "scaledTransformVisiblePointsOfKeyframe", "trainingSetup", "updateLearningRate", "setPositionLearningRate",
+                        "setFeatureLearningRate", "setOpacityLearningRate", "setScalingLearningRate", "setRotationLearningRate",
+                        "resetOpacity", "replaceTensorToOptimizer", "prunePoints", "densificationPostfix", "densifyAndSplit",
+                        "densifyAndClone", "densifyAndPrune", "addDensificationStats", "loadPly", "savePly", "percentDense",
+                        "setPercentDense", "exponLrFunc"]
+
+
+def build_host_tree(force=False):
+    """oracle/_ref/libref_host_{emu,hip}.so: the reference's src/gaussian_rasterizer.cpp, src/gaussian_renderer.cpp,
+    src/gaussian_trainer.cpp and src/gaussian_parameters.cpp compiled VERBATIM -- `g++ -c` on the files themselves, reached
+    through a tree of symbolic links in which only gaussian_model.h / gaussian_keyframe.h / gaussian_scene.h /
+    gaussian_trainer.h resolve to the stand-ins of oracle/ref_host/ -- together with the member functions of GaussianModel
+    extracted by name from src/gaussian_model.cpp (no rewrite: host/include/compat/ supplies the two LibTorch drifts) and
+    the glue of oracle/ref_host.cpp.  `hip`: linked against photo-slam_amd/lib/libcuda_rasterizer.so + libsimple_knn.so (the
+    CMake targets named like the reference's) and nothing else of this repository; `emu`: against
+    tests/emu/libcuda_rasterizer_emu.so with oracle/ref_host/emu_device.h force-included.
+    Returns {"emu": path, "hip": path} (None where absent)."""
+    have = {k: (v if os.path.exists(v) else None) for k, v in HOST_OUT.items()}
+    if not os.path.exists(MODEL_SRC):
+        return have
+    import shutil
+    import torch
+    root = os.path.dirname(HERE)
+    host_dir = os.path.join(root, "photo-slam_amd", "host")
+    sys.path.insert(0, host_dir)
+    import build_host
+    build_host.build("emu")
+    build_host.build("hip")
+    libs = {"emu": [build_host.outputs("emu")["cuda_rasterizer"]],
+            "hip": [build_host.outputs("hip")["cuda_rasterizer"], build_host.outputs("hip")["simple_knn"]]}
+    glue = os.path.join(HERE, "ref_host.cpp")
+    standin = os.path.join(HERE, "ref_host")
+    compat = os.path.join(host_dir, "include", "compat")
+    deps = [glue, MODEL_SRC, __file__] + [os.path.join(standin, f) for f in os.listdir(standin)] + \
+        [os.path.join(REF, "src", f) for f in HOST_SOURCES] + [os.path.join(REF, "include", f) for f in HOST_HEADERS_REF] + \
+        [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs] + libs["emu"] + libs["hip"]
+    if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in HOST_OUT.values()):
+        return have
+    tree = os.path.join(GEN, "hosttree")
+    shutil.rmtree(tree, ignore_errors=True)
+    os.makedirs(os.path.join(tree, "include"))
+    os.makedirs(os.path.join(tree, "src"))
+    for f in HOST_HEADERS_REF:
+        os.symlink(os.path.join(REF, "include", f), os.path.join(tree, "include", f))
+    for f in HOST_HEADERS_STANDIN:
+        os.symlink(os.path.join(standin, f), os.path.join(tree, "include", f))
+    for f in HOST_SOURCES:
+        os.symlink(os.path.join(REF, "src", f), os.path.join(tree, "src", f))
+    os.symlink(os.path.join(REF, "third_party"), os.path.join(tree, "third_party"))
+    text = open(MODEL_SRC).read()
+    body = "\n\n".join(_member_function(text, n) for n in HOST_MODEL_FUNCTIONS)
+    assert body.count(ADAM_KEY) == 6, "the Adam state key idiom changed in the reference"
+    with open(os.path.join(GEN, "ref_gaussian_model_functions.inc"), "w") as f:
+        f.write(f'#line 1 "{MODEL_SRC} (extract)"\n' + body + "\n")
+    base = os.path.dirname(torch.__file__)
+    torch_inc = ["-I" + os.path.join(base, "include"), "-I" + os.path.join(base, "include", "torch", "csrc", "api", "include")]
+    libdir = os.path.join(base, "lib")
+    common = ["g++", "-std=c++17", "-O2", "-fPIC", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w"]
+    flavour = {
+        # the reference's sources with NO prefix and no definitions beyond what any ROCm LibTorch consumer sets
+        "hip": dict(flags=["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-I" + compat, "-I" + tree, "-I" + os.path.join(tree, "include")] +
+                    torch_inc + ["-I/opt/rocm/include"],
+                    glue_flags=["-include", os.path.join(compat, "optimizer_key.h")],
+                    link=["-ltorch_hip", "-lc10_hip"]),
+        "emu": dict(flags=["-DREF_HOST_EMU=1", "-include", os.path.join(standin, "emu_device.h"), "-I" + tree,
+                           "-I" + os.path.join(tree, "include")] + torch_inc,
+                    glue_flags=["-include", os.path.join(compat, "optimizer_key.h")], link=[]),
+    }
+    try:
+        for kind, out in HOST_OUT.items():
+            fl = flavour[kind]
+            odir = os.path.join(GEN, "obj_" + kind)
+            os.makedirs(odir, exist_ok=True)
+            procs, objs = [], []
+            for f in HOST_SOURCES:
+                o = os.path.join(odir, f + ".o")
+                procs.append(subprocess.Popen(common + fl["flags"] + ["-c", os.path.join(tree, "src", f), "-o", o]))
+                objs.append(o)
+            o = os.path.join(odir, "ref_host.cpp.o")
+            procs.append(subprocess.Popen(common + fl["flags"] + fl["glue_flags"] + ["-I" + GEN, "-c", glue, "-o", o]))
+            objs.append(o)
+            if any(p.wait() != 0 for p in procs):
+                raise RuntimeError(f"the reference's host sources did not compile ({kind})")
+            link_dirs = sorted({os.path.dirname(l) for l in libs[kind]})
+            subprocess.check_call(["g++", "-shared", "-o", out] + objs + ["-L" + d for d in link_dirs] +
+                                  ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
+                                  ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + fl["link"] +
+                                  ["-Wl,--no-undefined", "-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in link_dirs])
+    finally:
+        shutil.rmtree(GEN, ignore_errors=True)
+    return dict(HOST_OUT)
 
 
 if __name__ == "__main__":
@@ -226,3 +335,4 @@ if __name__ == "__main__":
     print(build_loss(force="--force" in sys.argv))
     print(build_densify(force="--force" in sys.argv))
     print(build_link_consumer(force="--force" in sys.argv))
+    print(build_host_tree(force="--force" in sys.argv))

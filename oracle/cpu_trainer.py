@@ -228,11 +228,13 @@ def reference_reset_opacity(model, kind="cpu"):
 
 def train_sequence(cloud, cams, gt_images, iterations, densification_interval=0, densify_from_iter=0, opacity_reset_interval=0,
                    densify_until_iter=15000, densify_grad_threshold=0.0002, min_opacity=0.005, lambda_dssim=0.2, seed=0,
-                   kind="cpu", threads=None, on_iteration=None):
+                   kind="cpu", threads=None, on_iteration=None, keyframe_order=None, step_on_last_iteration=True):
     """trainingOnce's loop (src/gaussian_trainer.cpp:45-133) over the keyframes cams[(it - 1) % len(cams)], it = 1..iterations,
     with the reference's own densifyAndPrune / resetOpacity on the schedule of :108-127.  Returns dict(losses, points per
     iteration, densified_at, reset_at, model).  The split samples come from the default generator of `kind`'s device,
-    seeded once with `seed` (the hosts under test seed a generator of their own identically)."""
+    seeded once with `seed` (the hosts under test seed a generator of their own identically).
+    keyframe_order: the keyframe index of every iteration instead of the cycle (trainingOnce draws it with std::rand, :59);
+    step_on_last_iteration=False: trainingOnce's `if (iteration < opt.iterations_)` around the optimizer step (:129)."""
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
     oracle.build()
@@ -245,7 +247,7 @@ def train_sequence(cloud, cams, gt_images, iterations, densification_interval=0,
     losses, points, densified_at, reset_at = [], [], [], []
     for it in range(1, iterations + 1):
         model.update_learning_rate(it)
-        k = (it - 1) % len(cams)
+        k = keyframe_order[it - 1] if keyframe_order is not None else (it - 1) % len(cams)
         image, viewspace, visibility, radii = render(model, cams[k], bg)
         loss = (1.0 - lambda_dssim) * l1_loss(image, gts[k]) + lambda_dssim * (1.0 - ssim(image, gts[k]))
         loss.backward()
@@ -262,8 +264,9 @@ def train_sequence(cloud, cams, gt_images, iterations, densification_interval=0,
                 if opacity_reset_interval and it % opacity_reset_interval == 0:
                     reference_reset_opacity(model, kind)
                     reset_at.append(it)
-            model.optimizer.step()          # leaves without a gradient (fresh ones) are skipped, their step counters rest
-            model.optimizer.zero_grad(set_to_none=True)
+            if step_on_last_iteration or it < iterations:
+                model.optimizer.step()      # leaves without a gradient (fresh ones) are skipped, their step counters rest
+                model.optimizer.zero_grad(set_to_none=True)
             points.append(int(model.xyz.shape[0]))
         if on_iteration is not None:
             on_iteration(it, model, losses[-1])

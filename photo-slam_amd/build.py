@@ -1,78 +1,84 @@
-"""Builds libgsr_hip.so (the C-ABI product library) for gfx950 with hipcc, in-tree.
+"""Builds libgsr_hip.so (the C-ABI product library) for gfx950, in-tree, by driving the repository's CMakeLists.txt -- the ONE
+description of sources and flags (HIP language of CMake = clang++ -x hip --offload-arch=gfx950, what hipcc runs).
 
-  python photo-slam_amd/build.py [--force]
+  python photo-slam_amd/build.py [--force] [-v]
 
-hipcc cross-compiles without a GPU.  Translation units whose results must be bit-comparable
-with the CPU oracle (tile rectangles, kNN distances) are compiled with -ffp-contract=off; the
-blend kernels keep the default fast contraction (FMA).  -munsafe-fp-atomics selects the
-hardware global_atomic_add_f32 / ds_add_f32 instead of CAS loops.
+hipcc / clang cross-compile without a GPU.  Translation units whose results must be bit-comparable with the CPU oracle (tile
+rectangles, kNN distances) are compiled with -ffp-contract=off; the blend kernels keep the default fast contraction (FMA).
+-munsafe-fp-atomics selects the hardware global_atomic_add_f32 / ds_add_f32 instead of CAS loops; -fno-slp-vectorize: see
+CMakeLists.txt.  Experiment switches: GSR_EXTRA_FLAGS="-DGSR_EXP_..." (also "-save-temps=obj" for the ISA: the .s files land
+next to the objects under build/cmake/CMakeFiles/gsr_hip.dir/).
+
+On a box where the libraries arrive prebuilt (the GPU boxes: the snapshot carries the in-tree .so files) nothing is
+configured or compiled: an up-to-date output is returned as it is.
 """
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgsr_hip.so")
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ARCH = "gfx950"
-# (source, extra flags)
-SOURCES = [
-    ("gsr_api.hip", []),
-    ("preprocess.hip", ["-ffp-contract=off"]),
-    ("preprocess_bwd.hip", ["-ffp-contract=off"]),
-    ("knn.hip", ["-ffp-contract=off"]),
-    ("points.hip", ["-ffp-contract=off"]),
-    ("densify.hip", ["-ffp-contract=off"]),
-    ("sort.hip", []),
-    ("binning.hip", []),
-    ("blend_fwd.hip", []),
-    ("blend_bwd.hip", []),
-    ("train_ops.hip", []),
-]
-# -fno-slp-vectorize everywhere: on gfx950 the SLP vectoriser's v_pk_*_f32 pairings cost more issue cycles than the two plain
-# instructions they replace (pk_fma 5.6 against 2 x 2.5 for v_fmac, profiles/r02_a_valu_rate.json) AND need v_mov_b32s to
-# pair their operands (loss_fwd: 298 pk_fma + 254 mov instead of 625 v_fmac); measured per kernel at C3: blend_fwd 221 -> 210 us,
-# blend_bwd 592 -> 578 us, loss 134 -> 126 us (tools/gpu_r2m.sh).  The packed adds of the backward blend's butterfly are
-# written by hand (blend.h) and stay.
-COMMON = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-fno-slp-vectorize",
-          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+BUILD_DIR = os.path.join(ROOT, "build", "cmake")
+CMAKE_LISTS = os.path.join(ROOT, "CMakeLists.txt")
 
 
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    d += [os.path.join(HERE, "..", "include", "gsr.h"), os.path.abspath(__file__)]   # the flags live in this file
+    d += [os.path.join(ROOT, "include", "gsr.h"), CMAKE_LISTS]   # the flags live in CMakeLists.txt
     return d
 
 
-def build(force=False, verbose=False, save_temps=False):
-    extra_env = os.environ.get("GSR_EXTRA_FLAGS", "").split()   # experiment switches (-DGSR_EXP_...)
+def up_to_date(outputs, deps):
+    return all(os.path.exists(o) for o in outputs) and \
+        all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in outputs)
+
+
+def cmake_build(targets, verbose=False, extra_flags="", force=False):
+    """Configure (once, or when the experiment flags change) and build `targets` of the root CMakeLists.txt with Ninja.
+    `force`: the targets' objects are dropped first (ninja decides by mtime, like up_to_date() above)."""
+    import shutil
+    import torch
+    if force:
+        for t in targets:
+            shutil.rmtree(os.path.join(BUILD_DIR, "CMakeFiles", t + ".dir"), ignore_errors=True)
+    prefix = torch.utils.cmake_prefix_path + ";/opt/rocm"
+    cache = os.path.join(BUILD_DIR, "CMakeCache.txt")
+    configured_flags = None
+    if os.path.exists(cache):
+        for line in open(cache):
+            if line.startswith("GSR_EXTRA_FLAGS:"):
+                configured_flags = line.split("=", 1)[1].rstrip("\n")
+    quiet = None if verbose else subprocess.DEVNULL
+    if configured_flags != extra_flags or not os.path.exists(os.path.join(BUILD_DIR, "build.ninja")) or \
+            os.path.getmtime(CMAKE_LISTS) > os.path.getmtime(os.path.join(BUILD_DIR, "build.ninja")):
+        subprocess.check_call(["cmake", "-S", ROOT, "-B", BUILD_DIR, "-G", "Ninja", "-DCMAKE_PREFIX_PATH=" + prefix,
+                               "-DGSR_EXTRA_FLAGS=" + extra_flags], stdout=quiet, stderr=quiet)
+    cmd = ["cmake", "--build", BUILD_DIR, "--target"] + list(targets)
+    if verbose:
+        cmd += ["--verbose"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("cmake --build failed for " + " ".join(targets))
+
+
+def build(force=False, verbose=False):
+    extra = " ".join(os.environ.get("GSR_EXTRA_FLAGS", "").split())   # experiment switches (-DGSR_EXP_...)
     stamp = OUT + ".flags"   # a library built with experiment switches must never be mistaken for the product build
     built_with = open(stamp).read() if os.path.exists(stamp) else ""
-    if " ".join(extra_env) != built_with:
+    if extra != built_with:
         force = True
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in _deps()):
+    if not force and up_to_date([OUT], _deps()):
         return OUT
-    bdir = os.path.join(HERE, "build")
-    os.makedirs(bdir, exist_ok=True)
-    procs, objs = [], []
-    for src, extra in SOURCES:
-        o = os.path.join(bdir, src + ".o")
-        cmd = [HIPCC] + COMMON + extra + extra_env + ["-c", os.path.join(CSRC, src), "-o", o]
-        if save_temps:
-            cmd += ["-save-temps=obj"]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((subprocess.Popen(cmd, cwd=bdir), cmd))
-        objs.append(o)
-    for p, cmd in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs)
+    cmake_build(["gsr_hip"], verbose=verbose, extra_flags=extra, force=force)
+    os.utime(OUT)   # ninja leaves an up-to-date library alone; the mtime check above must see this build
     with open(stamp, "w") as f:
-        f.write(" ".join(extra_env))
+        f.write(extra)
     return OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, save_temps="--save-temps" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -9,8 +9,16 @@
 //
 //   auto key = optim_key(param);                  // instead of c10::guts::to_string(param.unsafeGetTensorImpl())
 //
-// and compile against either generation.  Nothing on the rasterizer side of the boundary changes.  (oracle/build_ref.py does
-// exactly this rewrite when it compiles the reference's own functions as the checker: ADAM_KEY.)
+// and compile against either generation.  Nothing on the rasterizer side of the boundary changes.
+//
+// ZERO-EDIT FORM.  All six occurrences have the shape  `auto key = c10::guts::to_string(impl); ... state[key] / find(key) /
+// erase(key); key = c10::guts::to_string(impl2);`  -- the key's type is never spelled.  On a LibTorch whose state map is keyed
+// by pointer this header therefore also supplies the missing  c10::guts::to_string(c10::TensorImpl*)  as an overload that
+// returns the pointer itself (next to `using std::to_string`, c10/util/string_utils.h, which has no pointer overload): with
+//     target_compile_options(gaussian_mapper PRIVATE -include compat/optimizer_key.h)
+// src/gaussian_model.cpp compiles UNCHANGED.  oracle/build_ref.py compiles the reference's own member functions exactly so
+// (no rewrite), as the checker of this repository's densification and as the model of the drop-in train step
+// (tests/test_reference_host.py).
 #pragma once
 #include <torch/torch.h>
 
@@ -33,3 +41,12 @@ inline Key optim_key(const at::Tensor& param)
 }  // namespace photoslam_compat
 
 using photoslam_compat::optim_key;
+
+namespace c10 { namespace guts {
+// only where the state map is NOT keyed by std::string (LibTorch >= 2.2); older LibTorch has its own c10::guts::to_string
+template <typename Key = photoslam_compat::optim_key_t, std::enable_if_t<!std::is_same_v<Key, std::string>, int> = 0>
+inline Key to_string(c10::TensorImpl* impl)
+{
+	return static_cast<Key>(impl);
+}
+}}  // namespace c10::guts

@@ -1,8 +1,7 @@
-// rasterize_points.cpp -- the torch <-> kernel boundary (replaces src/rasterize_points.cu:28-214 and
-// third_party/simple-knn/spatial.cu:15-26 of the reference) on top of the C-ABI of libgsr_hip.so.
+// rasterize_points.cpp -- the torch <-> kernel boundary (replaces src/rasterize_points.cu:28-214 of the reference;
+// third_party/simple-knn/spatial.cu:15-26 is spatial.cpp) on top of the C-ABI of libgsr_hip.so.
 // LibTorch supplies device memory and the current stream only.
 #include "rasterize_points.h"
-#include "spatial.h"
 
 #include <string>
 
@@ -480,17 +479,4 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
 		      "markVisible");
 	}
 	return present;
-}
-
-torch::Tensor distCUDA2(const torch::Tensor& points)
-{
-	const int P = static_cast<int>(points.size(0));
-	torch::Tensor means = torch::zeros({P}, points.options().dtype(torch::kFloat32));
-	if (P != 0) {
-		F32 pts(points);
-		torch::Tensor scratch = torch::empty({0}, points.options().dtype(torch::kByte));
-		check(gsr_knn_mean_dist2(P, pts.ptr, means.data_ptr<float>(), resize_tensor, &scratch, current_stream(points)),
-		      "distCUDA2");
-	}
-	return means;
 }
