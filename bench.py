@@ -44,6 +44,44 @@ PMC_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROO
                    reverse=True)
 
 
+SQ_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters_full.json"))), reverse=True)
+ISSUE_COST_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_blend_issue_cost.json"))),
+                          reverse=True)
+
+
+def stage_bounds(stages, top=6):
+    """What bounds each of the `top` largest stages, so that the claim rides in this record and not only in DESIGN.md:
+      * the two blend kernels: "valu-issue" -- SIMD cycles available per wave-VALU instruction issued (SQ counters of the newest
+        committed profile of this program: GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / SQ_INSTS_VALU) against the mean issue cost of
+        the visit loop's instruction mix (tools/isa_cost.py on the compiler's ISA, weighted with tools/valu_rate.hip's measured
+        cycles per instruction class); utilisation = cost / available.  Read from committed files, not measured in this run;
+      * the streaming stages: "hbm" with achieved = algorithmic bytes / stage time of THIS run against the 8 TB/s peak;
+      * the sorts and scans: "launch-latency" (6-12 launches of 5-20 us each) with the same achieved figure for reference."""
+    sq = json.load(open(os.path.join(ROOT, SQ_FILES[0]))) if SQ_FILES else {}
+    cost = json.load(open(os.path.join(ROOT, ISSUE_COST_FILES[0]))) if ISSUE_COST_FILES else {}
+    out = {}
+    for k in sorted(stages, key=lambda k: -stages[k]["ms"])[:top]:
+        st = stages[k]
+        frac = round(st["GBps"] / HBM_PEAK_GBS, 4) if st.get("GBps") else None
+        if k in ("blend_fwd", "blend_bwd"):
+            c = sq.get(f"gsr::{k}_kernel")
+            e = {"bound": "valu-issue", "ms": st["ms"], "hbm_frac_of_algorithmic_bytes": frac}
+            if c and c.get("SQ_INSTS_VALU"):
+                avail = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / c["SQ_INSTS_VALU"]
+                e["simd_cycles_per_valu_instruction"] = round(avail, 3)
+                e["sq_counters_source"] = SQ_FILES[0]
+                if k in cost:
+                    e["issue_cost_of_the_instruction_mix"] = cost[k]["mean_cycles_per_valu"]
+                    e["valu_issue_utilisation"] = round(cost[k]["mean_cycles_per_valu"] / avail, 3)
+                    e["issue_cost_source"] = f"{ISSUE_COST_FILES[0]} ({cost.get('cost_source', '')})"
+            out[k] = e
+        elif k in ("depth_sort", "tile_sort", "offset_scan"):
+            out[k] = {"bound": "launch-latency", "ms": st["ms"], "hbm_frac_of_algorithmic_bytes": frac}
+        else:
+            out[k] = {"bound": "hbm", "ms": st["ms"], "achieved_GBps": st.get("GBps"), "frac_of_8TBps": frac}
+    return out
+
+
 def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
                       touched_slots=None, lazy_window=0, fused_geom_adam=False):
     """Compulsory HBM bytes per stage (each array read/written once per stage that needs it), restated for
@@ -125,6 +163,105 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False, want_inputs=False):
     return out
 
 
+def dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, steps, stationary=True):
+    """What a maintainer gets from the API-only swap: the REFERENCE's own host code -- src/gaussian_trainer.cpp:45-133 calling
+    src/gaussian_renderer.cpp / src/gaussian_rasterizer.cpp, ATen activations, cat(dc.clone(), rest.clone()), include/loss_utils.h
+    through autograd (MIOpen convolutions), torch::optim::Adam, addDensificationStats -- compiled UNCHANGED
+    (oracle/build_ref.py: build_host_tree -> oracle/_ref/libref_host_hip.so, prebuilt: the reference tree does not exist on the
+    GPU box) and linked against lib/libcuda_rasterizer.so + lib/libsimple_knn.so only.  Same cloud, same keyframe, same ground
+    truth as `value`; a baseline beside it, never `value`.  Every iteration ends in torch::cuda::synchronize() + loss.item() as
+    the reference's loop does (:86,92), so wall-clock differences are step times: two calls of GaussianTrainer::trainingOnce
+    with n and n + steps iterations, (t2 - t1) / steps."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_host_hip.so")
+    if not os.path.exists(path):
+        return {"skipped": "oracle/_ref/libref_host_hip.so was never built (python __graft_entry__.py where /root/reference exists)"}
+    torch.ops.load_library(path)
+    rops = torch.ops.photoslam_reference_host
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    h = rops.create([t(cl.xyz), t(cl.features_dc), t(cl.features_rest), t(cl.opacity), t(cl.scaling), t(cl.rotation)], 3, 3,
+                    float(cl.extent), float(cl.extent))
+    rops.add_keyframe(h, 0, kf.world_view_transform_, kf.full_proj_transform_, kf.camera_center_, fovx, fovy, H, W, gt)
+    never = 1.0e9
+    opts = {"densify_from_iter": never, "opacity_reset_interval": never}    # statistics every iteration, no densification
+    if stationary:
+        opts.update({k: 0.0 for k in ("position_lr_init", "position_lr_final", "feature_lr", "opacity_lr", "scaling_lr", "rotation_lr")})
+    n0 = 6
+    try:
+        opts["iterations"] = float(n0)
+        rops.training_once(h, opts, 0)          # warm-up: MIOpen picks its kernels, the allocator fills
+        t1 = rops.training_once(h, opts, 0)
+        opts["iterations"] = float(n0 + steps)
+        t2 = rops.training_once(h, opts, 0)
+        log = rops.log(h)
+        peak = torch.cuda.max_memory_allocated(dev)
+    finally:
+        rops.destroy(h)
+        torch.cuda.empty_cache()
+    ms = (t2 - t1) / steps * 1e3
+    import re
+    ema = [float(m) for m in re.findall(r"ema_loss:([-\d.]+)", log)]
+    return {"steps": steps, "ms_per_step": round(ms, 3), "iters_per_s": round(1e3 / ms, 3),
+            "learning_rates": "0 (stationary, like `value`)" if stationary else "training",
+            "method": f"GaussianTrainer::trainingOnce with {n0} and {n0 + steps} iterations after a warm-up call; "
+                      f"({round(t2, 4)} s - {round(t1, 4)} s) / {steps}",
+            "ema_loss_last": ema[-1] if ema else None, "peak_allocated_MB": int(peak // 2**20),
+            "host_code": "the reference's src/gaussian_trainer.cpp, gaussian_renderer.cpp, gaussian_rasterizer.cpp, loss_utils.h, "
+                         "GaussianModel members -- compiled unchanged (oracle/_ref/libref_host_hip.so)",
+            "kernels": "lib/libcuda_rasterizer.so -> libgsr_hip.so through the reference's own signatures (no raw_params, no fused "
+                       "loss / Adam / statistics: the reference contract)"}
+
+
+def multi_gpu_preflight(torch, dist, backend, dev, world, rank, local_rank):
+    """Fail LOUDLY, before any timed work, when the node cannot run one rank per GPU over RCCL: device count, process-group
+    initialisation, one tiny all-gather and one tiny all-reduce whose results are checked on every rank (the first contact of
+    this program with a multi-GPU node is the driver's scaling run: a hang or a silent wrong answer there costs the round's
+    only curve).  Returns a dict for the JSON line."""
+    n_dev = torch.cuda.device_count()
+    shared = os.environ.get("GSR_BENCH_SHARE_GPU") == "1"
+    if world > 1 and not shared and n_dev <= local_rank:
+        raise SystemExit(f"bench.py preflight: rank {rank} (local rank {local_rank}) has no GPU: {n_dev} device(s) visible, "
+                         f"{world} ranks requested (one rank per GPU)")
+    t0 = time.perf_counter()
+    try:
+        import datetime
+        kw = dict(timeout=datetime.timedelta(seconds=180))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+    except Exception as e:
+        raise SystemExit(f"bench.py preflight: init_process_group({backend}) failed on rank {rank}: {e!r} "
+                         f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, "
+                         f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})")
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    mine = torch.full((4,), float(rank + 1), device=cdev)
+    gathered = torch.empty(world * 4, device=cdev)
+    dist.all_gather_into_tensor(gathered, mine)
+    want = torch.arange(1, world + 1, device=cdev, dtype=torch.float32).repeat_interleave(4)
+    if not torch.equal(gathered, want):
+        raise SystemExit(f"bench.py preflight: all-gather over {backend} returned {gathered.tolist()} on rank {rank}, wanted {want.tolist()}")
+    total = mine.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    if not torch.equal(total, torch.full((4,), world * (world + 1) / 2.0, device=cdev)):
+        raise SystemExit(f"bench.py preflight: all-reduce over {backend} returned {total.tolist()} on rank {rank}")
+    if cdev.type == "cuda":
+        torch.cuda.synchronize()
+    return {"devices_visible": n_dev, "ranks": world, "backend": backend, "all_gather_ok": True, "all_reduce_ok": True,
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
+def replica_checksum(torch, dist, tensors, dev, backend):
+    """Bit-level agreement of the replicas after the timed steps: every parameter tensor as int32 words summed in int64 (wraps:
+    a hash, not a norm) -- MIN and MAX over the ranks must agree."""
+    h = torch.stack([t.detach().contiguous().view(torch.int32).to(torch.int64).sum() for t in tensors])
+    if backend != "nccl":
+        h = h.cpu()
+    lo, hi = h.clone(), h.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi)), [int(x) for x in h.cpu()]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +296,10 @@ def main():
                     help="densify_run leg: GaussianModel::increasePcd of 5 k new points every N steps (0 = only the five timed calls "
                          "after the leg)")
     ap.add_argument("--no-knn-leg", dest="knn_leg", action="store_false", help="skip the simple-knn leg (100 k and 1 M points)")
+    ap.add_argument("--dropin-steps", type=int, default=20,
+                    help="steps of the dropin_unfused leg: the reference's own host code on these kernels (0 = skip)")
+    ap.add_argument("--dropin-only", action="store_true", help="run only the dropin_unfused leg (profiling)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic scene (SURVEY.md 8d: 0 for reported numbers, 1-4 for variance)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -203,14 +344,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        preflight = multi_gpu_preflight(torch, dist, backend, dev, world, rank, local_rank)
     lib = capi.load()  # raises if libgsr_hip.so is missing
 
     cfg = scene.CONFIGS[args.config]
-    cl = scene.make_config(args.config, seed=0, n_views=max(world, 1), P=args.points)
+    cl = scene.make_config(args.config, seed=args.seed, n_views=max(world, 1), P=args.points)
     if args.scene_order == "morton":
         # the same cloud, re-indexed along a Z-order curve (10 bits per axis)
         q = ((cl.xyz - cl.xyz.min(0)) / (np.ptp(cl.xyz, axis=0) + 1e-9) * 1023.0).astype(np.uint64)
@@ -229,13 +367,20 @@ def main():
     g.trainingSetup(opt)
     kf = GaussianKeyframe.from_camera(cam, dev)
     bg = torch.zeros(3, device=dev)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank + 1000 * args.seed)
     pipe = GaussianPipelineParams()
     # Ground truth = this view of the initial model + low-pass noise: a converged scene under refinement.
     noise = torch.nn.functional.avg_pool2d(torch.rand(3, H, W, generator=gen).unsqueeze(0), 5, 1, 2).squeeze(0).to(dev)
     with torch.no_grad():
         gt = (GaussianRenderer.render(kf, H, W, g, pipe, bg)[0] + 0.1 * (noise - 0.5)).clamp_(0.0, 1.0)
     mask = torch.ones(3, H, W, device=dev)
+    import math
+    fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+    if args.dropin_only:
+        print(json.dumps({"dropin_unfused": dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, max(args.dropin_steps, 1),
+                                                                stationary=not args.training_lr),
+                          "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H}}), flush=True)
+        return
     if args.densify_interval:
         opt.densification_interval_, opt.densify_from_iter_ = args.densify_interval, 0
     ts = TrainStep(g, opt, pipe, bg, world_size=world, cameras_extent=cl.extent,
@@ -250,8 +395,6 @@ def main():
         ops = torch.ops.photoslam_amd
         handle = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
                                     g.rotation_.detach(), 3, float(cl.extent), bg)
-        import math
-        fovx, fovy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
         ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window),
                                          "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
         # GSR_BENCH_PY_EXCHANGE=1: the collectives issued from Python around the C++ pieces (the round-2 arrangement, kept for
@@ -431,7 +574,7 @@ def main():
     # changes from step to step, so rows of the lazily stepped SH tensor keep becoming visible and catch up in the forward pass
     views_run = None
     if stationary and not args.raster_only and not dp and ops is not None:
-        cams4 = scene.make_config(args.config, seed=0, n_views=4, P=args.points).cameras
+        cams4 = scene.make_config(args.config, seed=args.seed, n_views=4, P=args.points).cameras
         kfs4 = [GaussianKeyframe.from_camera(c, dev) for c in cams4]
         n4 = max(args.steps, 40)
         for i in range(8):
@@ -451,12 +594,47 @@ def main():
 
     # ---- the same K steps with the training learning rates (the drifting synthetic workload), for the record
     train_run = None
+    replicas_identical = param_hash = None
     if stationary and not args.raster_only:
         set_lr_scale(1.0)
         el2, _ = timed(args.steps)
+        if dp and ops is not None:
+            # the replicas after steps that MOVED the parameters (the stationary legs cannot tell replicas apart)
+            replicas_identical, param_hash = replica_checksum(torch, dist, ops.trainer_params(handle), dev, backend)
         train_run = {"steps": args.steps, "ms_per_step": round(el2 / args.steps * 1e3, 3),
                      "iters_per_s": round(world * args.steps / el2, 3),
                      "note": "training learning rates from the same start: the synthetic scene inflates ~1 %/step (DESIGN.md section 7)"}
+
+    # ---- 100 steps with the training learning rates from a FRESH model (the drift makes "the first K steps" depend on K: this
+    # leg fixes K = 100 whatever --steps is), the C++ host's fused program
+    train_run_100 = None
+    if stationary and not args.raster_only and not dp and ops is not None and args.densify_leg_steps > 0:
+        g3 = GaussianModel.from_cloud(cl, device=dev)
+        h3 = ops.trainer_create(g3.xyz_.detach(), g3.features_.detach(), g3.opacity_.detach(), g3.scaling_.detach(),
+                                g3.rotation_.detach(), 3, float(cl.extent), bg)
+        del g3
+        ops.trainer_set_options(h3, {"lazy_sh_adam_window": float(args.sh_adam_window),
+                                     "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
+        def step3():
+            read_loss_deferred(ops.trainer_render_and_backward(h3, kf.world_view_transform_, kf.full_proj_transform_, kf.camera_center_,
+                                                               fovx, fovy, H, W, gt, mask))
+            ops.trainer_finish(h3)
+        for _ in range(args.warmup):
+            step3()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            step3()
+        barrier()
+        el3 = time.perf_counter() - t0
+        ops.trainer_destroy(h3)
+        train_run_100 = {"steps": 100, "warmup": args.warmup, "ms_per_step": round(el3 / 100 * 1e3, 3), "iters_per_s": round(100 / el3, 3),
+                         "note": "training learning rates, fresh model, 100 timed steps (no densification)"}
+
+    # ---- the reference's own host code on these kernels: what the API-only swap delivers (never `value`)
+    dropin_run = None
+    if rank == 0 and world == 1 and not dp and not args.raster_only and args.dropin_steps > 0:
+        dropin_run = dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, args.dropin_steps)
 
     # ---- BASELINE config C3 as stated ("with densify/prune + simple-knn"): the same program with the training learning rates and
     # densifyAndPrune every 100 steps (the reference's densification_interval_), on a fresh model; every step timed by its own
@@ -647,11 +825,26 @@ def main():
             out["changing_views_run"] = views_run
         if train_run:
             out["training_lr_run"] = train_run
+        if train_run_100:
+            out["training_lr_run_100"] = train_run_100
         if densify_run:
             out["densify_run"] = densify_run
+        if dropin_run:
+            out["dropin_unfused"] = dropin_run
+        # BASELINE.json's configuration AS STATED (C3 "with densify/prune") and the non-stationary figures, lifted next to `value`
+        # (`value` itself is the stationary leg: lr x 0, one fixed view, lazy rows in steady state -- the most favourable one)
+        out["stated_config"] = {
+            "value_is": "stationary leg (learning rates x 0, one fixed view)",
+            "densify_every_100_training_lr_iters_per_s": densify_run["iters_per_s"] if densify_run else None,
+            "training_lr_100_steps_iters_per_s": train_run_100["iters_per_s"] if train_run_100 else None,
+            "changing_views_iters_per_s": views_run["iters_per_s"] if views_run else None,
+            "reference_host_code_on_these_kernels_iters_per_s": dropin_run.get("iters_per_s") if dropin_run else None}
         if knn_run:
             out["knn"] = knn_run
         if dp:
+            out["preflight"] = preflight
+            out["replicas_identical"] = replicas_identical
+            out["replica_parameter_hash_rank0"] = param_hash
             out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                            "collectives_issued_by": "python (trainer.py classes)" if (ops is None or py_exchange) else
                                                     "the C++ host (host/src/keyframe_batch_exchange.cpp on c10d::ProcessGroup)",
@@ -683,7 +876,11 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "traffic_source": traffic_src and f"{traffic_src} (rocprofv3 --pmc of the same build; not measured in this run)",
-                               "raster_fwd_bwd_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               # the rasterizer alone (SH Adam as a separate pass: rasterizer bytes / rasterizer time); the fused
+                               # program's figure -- whose backward also carries the optimizer's bytes -- under its own key
+                               "raster_fwd_bwd_frac": out.get("rasterizer_only", {}).get("hbm_frac"),
+                               "fused_step_stage_bytes_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "bounds": stage_bounds(stages),
                                "stage_table_source": "median of 20 further steps of the SAME program with HIP events between all "
                                                      "stages (preprocess_bwd carries the fused Adam step of the SH tensor when "
                                                      "config.sh_adam_fused_into_backward); the dominant kernel's entry is its mean "

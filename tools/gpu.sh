@@ -16,6 +16,9 @@
 #   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
 #   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
 #   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
+#   dropin       bench.py --dropin-only: the reference's own host code (oracle/_ref/libref_host_hip.so) on these kernels, 20 steps at C3
+#   dropinstats  rocprofv3 --kernel-trace --stats of that leg -> kernel_stats_dropin_unfused_C3.csv
+#   seeds        benchq for scene seeds 0..4 -> seed_spread_C3.json (seeds 1-4 for variance)
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
 #   env:VAR=VAL  export VAR=VAL for the steps behind it (A/B runs; bench outputs get a _VAR_VAL suffix)
 TAG=${1:-r03_x}; shift
@@ -138,7 +141,9 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"]["kernel"], d["roofline"]["frac"], "raster frac", d["roofline"]["raster_fwd_bwd_frac"])
 print("stages", {k: v["ms"] for k, v in d["roofline"]["stages"].items()})
-for k in ("densify_run", "knn", "changing_views_run", "training_lr_run"):
+print("stated_config", json.dumps(d.get("stated_config")))
+print("dropin_unfused", json.dumps({k: v for k, v in d.get("dropin_unfused", {}).items() if k in ("ms_per_step", "iters_per_s", "method", "skipped", "peak_allocated_MB")}))
+for k in ("densify_run", "knn", "changing_views_run", "training_lr_run", "training_lr_run_100"):
     if k in d: print(k, json.dumps(d[k])[:600])
 cb = d.get("cpu_baseline", {})
 print("cpu", cb.get("value"), json.dumps(cb.get("runs", {}).get("C1", {}).get("gpu_fused_step_same_sequence")))
@@ -166,6 +171,24 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
 import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
             done ;;
     dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
+    dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
+    dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
+    seeds)  for sd in 0 1 2 3 4; do timeout 300 python bench.py --seed $sd --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_C3_seed$sd.json 2>>$OUT/bench_err.log; done
+            python - $OUT <<'PY'
+import json, sys, statistics as st
+out = {"runs": []}
+for sd in range(5):
+    d = json.load(open(f"{sys.argv[1]}/benchq_C3_seed{sd}.json"))
+    out["runs"].append({"seed": sd, "iters_per_s": d["value"], "ms_per_step": d["ms_per_step"], "median_ms_per_step": d["protocol"]["median_ms_per_step"],
+                        "visible": d["config"]["visible"], "instances": d["config"]["instances"],
+                        "raster_fwd_bwd_ms": d.get("rasterizer_only", {}).get("fwd_bwd_ms"), "blend_bwd_ms": d["roofline"]["stages"]["blend_bwd"]["ms"]})
+v = [r["iters_per_s"] for r in out["runs"]]
+out["iters_per_s_mean"], out["iters_per_s_stdev"], out["iters_per_s_min"], out["iters_per_s_max"] = round(st.mean(v), 2), round(st.stdev(v), 2), min(v), max(v)
+out["note"] = "bench.py --seed S (scene.make_config seed and the ground-truth noise): one box, one session; seed 0 is the reported number"
+json.dump(out, open(f"{sys.argv[1]}/seed_spread_C3.json", "w"), indent=1)
+print(json.dumps(out)[:900])
+PY
+            ;;
     env)    export "$arg"; SUF="${SUF}_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; echo "exported $arg" ;;   # env:VAR=VALUE for the steps behind it (A/B runs)
     py)     timeout 900 python tools/$arg > $OUT/${arg%.py}.log 2>&1; tail -30 $OUT/${arg%.py}.log | cut -c1-300 ;;
     *)      echo "unknown step $step" ;;
