@@ -215,9 +215,11 @@ def build_link_consumer(force=False):
             # GEN first: "gaussian_rasterizer.h" resolves to the generated copy, "rasterize_points.h" to the reference's own file
             subprocess.check_call(["g++", "-std=c++17", "-O1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
                                    "-I" + GEN, "-I" + os.path.join(REF, "include")] + ["-I" + i for i in inc] +
-                                  [src, "-o", out] + ["-L" + d for d in dirs] + ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
-                                  ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + extra +
-                                  ["-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in dirs] + ["-Wl,--no-as-needed"])
+                                  # LibTorch FIRST: a pip wheel's bundled ROCm runtime (torch/lib/libamdhip64.so, SONAME
+                                  # libamdhip64.so.7) then satisfies libgsr_hip.so's request for libamdhip64.so.7 -- one runtime
+                                  ["-Wl,--no-as-needed", src, "-o", out, "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + extra +
+                                  ["-L" + d for d in dirs] + ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
+                                  ["-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in dirs])
     finally:
         shutil.rmtree(GEN, ignore_errors=True)
     return dict(LINK_OUT)
@@ -323,7 +325,8 @@ def build_host_tree(force=False):
             subprocess.check_call(["g++", "-shared", "-o", out] + objs + ["-L" + d for d in link_dirs] +
                                   ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
                                   ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + fl["link"] +
-                                  ["-Wl,--no-undefined", "-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in link_dirs])
+                                  # --wrap=rand: the reference loop's std::rand() draws from the harness (oracle/ref_host.cpp)
+                                  ["-Wl,--no-undefined", "-Wl,--wrap=rand", "-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in link_dirs])
     finally:
         shutil.rmtree(GEN, ignore_errors=True)
     return dict(HOST_OUT)

@@ -247,7 +247,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
-	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
+	                            g.sort_scratch, stream, &kres, &vres, g.visible, g.sort_gsum0)) != GSR_OK)
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);

@@ -27,7 +27,10 @@ def test_scan(emu_lib_path, n, inclusive):
 
 
 @pytest.mark.parametrize("n,begin,end", [(1, 0, 8), (100, 0, 8), (4096, 0, 16), (4097, 0, 13), (9000, 0, 32),
-                                         (5000, 3, 9), (12345, 0, 5)])
+                                         (5000, 3, 9), (12345, 0, 5),
+                                         # > 32 blocks of 2048: several block GROUPS of the two-level prefix (sort.hip), the last one
+                                         # partial, one pass with fewer than 8 bits
+                                         (150_001, 0, 13)])
 def test_radix_sort_stable(emu_lib_path, n, begin, end):
     rng = np.random.default_rng(n + end)
     keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)

@@ -16,7 +16,6 @@ CMakeLists.txt builds under the names Photo-SLAM's gaussian_mapper links.
 
 On the host: the emulator build of the kernels at toy size.  On the GPU (-m gpu): BASELINE config C1 (50 k Gaussians @ 640x480)
 on the HIP kernels."""
-import ctypes
 import math
 import os
 import re
@@ -45,12 +44,11 @@ def _ops(kind):
     return (torch.ops.photoslam_reference_host_emu if kind == "emu" else torch.ops.photoslam_reference_host), path
 
 
-def _keyframe_order(n_keyframes, iterations, seed):
-    """src/gaussian_trainer.cpp:59: std::rand() / ((RAND_MAX + 1u) / size) after std::srand(seed) (oracle/ref_host.cpp seeds it)"""
-    libc = ctypes.CDLL(None)
-    libc.srand(ctypes.c_uint(seed))
+def _keyframe_order(draws, n_keyframes):
+    """src/gaussian_trainer.cpp:59: std::rand() / ((RAND_MAX + 1u) / size); `draws` = the values the loop's std::rand() returns
+    (oracle/ref_host.cpp: the library's own generator behind -Wl,--wrap=rand -- libc's is advanced by other libraries too)"""
     rand_max = 2147483647
-    return [libc.rand() // ((rand_max + 1) // n_keyframes) for _ in range(iterations)]
+    return [int(d) // ((rand_max + 1) // n_keyframes) for d in draws]
 
 
 def _session(ops, cl, dev, gts):
@@ -119,7 +117,7 @@ def run_training_once(ops, dev, cl, kind, note=""):
     h, cams = _session(ops, cl, dev, None)
     ops.destroy(h)
     gts = _ground_truth(oracle, cl, cams)
-    order = _keyframe_order(n_views, ITERATIONS, RAND_SEED)
+    order = _keyframe_order(ops.rand_preview(RAND_SEED, ITERATIONS), n_views)
     assert len(set(order)) > 1, "the random keyframe sequence visits one keyframe only: pick another RAND_SEED"
     cl_ref = scene.Cloud(cl.xyz, cl.features_dc, cl.features_rest, cl.scaling, cl.rotation, cl.opacity, cams, cl.extent)
     # the threshold that clones / splits a few per cent of the Gaussians at the fifth iteration of THIS scene
@@ -141,6 +139,7 @@ def run_training_once(ops, dev, cl, kind, note=""):
         seconds = ops.training_once(h, opts, RAND_SEED)
         log = ops.log(h)
         dump = ops.dump(h)
+        assert _keyframe_order(ops.rand_trace(), n_views) == order, "the loop drew other keyframes than the preview said"
     finally:
         ops.destroy(h)
     losses = _losses_from_log(log)

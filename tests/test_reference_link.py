@@ -41,6 +41,19 @@ def test_reference_declarations_link_and_run_on_the_gpu(oracle):
     _check_against_oracle(_run(_consumer("hip"), "cuda"), oracle, "hip-gfx950")
 
 
+def test_hip_consumer_loads_one_rocm_runtime_and_fails_loudly_without_a_device():
+    """The executable linked against lib/libcuda_rasterizer.so + lib/libsimple_knn.so + libphotoslam_host.so must come up with ONE
+    ROCm stack (round 4: CMake's ${TORCH_LIBRARIES} pulled the system's MIOpen / hipBLAS next to the wheel's bundled copies and the
+    process died inside library initialisation) and, on a box without a GPU, stop at the first HIP call with the library's own
+    message -- no CPU fallback, no segmentation fault."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the gpu-marked twin runs the consumer for real")
+    p = subprocess.run([_consumer("hip")], capture_output=True, text=True)
+    assert p.returncode == -6, (p.returncode, p.stderr[-400:])      # std::terminate on the uncaught std::runtime_error
+    assert "HIP runtime error" in p.stderr and "no ROCm-capable device" in p.stderr, p.stderr[-400:]
+
+
 def test_library_exports_the_reference_symbols():
     """the mangled names an object compiled against the reference headers asks for"""
     import sys

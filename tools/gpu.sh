@@ -73,7 +73,7 @@ pmc_pass() {  # $1 = mode (raster|full) -> $OUT/pmc_traffic_<mode>.json
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
     (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
-        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg > /tmp/pmc_$c.log 2>&1)
+        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 > /tmp/pmc_$c.log 2>&1)
   done
   python - "$OUT/pmc_traffic_$mode.json" <<'PY'
 import csv, glob, collections, json, sys
@@ -104,7 +104,7 @@ sq_pass() {  # $1 = mode (raster|full) -> $OUT/sq_counters_<mode>.json
   for set in "${sets[@]}"; do
     rm -rf /tmp/sq_$i
     (cd /tmp && timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$i -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
-        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg > /tmp/sq_$i.log 2>&1)
+        $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 > /tmp/sq_$i.log 2>&1)
     i=$((i+1))
   done
   python - "$OUT/sq_counters_$mode.json" <<'PY'
@@ -149,14 +149,14 @@ cb = d.get("cpu_baseline", {})
 print("cpu", cb.get("value"), json.dumps(cb.get("runs", {}).get("C1", {}).get("gpu_fused_step_same_sequence")))
 PY
             ;;
-    bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg$SUF.json 2>$OUT/bench_err.log
+    bench)  cfg=${arg:-C3}; timeout 500 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --dropin-steps 0 $( [ $cfg = C3 ] || echo --densify-leg-steps 0 ) > $OUT/bench_full_$cfg$SUF.json 2>$OUT/bench_err.log
             python -c "
 import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
-    benchq) cfg=${arg:-C3}; timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/benchq_$cfg$SUF.json 2>$OUT/bench_err.log   # quick A/B form: no densify leg
+    benchq) cfg=${arg:-C3}; timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_$cfg$SUF.json 2>$OUT/bench_err.log   # quick A/B form: no densify leg
             python -c "
 import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
-    kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg ;;
+    kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
     pmc)    pmc_pass ${arg:-raster} ;;
     sq)     sq_pass ${arg:-full} ;;
