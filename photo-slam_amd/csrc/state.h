@@ -47,10 +47,11 @@ static inline size_t scan_scratch_elems(int n) { return (size_t)scan_blocks(n) +
 // Radix sort bookkeeping (sort.hip): the blocks' digit counts hist[blocks][RADIX_BINS] and, per group of SORT_GROUP blocks,
 // their sums gsum[groups][RADIX_BINS] -- two group tables, alternating between the passes.
 constexpr int SORT_GROUP = 32;
-static inline size_t sort_gsum_elems(int n) { return (size_t)RADIX_BINS * div_up(sort_blocks(n), SORT_GROUP); }
+// (+ 32: the ticket of the histogram kernel's last-block pattern lives behind the table)
+static inline size_t sort_gsum_elems(int n) { return (size_t)RADIX_BINS * div_up(sort_blocks(n), SORT_GROUP) + 32; }
 static inline size_t sort_scratch_elems(int n)
 {
-	return (size_t)RADIX_BINS * sort_blocks(n) + 2 * sort_gsum_elems(n) + 64;
+	return (size_t)RADIX_BINS * sort_blocks(n) + 2 * sort_gsum_elems(n) + (RADIX_BINS + 32) + 64;   // + the digits' bases
 }
 
 // The 48-byte per-Gaussian record the blend kernels gather (3 x float4):

@@ -191,6 +191,7 @@ static inline float wave_writelane_f32(float old, float uniform_value, int dst_l
 }  // namespace hipemu
 
 static inline void __syncthreads() { hipemu::syncthreads(); }
+static inline void __threadfence() {}   // (blocks run one after another here: every store is visible to the next block)
 
 template <typename T>
 static inline T atomicAdd(T* p, T v)

@@ -78,7 +78,79 @@ def compute():
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# tests/golden/reference_C1.npz: the reference's sources on BASELINE config C1 (50 k Gaussians @ 640x480, seed 0) -- the size at
+# which the paths the small cases cannot reach meet the reference ITSELF: tile lists longer than one 256-entry batch (303),
+# 258 Gaussians with more than 64 tiles (the long-run sums of the backward pass), 212 730 instances = 104 radix-sort blocks
+# in four block groups.  The inputs are NOT stored (12 MB): they are regenerated from the seed and checked against a digest.
+# Stored: every integer output exactly, the image and final T at every second row (+ per-row sums of all rows), the gradients
+# at the visible Gaussians (the others must be exactly zero), the SH gradient for every fourth visible Gaussian in full and as
+# per-row L1 norms for all of them.
+
+
+def c1_inputs():
+    cl = scene.make_config("C1", seed=0)
+    cam = cl.cameras[0]
+    rng = np.random.default_rng(100)
+    return dict(bg=np.array([0.1, 0.2, 0.3], np.float32), xyz=cl.xyz, opacity=cl.get_opacity(), features=cl.get_features(),
+                scaling=cl.get_scaling(), rotation=cl.get_rotation(), viewmatrix=cam.viewmatrix, projmatrix=cam.projmatrix,
+                campos=cam.campos, tanfov=np.array([cam.tanfovx, cam.tanfovy], np.float32),
+                size=np.array([cam.W, cam.H, 3], np.int32), dpix=rng.standard_normal((3, cam.H, cam.W)).astype(np.float32))
+
+
+def inputs_digest(d):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(d):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(d[k]).tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+C1_GRADS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations")
+
+
+def reduce_c1(r_fields, grads):
+    """The stored form of one result (a dict of FIELDS + the gradient dict): see the header of this section."""
+    out = {}
+    vis = r_fields["radii"] > 0
+    for k in ("radii", "tiles_touched", "point_list", "n_contrib"):
+        out[k] = r_fields[k]
+    out["ranges"] = r_fields["ranges"].reshape(-1, 2)
+    out["tile_ids"] = (r_fields["keys_sorted"] >> np.uint64(32)).astype(np.uint32)
+    out["depth_bits"] = r_fields["depths"].view(np.uint32)[vis]
+    out["clamped"] = np.packbits(r_fields["clamped"].reshape(-1, 3)[vis].astype(bool))
+    for k in ("means2D", "conic_opacity", "rgb", "cov3D"):
+        out[k] = r_fields[k][vis]
+    for k in ("out_color", "final_T"):
+        a = r_fields[k]
+        img = a.reshape(-1, a.shape[-2], a.shape[-1])
+        out[k + "_even_rows"] = img[:, ::2]
+        out[k + "_row_sums"] = img.astype(np.float64).sum(-1)
+    for k in C1_GRADS:
+        g = grads[k].reshape(grads[k].shape[0], -1)
+        assert not g[~vis].any(), k          # culled Gaussians: exactly zero
+        out[k] = g[vis]
+    sh = grads["dL_dsh"].reshape(vis.shape[0], -1)
+    assert not sh[~vis].any()
+    out["dL_dsh_every_4th"] = sh[vis][::4]
+    out["dL_dsh_row_l1"] = np.abs(sh[vis].astype(np.float64)).sum(1)
+    return out
+
+
+def compute_c1():
+    d = c1_inputs()
+    r = run_reference(d)
+    out = reduce_c1({k: getattr(r, k) for k in FIELDS}, r.grads)
+    out["inputs_sha256"] = inputs_digest(d)
+    return out
+
+
 if __name__ == "__main__":
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_small.npz")
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "reference_small.npz")
     np.savez_compressed(path, **compute())
-    print("written", os.path.getsize(path), "bytes")
+    print("written", path, os.path.getsize(path), "bytes")
+    path = os.path.join(here, "reference_C1.npz")
+    np.savez_compressed(path, **compute_c1())
+    print("written", path, os.path.getsize(path), "bytes")

@@ -185,7 +185,9 @@ def _check_backend_against_fixture(lib_path, dev, oracle, name):
         if precomp and k in ("dL_dsh", "dL_dscales", "dL_drotations"):
             continue
         a, b = np.asarray(r.grads[k], np.float64).ravel(), np.asarray(want[k], np.float64).ravel()
-        assert np.abs(a - b).sum() <= 2e-4 * (np.abs(b).sum() + 1e-30), k
+        # north_star: gradients within 1e-4 relative L1 of the reference's (measured: <= 2.1e-6 here, the reference summing with
+        # float atomics in thread order)
+        assert np.abs(a - b).sum() <= 1e-4 * (np.abs(b).sum() + 1e-30), (k, np.abs(a - b).sum() / (np.abs(b).sum() + 1e-30))
 
 
 @pytest.mark.gpu
@@ -199,6 +201,92 @@ def test_hip_matches_the_reference_fixture(oracle, name):
 def test_emulated_hip_kernels_match_the_reference_fixture(emu_lib_path, oracle, name):
     import torch
     _check_backend_against_fixture(emu_lib_path, torch.device("cpu"), oracle, name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The mid-size fixture tests/golden/reference_C1.npz (make_reference_golden.py: compute_c1): the reference's own sources on
+# BASELINE config C1 -- multi-batch tile lists, Gaussians with more than 64 tiles, a radix sort over four block groups.
+FIXTURE_C1 = os.path.join(HERE, "golden", "reference_C1.npz")
+
+
+def _c1():
+    import make_reference_golden as mg
+    want = np.load(FIXTURE_C1)
+    d = mg.c1_inputs()
+    assert np.array_equal(mg.inputs_digest(d), want["inputs_sha256"]), \
+        "scene.make_config('C1', seed=0) no longer generates the cloud the fixture was made from (numpy generator change?)"
+    return mg, d, want
+
+
+def _rel_l1(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.abs(a - b).sum() / (np.abs(b).sum() + 1e-30))
+
+
+@needs_reference
+def test_reference_C1_fixture_is_current():
+    mg, d, want = _c1()
+    got = mg.compute_c1()
+    assert sorted(want.files) == sorted(got.keys())
+    for k in want.files:
+        assert np.array_equal(want[k], got[k]), k
+
+
+def test_oracle_matches_the_reference_C1_fixture(oracle):
+    """the oracle at 50 k Gaussians @ 640x480 against the reference's outputs: forward bit for bit, gradients to 1e-5"""
+    mg, d, want = _c1()
+    res, color, radii, grads = _oracle_run(oracle, d)
+    fields = {k: getattr(res, k) for k in ("tiles_touched", "point_list", "n_contrib", "ranges", "keys_sorted", "depths", "clamped",
+                                            "means2D", "conic_opacity", "rgb", "cov3D", "final_T")}
+    fields.update(radii=radii, out_color=color)
+    got = mg.reduce_c1(fields, grads)
+    for k in want.files:
+        if k == "inputs_sha256":
+            continue
+        if k.startswith("dL_"):
+            # (per-row L1 norms: sums of 48 magnitudes in double, the rows themselves to 1e-5)
+            assert _rel_l1(got[k], want[k]) <= 1e-5, (k, _rel_l1(got[k], want[k]))
+        elif k.endswith("_row_sums"):
+            assert np.allclose(got[k], want[k], rtol=0, atol=1e-9), k
+        else:
+            assert np.array_equal(got[k], want[k]), k          # integers AND forward floats: bit for bit
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_reference_C1_fixture(oracle):
+    """the HIP kernels on the MI355X against the reference's outputs at C1, no oracle in between (except the flags of pixels
+    whose skip / terminate decision lies inside exp() rounding noise): integers exact, per-Gaussian floats bit for bit, image
+    1e-4 mean abs, every gradient 1e-4 relative L1"""
+    import torch
+    mg, d, want = _c1()
+    cl, cam = _Cloud(d), _Camera(d)
+    r = parity.run_backend(None, torch.device("cuda", 0), cl, cam, d["bg"], sh_degree=3, dL_dpix=d["dpix"])
+    vis = want["radii"] > 0
+    assert np.array_equal(r.radii, want["radii"]) and np.array_equal(r.tiles_touched, want["tiles_touched"])
+    assert np.array_equal(r.depth_key[vis], want["depth_bits"]) and (r.depth_key[~vis] == 0xFFFFFFFF).all()
+    rec = r.rec[vis]
+    assert np.array_equal(rec[:, 0:2], want["means2D"]) and np.array_equal(rec[:, 2:6], want["conic_opacity"])
+    assert np.array_equal(rec[:, 6:9], want["rgb"]) and np.array_equal(r.cov3D[vis], want["cov3D"])
+    assert r.R == want["point_list"].shape[0] and np.array_equal(r.point_list, want["point_list"])
+    assert np.array_equal(r.tile_keys, want["tile_ids"]) and np.array_equal(r.ranges, want["ranges"])
+    assert int((want["ranges"][:, 1] - want["ranges"][:, 0]).max()) > 256 and int((want["tiles_touched"] > 64).sum()) > 100
+    ores, _, _, _ = _oracle_run(oracle, d)
+    solid = ores.fragile.reshape(cam.H, cam.W) == 0
+    assert solid.mean() > 0.99
+    assert np.array_equal(r.n_contrib[solid], want["n_contrib"].reshape(cam.H, cam.W)[solid])
+    assert np.abs(r.out_color[:, ::2] - want["out_color_even_rows"]).mean() <= 1e-4
+    assert np.abs(r.out_color.astype(np.float64).sum(-1) - want["out_color_row_sums"]).max() <= 1e-4 * cam.W
+    assert np.abs(r.final_T[::2] - want["final_T_even_rows"][0]).max() <= 1e-5
+    worst = {}
+    for k in mg.C1_GRADS:
+        g = r.grads[k].reshape(vis.shape[0], -1)
+        assert not g[~vis].any(), k
+        worst[k] = _rel_l1(g[vis], want[k])
+    sh = r.grads["dL_dsh"].reshape(vis.shape[0], -1)
+    assert not sh[~vis].any()
+    worst["dL_dsh"] = max(_rel_l1(sh[vis][::4], want["dL_dsh_every_4th"]), _rel_l1(np.abs(sh[vis].astype(np.float64)).sum(1), want["dL_dsh_row_l1"]))
+    assert max(worst.values()) <= 1e-4, worst
+    print("HIP vs the reference's sources at C1, relative L1 per gradient:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
 needs_reference_loss = pytest.mark.skipif(not os.path.exists("/root/reference/include/loss_utils.h") and
