@@ -75,6 +75,16 @@ typedef struct gsr_sh_adam {
 	                                            formed in double as torch does (0.999f instead of 0.999 is 1e-5 of the step) */
 	int step;                    /* >= 1: the step being taken (bias correction) */
 	const gsr_sh_adam_lazy* lazy; /* NULL = eager: every row takes the step in gsr_backward */
+	/* Where the optimizer work that gsr_forward / gsr_backward fork next to their own kernels runs.  Zero in every field = the
+	 * measured-best arrangement on MI355X (DESIGN.md sections 5, 9.1) -- a zero-initialised struct is the fast one.  None of
+	 * them changes a result.  The environment variables named here OVERRIDE the fields when set (A/B handles of the bench
+	 * sessions); a process that never sets them is governed by the fields alone. */
+	int no_side_stream;          /* 1: no second stream at all -- the lazy rows' slice and the culled rows of the eager step run on
+	                                the caller's stream (GSR_SH_ADAM_SIDE_STREAM=0 / 1) */
+	int lazy_slice_late;         /* 1: this step's slice of the lazy rows is forked behind the backward blend instead of next to it
+	                                (GSR_LAZY_SLICE_EARLY=0 / 1; measured: next to the blend C3 1.625 -> 1.613 ms) */
+	int side_blocks;             /* eager mode: workgroups of the culled rows' kernel on the second stream; 0 = 256 (measured best
+	                                of 64 / 256 / 1024 / 2048; GSR_SH_ADAM_SIDE_BLOCKS) */
 } gsr_sh_adam;
 
 /* Extension: optimizer-in-backward for the four per-Gaussian geometry tensors (see gsr_backward_args.geom_adam).  One entry per

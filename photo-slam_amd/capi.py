@@ -44,7 +44,9 @@ class ShAdamLazy(C.Structure):
 
 class ShAdam(C.Structure):
     _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_double), ("lr_tail", C.c_double),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int), ("lazy", C.POINTER(ShAdamLazy))]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int), ("lazy", C.POINTER(ShAdamLazy)),
+                # scheduling switches, 0 = the measured-best arrangement (include/gsr.h)
+                ("no_side_stream", C.c_int), ("lazy_slice_late", C.c_int), ("side_blocks", C.c_int)]
 
 
 def make_sh_adam(sh, d):
@@ -52,7 +54,8 @@ def make_sh_adam(sh, d):
     lazy mode (gsr_sh_adam_lazy) -- row_step (int32 [P]), window, lr_past / lr_tail_past (most recent step first).  Returns
     (struct, objects to keep alive)."""
     adam = ShAdam(sh.data_ptr(), d["exp_avg"].data_ptr(), d["exp_avg_sq"].data_ptr(), float(d["lr"]), float(d["lr_tail"]),
-                  float(d["beta1"]), float(d["beta2"]), float(d["eps"]), int(d["step"]), None)
+                  float(d["beta1"]), float(d["beta2"]), float(d["eps"]), int(d["step"]), None,
+                  int(d.get("no_side_stream", 0)), int(d.get("lazy_slice_late", 0)), int(d.get("side_blocks", 0)))
     keep = [adam]
     if d.get("row_step") is not None:
         z = ShAdamLazy()

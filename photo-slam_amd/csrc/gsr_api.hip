@@ -62,11 +62,28 @@ struct HostSync {
 	}
 };
 static thread_local HostSync t_sync;
-// GSR_SH_ADAM_SIDE_STREAM=0: no second stream (A/B timing, debugging)
-static bool side_stream_enabled()
+// Scheduling switches live in the caller's struct (gsr_sh_adam: no_side_stream, lazy_slice_late, side_blocks; zero = the
+// measured-best arrangement).  The environment variable of a switch, when SET, overrides the field -- the A/B handle of the
+// bench sessions; read once per process.
+static int env_int(const char* name, int unset)
 {
-	static const bool on = [] { const char* e = getenv("GSR_SH_ADAM_SIDE_STREAM"); return !(e && e[0] == '0'); }();
-	return on;
+	const char* e = getenv(name);
+	return (e && *e) ? atoi(e) : unset;
+}
+static bool side_stream_enabled(const gsr_sh_adam* o)
+{
+	static const int env = env_int("GSR_SH_ADAM_SIDE_STREAM", -1);
+	return env >= 0 ? env != 0 : !(o && o->no_side_stream);
+}
+static bool lazy_slice_early(const gsr_sh_adam* o)
+{
+	static const int env = env_int("GSR_LAZY_SLICE_EARLY", -1);
+	return env >= 0 ? env != 0 : !(o && o->lazy_slice_late);
+}
+static int side_blocks(const gsr_sh_adam* o)
+{
+	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
+	return env >= 0 ? env : (o && o->side_blocks > 0 ? o->side_blocks : 256);
 }
 
 // Optional per-stage HIP-event timing (gsr_profile_*): events are recorded on the caller's
@@ -247,7 +264,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
-	                            g.sort_scratch, stream, &kres, &vres, g.visible, g.sort_gsum0)) != GSR_OK)
+	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);
@@ -322,6 +339,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	if (a->dL_dcolor_view && !a->shs) return GSR_ERR_INVALID_ARG;
 	if (a->scales && (!a->dL_dscale || !a->dL_drot) && !a->geom_adam) return GSR_ERR_INVALID_ARG;
 	if (a->R > 0 && !a->binning_buffer) return GSR_ERR_INVALID_ARG;
+	// (a stream cannot be made to wait for an event of its own future: refused HERE, before anything is enqueued and before the
+	// lazy rows' catch-up has advanced a step counter)
+	if (a->color_view_ready_stream && a->dL_dcolor_view && a->color_view_ready_stream == stream_) return GSR_ERR_INVALID_ARG;
 	hipStream_t stream = (hipStream_t)stream_;
 	const int P = a->P, W = a->width, H = a->height, R = a->R;
 	const int grid_x = div_up(W, TILE), grid_y = div_up(H, TILE), tiles = grid_x * grid_y;
@@ -392,7 +412,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	auto launch_lazy_slice = [&]() -> int {
 		const int* radii = pre_slice ? nullptr : (a->radii ? a->radii : g.radii);
 		const int mode = pre_slice ? 3 : 0;
-		if (!side_stream_enabled()) return launch_sh_adam_lazy(P, radii, la, stream, mode);
+		if (!side_stream_enabled(a->sh_adam)) return launch_sh_adam_lazy(P, radii, la, stream, mode);
 		int s2 = t_sync.init_side();
 		if (s2 != GSR_OK) return s2;
 		GSR_HIP(hipEventRecord(t_sync.fork, stream));
@@ -405,22 +425,22 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	};
 	if (lazy) {
 		// (forked next to the backward blend, below)
-	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled()) {
+	} else if (a->sh_adam && a->M == 16 && a->D >= 0 && a->D <= 3 && side_stream_enabled(a->sh_adam)) {
 		const gsr_sh_adam& o = *a->sh_adam;
 		if ((st = t_sync.init_side()) != GSR_OK) return st;
 		const RowAdam ra = {o.param, o.exp_avg, o.exp_avg_sq, adam_scalars(o.lr, o.lr_tail, o.beta1, o.beta2, o.eps, o.step)};
 		GSR_HIP(hipEventRecord(t_sync.fork, stream));
 		GSR_HIP(hipStreamWaitEvent(t_sync.side, t_sync.fork, 0));
-		st = launch_sh_adam_culled(P, a->radii ? a->radii : g.radii, ra, t_sync.side);
+		st = launch_sh_adam_culled(P, a->radii ? a->radii : g.radii, ra, t_sync.side, side_blocks(a->sh_adam));
 		GSR_HIP(hipEventRecord(t_sync.join, t_sync.side));
 		side_busy = true;
 		if (st != GSR_OK) return fail(st);
 	}
-	// The lazy rows' slice is forked HERE, next to the backward blend (GSR_LAZY_SLICE_EARLY=0: behind the blend, next to the
+	// The lazy rows' slice is forked HERE, next to the backward blend (gsr_sh_adam.lazy_slice_late: behind the blend, next to the
 	// per-Gaussian kernels, as until r03_r).  Round 2 measured the two placements equal; since the fused SH step keeps its
 	// parameter rows in LDS (16 instead of 24 waves per CU) it is the one that suffers from a neighbour: same box, C3 1.660 ->
 	// 1.637 ms, a C5 view 1.768 -> 1.738 (the blend pays 5-13 us, the per-Gaussian stage gains 30-40).
-	static const bool slice_early = [] { const char* e = getenv("GSR_LAZY_SLICE_EARLY"); return !(e && e[0] == '0'); }();
+	const bool slice_early = lazy_slice_early(a->sh_adam);
 	if (lazy && slice_early && (st = launch_lazy_slice()) != GSR_OK) return fail(st);
 	PROF_BWD(0);
 	// per-instance gradient slots of the blend backward (48 B/instance, inside the binning buffer);
@@ -478,7 +498,6 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.geom = geom;
 	pb.notify_stream = nullptr; pb.notify_event = nullptr;
 	if (a->color_view_ready_stream && a->dL_dcolor_view) {
-		if (a->color_view_ready_stream == stream_) return fail(GSR_ERR_INVALID_ARG);
 		if ((st = t_sync.init_notify()) != GSR_OK) return fail(st);
 		pb.notify_stream = a->color_view_ready_stream;
 		pb.notify_event = (void*)t_sync.notify;

@@ -187,7 +187,7 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
                               float* dL_dsh, const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy = nullptr);
 
 // this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
-int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream);
+int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream, int max_blocks);
 
 // lazy mode: the zero-gradient steps rows are behind (preprocess_bwd.hip: sh_adam_lazy_kernel).  mode 0: this step's slice,
 // rows with radii <= 0, up to a.step (the fused backward); 1: every row of every block (gsr_sh_adam_flush); 2: this step's slice,

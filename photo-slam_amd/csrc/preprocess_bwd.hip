@@ -547,13 +547,13 @@ sh_adam_culled_kernel(int P, const int* __restrict__ radii, const RowAdam a)
 		sh_adam_culled_item(t, radii, a);
 }
 
-int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream)
+int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream, int max_blocks)
 {
 	if (P <= 0) return GSR_OK;
 	if ((reinterpret_cast<uintptr_t>(adam.param) | reinterpret_cast<uintptr_t>(adam.exp_avg) | reinterpret_cast<uintptr_t>(adam.exp_avg_sq)) & 15)
 		return GSR_ERR_UNSUPPORTED;
 	const long long items = (long long)P * ROW_F4;
-	static const int max_blocks = [] { const char* e = getenv("GSR_SH_ADAM_SIDE_BLOCKS"); return e ? atoi(e) : 256; }();   // measured at C3: 256 blocks 1.927 ms / step, 1024: 1.954, 2048: 2.075, no side stream: 2.004
+	// max_blocks (gsr_sh_adam.side_blocks; default 256) -- measured at C3: 256 blocks 1.927 ms / step, 1024: 1.954, 2048: 2.075, no side stream: 2.004
 	long long blocks = (items + 255) / 256;
 	if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
 	GSR_LAUNCH(sh_adam_culled_kernel, (int)blocks, 256, stream, P, radii, adam);

@@ -139,42 +139,25 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 }
 
 // ------------------------------------------------------------------ radix sort
-// Pass structure (per digit of up to 8 bits): histogram -> scatter -- TWO launches (round 3: three; round 1: five).
-// Block b always owns elements [b*SORT_CHUNK, (b+1)*SORT_CHUNK); wave w of the block owns the SORT_ITEMS_PER_WAVE-element
-// sub-range starting at w*SORT_ITEMS_PER_WAVE and walks it in rounds of 64 lane-consecutive elements, so the original order
-// inside a digit is (wave, round, lane).
-//
-// Where block b's elements of digit d go = (elements with a smaller digit) + (elements of digit d in the blocks before b).
-// Until round 3 a kernel of its own scanned every digit's row of a [bin][block] table between the two launches
-// (radix_row_prefix: 5.8 us per pass for 1 MB of table -- a launch slot, not work).  Now the blocks form GROUPS of SORT_GROUP:
-// the histogram kernel leaves its counts as the row hist[b][.] (ONE contiguous store; the [bin][block] layout cost 256 scattered
-// words per block) and adds them to the group's row gsum[b / SORT_GROUP][.] (one atomic per non-empty digit: integers, so the
-// result does not depend on the order).  The block that finishes LAST (a ticket counter behind a release fence -- no block
-// ever waits for another) turns the group rows into their exclusive prefix over the groups, in place, and leaves the digits'
-// bases dbase[.]; the scatter kernel's thread d then needs gsum[its group][d], dbase[d] and the hist rows of the blocks in
-// front of it inside its group (<= 31, coalesced over d).  (First form of this round, measured: every scatter block summing
-// all group rows itself -- 3 046 blocks x 127 rows x 512 B = 200 MB of L2 reads per pass over the instances, +8 us per
-// scatter launch, a net loss against the row-prefix kernel it replaced.)
-// gsum and the ticket have to be zero before the histogram kernel runs: two tables alternate between the passes, pass p's
-// histogram kernel clears the one pass p + 1 will use, the last block resets the ticket, and the first pass's table is cleared
-// by the caller (the forward pass's one memset covers the depth sort's) or by a memset here.
+// Pass structure (per 8-bit digit):  histogram -> exclusive scan of the [bin][block] table
+// -> scatter.  Block b always owns elements [b*4096, (b+1)*4096); wave w of the block owns
+// the 1024-element sub-range starting at w*1024 and walks it in 16 rounds of 64 lane-
+// consecutive elements, so the original order inside a digit is (wave, round, lane).
 
 __global__ void __launch_bounds__(SORT_THREADS)
-radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist,
-                  uint32_t* gsum, uint32_t* __restrict__ gsum_next, uint32_t* __restrict__ dbase, uint32_t* ticket, int ngroups,
+radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks,
                   const uint32_t* __restrict__ n_dev, int skip_invalid)
 {
 	// n_dev (nullable): the number of elements lives on the device (the compacted depth sort: set by the first pass's
-	// scatter); blocks beyond it still write their (all-zero) histogram rows.  skip_invalid: keys equal to
+	// scatter); blocks beyond it still write their (all-zero) histogram columns.  skip_invalid: keys equal to
 	// RADIX_INVALID_KEY are no elements at all (culled Gaussians: never counted, never scattered).
 	__shared__ uint32_t s_hist[RADIX_BINS];
 	s_hist[threadIdx.x] = 0;
-	if (gsum_next && (int)blockIdx.x < ngroups) gsum_next[(size_t)blockIdx.x * RADIX_BINS + threadIdx.x] = 0u;   // for the next pass
 	if (n_dev) n = min(n, (int)*n_dev);
 	__syncthreads();
 	const uint32_t dmask = (1u << nbits) - 1u;
 	const int wbase = blockIdx.x * SORT_CHUNK + wave_id() * SORT_ITEMS_PER_WAVE;
-	// all loads in flight before the first atomic (one HBM latency per wave instead of SORT_ROUNDS)
+	// all 16 loads in flight before the first ballot (one HBM latency per wave instead of sixteen)
 	uint32_t key[SORT_ROUNDS];
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
@@ -189,46 +172,34 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 		if (i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY)) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
 	}
 	__syncthreads();
-	// (digits beyond the pass's -- 128 of the 256 in a 7-bit pass of the tile sort -- are never read: not written either)
-	const bool used = (int)threadIdx.x < (1 << nbits);
-	if (used) {
-		const uint32_t c = s_hist[threadIdx.x];
-		hist[(size_t)blockIdx.x * RADIX_BINS + threadIdx.x] = c;
-		if (c) atomicAdd(&gsum[(size_t)(blockIdx.x / SORT_GROUP) * RADIX_BINS + threadIdx.x], c);
-	}
-	// The last block to get here finishes the group table (threadFenceReduction pattern: every thread's stores and atomics are
-	// released at agent scope before the block takes its ticket; the block that draws the last ticket acquires and sees them all)
-	__shared__ uint32_t s_last;
-	__threadfence();
-	__syncthreads();
-	if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == (uint32_t)gridDim.x - 1u ? 1u : 0u;
-	__syncthreads();
-	if (!s_last) return;
-	__threadfence();
-	uint32_t run = 0;
-	if (used) {
-#pragma unroll 4
-		for (int gq = 0; gq < ngroups; gq++) {
-			uint32_t* p = gsum + (size_t)gq * RADIX_BINS + threadIdx.x;
-			const uint32_t v = __atomic_load_n(p, __ATOMIC_RELAXED);   // (the adds were atomics: read them at the same scope)
-			*p = run;                                                  // exclusive over the groups
-			run += v;
-		}
-	}
+	// (rows beyond the pass's digits -- 128 of the 256 in a 7-bit pass of the tile sort -- are never read: not written either)
+	if ((int)threadIdx.x < (1 << nbits)) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// One workgroup per digit: exclusive scan of that digit's row hist[d][0..nblocks) in place, row total to
+// totals[d].  Together with a 256-entry scan of the totals inside the scatter kernel this replaces the
+// generic three-launch scan of the whole [256][nblocks] table (3 launches per pass instead of 5).
+__global__ void __launch_bounds__(SCAN_THREADS)
+radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
+{
 	__shared__ uint32_t s_wave[4];
-	uint32_t all;
-	const uint32_t base = block_excl_scan_256(run, &all, s_wave);       // elements with a smaller digit
-	dbase[threadIdx.x] = base;
-	if (threadIdx.x == 0) {
-		dbase[RADIX_BINS] = all;   // the elements that exist
-		*ticket = 0u;              // ready for the next pass
+	uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+	uint32_t carry = 0;
+	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+		const int i = base + (int)threadIdx.x;
+		const uint32_t v = i < nblocks ? row[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
+		if (i < nblocks) row[i] = carry + ex;
+		carry += tot;
 	}
+	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
-                     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, const uint32_t* __restrict__ dbase,
+                     const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks,
                      const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out)
 {
 	if (n_dev) n = min(n, (int)*n_dev);
@@ -258,19 +229,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
 		val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
 	}
-	// Digit tid's place among the blocks, from the two-level tables (header): the loads are independent of the keys and go
-	// out right behind them.  before = elements of the digit in the groups in front of this block's, within = in the blocks in
-	// front of it inside its group, base = elements with a smaller digit.
-	const bool used = tid < (1 << nbits);   // (the rows of the digits this pass does not have are neither written nor read)
-	uint32_t before = 0, within = 0, base = 0;
-	if (used) {
-		const int grp = (int)blockIdx.x / SORT_GROUP;
-		before = gsum[(size_t)grp * RADIX_BINS + tid];
-		base = dbase[tid];
-#pragma unroll 8
-		for (int b = grp * SORT_GROUP; b < (int)blockIdx.x; b++) within += hist[(size_t)b * RADIX_BINS + tid];
-	}
-	uint32_t live = (1u << SORT_ROUNDS) - 1u;   // bit r: element r of this lane exists (in range and, when skip_invalid, not the invalid key)
+	uint32_t live = 0xFFFFu;   // bit r: element r of this lane exists (in range and, when skip_invalid, not the invalid key)
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const int i = wbase + r * 64 + l;
@@ -293,12 +252,15 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
 		const uint32_t tot = c0 + c1 + c2 + c3;
 		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
+		uint32_t all;
+		const bool used = tid < (1 << nbits);   // (the rows of the digits this pass does not have are neither written nor scanned)
+		const uint32_t digit_base = block_excl_scan_256(used ? totals[tid] : 0u, &all, s_wave);   // elements with a smaller digit
 		s_whist[0][tid] = lstart;
 		s_whist[1][tid] = lstart + c0;
 		s_whist[2][tid] = lstart + c0 + c1;
 		s_whist[3][tid] = lstart + c0 + c1 + c2;
-		s_gbase[tid] = base + before + within - lstart;
-		if (count_out && blockIdx.x == 0 && tid == 0) *count_out = dbase[RADIX_BINS];   // the elements that exist: later passes run over them only
+		s_gbase[tid] = digit_base + (used ? hist_rows[(size_t)tid * nblocks + blockIdx.x] : 0u) - lstart;
+		if (count_out && blockIdx.x == 0 && tid == 0) *count_out = all;   // the elements that exist: later passes run over them only
 	}
 	__syncthreads();
 	// (block_total is the same in every thread: block_excl_scan_256 returns the block sum to all)
@@ -334,23 +296,18 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
-                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count,
-                      uint32_t* gsum0_zeroed)
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count)
 {
 	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
 	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
-	// gsum0_zeroed (nullable): sort_gsum_elems(n) words the caller has ALREADY zeroed on this stream (the first pass's group
-	// table); without it the table lives in `scratch` and is cleared here (one memset more in the stream).
 	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
 	*keys_res = (passes % 2) ? keys_pong : keys_ping;
 	*vals_res = (passes % 2) ? vals_pong : vals_ping;
 	if (n <= 0) return GSR_OK;
 	const int nb = sort_blocks(n);
-	const int ngroups = div_up(nb, SORT_GROUP);
-	uint32_t* hist = scratch;                                              // [nb][RADIX_BINS]
-	uint32_t* gsum[2] = {scratch + (size_t)RADIX_BINS * nb,                // [ngroups][RADIX_BINS] + the ticket, even passes
-	                     scratch + (size_t)RADIX_BINS * nb + sort_gsum_elems(n)};   // odd passes
-	uint32_t* dbase = scratch + (size_t)RADIX_BINS * nb + 2 * sort_gsum_elems(n);   // [RADIX_BINS + 1]
+	const int hist_elems = RADIX_BINS * nb;
+	uint32_t* hist = scratch;
+	uint32_t* totals = scratch + hist_elems;
 	if (passes == 0) {
 		// degenerate: nothing to sort on; result must still be materialised in the ping buffers
 		GSR_HIP(hipMemcpyAsync(keys_ping, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
@@ -358,9 +315,6 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		else return GSR_ERR_INVALID_ARG;
 		return GSR_OK;
 	}
-	if (gsum0_zeroed) gsum[0] = gsum0_zeroed;
-	else GSR_HIP(hipMemsetAsync(gsum[0], 0, sort_gsum_elems(n) * sizeof(uint32_t), stream));
-	uint32_t* ticket = gsum[0] + (size_t)RADIX_BINS * ngroups;   // (behind the first table: zeroed with it, reset by its last user)
 	const uint32_t* kin = keys_in;
 	const uint32_t* vin = vals_in;
 	// the key bits are spread evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): a pass scatters into 2^nbits streams,
@@ -373,13 +327,10 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
 		const uint32_t* n_dev = (compact_count && p > 0) ? compact_count : nullptr;
 		const int skip = (compact_count && p == 0) ? 1 : 0;
-		uint32_t* g_now = gsum[p & 1];
-		uint32_t* g_next = p + 1 < passes ? gsum[(p + 1) & 1] : nullptr;
-		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, g_now, g_next, dbase, ticket, ngroups,
-		           n_dev, skip);
+		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip);
+		GSR_LAUNCH(radix_row_prefix_kernel, 1 << nbits, SCAN_THREADS, stream, hist, totals, nb);
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
-		           (const uint32_t*)hist, (const uint32_t*)g_now, (const uint32_t*)dbase, n_dev, skip,
-		           skip ? compact_count : (uint32_t*)nullptr);
+		           (const uint32_t*)hist, (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr);
 		kin = kout;
 		vin = vout;
 	}

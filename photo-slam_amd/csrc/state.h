@@ -44,14 +44,11 @@ static inline int scan_items_per_block(int n)
 }
 static inline int scan_blocks(int n) { return n > 0 ? div_up(n, scan_items_per_block(n)) : 1; }
 static inline size_t scan_scratch_elems(int n) { return (size_t)scan_blocks(n) + 64; }
-// Radix sort bookkeeping (sort.hip): the blocks' digit counts hist[blocks][RADIX_BINS] and, per group of SORT_GROUP blocks,
-// their sums gsum[groups][RADIX_BINS] -- two group tables, alternating between the passes.
-constexpr int SORT_GROUP = 32;
-// (+ 32: the ticket of the histogram kernel's last-block pattern lives behind the table)
-static inline size_t sort_gsum_elems(int n) { return (size_t)RADIX_BINS * div_up(sort_blocks(n), SORT_GROUP) + 32; }
+// histogram [RADIX_BINS][blocks] + its scanned copy + scan spine
 static inline size_t sort_scratch_elems(int n)
 {
-	return (size_t)RADIX_BINS * sort_blocks(n) + 2 * sort_gsum_elems(n) + (RADIX_BINS + 32) + 64;   // + the digits' bases
+	size_t h = (size_t)RADIX_BINS * sort_blocks(n);
+	return 2 * h + scan_scratch_elems((int)h) + 64;
 }
 
 // The 48-byte per-Gaussian record the blend kernels gather (3 x float4):
@@ -85,7 +82,6 @@ struct GeometryState {
 	// serialise a few thousand same-address atomics (~12 ns each) inside preprocess_fwd
 	uint32_t* long_runs;      // [LONG_LISTS * long_list_capacity(P)]
 	uint32_t* long_counts;    // [LONG_LISTS * LONG_COUNT_STRIDE] entries per sub-list, one cache line apart (zeroed per forward)
-	uint32_t* sort_gsum0;     // [sort_gsum_elems(P)] the depth sort's first group table (zeroed per forward: sort.hip)
 	uint32_t  long_capacity;  // long_list_capacity(P)
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
@@ -109,18 +105,18 @@ struct GeometryState {
 		g.rect_sorted = c.take<uint2>(P);
 		g.visible = c.take<uint32_t>(32);
 		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
-		// the three arrays the forward pass has to find zeroed sit next to each other: ONE memset (zeroed_bytes())
+		// the two arrays the forward pass has to find zeroed sit next to each other: ONE memset (zeroed_bytes())
 		g.counters = c.take<uint32_t>(NUM_COUNTERS);
 		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
-		g.sort_gsum0 = c.take<uint32_t>(sort_gsum_elems((int)P));
-		g.zeroed_end = reinterpret_cast<const char*>(g.sort_gsum0 + sort_gsum_elems((int)P));
 		g.long_capacity = (uint32_t)long_list_capacity(P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
-	// [counters, end of sort_gsum0): zeroed per forward pass
-	const char* zeroed_end;
-	size_t zeroed_bytes() const { return (size_t)(zeroed_end - reinterpret_cast<const char*>(counters)); }
+	// [counters, end of long_counts): zeroed per forward pass
+	size_t zeroed_bytes() const
+	{
+		return (size_t)(reinterpret_cast<const char*>(long_counts + (size_t)LONG_LISTS * LONG_COUNT_STRIDE) - reinterpret_cast<const char*>(counters));
+	}
 };
 
 static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }
@@ -205,9 +201,7 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
-                      uint32_t* compact_count = nullptr, uint32_t* gsum0_zeroed = nullptr);
-// gsum0_zeroed (nullable): sort_gsum_elems(n) words the caller has zeroed on the stream already (the first pass's group
-// table, sort.hip); without it the sort clears a table of its own with one memset.
+                      uint32_t* compact_count = nullptr);
 // compact_count (nullable, a device word): keys equal to RADIX_INVALID_KEY are "no element": the first pass drops them and
 // leaves the number of remaining elements in *compact_count; the later passes read it and touch that many elements only.
 // The result buffers then hold that many sorted pairs followed by undefined content.

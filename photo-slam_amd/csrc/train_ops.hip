@@ -619,7 +619,9 @@ int gsr_adam_step_multi(int count, const gsr_adam_multi_tensor* tensors, double 
 		q.param[used] = t.param; q.grad[used] = t.grad; q.exp_avg[used] = t.exp_avg; q.exp_avg_sq[used] = t.exp_avg_sq;
 		q.n[used] = t.n;
 		q.s[used] = adam_scalars(t.lr, t.lr, beta1, beta2, eps, t.step);
-		q.grad_scale[used] = t.grad_scale;
+		// (a zero-initialised struct -- the idiom of every gsr struct -- means "no scaling", not "multiply the gradient by 0")
+		if (!(t.grad_scale >= 0.0f) || t.grad_scale > 3.0e38f) return GSR_ERR_INVALID_ARG;   // negative, NaN, Inf
+		q.grad_scale[used] = t.grad_scale == 0.0f ? 1.0f : t.grad_scale;
 		q.first_block[used] = (int)blocks;
 		blocks += (t.n + 1023) / 1024;
 		if (blocks > 0x7FFFFFFFll) return GSR_ERR_UNSUPPORTED;
