@@ -543,6 +543,25 @@ def main():
         for k, v in capi.profile_read(lib).items():
             stage_ms.setdefault(k, []).append(v)
     torch.cuda.synchronize()
+    # ---- data-parallel runs: what every rank's compute stream WAITED for (HIP events around each Work::wait() in the C++ host:
+    # the exposed communication of the step) and every rank's stage table, so that a bad scaling curve can be read from one run
+    exchange_wait = per_rank = None
+    if dp and ops is not None and not py_exchange:
+        ops.trainer_set_options(handle, {"profile_exchange": 1.0})
+        waits = []
+        for _ in range(20):
+            one_step()
+            waits.append(ops.trainer_exchange_wait_ms(handle))
+        ops.trainer_set_options(handle, {"profile_exchange": 0.0})
+        mine = {"rank": rank, "all_gather_wait_ms_median": round(float(np.median([w[0] for w in waits])), 4),
+                "all_reduce_wait_ms_median": round(float(np.median([w[1] for w in waits])), 4),
+                "stage_ms_median": {k: round(float(np.median([m for m in v if m >= 0])), 4) for k, v in stage_ms.items() if any(m >= 0 for m in v)}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        exchange_wait = {"all_gather_wait_ms_max_over_ranks": max(r["all_gather_wait_ms_median"] for r in per_rank),
+                         "all_reduce_wait_ms_max_over_ranks": max(r["all_reduce_wait_ms_median"] for r in per_rank),
+                         "method": "HIP events on the compute stream in front of and behind every Work::wait() "
+                                   "(host/src/keyframe_batch_exchange.cpp: markWait), median of 20 steps per rank"}
     # ---- the rasterizer alone: the same legs with the SH Adam step as a separate pass (not fused into backward), so that
     # "rendered Mpix/s (fwd+bwd)" prices rasterizer work only; reported next to the fused program's figures, never as `value`
     unfused_ms = {}
@@ -843,6 +862,8 @@ def main():
             out["knn"] = knn_run
         if dp:
             out["preflight"] = preflight
+            out["exposed_communication"] = exchange_wait
+            out["per_rank"] = per_rank
             out["replicas_identical"] = replicas_identical
             out["replica_parameter_hash_rank0"] = param_hash
             out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),

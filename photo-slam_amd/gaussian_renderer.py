@@ -36,7 +36,7 @@ class GaussianRenderer:
     @staticmethod
     def render(viewpoint_camera, image_height, image_width, pc, pipe, bg_color, override_color=None,
                scaling_modifier=1.0, use_override_color=False, fuse_activations=True, sh_grad_view=None, sh_adam=None, view_stats=None,
-               geom_adam=None, training_outputs_only=False):
+               geom_adam=None, training_outputs_only=False, cull_empty_tiles=False):
         """returns (render, viewspace_points, visibility_filter, radii)
 
         fuse_activations (extension; False = the reference data flow): hand the raw opacity / scaling / rotation
@@ -45,7 +45,12 @@ class GaussianRenderer:
 
         sh_grad_view, sh_adam, view_stats, geom_adam (extensions; None = the reference data flow): see
         GaussianRasterizationSettings.  training_outputs_only: the viewspace gradient and dL_dcov3D are not computed (for a caller
-        whose densification statistics are fused: view_stats); implied by geom_adam."""
+        whose densification statistics are fused: view_stats); implied by geom_adam.  cull_empty_tiles: instances of tiles in which
+        no pixel can blend the Gaussian leave the list (same image and gradients; off by default -- measured a wash, DESIGN.md
+        section 10); the environment variable GSR_CULL_EMPTY_TILES=0/1, when set, overrides the argument (an A/B handle)."""
+        env = os.environ.get("GSR_CULL_EMPTY_TILES")
+        if env:
+            cull_empty_tiles = env == "1"
         # (with the fused geometry step nobody reads its gradient and the rasterizer never reads its values: no zero fill then)
         slim = geom_adam is not None or training_outputs_only
         screenspace_points = (torch.empty_like if slim else torch.zeros_like)(pc.getXYZ(), requires_grad=True)
@@ -62,7 +67,7 @@ class GaussianRenderer:
             viewpoint_camera.camera_center_, False, raw,
             sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats,
             geom_adam if raw == 7 else None, bool((geom_adam is not None or training_outputs_only) and raw == 7),
-            cull_empty_tiles_=os.environ.get("GSR_CULL_EMPTY_TILES", "0") == "1")   # opt-in: measured a wash
+            cull_empty_tiles_=bool(cull_empty_tiles))
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points

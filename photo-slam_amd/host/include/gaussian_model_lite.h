@@ -206,6 +206,7 @@ public:
 	// backward at which the colour gradients are complete (gsr_backward_args.color_view_ready_stream): it overlaps the SH
 	// backward kernel instead of following it.  A hipStream_t from LibTorch's pool, created on first use; null on the host.
 	void* gather_stream_ = nullptr;
+	bool gather_stream_in_use_ = false;   // this step hands gather_stream_ to the exchange (early_gather_)
 	// Data-parallel keyframe batches with the view-factored exchange (include/gsr.h, gsr_sh_grad_from_views): backward
 	// then leaves the clamp-masked colour gradient of this view in sh_grad_view_ and no gradient on features_; after the
 	// driver has gathered the views of all ranks, setFeaturesGradFromViews() installs the batch-mean SH gradient.  It reads
@@ -232,10 +233,29 @@ public:
 	// same iterations as fused_sh_adam_.  The viewspace gradient and dL_dcov3D are then not written either.
 	bool fused_geom_adam_ = true;
 	bool factored_exchange_ = false;
+	// Scheduling / list-building switches, each at its measured-best value; none changes a result.  They
+	// are options of THIS object -- a SLAM process that links the library decides per TrainStep -- and the environment variables
+	// of the bench sessions (GSR_CULL_EMPTY_TILES, GSR_EARLY_GATHER, GSR_LAZY_SLICE_EARLY, GSR_SH_ADAM_SIDE_STREAM) only override.
+	bool cull_empty_tiles_ = false;   // instances of tiles no pixel of which can blend the Gaussian leave the list (a wash on MI355X)
+	bool early_gather_ = true;        // the exchange's all-gather waits for the colour gradients only, not for the whole backward pass
+	bool lazy_slice_late_ = false;    // the lazy SH rows' slice behind the backward blend instead of next to it
+	bool no_side_stream_ = false;     // no second stream inside gsr_forward / gsr_backward
+	// exposed communication of the data-parallel step: the time the compute stream spent waiting for a collective (HIP events
+	// around every Work::wait(), recorded only while profile_exchange_ is set); read with exchangeWaitMs()
+	bool profile_exchange_ = false;
+	std::vector<double> exchangeWaitMs();
+	void markWait(int k);   // {all-gather wait, all-reduce wait} of the last data-parallel step, in ms
 	// pipeline flags of the render call (include/gaussian_parameters.h; every shipped config leaves both off).  The fused
 	// optimizer paths above are taken only when render() keeps the tensors they step inside the rasterizer.
 	GaussianPipelineParams pipe_;
 	torch::Tensor sh_send_;        // [P + 1, 3]: rows 0 .. P-1 = sh_grad_view_, row P = this view's camera centre (one all-gather)
+	// [N, P + 1, 3]: what the all-gather writes.  PERSISTENT (re-allocated only when P or N changes) and sized in
+	// renderAndBackward() BEFORE the forward and backward passes are enqueued: the early gather writes it from a second stream
+	// that is ordered only behind "the colour gradients are complete", i.e. while the tail of the backward pass still runs -- a
+	// buffer taken from the caching allocator at that point could be a block the pass has just released and still writes
+	// (record_stream protects the free side, not the first use on a foreign stream).
+	torch::Tensor sh_gathered_;
+	void* wait_events_[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: before / after the gather wait, before / after the reduce wait
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	// ... or rebuilds it and takes the Adam step of features_ in the same pass (gsr_sh_adam_from_views): the mean gradient

@@ -41,7 +41,8 @@ public:
 	    torch::Tensor sh_grad_view = torch::Tensor() /* extension: GaussianRasterizationExtensions::sh_grad_view_ */,
 	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationExtensions::sh_adam_ */,
 	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationExtensions::view_stats_ */,
-	    GeomAdamStep geom_adam = GeomAdamStep() /* extension: GaussianRasterizationExtensions::geom_adam_ */)
+	    GeomAdamStep geom_adam = GeomAdamStep() /* extension: GaussianRasterizationExtensions::geom_adam_ */,
+	    bool cull_empty_tiles = false /* extension: GaussianRasterizationExtensions::cull_empty_tiles_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -66,9 +67,10 @@ public:
 		if (sh_in_rasterizer) ext.sh_grad_view_ = sh_grad_view;
 		if (sh_in_rasterizer) ext.sh_adam_ = sh_adam;
 		ext.view_stats_ = view_stats;
-		// (the same image and gradients either way; opt-in with GSR_CULL_EMPTY_TILES=1: measured a wash)
-		static const bool cull_empty_tiles = [] { const char* e = std::getenv("GSR_CULL_EMPTY_TILES"); return e && e[0] == '1'; }();
-		ext.cull_empty_tiles_ = cull_empty_tiles;
+		// (the same image and gradients either way; off by default: measured a wash, DESIGN.md section 10.  The caller's
+		// argument decides; the environment variable GSR_CULL_EMPTY_TILES=0/1, when set, overrides it -- an A/B handle)
+		static const int cull_env = [] { const char* e = std::getenv("GSR_CULL_EMPTY_TILES"); return (e && *e) ? (e[0] == '1' ? 1 : 0) : -1; }();
+		ext.cull_empty_tiles_ = cull_env >= 0 ? cull_env != 0 : cull_empty_tiles;
 		// the fused geometry step needs the raw leaves in the rasterizer (it steps opacity_ / scaling_ / rotation_ themselves)
 		if (ext.raw_params_ == 7 && !pipe.compute_cov3D_) ext.geom_adam_ = geom_adam;
 		GaussianRasterizerEx rasterizer(raster_settings, ext);

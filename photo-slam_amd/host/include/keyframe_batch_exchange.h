@@ -60,8 +60,11 @@ public:
 	// gather_stream (a hipStream_t; null = the current stream): the all-gather is issued with THAT stream current, so it waits
 	// for whatever the stream waits for -- TrainStep hands over the stream gsr_backward made wait for "dL_dcolor_view is
 	// complete", and the gather overlaps the last kernel of the backward pass.
+	// gathered (optional): the [N, P + 1, 3] buffer the all-gather writes, allocated by the caller BEFORE the backward pass was
+	// enqueued (TrainStep::sh_gathered_); without it one is allocated here, and a gather on a second stream is then made to wait
+	// for the compute stream's tail first (a fresh block of the caching allocator may still be written by the pass).
 	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
-	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr);
+	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr, torch::Tensor gathered = torch::Tensor());
 	struct Part {
 		int64_t row0 = 0;
 		torch::Tensor views;   // [N, rows, 3]

@@ -26,6 +26,10 @@ struct ShAdamStep {
 	// above): a hipStream_t that is made to wait for the point inside backward at which dL_dcolor_view is complete -- the
 	// exchange issues its all-gather there and overlaps the last kernel of the pass
 	void* color_view_ready_stream = nullptr;
+	// scheduling of the optimizer work the library forks next to its own kernels (gsr_sh_adam: zero = the measured-best
+	// arrangement; the environment variables GSR_SH_ADAM_SIDE_STREAM / GSR_LAZY_SLICE_EARLY / GSR_SH_ADAM_SIDE_BLOCKS override)
+	bool no_side_stream = false, lazy_slice_late = false;
+	int side_blocks = 0;
 };
 
 // (num_rendered, out_color[3,H,W], radii[P] i32, geomBuffer u8, binningBuffer u8, imgBuffer u8)

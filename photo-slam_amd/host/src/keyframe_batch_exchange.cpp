@@ -8,7 +8,9 @@
 #include "gaussian_model_lite.h"
 
 #ifndef GSR_HOST_NO_HIP
+#include <ATen/hip/HIPEvent.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <hip/hip_runtime_api.h>
 #endif
 
 torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
@@ -91,7 +93,7 @@ void GradientReduction::waitAll()
 }
 
 ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
-                                           std::vector<torch::Tensor> others, void* gather_stream)
+                                           std::vector<torch::Tensor> others, void* gather_stream, torch::Tensor gathered)
     : pg_(std::move(pg))
 {
 	const int64_t N = pg_->getSize(), P = send.size(0) - 1;
@@ -104,7 +106,9 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	// (row P: the camera centre.  TrainStep::renderAndBackward wrote it BEFORE backward -- a gather that does not wait for the
 	// end of the backward pass must not depend on a copy queued behind it; other callers get it written here)
 	if (!gather_stream) send.select(0, P).copy_(camera_center.detach().reshape({3}).to(o));
-	gathered_ = torch::empty({N, P + 1, 3}, o);
+	const bool own_buffer = !(gathered.defined() && gathered.size(0) == N && gathered.size(1) == P + 1 && gathered.is_contiguous() &&
+	                          gathered.device() == send.device());
+	gathered_ = own_buffer ? torch::empty({N, P + 1, 3}, o) : gathered;
 	auto in = send.unsqueeze(0);   // ([1, P + 1, 3]: gloo checks the input against a 1/N chunk of the output)
 	Part p;
 	p.row0 = 0;
@@ -119,6 +123,14 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 		send.record_stream(side.unwrap());
 		gathered_.record_stream(side.unwrap());
 		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+		if (own_buffer) {
+			// allocated just now, behind the enqueued backward pass: the block may be one the pass has released and still writes --
+			// the second stream waits for the compute stream's tail before RCCL touches it (the caller-provided buffer of
+			// TrainStep needs no such wait: it existed before the pass was enqueued)
+			at::cuda::CUDAEvent tail;
+			tail.record(prev);
+			tail.block(side);
+		}
 		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
 		p.work = pg_->_allgather_base(gathered_, in);
 		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
@@ -155,6 +167,37 @@ void ViewFactoredExchange::waitAll()
 
 // ---- TrainStep: the data-parallel step --------------------------------------------------------------------------------------
 
+// profile_exchange_: HIP events on the compute stream in front of and behind a Work::wait() -- the elapsed time between the two
+// is the time the stream idled for the collective (0 when it had landed already): the EXPOSED communication of the step.
+void TrainStep::markWait(int k)
+{
+#ifndef GSR_HOST_NO_HIP
+	if (!profile_exchange_ || !gaussians_->xyz_.is_cuda()) return;
+	auto& ev = wait_events_[k];
+	if (!ev) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreate(&e) != hipSuccess) return;
+		ev = e;
+	}
+	(void)hipEventRecord(static_cast<hipEvent_t>(ev), c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(gaussians_->xyz_.device().index()).stream());
+#else
+	(void)k;
+#endif
+}
+
+std::vector<double> TrainStep::exchangeWaitMs()
+{
+	std::vector<double> out{-1.0, -1.0};
+#ifndef GSR_HOST_NO_HIP
+	for (int j = 0; j < 2; j++) {
+		auto a = static_cast<hipEvent_t>(wait_events_[2 * j]), b = static_cast<hipEvent_t>(wait_events_[2 * j + 1]);
+		float ms = 0.f;
+		if (a && b && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) out[static_cast<size_t>(j)] = ms;
+	}
+#endif
+	return out;
+}
+
 void TrainStep::setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool factored)
 {
 	process_group_ = std::move(pg);
@@ -176,7 +219,8 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 	if (factored_exchange_) {
 		std::vector<torch::Tensor> others;
 		for (int i : {0, 2, 3, 4}) others.push_back(params[static_cast<size_t>(i)].grad());
-		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others, gather_stream_);
+		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others,
+		                                            gather_stream_in_use_ ? gather_stream_ : nullptr, sh_gathered_);
 	} else {
 		std::vector<torch::Tensor> grads;
 		for (auto& p : params) grads.push_back(p.grad());
@@ -210,7 +254,9 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 				// the SH gradient is rebuilt from the gathered views (reads xyz_: before ITS update) and applied part by part as
 				// each all-gather lands, while the all-reduce of the other four tensors is on the links
 				for (int k = 0; k < vf->parts(); k++) {
+					markWait(0);   // (profile_exchange_: how long does the compute stream wait for the all-gather?)
 					const auto& p = vf->part(k);
+					markWait(1);
 					stepFeaturesFromViews(vf->centres(), p.views, p.row0, k == 0);
 				}
 				finishFeaturesFromViews();
@@ -220,7 +266,9 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 				setFeaturesGradFromViews(vf->centres(), views.size() == 1 ? views[0] : torch::cat(views, 1));
 				finishAdamGroup(1);
 			}
+			markWait(2);
 			vf->reduction().waitAll();                    // ONE collective for the four small tensors (a SUM) ...
+			markWait(3);
 			finishGeomAdam(vf->reduction().gradScale());   // ... and one Adam launch that applies the 1/N
 		} else {
 			// each tensor is updated as soon as ITS reduction has landed (largest first)

@@ -166,6 +166,11 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "fused_sh_adam") t->fused_sh_adam_ = v != 0.0;
 		else if (k == "lazy_sh_adam_window") t->lazy_sh_adam_window_ = (int)v;
 		else if (k == "fused_geom_adam") t->fused_geom_adam_ = v != 0.0;
+		else if (k == "cull_empty_tiles") t->cull_empty_tiles_ = v != 0.0;
+		else if (k == "early_gather") t->early_gather_ = v != 0.0;
+		else if (k == "lazy_slice_late") t->lazy_slice_late_ = v != 0.0;
+		else if (k == "no_side_stream") t->no_side_stream_ = v != 0.0;
+		else if (k == "profile_exchange") t->profile_exchange_ = v != 0.0;
 		else if (k == "convert_SHs") t->pipe_.convert_SHs_ = v != 0.0;
 		else if (k == "compute_cov3D") t->pipe_.compute_cov3D_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
@@ -242,6 +247,7 @@ bool trainer_densify_due(int64_t h) { return get(h)->densifyDue(); }
 void trainer_set_factored_exchange(int64_t h, bool on) { get(h)->factored_exchange_ = on; }
 torch::Tensor trainer_sh_grad_view(int64_t h) { return get(h)->sh_grad_view_; }
 torch::Tensor trainer_sh_send_buffer(int64_t h) { return get(h)->sh_send_; }
+std::vector<double> trainer_exchange_wait_ms(int64_t h) { return get(h)->exchangeWaitMs(); }
 void trainer_features_grad_from_views(int64_t h, torch::Tensor campos_views, torch::Tensor views)
 {
 	get(h)->setFeaturesGradFromViews(campos_views, views);
@@ -337,6 +343,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);
 	m.def("trainer_sh_grad_view", &trainer_sh_grad_view);
 	m.def("trainer_sh_send_buffer", &trainer_sh_send_buffer);
+	m.def("trainer_exchange_wait_ms", &trainer_exchange_wait_ms);
 	m.def("trainer_features_grad_from_views", &trainer_features_grad_from_views);
 	m.def("trainer_features_step_from_views", &trainer_features_step_from_views);
 	m.def("trainer_increase_pcd", &trainer_increase_pcd);

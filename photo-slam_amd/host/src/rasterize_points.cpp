@@ -60,6 +60,9 @@ void fill_sh_adam(const ShAdamStep& s, float* param, gsr_sh_adam& adam, gsr_sh_a
 	adam.lr = s.lr; adam.lr_tail = s.lr_tail;
 	adam.beta1 = s.beta1; adam.beta2 = s.beta2; adam.eps = s.eps;
 	adam.step = s.step;
+	adam.no_side_stream = s.no_side_stream ? 1 : 0;
+	adam.lazy_slice_late = s.lazy_slice_late ? 1 : 0;
+	adam.side_blocks = s.side_blocks;
 	if (s.row_step.defined()) {
 		if (s.row_step.scalar_type() != torch::kInt32 || !s.row_step.is_contiguous() || s.row_step.numel() != s.exp_avg.size(0) ||
 		    s.row_step.device() != s.exp_avg.device())

@@ -197,9 +197,16 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_send_ = torch::empty({P + 1, 3}, g->xyz_.options().requires_grad(false));
 		sh_grad_view_ = sh_send_.narrow(0, 0, P);
 		sh_send_.select(0, P).copy_(kf->camera_center_.detach().reshape({3}));
+		if (process_group_) {
+			const int64_t N = process_group_->getSize();
+			if (!sh_gathered_.defined() || sh_gathered_.size(0) != N || sh_gathered_.size(1) != P + 1 ||
+			    sh_gathered_.device() != sh_send_.device())
+				sh_gathered_ = torch::empty({N, P + 1, 3}, sh_send_.options());
+		}
 	} else {
 		sh_send_ = torch::Tensor();
 		sh_grad_view_ = torch::Tensor();
+		sh_gathered_ = torch::Tensor();
 	}
 	ShAdamStep sh_adam;
 	const auto& o = g->opt_;
@@ -267,14 +274,19 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	}
 	if (!lazy) g->syncFeatures();   // the render below reads every visible row as it is
 #ifndef GSR_HOST_NO_HIP
-	// GSR_EARLY_GATHER=0: the gather is issued on the compute stream behind the whole backward pass (A/B timing)
-	static const bool early_gather = [] { const char* e = getenv("GSR_EARLY_GATHER"); return !e || atoi(e) != 0; }();
+	// early_gather_ (GSR_EARLY_GATHER=0/1 overrides): off = the gather is issued on the compute stream behind the whole backward pass
+	static const int early_env = [] { const char* e = getenv("GSR_EARLY_GATHER"); return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+	const bool early_gather = early_env >= 0 ? early_env != 0 : early_gather_;
+	gather_stream_in_use_ = false;
 	if (early_gather && factored_exchange_ && process_group_ && g->xyz_.is_cuda()) {
 		// the exchange's gather waits for the colour gradients only, not for the whole backward pass (keyframe_batch_exchange.cpp)
 		if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, g->xyz_.device().index()).stream();
 		sh_adam.color_view_ready_stream = gather_stream_;
+		gather_stream_in_use_ = true;
 	}
 #endif
+	sh_adam.no_side_stream = no_side_stream_;
+	sh_adam.lazy_slice_late = lazy_slice_late_;
 	GeomAdamStep geom_adam;
 	// (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then skips it -- no
 	// gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)
@@ -301,7 +313,8 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	if (iteration_ < o.densify_until_iter_) view_stats = {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 	g->in_lazy_step_ = lazy;
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
-	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats, geom_adam);
+	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats, geom_adam,
+	                                    cull_empty_tiles_);
 	g->in_lazy_step_ = false;
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
@@ -421,7 +434,20 @@ void TrainStep::finishGeomAdam(float grad_scale)
 {
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
-	if (iteration_ >= g->opt_.iterations_ || g->groups_.size() != 5) return;
+	if (iteration_ >= g->opt_.iterations_) return;
+	if (g->groups_.size() != 5) {
+		// another parameter layout than trainingSetup()'s five groups: every group but the SH tensor's (stepped from the views)
+		// takes its own pass, the 1/N of the summed gradients applied first -- never a silent return: in the factored
+		// data-parallel step this function is the ONLY consumer of those gradients
+		for (int gi = 0; gi < static_cast<int>(g->groups_.size()); gi++) {
+			if (gi == 1) continue;
+			auto grad = g->groups_[static_cast<size_t>(gi)].param.grad();
+			if (!grad.defined()) continue;
+			if (grad_scale != 1.0f) grad.mul_(grad_scale);
+			finishAdamGroup(gi);
+		}
+		return;
+	}
 	std::vector<AdamMultiEntry> entries;
 	for (int gi : {0, 2, 3, 4}) {
 		auto& grp = g->groups_[static_cast<size_t>(gi)];
