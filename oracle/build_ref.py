@@ -234,10 +234,11 @@ HOST_SOURCES = ["gaussian_rasterizer.cpp", "gaussian_renderer.cpp", "gaussian_tr
 HOST_HEADERS_REF = ["gaussian_renderer.h", "gaussian_rasterizer.h", "rasterize_points.h", "operate_points.h", "loss_utils.h",
                     "sh_utils.h", "general_utils.h", "gaussian_parameters.h", "types.h"]
 # OUR stand-ins for the four headers that need Sophus / Eigen / OpenCV / ORB-SLAM3 (oracle/ref_host/)
-HOST_HEADERS_STANDIN = ["gaussian_model.h", "gaussian_keyframe.h", "gaussian_scene.h", "gaussian_trainer.h"]
+HOST_HEADERS_STANDIN = ["gaussian_model.h", "gaussian_keyframe.h", "gaussian_scene.h", "gaussian_trainer.h", "sophus_standin.h"]
 # every member function oracle/ref_host/gaussian_model.h declares, extracted verbatim by name from src/gaussian_model.cpp
 HOST_MODEL_FUNCTIONS = ["getScalingActivation", "getRotationActivation", "getXYZ", "getFeatures", "getOpacityActivation",
-                        "getCovarianceActivation", "oneUpShDegree", "setShDegree", "increasePcd", "scaledTransformationPostfix",
+                        "getCovarianceActivation", "oneUpShDegree", "setShDegree", "increasePcd", "applyScaledTransformation",
+                        "scaledTransformationPostfix",
                         "scaledTransformVisiblePointsOfKeyframe", "trainingSetup", "updateLearningRate", "setPositionLearningRate",
                         "setFeatureLearningRate", "setOpacityLearningRate", "setScalingLearningRate", "setRotationLearningRate",
                         "resetOpacity", "replaceTensorToOptimizer", "prunePoints", "densificationPostfix", "densifyAndSplit",

@@ -3,9 +3,9 @@
  *
  * The reference's header (include/gaussian_model.h:18-36) pulls in Sophus, Eigen, OpenCV (through tensor_utils.h) and
  * ORB-SLAM3 types, none of which exist in this image.  This file declares class GaussianModel with the members of
- * include/gaussian_model.h:59-193 -- same names, same types, same order of the data members -- minus the three methods whose
- * SIGNATURES need those libraries (createFromPcd: std::map<point3D_id_t, Point3D>; applyScaledTransformation: Sophus::SE3f;
- * saveSparsePointsPly is never called on the path).  The member FUNCTIONS are not restated anywhere: oracle/build_ref.py
+ * include/gaussian_model.h:59-193 -- same names, same types, same order of the data members -- minus createFromPcd (its
+ * signature needs std::map<point3D_id_t, Point3D> with Eigen members) and saveSparsePointsPly (never called on the path);
+ * applyScaledTransformation takes the stand-in Sophus::SE3f of sophus_standin.h.  The member FUNCTIONS are not restated anywhere: oracle/build_ref.py
  * extracts them verbatim, by name, from /root/reference/src/gaussian_model.cpp into a generated include file.
  *
  * Who includes it: the reference's own src/gaussian_renderer.cpp / src/gaussian_trainer.cpp / include/gaussian_renderer.h
@@ -37,6 +37,7 @@
 #include "general_utils.h"
 #include "sh_utils.h"
 #include "gaussian_parameters.h"
+#include "sophus_standin.h"                  /* ours: Sophus::SE3f / tensor_utils::EigenMatrix2TorchTensor for one signature */
 
 #ifndef REF_DEVICE
 #define REF_DEVICE torch::kCUDA
@@ -68,6 +69,7 @@ public:
     void increasePcd(std::vector<float> points, std::vector<float> colors, const int iteration);
     void increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& new_colors, const int iteration);
 
+    void applyScaledTransformation(const float s, const Sophus::SE3f T);   /* (the reference's default arguments need Eigen) */
     void scaledTransformationPostfix(
         torch::Tensor& new_xyz,
         torch::Tensor& new_scaling);

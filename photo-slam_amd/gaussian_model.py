@@ -626,3 +626,42 @@ class GaussianModel:
         self.opacity_ = new
         if self.optimizer_ is not None:
             self.optimizer_.replace_param(old, new)
+
+    # ---- loop closure (src/gaussian_model.cpp:379-475) ------------------------------------------------------------------------
+    def _replace_leaf(self, name, values):
+        """replaceTensorToOptimizer (:567-586): a fresh leaf, zero Adam moments, the step counter carried"""
+        new = values.detach().contiguous().clone().requires_grad_(True)
+        old = getattr(self, name)
+        setattr(self, name, new)
+        if self.optimizer_ is not None:
+            self.optimizer_.replace_param(old, new)
+
+    def applyScaledTransformation(self, s, T):
+        """every point p <- s R p + t (transformPoints on the scaled positions, :385-388), then -- as shipped -- `scaling_ *= s` on
+        the LOG-scales (:395: mirrored, not fixed); xyz and scaling become fresh leaves with zero moments
+        (scaledTransformationPostfix :398-411).  T: the 4x4 matrix [R t; 0 1], row-major."""
+        from . import operate_points as op
+        with torch.no_grad():
+            pts = (self.xyz_.detach() * s).contiguous()
+            T_tensor = torch.as_tensor(T, dtype=torch.float32, device=pts.device).transpose(0, 1)
+            pts = op.transformPoints(pts, T_tensor)
+            scl = self.scaling_.detach() * s
+        self._replace_leaf("xyz_", pts)
+        self._replace_leaf("scaling_", scl)
+
+    def scaledTransformVisiblePointsOfKeyframe(self, point_not_transformed_flags, diff_pose, kf_world_view_transform,
+                                               kf_full_proj_transform, kf_creation_iter, stable_num_iter_existence, num_transformed=0,
+                                               scale=1.0):
+        """:408-475.  In place on point_not_transformed_flags; returns the new num_transformed.  rotation_ becomes the NORMALISED
+        (and, for the moved points, rotated) quaternions; xyz and rotation get zero moments."""
+        from . import operate_points as op
+        with torch.no_grad():
+            points = self.xyz_.detach().clone()
+            rots = self.getRotationActivation().detach().clone()
+            unstable = (self.exist_since_iter_ - kf_creation_iter).abs() < stable_num_iter_existence
+            num_transformed = op.scaleAndTransformThenMarkVisiblePoints(points, rots, point_not_transformed_flags, unstable, diff_pose,
+                                                                        kf_world_view_transform, kf_full_proj_transform,
+                                                                        num_transformed, scale)
+        self._replace_leaf("xyz_", points)
+        self._replace_leaf("rotation_", rots)
+        return num_transformed

@@ -66,6 +66,19 @@ public:
 	void increasePcd(std::vector<float> points, std::vector<float> colors, const int iteration);
 	void increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& new_colors, const int iteration);
 	void oneUpShDegree();
+	// Loop closure (src/gaussian_model.cpp:379-475; callers: src/gaussian_mapper.cpp loop-closure handling).
+	// applyScaledTransformation: every point p <- s R p + t (transformPoints on the scaled positions), then -- exactly as
+	// shipped -- `scaling_ *= s` on the LOG-scales (:395; not log(s) added: mirrored, not fixed), and the Adam moments of xyz and
+	// scaling are zeroed, their step counters kept (scaledTransformationPostfix -> replaceTensorToOptimizer :567-586).
+	// T: the 4x4 matrix [R t; 0 1], row-major (the reference takes a Sophus::SE3f and hands its matrix on).
+	void applyScaledTransformation(const float s, torch::Tensor T);
+	// The points a keyframe sees and that exist for fewer than stable_num_iter_existence iterations around its creation are
+	// moved by diff_pose (scaleAndTransformThenMarkVisiblePoints: positions AND rotations), flags of moved points are cleared,
+	// rotation_ becomes the NORMALISED (and rotated) quaternions, moments of xyz and rotation are zeroed (:408-475).
+	void scaledTransformVisiblePointsOfKeyframe(torch::Tensor& point_not_transformed_flags, torch::Tensor& diff_pose,
+	                                            torch::Tensor& kf_world_view_transform, torch::Tensor& kf_full_proj_transform,
+	                                            const int kf_creation_iter, const int stable_num_iter_existence, int& num_transformed,
+	                                            const float scale = 1.0f);
 	void resetOpacity();
 	bool intended_opacity_reset_ = false;   // see resetOpacity(): false = the reference as shipped
 	void prunePoints(torch::Tensor& mask);

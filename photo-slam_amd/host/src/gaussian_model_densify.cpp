@@ -16,6 +16,7 @@
 #include <c10/hip/HIPStream.h>
 #endif
 #include "spatial.h"
+#include "operate_points.h"
 
 namespace {
 torch::Tensor inverse_sigmoid(const torch::Tensor& x) { return torch::log(x / (1 - x)); }   // include/general_utils.h
@@ -207,6 +208,39 @@ void GaussianModel::resetOpacity()
 	auto bound = intended_opacity_reset_ ? torch::ones_like(act) * 0.01 : torch::ones_like(act * 0.01);
 	auto fresh = inverse_sigmoid(torch::min(act, bound)).detach().clone();
 	replaceParam(2, fresh, torch::Tensor(), torch::Tensor());
+}
+
+// ---- loop closure (src/gaussian_model.cpp:379-475) -------------------------------------------------------------------------
+
+void GaussianModel::applyScaledTransformation(const float s, torch::Tensor T)
+{
+	torch::NoGradGuard ng;
+	// pt <- (s * Ryw * pt + tyw), :385-388: the positions are scaled in place, then transformed with the transposed matrix
+	// (tensor_utils::EigenMatrix2TorchTensor(T.matrix()).transpose(0, 1): transformPoints reads it column-major)
+	auto pts = (xyz_.detach() * s).contiguous();
+	auto T_tensor = T.to(pts.device(), torch::kFloat32).transpose(0, 1);
+	transformPoints(pts, T_tensor);
+	// `this->scaling_ *= s` (:395): the log-scales multiplied by s, as shipped
+	auto scl = (scaling_.detach() * s).contiguous();
+	// scaledTransformationPostfix (:398-411): fresh leaves in groups 0 (xyz) and 4 (scaling; group 3 of the five here), zero
+	// moments, the step counters stay
+	replaceParam(0, pts, torch::Tensor(), torch::Tensor());
+	replaceParam(3, scl, torch::Tensor(), torch::Tensor());
+}
+
+void GaussianModel::scaledTransformVisiblePointsOfKeyframe(torch::Tensor& point_not_transformed_flags, torch::Tensor& diff_pose,
+                                                           torch::Tensor& kf_world_view_transform, torch::Tensor& kf_full_proj_transform,
+                                                           const int kf_creation_iter, const int stable_num_iter_existence,
+                                                           int& num_transformed, const float scale)
+{
+	torch::NoGradGuard ng;
+	auto points = xyz_.detach().clone();                 // (the reference works on the leaf's storage and replaces the leaf anyway)
+	auto rots = getRotationActivation().detach().clone();
+	auto point_unstable_flags = torch::abs(exist_since_iter_ - kf_creation_iter) < stable_num_iter_existence;   // :433-436
+	scaleAndTransformThenMarkVisiblePoints(points, rots, point_not_transformed_flags, point_unstable_flags, diff_pose,
+	                                       kf_world_view_transform, kf_full_proj_transform, num_transformed, scale);
+	replaceParam(0, points, torch::Tensor(), torch::Tensor());   // :463  param_groups[0] = xyz_
+	replaceParam(4, rots, torch::Tensor(), torch::Tensor());     // :465  param_groups[5] = rotation_ (group 4 of the five here)
 }
 
 // ---- rebuilds as stream compaction (csrc/densify.hip, include/gsr.h) ------------------------------------------------

@@ -215,6 +215,18 @@ int64_t trainer_create_from_ply(std::string path, int64_t sh_degree, double spat
 	return g_next++;
 }
 void trainer_reset_opacity(int64_t h) { get(h)->gaussians_->resetOpacity(); }
+void trainer_apply_scaled_transformation(int64_t h, double s, torch::Tensor T) { get(h)->gaussians_->applyScaledTransformation((float)s, T); }
+// -> (flags after the call, number of points moved)
+std::tuple<torch::Tensor, int64_t> trainer_scaled_transform_visible(int64_t h, torch::Tensor flags, torch::Tensor diff_pose,
+                                                                    torch::Tensor view, torch::Tensor proj, int64_t kf_creation_iter,
+                                                                    int64_t stable_num_iter_existence, double scale)
+{
+	int moved = 0;
+	auto f = flags.clone();
+	get(h)->gaussians_->scaledTransformVisiblePointsOfKeyframe(f, diff_pose, view, proj, (int)kf_creation_iter, (int)stable_num_iter_existence,
+	                                                          moved, (float)scale);
+	return {f, (int64_t)moved};
+}
 void trainer_prune_points(int64_t h, torch::Tensor mask) { get(h)->gaussians_->prunePoints(mask); }
 void trainer_one_up_sh_degree(int64_t h) { get(h)->gaussians_->oneUpShDegree(); }
 std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five groups, then exp_avg_sq
@@ -334,6 +346,8 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_save_ply", &trainer_save_ply);
 	m.def("trainer_create_from_ply", &trainer_create_from_ply);
 	m.def("trainer_reset_opacity", &trainer_reset_opacity);
+	m.def("trainer_apply_scaled_transformation", &trainer_apply_scaled_transformation);
+	m.def("trainer_scaled_transform_visible", &trainer_scaled_transform_visible);
 	m.def("trainer_prune_points", &trainer_prune_points);
 	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
 	m.def("trainer_moments", &trainer_moments);
