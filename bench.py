@@ -262,6 +262,86 @@ def replica_checksum(torch, dist, tensors, dev, backend):
     return bool(torch.equal(lo, hi)), [int(x) for x in h.cpu()]
 
 
+def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
+    """BASELINE config C5's SHAPE on one GPU (`--mapper-loop`, opt-in): 4 M Gaussians @ 752x480, the fused train step cycling
+    through EIGHT keyframes, and the map maintenance of GaussianMapper::trainForOneIteration / run (src/gaussian_mapper.cpp:614-774,
+    371-542) on its schedule: increasePcd of 5 k new map points every 10 iterations (a new keyframe's points, :854,955),
+    densifyAndPrune every 100, one resetOpacity (iteration 150), one oneUpShDegree (iteration 200; the model starts at degree 2).
+    Training learning rates.  One HIP event per iteration: it/s over the whole loop and the cost of each kind of event above the
+    median plain step.  (ORB-SLAM3's pose feed is not part of the measured step: the keyframes are the scene's camera arc.)"""
+    import math
+    cl = scene.make_config("C5", seed=seed, n_views=8)
+    cams = cl.cameras
+    W, H, P = cams[0].W, cams[0].H, cl.xyz.shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bg = torch.zeros(3, device=dev)
+    feats = np.concatenate([cl.features_dc, cl.features_rest], 1)
+    h = ops.trainer_create(t(cl.xyz), t(feats), t(cl.opacity), t(cl.scaling), t(cl.rotation), 3, float(cl.extent), bg)
+    ops.trainer_set_options(h, {"lazy_sh_adam_window": float(sh_adam_window), "densify": 1.0, "cameras_extent": float(cl.extent),
+                                "seed": float(seed), "densify_from_iter": 0.0, "densification_interval": 100.0,
+                                "opacity_reset_interval": 150.0, "active_sh_degree": 2.0})
+    kfs, gts = [], []
+    gen = torch.Generator(device="cpu").manual_seed(4321 + seed)
+    for c in cams:
+        view, proj, cen = t(c.viewmatrix), t(c.projmatrix), t(c.campos)
+        fov = (2 * math.atan(c.tanfovx), 2 * math.atan(c.tanfovy))
+        img = ops.trainer_render(h, view, proj, cen, fov[0], fov[1], H, W, bg)[0]
+        noise = torch.nn.functional.avg_pool2d(torch.rand(3, H, W, generator=gen).unsqueeze(0), 5, 1, 2).squeeze(0).to(dev)
+        kfs.append((view, proj, cen, fov))
+        gts.append((img.detach() + 0.1 * (noise - 0.5)).clamp_(0.0, 1.0))
+    mask = torch.ones(3, H, W, device=dev)
+    rng = np.random.default_rng(5 + seed)
+    new_pts = t(rng.uniform([-3, -1.5, -3], [3, 1.5, 3], (5000, 3)).astype(np.float32))
+    new_cols = torch.rand(5000, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+
+    def step(i):
+        view, proj, cen, fov = kfs[i % 8]
+        ops.trainer_render_and_backward(h, view, proj, cen, fov[0], fov[1], H, W, gts[i % 8], mask)
+        ops.trainer_finish(h)           # statistics, densifyAndPrune / resetOpacity on their schedule, Adam
+
+    for i in range(8):                  # warm-up (allocator, lazy rows): iterations 1..8 of the schedule, untimed
+        step(i)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    kinds = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    points = [int(ops.trainer_params(h)[0].shape[0])]
+    for i in range(steps):
+        it = 8 + i + 1                  # the trainer's iteration counter of this step
+        step(8 + i)
+        kind = "plain"
+        if it % 100 == 0:
+            kind = "densifyAndPrune"
+        elif it % 150 == 0:
+            kind = "resetOpacity"
+        if it == 200:
+            ops.trainer_one_up_sh_degree(h)
+            kind = kind if kind != "plain" else "oneUpShDegree"
+        if it % 10 == 0:
+            ops.trainer_increase_pcd(h, new_pts, new_cols, it, False)
+            kind = kind + "+increasePcd" if kind != "plain" else "increasePcd"
+        kinds.append(kind)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+    plain = float(np.median([per[i] for i in range(steps) if kinds[i] == "plain"]))
+    events = {}
+    for k in sorted(set(kinds) - {"plain"}):
+        v = [float(per[i]) for i in range(steps) if kinds[i] == k]
+        events[k] = {"count": len(v), "ms_per_step_median": round(float(np.median(v)), 3), "ms_over_a_plain_step_median": round(float(np.median(v)) - plain, 3)}
+    P_end = int(ops.trainer_params(h)[0].shape[0])
+    ops.trainer_destroy(h)
+    torch.cuda.empty_cache()
+    return {"workload": "C5 shape: EuRoC MH_01, 4 M Gaussians @ 752x480, eight keyframes in rotation, full mapper-loop maintenance, one GPU",
+            "steps": steps, "iters_per_s": round(steps / el, 3), "ms_per_step_mean": round(el / steps * 1e3, 3),
+            "ms_plain_step_median": round(plain, 3), "events": events, "gaussians_start": P, "gaussians_end": P_end,
+            "learning_rates": "training", "sh_degree": "2, then 3 from iteration 200 (oneUpShDegree)",
+            "schedule": "increasePcd(5 k) every 10 iterations, densifyAndPrune every 100, resetOpacity at 150, oneUpShDegree at 200",
+            "note": "one HIP event per iteration; an iteration's time includes the maintenance calls that follow its optimizer step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +380,10 @@ def main():
                     help="steps of the dropin_unfused leg: the reference's own host code on these kernels (0 = skip)")
     ap.add_argument("--dropin-only", action="store_true", help="run only the dropin_unfused leg (profiling)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic scene (SURVEY.md 8d: 0 for reported numbers, 1-4 for variance)")
+    ap.add_argument("--mapper-loop", action="store_true",
+                    help="run ONLY the C5-shaped mapper-loop leg (4 M @ 752x480, eight keyframes, increasePcd / densify / opacity reset / "
+                         "oneUpShDegree on the mapper's schedule) and print its JSON")
+    ap.add_argument("--mapper-loop-steps", type=int, default=300)
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -346,6 +430,13 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         preflight = multi_gpu_preflight(torch, dist, backend, dev, world, rank, local_rank)
     lib = capi.load()  # raises if libgsr_hip.so is missing
+    if args.mapper_loop:
+        sys.path.insert(0, os.path.join(ROOT, "photo-slam_amd", "host"))
+        import build_host
+        torch.ops.load_library(build_host.build("hip"))
+        print(json.dumps({"mapper_loop": mapper_loop_leg(torch, dev, torch.ops.photoslam_amd, scene, args.mapper_loop_steps, args.seed,
+                                                         args.sh_adam_window)}), flush=True)
+        return
 
     cfg = scene.CONFIGS[args.config]
     cl = scene.make_config(args.config, seed=args.seed, n_views=max(world, 1), P=args.points)

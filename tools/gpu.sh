@@ -16,6 +16,7 @@
 #   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
 #   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
 #   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
+#   mapper       bench.py --mapper-loop: the C5-shaped mapper loop on one GPU (4 M @ 752x480, eight keyframes, map maintenance) -> mapper_loop_C5.json
 #   dropin       bench.py --dropin-only: the reference's own host code (oracle/_ref/libref_host_hip.so) on these kernels, 20 steps at C3
 #   dropinstats  rocprofv3 --kernel-trace --stats of that leg -> kernel_stats_dropin_unfused_C3.csv
 #   seeds        benchq for scene seeds 0..4 -> seed_spread_C3.json (seeds 1-4 for variance)
@@ -171,6 +172,7 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
 import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
             done ;;
     dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
+    mapper) timeout 900 python bench.py --mapper-loop > $OUT/mapper_loop_C5.json 2>$OUT/mapper_err.log; cut -c1-1500 $OUT/mapper_loop_C5.json; tail -3 $OUT/mapper_err.log ;;
     dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
     dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
     seeds)  for sd in 0 1 2 3 4; do timeout 300 python bench.py --seed $sd --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_C3_seed$sd.json 2>>$OUT/bench_err.log; done
