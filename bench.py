@@ -285,7 +285,8 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
     for c in cams:
         view, proj, cen = t(c.viewmatrix), t(c.projmatrix), t(c.campos)
         fov = (2 * math.atan(c.tanfovx), 2 * math.atan(c.tanfovy))
-        img = ops.trainer_render(h, view, proj, cen, fov[0], fov[1], H, W, bg)[0]
+        with torch.no_grad():
+            img = ops.trainer_render(h, view, proj, cen, fov[0], fov[1], H, W, False, False, True)[0]
         noise = torch.nn.functional.avg_pool2d(torch.rand(3, H, W, generator=gen).unsqueeze(0), 5, 1, 2).squeeze(0).to(dev)
         kfs.append((view, proj, cen, fov))
         gts.append((img.detach() + 0.1 * (noise - 0.5)).clamp_(0.0, 1.0))

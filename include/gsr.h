@@ -148,6 +148,11 @@ typedef struct gsr_forward_args {
  * list.  0 = the reference's lists, bit for bit.  Measured: 26-40 % of the instances go, the sort and
  * the blend kernels gain what the test costs in the emission -- both hosts leave it off unless GSR_CULL_EMPTY_TILES=1. */
 #define GSR_CULL_EMPTY_TILES 8
+/* ... and one for introspection (ignored by gsr_backward): the forward pass ALSO leaves the 3-D covariances it computed in the
+ * geometry buffer (24 bytes per visible Gaussian; the reference's geomState.cov3D).  Nothing in the library reads them back --
+ * gsr_backward recomputes them from scales / rotations, the same arithmetic and the same bits -- so by default they are not
+ * written; the test-suite's view into the buffer (tests/dev) asks for them. */
+#define GSR_STORE_COV3D 16
 
 /* Rasterizer::forward, cuda_rasterizer/rasterizer_impl.cu:198-336.
  * Fills out_color and radii, returns the number of (tile, Gaussian) instances in

@@ -467,7 +467,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.P = P; pb.D = a->D; pb.M = a->M;
 	pb.means3D = a->means3D; pb.radii = a->radii ? a->radii : g.radii; pb.shs = a->shs; pb.clamped = g.clamped;
 	pb.scales = a->scales; pb.rotations = a->rotations; pb.scale_modifier = a->scale_modifier;
-	pb.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
+	pb.cov3D = a->cov3D_precomp;   // (null: preprocess_bwd recomputes the covariance from scales / rotations, kernels.h)
 	pb.view = a->viewmatrix; pb.proj = a->projmatrix; pb.campos = a->campos;
 	pb.focal_y = H / (2.0f * a->tan_fovy);
 	pb.focal_x = W / (2.0f * a->tan_fovx);

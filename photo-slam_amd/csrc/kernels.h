@@ -124,7 +124,7 @@ struct PreprocessBwdParams {
 	const float* scales;
 	const float* rotations;
 	float scale_modifier;
-	const float* cov3D;     // geom.cov3D or cov3D_precomp
+	const float* cov3D;     // cov3D_precomp, or null: recomputed from scales / rotations (compute_cov3D)
 	const float* view;      // [16] device
 	const float* proj;      // [16] device
 	const float* campos;    // [3] device
@@ -198,5 +198,46 @@ int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t 
 // simple-knn
 size_t knn_scratch_bytes(int P);
 int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipStream_t stream);
+
+// computeCov3D, forward.cu:118-152 (M = S*R with S diagonal: M[c][r] = s_r * R[c][r]; Sigma = transpose(M) * M), with the
+// activations of raw_params applied first (getScalingActivation / getRotationActivation, gaussian_model.cpp:48-56).
+// ONE function for the forward preprocess, which needs Sigma for the projection, and for the backward preprocess, which
+// needs it again for computeCov2DCUDA (backward.cu:144-274): the reference stores 24 bytes per Gaussian in between
+// (geomState.cov3D), here the backward pass recomputes them from the scale and rotation it loads anyway -- both translation
+// units are compiled with -ffp-contract=off, so the two evaluations are the same bits.
+__device__ __forceinline__ void compute_cov3D(const float* __restrict__ scales, const float* __restrict__ rotations, size_t idx,
+                                              float scale_modifier, int raw_params, float c3[6])
+{
+	float sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
+	if (raw_params & GSR_RAW_SCALING) {   // getScalingActivation, gaussian_model.cpp:48-51
+		sx = expf(sx);
+		sy = expf(sy);
+		sz = expf(sz);
+	}
+	const float s0 = scale_modifier * sx, s1 = scale_modifier * sy, s2 = scale_modifier * sz;
+	float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+	if (raw_params & GSR_RAW_ROTATION) {  // getRotationActivation: F::normalize (eps 1e-12), :53-56
+		const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+		q.x = q.x / qn;
+		q.y = q.y / qn;
+		q.z = q.z / qn;
+		q.w = q.w / qn;
+	}
+	const float r = q.x, x = q.y, y = q.z, z = q.w;
+	// R[c][r] (glm column-major) exactly as written at forward.cu:135-139
+	const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+	const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+	const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+	const float M00 = s0 * R00, M01 = s1 * R01, M02 = s2 * R02;
+	const float M10 = s0 * R10, M11 = s1 * R11, M12 = s2 * R12;
+	const float M20 = s0 * R20, M21 = s1 * R21, M22 = s2 * R22;
+	// Sigma = transpose(M) * M:  Sigma[c][r] = M[r][0]*M[c][0] + M[r][1]*M[c][1] + M[r][2]*M[c][2]
+	c3[0] = M00 * M00 + M01 * M01 + M02 * M02;
+	c3[1] = M10 * M00 + M11 * M01 + M12 * M02;
+	c3[2] = M20 * M00 + M21 * M01 + M22 * M02;
+	c3[3] = M10 * M10 + M11 * M11 + M12 * M12;
+	c3[4] = M20 * M10 + M21 * M11 + M22 * M12;
+	c3[5] = M20 * M20 + M21 * M21 + M22 * M22;
+}
 
 }  // namespace gsr

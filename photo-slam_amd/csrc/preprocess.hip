@@ -83,36 +83,7 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 #pragma unroll
 				for (int i = 0; i < 6; i++) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
 			} else {
-				float sx = p.scales[3 * idx], sy = p.scales[3 * idx + 1], sz = p.scales[3 * idx + 2];
-				if (p.raw_params & GSR_RAW_SCALING) {   // getScalingActivation, gaussian_model.cpp:48-51
-					sx = expf(sx);
-					sy = expf(sy);
-					sz = expf(sz);
-				}
-				const float s0 = p.scale_modifier * sx, s1 = p.scale_modifier * sy, s2 = p.scale_modifier * sz;
-				float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
-				if (p.raw_params & GSR_RAW_ROTATION) {  // getRotationActivation: F::normalize (eps 1e-12), :53-56
-					const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-					q.x = q.x / qn;
-					q.y = q.y / qn;
-					q.z = q.z / qn;
-					q.w = q.w / qn;
-				}
-				const float r = q.x, x = q.y, y = q.z, z = q.w;
-				// R[c][r] (glm column-major) exactly as written at forward.cu:135-139
-				const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
-				const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
-				const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
-				const float M00 = s0 * R00, M01 = s1 * R01, M02 = s2 * R02;
-				const float M10 = s0 * R10, M11 = s1 * R11, M12 = s2 * R12;
-				const float M20 = s0 * R20, M21 = s1 * R21, M22 = s2 * R22;
-				// Sigma = transpose(M) * M:  Sigma[c][r] = M[r][0]*M[c][0] + M[r][1]*M[c][1] + M[r][2]*M[c][2]
-				c3[0] = M00 * M00 + M01 * M01 + M02 * M02;
-				c3[1] = M10 * M00 + M11 * M01 + M12 * M02;
-				c3[2] = M20 * M00 + M21 * M01 + M22 * M02;
-				c3[3] = M10 * M10 + M11 * M11 + M12 * M12;
-				c3[4] = M20 * M10 + M21 * M11 + M22 * M12;
-				c3[5] = M20 * M20 + M21 * M21 + M22 * M22;
+				compute_cov3D(p.scales, p.rotations, (size_t)idx, p.scale_modifier, p.raw_params, c3);   // (kernels.h: shared with the backward pass)
 			}
 
 			// computeCov2D, forward.cu:74-113
@@ -163,9 +134,9 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 			const int rmaxy = min(p.grid_y, max(0, f2i((piy + mr + TILE - 1) / TILE)));
 			const uint32_t tiles = (uint32_t)(rmaxy - rminy) * (uint32_t)(rmaxx - rminx);
 			if (tiles == 0) break;
-			// (written only now: the backward pass reads the covariance of VISIBLE Gaussians only, and a third of the Gaussians in
-			// front of the camera end here with no tile -- 24 bytes each that nobody would read)
-			if (p.cov3D_precomp == nullptr) {
+			// GSR_STORE_COV3D only (the parity view of the test-suite): the backward pass recomputes the covariance from scale and
+			// rotation (kernels.h: compute_cov3D) -- 24 bytes per visible Gaussian neither written here nor gathered there
+			if (p.cov3D_precomp == nullptr && (p.raw_params & GSR_STORE_COV3D)) {
 #pragma unroll
 				for (int i = 0; i < 6; i++) g.cov3D[6 * (size_t)idx + i] = c3[i];
 			}

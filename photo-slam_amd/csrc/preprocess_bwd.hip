@@ -340,8 +340,12 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	if (vis) {
 		// ------------------------------------------------------------------ computeCov2DCUDA, backward.cu:144-274
 		float c3[6];
+		if (p.cov3D) {   // a covariance the caller precomputed (cov3D_precomp)
 #pragma unroll
-		for (int i = 0; i < 6; i++) c3[i] = p.cov3D[6 * (size_t)idx + i];
+			for (int i = 0; i < 6; i++) c3[i] = p.cov3D[6 * (size_t)idx + i];
+		} else {         // the forward preprocess's own: recomputed, the same bits (kernels.h)
+			compute_cov3D(p.scales, p.rotations, (size_t)idx, p.scale_modifier, p.raw_params, c3);
+		}
 		float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
 		float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
 		const float tz0 = V[2] * mx + V[6] * my + V[10] * mz + V[14];

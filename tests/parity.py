@@ -71,7 +71,9 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
                  projmatrix=_t(cam.projmatrix, dev), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, image_height=cam.H,
                  image_width=cam.W, sh=empty if use_colors_precomp else _t(_features(cl, sh_coeffs), dev), degree=sh_degree,
                  campos=_t(cam.campos, dev), prefiltered=False)
-        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a, raw_params=flags)
+        # (| 16 = GSR_STORE_COV3D: this function hands out a view of the covariances the forward pass computed; the product path
+        # does not store them -- gsr_backward recomputes them, and every backward comparison below exercises exactly that)
+        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(**a, raw_params=flags | 16)
         r = BackendResult()
         r.R, r.out_color, r.radii = R, color.cpu().numpy(), radii.cpu().numpy()
         if P:
