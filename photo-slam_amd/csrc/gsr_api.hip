@@ -80,6 +80,13 @@ static bool lazy_slice_early(const gsr_sh_adam* o)
 	static const int env = env_int("GSR_LAZY_SLICE_EARLY", -1);
 	return env >= 0 ? env != 0 : !(o && o->lazy_slice_late);
 }
+// GSR_COV3D_STORED=1 (A/B handle only): the round-3 arrangement -- the forward pass stores the 3-D covariances, the backward pass
+// gathers them -- instead of recomputing them in preprocess_bwd (kernels.h: compute_cov3D); same bits either way
+static bool cov3D_stored()
+{
+	static const int env = env_int("GSR_COV3D_STORED", 0);
+	return env != 0;
+}
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -245,7 +252,8 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.W = W; pp.H = H; pp.tan_fovx = a->tan_fovx; pp.tan_fovy = a->tan_fovy;
 	pp.focal_y = H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:221-222
 	pp.focal_x = W / (2.0f * a->tan_fovx);
-	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii; pp.raw_params = a->raw_params;
+	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
+	pp.raw_params = a->raw_params | (cov3D_stored() ? GSR_STORE_COV3D : 0);
 	pp.ranges = im.ranges; pp.tiles = tiles;   // zeroed there: rasterizer_impl.cu:310
 	pp.lazy = LazyAdam{};
 	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
@@ -468,6 +476,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.means3D = a->means3D; pb.radii = a->radii ? a->radii : g.radii; pb.shs = a->shs; pb.clamped = g.clamped;
 	pb.scales = a->scales; pb.rotations = a->rotations; pb.scale_modifier = a->scale_modifier;
 	pb.cov3D = a->cov3D_precomp;   // (null: preprocess_bwd recomputes the covariance from scales / rotations, kernels.h)
+	if (!pb.cov3D && cov3D_stored()) pb.cov3D = g.cov3D;
 	pb.view = a->viewmatrix; pb.proj = a->projmatrix; pb.campos = a->campos;
 	pb.focal_y = H / (2.0f * a->tan_fovy);
 	pb.focal_x = W / (2.0f * a->tan_fovx);

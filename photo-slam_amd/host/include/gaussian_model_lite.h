@@ -155,7 +155,7 @@ public:
 
 private:
 	torch::Tensor& paramByIndex(int i);
-	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq);
+	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq, bool rows_kept = false);
 	// gsr_densify_select + one host read + gsr_densify_gather; returns kept, clones, child parents, split, clone-selected, rows
 	std::array<int64_t, 6> compact(struct gsr_densify_select_args& sel, c10::optional<at::Generator> generator);
 	static void* hostStream(const torch::Tensor& t);   // the current HIP stream of the tensor's device (null on the host)

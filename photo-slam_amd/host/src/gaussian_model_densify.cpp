@@ -104,11 +104,16 @@ void GaussianModel::increasePcd(torch::Tensor& new_point_cloud, torch::Tensor& n
 void GaussianModel::appendRows(const std::array<torch::Tensor, 5>& rows, int iteration)
 {
 	torch::NoGradGuard ng;
-	syncFeatures();   // the SH tensor is re-seated: no row may be behind (lazy SH Adam)
 	const int64_t P = xyz_.size(0), n = rows[0].size(0);
 	const bool have_state = groups_.size() == 5;
 	bool live = arena_.capacity >= P + n && arena_.params[0][0][0].defined() && arena_.params[0][0][0].device() == xyz_.device();
 	for (int i = 0; live && i < 5; i++) live = paramByIndex(i).data_ptr() == arena_.params[arena_.cur][i][0].data_ptr();
+	// Lazy SH Adam: rows of the SH tensor may be steps behind.  An append IN PLACE moves no existing row, so they may stay
+	// behind -- the new rows join up to date (zero moments: the zero-gradient steps they would take change nothing), and the
+	// 1152 B per Gaussian of a flush (1 ms at 4 M Gaussians, measured: the mapper-loop leg of bench.py inserts every 10
+	// iterations) are not paid.  Every other case re-seats the tensor: no row may be behind then.
+	const bool keep_lazy = live && have_state && features_row_step_.defined();
+	if (!keep_lazy) syncFeatures();
 	if (!exist_since_iter_.defined()) exist_since_iter_ = torch::zeros({P}, xyz_.options().dtype(torch::kInt32).requires_grad(false));
 	auto old_exist = exist_since_iter_;
 	std::array<torch::Tensor, 5> old_param;
@@ -134,9 +139,11 @@ void GaussianModel::appendRows(const std::array<torch::Tensor, 5>& rows, int ite
 		b[0].narrow(0, P, n).copy_(rows[i].reshape(b[0].narrow(0, P, n).sizes()));
 		b[1].narrow(0, P, n).zero_();
 		b[2].narrow(0, P, n).zero_();
-		if (have_state) replaceParam(i, b[0], b[1], b[2]);
+		if (have_state) replaceParam(i, b[0], b[1], b[2], /*rows_kept=*/keep_lazy);
 		else replaceParam(i, b[0], torch::Tensor(), torch::Tensor());
 	}
+	if (keep_lazy)
+		features_row_step_ = torch::cat({features_row_step_, torch::full({n}, groups_[1].step, features_row_step_.options())});
 	auto exist = arena_.exist[arena_.cur].narrow(0, 0, P + n);
 	if (old_exist.data_ptr() != exist.data_ptr()) exist.narrow(0, 0, P).copy_(old_exist);
 	exist.narrow(0, P, n).fill_(iteration);
@@ -184,9 +191,11 @@ torch::Tensor& GaussianModel::paramByIndex(int i)
 
 // replaceTensorToOptimizer (src/gaussian_model.cpp:567-586) for the fused optimizer: the group keeps its
 // hyper-parameters, the moments are the given tensors or zeros.
-void GaussianModel::replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq)
+void GaussianModel::replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq, bool rows_kept)
 {
-	if (group == 1) syncFeatures();
+	// rows_kept: `fresh` is the old tensor's storage with rows appended -- the lazily stepped rows of the SH tensor stay where
+	// (and as far behind as) they are; everything else re-seats the tensor and needs every row up to date first
+	if (group == 1 && !rows_kept) syncFeatures();
 	fresh = fresh.contiguous().set_requires_grad(true);
 	paramByIndex(group) = fresh;
 	if (static_cast<size_t>(group) < groups_.size()) {

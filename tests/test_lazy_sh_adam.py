@@ -65,6 +65,13 @@ def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
     bg = torch.zeros(3, device=dev)
     options = {"densify": 1.0, "cameras_extent": float(cl.extent), "seed": 7.0, "densify_from_iter": 1.0, "densification_interval": 4.0,
                "opacity_reset_interval": 6.0, "densify_grad_threshold": 2e-5}
+    # new map points (GaussianModel::increasePcd) behind iterations 2, 5 and 6: the first before any rebuild (the tensors are
+    # re-seated: every lazy row is flushed), the others appended IN PLACE into the arena the densification of iteration 4 left
+    # (the lazy rows stay behind, the new rows join up to date)
+    rng_ins = np.random.default_rng(3)
+    new_pts = t(rng_ins.uniform([-3, -1.5, -3], [3, 1.5, 3], (40, 3)).astype(np.float32))
+    new_cols = t(rng_ins.random((40, 3)).astype(np.float32))
+    insert_after = (2, 5, 6)
 
     def same(a, b, what):
         if dev.type == "cpu":
@@ -85,6 +92,8 @@ def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
             losses.append(float(ops.trainer_render_and_backward(h, t(c.viewmatrix), t(c.projmatrix), t(c.campos), 2 * math.atan(c.tanfovx),
                                                                 2 * math.atan(c.tanfovy), c.H, c.W, gts[it % 3], mask)))
             ops.trainer_finish(h)
+            if it + 1 in insert_after:
+                ops.trainer_increase_pcd(h, new_pts, new_cols, it + 1, False)
         results[window] = (losses, [x.detach().clone() for x in ops.trainer_params(h)], [x.clone() for x in ops.trainer_moments(h)])
         ops.trainer_destroy(h)
     assert results[3][1][0].shape[0] != P   # the model was rebuilt in between
@@ -103,7 +112,11 @@ def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
             ts = TrainStep(g, opt, GaussianPipelineParams(), bg, cameras_extent=float(cl.extent), densify=True, seed=7,
                            lazy_sh_adam_window=window)
             kfs = [GaussianKeyframe.from_camera(c, dev) for c in cams]
-            losses = [float(ts.trainForOneIteration(kfs[it % 3], gts[it % 3], mask)) for it in range(iterations)]
+            losses = []
+            for it in range(iterations):
+                losses.append(float(ts.trainForOneIteration(kfs[it % 3], gts[it % 3], mask)))
+                if it + 1 in insert_after:
+                    g.increasePcd(new_pts, new_cols, it + 1)
             if window:
                 assert g.optimizer_.is_lazy(g._features)   # rows ARE behind at this point ...
             feats = g.features_                             # ... and this read brings them up to date
