@@ -287,6 +287,34 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
  * step (this step's 1/window of the row blocks catches up to `step`).  Same contract as the single-GPU lazy mode otherwise (pass the struct to
  * gsr_forward_args.sh_adam of the step; gsr_sh_adam_flush before anything else touches the tensor); results bit-identical to
  * the eager update (tests/test_lazy_sh_adam.py). */
+/* PACKED exchange of the colour gradients.  Most rows of a view's [P,3] colour gradient are all-zero words (a view sees about
+ * half of a 2 M-Gaussian map; the culled rest is zero), so a rank may send only the rows its view SEES (lit, or carrying the
+ * -0.0f visibility marker) -- the same information in (1 bit + 1/16 word) per Gaussian + 12 B per seen Gaussian:
+ *
+ *   message (uint32 words; gsr_packed_view_words(P, capacity)):
+ *     [0] K = seen rows   [1] P   [2] capacity (rows)   [3] 1 if K > capacity (rows beyond it were DROPPED: a caller's bug)
+ *     [4..6] the view's camera centre (3 floats)   [7] 0
+ *     prefix[ceil(P/64)]   seen rows in front of the 64-row group (exclusive)
+ *     mask  [2 ceil(P/64)] bit (i % 64) of the 64-bit word i / 64: row i is seen (low word first)
+ *     rows  [3 capacity]   the seen rows in index order (floats)
+ *
+ * gsr_pack_color_view builds one message from a view's dL_dcolor_view (four launches; scratch = gsr_pack_scratch_bytes(P));
+ * `capacity` must be the same on every rank (the messages travel through ONE all-gather of equal chunks): the ranks agree on
+ * max_v K_v beforehand -- K of a view is its number of visible Gaussians, which gsr_forward leaves for the calling thread in
+ * gsr_last_visible_count().  gsr_sh_grad_from_packed_views / gsr_sh_adam_from_packed_views are gsr_sh_grad_from_views /
+ * gsr_sh_adam_from_views on n_views such messages, msg_stride words apart: bit-identical results (the same rows, the same
+ * order of the views).  At 2 M Gaussians, 47 % seen: 11.7 MB instead of 24 MB per rank on every link. */
+size_t gsr_packed_view_words(int P, int capacity_rows);
+size_t gsr_pack_scratch_bytes(int P);
+int gsr_pack_color_view(int P, const float* dL_dcolor_view, const float* campos, int capacity_rows, uint32_t* message, void* scratch,
+                        void* stream);
+int gsr_sh_grad_from_packed_views(int P, int D, int M, int n_views, const float* means3D, const uint32_t* messages,
+                                  long long msg_stride, float scale, float* dL_dsh, void* stream);
+int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float* means3D, const uint32_t* messages,
+                                  long long msg_stride, float scale, float* shs, const gsr_sh_adam* sh_adam, void* stream);
+/* Gaussians with radii > 0 in the last gsr_forward of the calling thread (-1 before the first) */
+int gsr_last_visible_count(void);
+
 /* ahead == 0: after the last gsr_sh_adam_from_views range of the step -- row blocks b with b % window == step % window, every
  * row that is behind catches up to `step`.  ahead != 0 (window >= 3): BEFORE the step's gsr_sh_adam_from_views calls (what
  * gsr_backward does on its second stream in the view-factored mode) -- row blocks b with b % (window - 1) == step % (window - 1)

@@ -62,6 +62,7 @@ struct HostSync {
 	}
 };
 static thread_local HostSync t_sync;
+static thread_local int t_last_visible = -1;   // gsr_last_visible_count()
 // Scheduling switches live in the caller's struct (gsr_sh_adam: no_side_stream, lazy_slice_late, side_blocks; zero = the
 // measured-best arrangement).  The environment variable of a switch, when SET, overrides the field -- the A/B handle of the
 // bench sessions; read once per process.
@@ -282,8 +283,12 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));
-	unsigned long long R64 = 0;
-	for (int i = 0; i < NUM_COUNTERS; i++) R64 += t_sync.pinned[i];
+	unsigned long long R64 = 0, V64 = 0;
+	for (int i = 0; i < NUM_COUNTERS; i += 2) {   // (even words: tiles; odd words: visible Gaussians -- preprocess_fwd)
+		R64 += t_sync.pinned[i];
+		V64 += t_sync.pinned[i + 1];
+	}
+	t_last_visible = (int)V64;
 	if (R64 > 0x7FFFFFFFull) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
 	const int R = (int)R64;
 	char* bin_chunk = binningBuffer(binning_ctx, binning_bytes(R));
@@ -561,6 +566,56 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 	return launch_sh_grad_from_views(P, D, M, n_views, means3D, campos, campos_stride, dL_dcolor_views, view_stride, scale,
 	                                 nullptr, &ra, (hipStream_t)stream_, o->lazy ? &la : nullptr);
 }
+
+size_t gsr_packed_view_words(int P, int capacity_rows) { return (P < 0 || capacity_rows < 0) ? 0 : packed_view_words(P, capacity_rows); }
+size_t gsr_pack_scratch_bytes(int P) { return P <= 0 ? 0 : (scan_scratch_elems((int)pack_groups(P)) + 64) * sizeof(uint32_t); }
+
+int gsr_pack_color_view(int P, const float* dL_dcolor_view, const float* campos, int capacity_rows, uint32_t* message, void* scratch,
+                        void* stream_)
+{
+	if (P < 0 || capacity_rows < 0 || (capacity_rows & 3)) return GSR_ERR_INVALID_ARG;   // (a multiple of 4 rows: the messages stay 16-byte aligned)
+	if (P == 0) return GSR_OK;
+	if (!dL_dcolor_view || !campos || !message || !scratch) return GSR_ERR_INVALID_ARG;
+	return launch_pack_color_view(P, dL_dcolor_view, campos, capacity_rows, message, static_cast<uint32_t*>(scratch), (hipStream_t)stream_);
+}
+
+int gsr_sh_grad_from_packed_views(int P, int D, int M, int n_views, const float* means3D, const uint32_t* messages, long long msg_stride,
+                                  float scale, float* dL_dsh, void* stream_)
+{
+	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || msg_stride < 0 || (msg_stride & 1)) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!means3D || !messages || !dL_dsh || (reinterpret_cast<uintptr_t>(messages) & 7)) return GSR_ERR_INVALID_ARG;
+	PackedViews pk;
+	pk.msgs = messages;
+	pk.stride = msg_stride;
+	return launch_sh_grad_from_views(P, D, M, n_views, means3D, nullptr, 0, nullptr, 0, scale, dL_dsh, nullptr, (hipStream_t)stream_,
+	                                 nullptr, pk);
+}
+
+int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float* means3D, const uint32_t* messages, long long msg_stride,
+                                  float scale, float* shs, const gsr_sh_adam* o, void* stream_)
+{
+	if (P < 0 || n_views < 1 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || msg_stride < 0 || (msg_stride & 1)) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!means3D || !messages || (reinterpret_cast<uintptr_t>(messages) & 7) || !shs || !o || !o->exp_avg || !o->exp_avg_sq || o->step < 1)
+		return GSR_ERR_INVALID_ARG;
+	if (o->param && o->param != shs) return GSR_ERR_INVALID_ARG;
+	const RowAdam ra = {shs, o->exp_avg, o->exp_avg_sq, adam_scalars(o->lr, o->lr_tail, o->beta1, o->beta2, o->eps, o->step)};
+	LazyAdam la{};
+	if (o->lazy) {
+		gsr_sh_adam with_param = *o;
+		with_param.param = shs;
+		const int st = make_lazy_adam(with_param, shs, M, la);
+		if (st != GSR_OK) return st;
+	}
+	PackedViews pk;
+	pk.msgs = messages;
+	pk.stride = msg_stride;
+	return launch_sh_grad_from_views(P, D, M, n_views, means3D, nullptr, 0, nullptr, 0, scale, nullptr, &ra, (hipStream_t)stream_,
+	                                 o->lazy ? &la : nullptr, pk);
+}
+
+int gsr_last_visible_count(void) { return t_last_visible; }
 
 int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, int ahead, void* stream_)
 {

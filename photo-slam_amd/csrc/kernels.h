@@ -180,11 +180,23 @@ static inline bool sh_rows_path(const float* shs, int M, int D, bool factored, b
 	return shs && 3 * M == 48 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0 && D >= 0 && D <= 3 &&
 	       (factored || adam || (dL_dsh && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0));
 }
+// Packed colour-gradient messages (include/gsr.h: gsr_pack_color_view): layout helpers shared by the packer and the decoder
+constexpr int PACK_HEADER = 8;
+static inline size_t pack_groups(int P) { return ((size_t)P + 63) / 64; }
+static inline size_t pack_prefix_words(int P) { return (pack_groups(P) + 3) & ~(size_t)3; }
+static inline size_t pack_mask_words(int P) { return (2 * pack_groups(P) + 3) & ~(size_t)3; }
+static inline size_t packed_view_words(int P, int capacity) { return PACK_HEADER + pack_prefix_words(P) + pack_mask_words(P) + 3 * (size_t)capacity + 4; }
+int launch_pack_color_view(int P, const float* view, const float* campos, int capacity, uint32_t* msg, uint32_t* scratch, hipStream_t stream);
+struct PackedViews {   // n_views messages, `stride` words apart; null msgs = the dense [n_views, P, 3] form
+	const uint32_t* msgs = nullptr;
+	long long stride = 0;
+};
 // dL_dsh from the per-view colour gradients of a keyframe batch (gsr_sh_grad_from_views)
 struct RowAdam;   // shrows.h: Adam state + scalars of the fused row update (null = write the gradient rows)
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                               long long campos_stride, const float* dL_dcolor_views, long long view_stride, float scale,
-                              float* dL_dsh, const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy = nullptr);
+                              float* dL_dsh, const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy = nullptr,
+                              PackedViews packed = PackedViews());
 
 // this step's Adam update of the [P,16,3] SH rows of the CULLED Gaussians (radii <= 0; zero gradient): gsr_backward, side stream
 int launch_sh_adam_culled(int P, const int* radii, const RowAdam& adam, hipStream_t stream, int max_blocks);

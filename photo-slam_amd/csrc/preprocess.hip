@@ -238,8 +238,15 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	// host adds up (same-address atomics serialise at ~12 ns each: 31 k waves on ONE word cost 0.37 ms).
 	// Replaces reading back the last element of the scan (rasterizer_impl.cu:281), so the host copy
 	// can overlap the depth sort.
+	const unsigned long long wave_ballot_of_visible = wave_ballot(my_tiles != 0u);
 	const uint32_t wsum = wave_sum_u32(my_tiles);
-	if (lane_id() == 0 && wsum) atomicAdd(&g.counters[(blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS - 1)], wsum);
+	// even words: tiles touched (their total is num_rendered); odd words: visible Gaussians (gsr_last_visible_count: sizes the
+	// packed exchange of a keyframe batch) -- per-wave sums spread over NUM_COUNTERS / 2 slots (same-address atomics serialise)
+	if (lane_id() == 0 && wsum) {
+		uint32_t* slot = &g.counters[2 * ((blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS / 2 - 1))];
+		atomicAdd(slot, wsum);
+		atomicAdd(slot + 1, (uint32_t)__popcll(wave_ballot_of_visible));
+	}
 	// Gaussians whose run of instance slots is too long for one lane of the backward preprocess (state.h: LONG_RUN): listed
 	// here, one atomic per wave that has any (a few thousand entries at C3); the list order is irrelevant to the results
 	const unsigned long long lm = wave_ballot(in_range && my_tiles > LONG_RUN);

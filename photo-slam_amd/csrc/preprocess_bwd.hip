@@ -712,11 +712,15 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 // (row_step keeps counting what it has taken); a row with a gradient first takes the zero-gradient steps it is behind (the
 // forward pass only caught up the rows THIS rank's view sees; another rank's view may light a row this rank culled), then this
 // step, and row_step[i] = step.  The dense 1152 B per Gaussian become 1152 B per Gaussian SOME view of the batch sees.
-template <int DEG, bool ADAM, bool LAZY>
+// PACKED: the views arrive as the messages of gsr_pack_color_view (include/gsr.h) -- a bit per Gaussian says whether the view sees
+// it, its row sits at (seen rows in front of the 64-row group) + (seen rows in front of it inside the group); the camera centre
+// rides in the header.  Same rows, same order of the views: the same bits as the dense form.
+template <int DEG, bool ADAM, bool LAZY, bool PACKED>
 __global__ void __launch_bounds__(SHB_THREADS) GSR_WAVES_PER_EU(4, 8)
 sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos,
                           long long campos_stride, const float* __restrict__ views, long long view_stride, float scale,
-                          float* __restrict__ dL_dsh, const RowAdam adam, const LazyAdam lz)
+                          float* __restrict__ dL_dsh, const RowAdam adam, const LazyAdam lz, const PackedViews pk,
+                          int pk_prefix_words, int pk_mask_words)
 {
 	__shared__ float4 s_rows[SHB_THREADS / 64][STAGE_ROWS][ROW_F4_PAD];
 	__shared__ uint32_t s_lag[SHB_THREADS / 64][STAGE_ROWS];
@@ -738,7 +742,19 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 #pragma unroll 1
 	for (int v = 0; v < n_views; v++) {
 		float r = 0.f, g = 0.f, b = 0.f;
-		if (in_range) {
+		const uint32_t* msg = nullptr;
+		if (PACKED) {
+			msg = pk.msgs + (size_t)v * (size_t)pk.stride;
+			if (in_range) {
+				const uint32_t* prefix = msg + PACK_HEADER;
+				const unsigned long long mw = reinterpret_cast<const unsigned long long*>(prefix + pk_prefix_words)[idx >> 6];
+				if ((mw >> (idx & 63)) & 1ull) {
+					const uint32_t rank = prefix[idx >> 6] + (uint32_t)__popcll(mw & ((1ull << (idx & 63)) - 1ull));
+					const float* c = reinterpret_cast<const float*>(prefix + pk_prefix_words + pk_mask_words) + 3 * (size_t)rank;
+					r = c[0]; g = c[1]; b = c[2];
+				}
+			}
+		} else if (in_range) {
 			const float* c = views + (size_t)v * (size_t)view_stride + (size_t)idx * 3;
 			r = c[0]; g = c[1]; b = c[2];
 		}
@@ -746,7 +762,7 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 		any = any || (__float_as_uint(r) | __float_as_uint(g) | __float_as_uint(b)) != 0u;
 		// culled in this view (or every channel clamped): nothing to add, and most Gaussians are outside most views
 		if (r != 0.f || g != 0.f || b != 0.f) {
-			const float* cp = campos + (size_t)v * (size_t)campos_stride;
+			const float* cp = PACKED ? reinterpret_cast<const float*>(msg + 4) : campos + (size_t)v * (size_t)campos_stride;
 			const float ox = mx - cp[0], oy = my - cp[1], oz = mz - cp[2];
 			const float len = sqrtf(ox * ox + oy * oy + oz * oz);   // forward.cu:27-28
 			const ShDir d = sh_dir(ox / len, oy / len, oz / len);
@@ -835,9 +851,10 @@ sh_grad_from_views_generic_kernel(int P, int D, int M, int n_views, const float*
 
 int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* means3D, const float* campos,
                               long long campos_stride, const float* views, long long view_stride, float scale, float* dL_dsh,
-                              const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy)
+                              const RowAdam* adam, hipStream_t stream, const LazyAdam* lazy, PackedViews packed)
 {
 	if (P == 0) return GSR_OK;
+	const int pkp = (int)pack_prefix_words(P), pkm = (int)pack_mask_words(P);
 	if (campos_stride == 0) campos_stride = 3;
 	if (view_stride == 0) view_stride = 3ll * P;
 	float* rows = adam ? adam->param : dL_dsh;
@@ -845,21 +862,25 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 	if (adam && (!rows_ok || ((reinterpret_cast<uintptr_t>(adam->exp_avg) | reinterpret_cast<uintptr_t>(adam->exp_avg_sq)) & 15)))
 		return GSR_ERR_UNSUPPORTED;   // the fused step exists for aligned [P,16,3] rows only
 	if (lazy && !adam) return GSR_ERR_INVALID_ARG;
+	if (packed.msgs && !rows_ok) return GSR_ERR_UNSUPPORTED;   // the packed form exists for aligned [P,16,3] rows only
 	if (rows_ok) {
 		const int g = div_up(P, SHB_THREADS);
 		const RowAdam ra = adam ? *adam : RowAdam{};
 		const LazyAdam lz = lazy ? *lazy : LazyAdam{};
+#define GSR_SHV_LAUNCH(DEG, A, L, K)                                                                                          \
+	GSR_LAUNCH((sh_grad_from_views_kernel<DEG, A, L, K>), g, SHB_THREADS, stream, P, n_views, means3D, campos, campos_stride,   \
+	           views, view_stride, scale, dL_dsh, ra, lz, packed, pkp, pkm)
 #define GSR_SHV(DEG)                                                                                                          \
 	do {                                                                                                                      \
-		if (adam && lazy)                                                                                                     \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true, true>), g, SHB_THREADS, stream, P, n_views, means3D, campos,    \
-			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
-		else if (adam)                                                                                                        \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, true, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,   \
-			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
-		else                                                                                                                  \
-			GSR_LAUNCH((sh_grad_from_views_kernel<DEG, false, false>), g, SHB_THREADS, stream, P, n_views, means3D, campos,  \
-			           campos_stride, views, view_stride, scale, dL_dsh, ra, lz);                                             \
+		if (packed.msgs) {                                                                                                    \
+			if (adam && lazy) GSR_SHV_LAUNCH(DEG, true, true, true);                                                          \
+			else if (adam) GSR_SHV_LAUNCH(DEG, true, false, true);                                                            \
+			else GSR_SHV_LAUNCH(DEG, false, false, true);                                                                     \
+		} else {                                                                                                              \
+			if (adam && lazy) GSR_SHV_LAUNCH(DEG, true, true, false);                                                         \
+			else if (adam) GSR_SHV_LAUNCH(DEG, true, false, false);                                                           \
+			else GSR_SHV_LAUNCH(DEG, false, false, false);                                                                    \
+		}                                                                                                                     \
 	} while (0)
 		if (D == 3)
 			GSR_SHV(3);
@@ -870,10 +891,87 @@ int launch_sh_grad_from_views(int P, int D, int M, int n_views, const float* mea
 		else
 			GSR_SHV(0);
 #undef GSR_SHV
+#undef GSR_SHV_LAUNCH
 	} else {
 		GSR_LAUNCH(sh_grad_from_views_generic_kernel, div_up(P, 128), 128, stream, P, D, M, n_views, means3D, campos,
 		           campos_stride, views, view_stride, scale, dL_dsh);
 	}
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gsr_pack_color_view (include/gsr.h): one view's [P,3] colour gradient as a message of its SEEN rows.  A row is seen when any
+// of its three words is non-zero (a lit row, or the -0.0f marker of a visible Gaussian whose gradient is all zero); the order
+// of the packed rows is the index order, so the decoder needs only the count in front of each 64-row group (an exclusive scan
+// of the groups' popcounts, launch_scan_u32) and the 64-bit mask of the group.
+__global__ void __launch_bounds__(256)
+pack_mask_kernel(int P, const float* __restrict__ view, uint32_t* __restrict__ counts, uint32_t* __restrict__ mask)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	bool seen = false;
+	if (idx < P) {
+		const float* c = view + 3 * (size_t)idx;
+		seen = (__float_as_uint(c[0]) | __float_as_uint(c[1]) | __float_as_uint(c[2])) != 0u;
+	}
+	const unsigned long long m = wave_ballot(seen);
+	const int group = idx >> 6;   // wave-uniform: blocks of 256 threads start at multiples of 64
+	if (lane_id() == 0 && (size_t)group < pack_groups(P)) {
+		counts[group] = (uint32_t)__popcll(m);
+		mask[2 * (size_t)group] = (uint32_t)m;
+		mask[2 * (size_t)group + 1] = (uint32_t)(m >> 32);
+	}
+}
+
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(int P, const float* __restrict__ view, const float* __restrict__ campos, int capacity, uint32_t* __restrict__ msg,
+                 int prefix_words, int mask_words)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const uint32_t* prefix = msg + PACK_HEADER;
+	float* rows = reinterpret_cast<float*>(msg + PACK_HEADER + prefix_words + mask_words);
+	float r = 0.f, g = 0.f, b = 0.f;
+	bool seen = false;
+	if (idx < P) {
+		const float* c = view + 3 * (size_t)idx;
+		r = c[0]; g = c[1]; b = c[2];
+		seen = (__float_as_uint(r) | __float_as_uint(g) | __float_as_uint(b)) != 0u;
+	}
+	const unsigned long long m = wave_ballot(seen);
+	const int group = idx >> 6;
+	const bool group_exists = (size_t)group < pack_groups(P);
+	const uint32_t first = group_exists ? prefix[group] : 0u;
+	if (seen) {
+		const uint32_t rank = first + (uint32_t)__popcll(m & lanemask_lt());
+		if (rank < (uint32_t)capacity) {
+			rows[3 * (size_t)rank] = r;
+			rows[3 * (size_t)rank + 1] = g;
+			rows[3 * (size_t)rank + 2] = b;
+		}
+	}
+	if (group_exists && (size_t)group == pack_groups(P) - 1 && lane_id() == 0) {   // the last group knows the total
+		const uint32_t K = first + (uint32_t)__popcll(m);
+		msg[0] = K;
+		msg[1] = (uint32_t)P;
+		msg[2] = (uint32_t)capacity;
+		msg[3] = K > (uint32_t)capacity ? 1u : 0u;
+		msg[4] = __float_as_uint(campos[0]);
+		msg[5] = __float_as_uint(campos[1]);
+		msg[6] = __float_as_uint(campos[2]);
+		msg[7] = 0u;
+	}
+}
+
+int launch_pack_color_view(int P, const float* view, const float* campos, int capacity, uint32_t* msg, uint32_t* scratch, hipStream_t stream)
+{
+	if (P <= 0) return GSR_OK;
+	const int groups = (int)pack_groups(P), pw = (int)pack_prefix_words(P), mw = (int)pack_mask_words(P);
+	uint32_t* prefix = msg + PACK_HEADER;
+	GSR_LAUNCH(pack_mask_kernel, div_up(P, 256), 256, stream, P, view, prefix, prefix + pw);
+	// the groups' counts -> the seen rows in front of each group, in place
+	int st = launch_scan_u32(prefix, nullptr, prefix, groups, false, scratch, stream);
+	if (st != GSR_OK) return st;
+	GSR_LAUNCH(pack_rows_kernel, div_up(P, 256), 256, stream, P, view, campos, capacity, msg, pw, mw);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

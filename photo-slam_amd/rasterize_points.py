@@ -276,6 +276,66 @@ def shAdamFromViews(means3D, campos_views, dL_dcolor_views, degree, scale, sh, s
         capi.check(lib, st, "shAdamFromViews")
 
 
+def lastVisibleCount():
+    """gsr_last_visible_count: Gaussians with radii > 0 in this thread's last RasterizeGaussiansCUDA (sizes the packed exchange)"""
+    return int(_lib().gsr_last_visible_count())
+
+
+def packedViewWords(P, capacity):
+    lib = _lib()
+    lib.gsr_packed_view_words.restype = C.c_size_t
+    return int(lib.gsr_packed_view_words(int(P), int(capacity)))
+
+
+def packColorView(dL_dcolor_view, campos, capacity, message=None):
+    """gsr_pack_color_view (include/gsr.h): the [P,3] colour gradient of one view as a message of its SEEN rows (int32 tensor of
+    packedViewWords(P, capacity) words; capacity: a multiple of 4, the same on every rank)."""
+    lib = _lib()
+    P = dL_dcolor_view.size(0)
+    _check_device(lib, dL_dcolor_view, campos)
+    words = packedViewWords(P, capacity)
+    if message is None:
+        message = torch.empty(words, dtype=torch.int32, device=dL_dcolor_view.device)
+    if message.numel() < words or message.dtype != torch.int32 or not message.is_contiguous():
+        raise RuntimeError("message must be a contiguous int32 tensor of packedViewWords(P, capacity) words")
+    if P != 0:
+        lib.gsr_pack_scratch_bytes.restype = C.c_size_t
+        scratch = torch.empty(int(lib.gsr_pack_scratch_bytes(int(P))), dtype=torch.uint8, device=dL_dcolor_view.device)
+        v, c = dL_dcolor_view.contiguous(), campos.contiguous().float()
+        capi.check(lib, lib.gsr_pack_color_view(int(P), C.c_void_p(v.data_ptr()), C.c_void_p(c.data_ptr()), int(capacity),
+                                                C.c_void_p(message.data_ptr()), C.c_void_p(scratch.data_ptr()), _stream_ptr(v)),
+                   "packColorView")
+    return message
+
+
+def shGradFromPackedViews(means3D, messages, msg_stride, n_views, degree, M, scale):
+    """gsr_sh_grad_from_packed_views: shGradFromViews on n_views messages of packColorView, msg_stride words apart"""
+    lib = _lib()
+    P = means3D.size(0)
+    _check_device(lib, means3D, messages)
+    out = torch.empty(P, M, 3, dtype=torch.float32, device=means3D.device)
+    if P != 0:
+        k1, p1 = _ptr(means3D)
+        capi.check(lib, lib.gsr_sh_grad_from_packed_views(int(P), int(degree), int(M), int(n_views), p1, C.c_void_p(messages.data_ptr()),
+                                                          C.c_longlong(int(msg_stride)), C.c_float(float(scale)),
+                                                          C.c_void_p(out.data_ptr()), _stream_ptr(means3D)), "shGradFromPackedViews")
+    return out
+
+
+def shAdamFromPackedViews(means3D, messages, msg_stride, n_views, degree, scale, sh, sh_adam):
+    """gsr_sh_adam_from_packed_views: shAdamFromViews on n_views messages of packColorView"""
+    lib = _lib()
+    P = means3D.size(0)
+    _check_device(lib, means3D, messages, sh)
+    if P != 0:
+        k1, p1 = _ptr(means3D)
+        adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
+        capi.check(lib, lib.gsr_sh_adam_from_packed_views(int(P), int(degree), int(sh.size(1)), int(n_views), p1,
+                                                          C.c_void_p(messages.data_ptr()), C.c_longlong(int(msg_stride)),
+                                                          C.c_float(float(scale)), C.c_void_p(sh.data_ptr()), C.byref(adam),
+                                                          _stream_ptr(means3D)), "shAdamFromPackedViews")
+
+
 def shAdamLazySlice(sh, sh_adam, ahead=False):
     """gsr_sh_adam_lazy_slice (include/gsr.h): this step's slice of the row blocks of the lazily stepped [P,16,3] tensor catches
     up -- after the step's shAdamFromViews calls to sh_adam["step"], or (ahead) before them to step - 1 (what the rasterizer's
