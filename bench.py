@@ -385,6 +385,10 @@ def main():
                     help="run ONLY the C5-shaped mapper-loop leg (4 M @ 752x480, eight keyframes, increasePcd / densify / opacity reset / "
                          "oneUpShDegree on the mapper's schedule) and print its JSON")
     ap.add_argument("--mapper-loop-steps", type=int, default=300)
+    ap.add_argument("--exchange-form", default="auto", choices=["auto", "dense", "packed"],
+                    help="data-parallel runs, view-factored exchange: every rank sends its whole [P + 1, 3] colour-gradient buffer (dense), "
+                         "only the rows its view sees (packed: include/gsr.h gsr_pack_color_view), or whichever a guarded trial of both "
+                         "measures faster on this node (auto)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
     args = ap.parse_args()
@@ -599,6 +603,37 @@ def main():
 
     stationary = not args.training_lr
     set_lr_scale(0.0 if stationary else 1.0)
+    # ---- the form of the view-factored exchange (data-parallel runs driven by the C++ host): a guarded trial of both forms
+    # with frozen parameters (learning rates x 0: the replicas cannot drift apart whatever happens), every rank adopting the
+    # decision of the slowest one; a packed form that fails on this node (it has only ever run at one rank on hardware) leaves
+    # the dense form in place instead of taking the run down
+    exchange_form = None
+    if dp and factored and ops is not None and not py_exchange:
+        exchange_form = {"requested": args.exchange_form}
+        def trial(packed, n=12):
+            ops.trainer_set_options(handle, {"packed_exchange": 1.0 if packed else 0.0, "lr_scale": 0.0})
+            for _ in range(4):
+                one_step()
+            el, _ = timed(n)
+            return el / n * 1e3
+        choice = args.exchange_form
+        if choice == "auto":
+            for _ in range(max(args.sh_adam_window, 8)):     # (both forms are compared in the lazy rows' steady state)
+                one_step()
+            t_dense = trial(False)
+            try:
+                t_packed = trial(True)
+                ok = 1.0
+            except Exception as e:                            # noqa: BLE001 -- any failure of the untested form means "dense"
+                t_packed, ok = float("inf"), 0.0
+                exchange_form["packed_trial_error"] = repr(e)[:300]
+            flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            choice = "packed" if float(flag.item()) > 0 and t_packed < t_dense else "dense"
+            exchange_form.update({"dense_ms_per_step": round(t_dense, 4), "packed_ms_per_step": round(t_packed, 4) if ok else None})
+        ops.trainer_set_options(handle, {"packed_exchange": 1.0 if choice == "packed" else 0.0, "lr_scale": 0.0 if stationary else 1.0})
+        exchange_form["used"] = choice
     # lazy SH Adam (--sh-adam-window): the rotating catch-up of the culled rows reaches its steady state (every flushed row
     # `window` steps behind) after `window` steps -- the steps that the requested warm-up does not cover are run before it,
     # untimed, so that the timed region does a steady state's work per step
@@ -962,7 +997,7 @@ def main():
                            "collectives_issued_by": "python (trainer.py classes)" if (ops is None or py_exchange) else
                                                     "the C++ host (host/src/keyframe_batch_exchange.cpp on c10d::ProcessGroup)",
                            "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
-                           "exchange": "view-factored" if factored else "all-reduce"}
+                           "exchange": "view-factored" if factored else "all-reduce", "exchange_form": exchange_form}
         traffic = traffic_src = None
         # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, tools/gpu_pmc.sh), corrected as
         # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only, on the

@@ -916,7 +916,7 @@ pack_mask_kernel(int P, const float* __restrict__ view, uint32_t* __restrict__ c
 	}
 	const unsigned long long m = wave_ballot(seen);
 	const int group = idx >> 6;   // wave-uniform: blocks of 256 threads start at multiples of 64
-	if (lane_id() == 0 && (size_t)group < pack_groups(P)) {
+	if (lane_id() == 0 && (size_t)group < (((size_t)P + 63) >> 6)) {
 		counts[group] = (uint32_t)__popcll(m);
 		mask[2 * (size_t)group] = (uint32_t)m;
 		mask[2 * (size_t)group + 1] = (uint32_t)(m >> 32);
@@ -939,7 +939,8 @@ pack_rows_kernel(int P, const float* __restrict__ view, const float* __restrict_
 	}
 	const unsigned long long m = wave_ballot(seen);
 	const int group = idx >> 6;
-	const bool group_exists = (size_t)group < pack_groups(P);
+	const size_t groups = ((size_t)P + 63) >> 6;   // (pack_groups: a host helper)
+	const bool group_exists = (size_t)group < groups;
 	const uint32_t first = group_exists ? prefix[group] : 0u;
 	if (seen) {
 		const uint32_t rank = first + (uint32_t)__popcll(m & lanemask_lt());
@@ -949,7 +950,7 @@ pack_rows_kernel(int P, const float* __restrict__ view, const float* __restrict_
 			rows[3 * (size_t)rank + 2] = b;
 		}
 	}
-	if (group_exists && (size_t)group == pack_groups(P) - 1 && lane_id() == 0) {   // the last group knows the total
+	if (group_exists && (size_t)group == groups - 1 && lane_id() == 0) {   // the last group knows the total
 		const uint32_t K = first + (uint32_t)__popcll(m);
 		msg[0] = K;
 		msg[1] = (uint32_t)P;

@@ -251,6 +251,12 @@ public:
 	// of the bench sessions (GSR_CULL_EMPTY_TILES, GSR_EARLY_GATHER, GSR_LAZY_SLICE_EARLY, GSR_SH_ADAM_SIDE_STREAM) only override.
 	bool cull_empty_tiles_ = false;   // instances of tiles no pixel of which can blend the Gaussian leave the list (a wash on MI355X)
 	bool early_gather_ = true;        // the exchange's all-gather waits for the colour gradients only, not for the whole backward pass
+	// The view-factored exchange in its PACKED form (include/gsr.h: gsr_pack_color_view): every rank sends only the rows its
+	// view sees -- 11.7 MB instead of 24 MB per rank and link at 2 M Gaussians.  The ranks agree on the message capacity by
+	// exchanging their views' visible counts (one int each) on the gather stream right behind the forward pass; the host reads
+	// them after it has queued the backward pass.  Off by default until a multi-GPU node has measured it (bench.py picks the
+	// faster form in a guarded trial); bit-identical results (tests/test_packed_views.py, tests/test_train_step.py).
+	bool packed_exchange_ = false;
 	bool lazy_slice_late_ = false;    // the lazy SH rows' slice behind the backward blend instead of next to it
 	bool no_side_stream_ = false;     // no second stream inside gsr_forward / gsr_backward
 	// exposed communication of the data-parallel step: the time the compute stream spent waiting for a collective (HIP events
@@ -268,6 +274,14 @@ public:
 	// buffer taken from the caching allocator at that point could be a block the pass has just released and still writes
 	// (record_stream protects the free side, not the first use on a foreign stream).
 	torch::Tensor sh_gathered_;
+	// packed form: the message buffers (int32; persistent like sh_gathered_), the pack kernels' scratch and the count exchange
+	torch::Tensor sh_packed_send_, sh_packed_gathered_, sh_pack_scratch_;
+	torch::Tensor count_own_pinned_, count_own_dev_, counts_dev_, counts_pinned_;
+	void* counts_event_ = nullptr;     // hipEvent_t behind the counts' copy to the host
+	bool packed_this_step_ = false;
+	void beginCountExchange();         // behind the forward pass: this view's visible count to every rank
+	int64_t finishCountExchange();     // -> the capacity every rank uses (max count, rounded up to 4 rows)
+	void stepFeaturesFromPackedViews(torch::Tensor messages, int64_t msg_stride, int64_t n_views);
 	void* wait_events_[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: before / after the gather wait, before / after the reduce wait
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);

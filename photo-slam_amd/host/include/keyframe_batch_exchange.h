@@ -65,9 +65,21 @@ public:
 	// for the compute stream's tail first (a fresh block of the caching allocator may still be written by the pass).
 	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, torch::Tensor send, torch::Tensor camera_center,
 	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr, torch::Tensor gathered = torch::Tensor());
+	// The PACKED form (include/gsr.h: gsr_pack_color_view): every rank sends the rows its view SEES.  color_view: this view's
+	// [P,3] colour gradient; capacity: rows a message holds -- max over the ranks of their views' visible counts, agreed
+	// beforehand (TrainStep exchanges the counts right behind the forward pass); send / gathered: persistent int32 buffers of
+	// packedViewWords(P, P rounded up) and N times that; the message is built and the gather issued with gather_stream current.
+	struct Packed {
+		torch::Tensor color_view, send, gathered, scratch;
+		int64_t capacity = 0;
+	};
+	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, Packed packed, torch::Tensor camera_center,
+	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr);
 	struct Part {
 		int64_t row0 = 0;
 		torch::Tensor views;   // [N, rows, 3]
+		torch::Tensor messages;   // packed form: int32 [N * msg_stride], the N messages
+		int64_t msg_stride = 0;   // words between two messages (0 = the dense form above)
 		c10::intrusive_ptr<c10d::Work> work;
 	};
 	int parts() const { return static_cast<int>(parts_.size()); }

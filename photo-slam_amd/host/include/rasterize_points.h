@@ -120,6 +120,20 @@ torch::Tensor shGradFromViews(const torch::Tensor& means3D, const torch::Tensor&
 void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_views, const torch::Tensor& dL_dcolor_views,
                      const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam);
 
+// The PACKED form of the exchange (include/gsr.h: gsr_pack_color_view): a view's [P,3] colour gradient as a message of the rows the
+// view SEES (mask + rows + camera centre).  lastVisibleCount(): radii > 0 in this thread's last RasterizeGaussiansCUDA (= the
+// rows a message of that view holds); packedViewWords(): int32 words of a message with room for `capacity` rows (a multiple of 4,
+// the same on every rank); packColorView(): writes `message` (int32, >= packedViewWords words; `scratch` is a uint8 tensor grown as
+// needed) on the CURRENT stream; the two consumers are shGradFromViews / shAdamFromViews on n_views messages msg_stride words apart.
+int lastVisibleCount();
+int64_t packedViewWords(int64_t P, int64_t capacity);
+void packColorView(const torch::Tensor& dL_dcolor_view, const torch::Tensor& campos, int64_t capacity, torch::Tensor& message,
+                   torch::Tensor& scratch);
+torch::Tensor shGradFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
+                                    const int degree, const int M, const float scale);
+void shAdamFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
+                           const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam);
+
 // gsr_sh_adam_flush: lazy mode -- every row of `sh` takes the zero-gradient steps it is behind, up to sh_adam.step = the number
 // of Adam steps the tensor has taken (sh_adam.lr / lr_tail belong to that step)
 void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam);

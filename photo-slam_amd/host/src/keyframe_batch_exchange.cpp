@@ -143,6 +143,42 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others), /*sum_only=*/true);
 }
 
+ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, Packed pk, torch::Tensor camera_center,
+                                           std::vector<torch::Tensor> others, void* gather_stream)
+    : pg_(std::move(pg))
+{
+	const int64_t N = pg_->getSize(), P = pk.color_view.size(0);
+	if (pg_->getBackendName() == "gloo" && pk.color_view.is_cuda())
+		throw std::runtime_error("ViewFactoredExchange: gloo moves host tensors; use the RCCL backend for device tensors");
+	const int64_t words = packedViewWords(P, pk.capacity);
+	if (pk.send.numel() < words || pk.gathered.numel() < N * words)
+		throw std::runtime_error("ViewFactoredExchange: the packed buffers are too small for this capacity");
+	auto send = pk.send.narrow(0, 0, words);
+	gathered_ = pk.gathered.narrow(0, 0, N * words);
+	Part p;
+	p.msg_stride = words;
+	p.messages = gathered_;
+	auto issue = [&]() {
+		packColorView(pk.color_view, camera_center.detach().reshape({3}), pk.capacity, send, pk.scratch);   // four launches, current stream
+		p.work = pg_->_allgather_base(gathered_, send);
+	};
+#ifndef GSR_HOST_NO_HIP
+	if (gather_stream && pk.color_view.is_cuda()) {
+		// (as the dense form: the stream that waits only for "dL_dcolor_view is complete" is made current -- the message is
+		// built there and ProcessGroupNCCL orders the gather behind it)
+		const auto idx = pk.color_view.device().index();
+		auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream), idx);
+		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+		issue();
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
+	} else
+#endif
+		issue();
+	parts_.push_back(p);
+	reduction_ = std::make_unique<GradientReduction>(pg_, std::move(others), /*sum_only=*/true);
+}
+
 torch::Tensor ViewFactoredExchange::centres()
 {
 	part(0);   // (the centres travel with the colour gradients)
@@ -198,6 +234,61 @@ std::vector<double> TrainStep::exchangeWaitMs()
 	return out;
 }
 
+// The packed exchange: every rank's message must have room for the LARGEST view of the batch.  A view's row count is its
+// number of visible Gaussians, which the forward pass leaves on the host (gsr_last_visible_count); the ranks all-gather the
+// counts -- one int each -- on the gather stream right behind the forward pass, i.e. next to the forward blend, the loss and
+// the whole backward pass, and the host picks the result up after it has queued those (no bubble: the device has ~1 ms of
+// work in front of it; the host waits at most for a collective of N ints that was issued long before).
+void TrainStep::beginCountExchange()
+{
+	torch::NoGradGuard ng;
+	const int64_t N = process_group_->getSize();
+	const int V = lastVisibleCount();
+	const auto& xyz = gaussians_->xyz_;
+	if (!xyz.is_cuda()) {   // gloo, host tensors: synchronous
+		auto own = torch::full({1}, V, torch::kInt32);
+		counts_pinned_ = torch::empty({N}, torch::kInt32);
+		process_group_->_allgather_base(counts_pinned_, own)->wait();
+		return;
+	}
+#ifndef GSR_HOST_NO_HIP
+	const auto idx = xyz.device().index();
+	if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, idx).stream();
+	if (!count_own_pinned_.defined() || counts_pinned_.numel() != N) {
+		count_own_pinned_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+		counts_pinned_ = torch::empty({N}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+		count_own_dev_ = torch::empty({1}, xyz.options().dtype(torch::kInt32).requires_grad(false));
+		counts_dev_ = torch::empty({N}, xyz.options().dtype(torch::kInt32).requires_grad(false));
+	}
+	if (!counts_event_) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("beginCountExchange: hipEventCreate failed");
+		counts_event_ = e;
+	}
+	count_own_pinned_.data_ptr<int32_t>()[0] = V;   // (the previous step's copy was waited for in finishCountExchange)
+	auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream_), idx);
+	const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+	count_own_dev_.copy_(count_own_pinned_, /*non_blocking=*/true);
+	process_group_->_allgather_base(counts_dev_, count_own_dev_)->wait();   // (stream-side: the gather stream waits, not the host)
+	counts_pinned_.copy_(counts_dev_, /*non_blocking=*/true);
+	(void)hipEventRecord(static_cast<hipEvent_t>(counts_event_), side.stream());
+	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
+#endif
+}
+
+int64_t TrainStep::finishCountExchange()
+{
+#ifndef GSR_HOST_NO_HIP
+	if (gaussians_->xyz_.is_cuda() && counts_event_ && hipEventSynchronize(static_cast<hipEvent_t>(counts_event_)) != hipSuccess)
+		throw std::runtime_error("finishCountExchange: waiting for the visible counts failed");
+#endif
+	int64_t most = 0;
+	const int32_t* c = counts_pinned_.data_ptr<int32_t>();
+	for (int64_t i = 0; i < counts_pinned_.numel(); i++) most = std::max<int64_t>(most, c[i]);
+	return (most + 3) / 4 * 4;   // (a multiple of 4 rows: the messages stay 16-byte aligned)
+}
+
 void TrainStep::setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool factored)
 {
 	process_group_ = std::move(pg);
@@ -219,8 +310,19 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 	if (factored_exchange_) {
 		std::vector<torch::Tensor> others;
 		for (int i : {0, 2, 3, 4}) others.push_back(params[static_cast<size_t>(i)].grad());
-		vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others,
-		                                            gather_stream_in_use_ ? gather_stream_ : nullptr, sh_gathered_);
+		if (packed_this_step_) {
+			ViewFactoredExchange::Packed pk;
+			pk.color_view = sh_grad_view_;
+			pk.send = sh_packed_send_;
+			pk.gathered = sh_packed_gathered_;
+			pk.scratch = sh_pack_scratch_;
+			pk.capacity = finishCountExchange();
+			vf = std::make_unique<ViewFactoredExchange>(process_group_, pk, kf->camera_center_, others,
+			                                            gather_stream_in_use_ ? gather_stream_ : nullptr);
+			sh_pack_scratch_ = pk.scratch;   // (grown on first use: kept)
+		} else
+			vf = std::make_unique<ViewFactoredExchange>(process_group_, sh_send_, kf->camera_center_, others,
+			                                            gather_stream_in_use_ ? gather_stream_ : nullptr, sh_gathered_);
 	} else {
 		std::vector<torch::Tensor> grads;
 		for (auto& p : params) grads.push_back(p.grad());
@@ -257,7 +359,8 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 					markWait(0);   // (profile_exchange_: how long does the compute stream wait for the all-gather?)
 					const auto& p = vf->part(k);
 					markWait(1);
-					stepFeaturesFromViews(vf->centres(), p.views, p.row0, k == 0);
+					if (p.msg_stride) stepFeaturesFromPackedViews(p.messages, p.msg_stride, process_group_->getSize());
+					else stepFeaturesFromViews(vf->centres(), p.views, p.row0, k == 0);
 				}
 				finishFeaturesFromViews();
 			} else {   // other SH layouts: gradient tensor + separate pass (whole batch)

@@ -169,6 +169,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "active_sh_degree") t->gaussians_->active_sh_degree_ = std::min((int)v, t->gaussians_->max_sh_degree_);
 		else if (k == "cull_empty_tiles") t->cull_empty_tiles_ = v != 0.0;
 		else if (k == "early_gather") t->early_gather_ = v != 0.0;
+		else if (k == "packed_exchange") t->packed_exchange_ = v != 0.0;
 		else if (k == "lazy_slice_late") t->lazy_slice_late_ = v != 0.0;
 		else if (k == "no_side_stream") t->no_side_stream_ = v != 0.0;
 		else if (k == "profile_exchange") t->profile_exchange_ = v != 0.0;

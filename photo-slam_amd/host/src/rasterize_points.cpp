@@ -425,6 +425,65 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 	      "shAdamFromViews");
 }
 
+int lastVisibleCount() { return gsr_last_visible_count(); }
+
+int64_t packedViewWords(int64_t P, int64_t capacity) { return static_cast<int64_t>(gsr_packed_view_words(static_cast<int>(P), static_cast<int>(capacity))); }
+
+void packColorView(const torch::Tensor& dL_dcolor_view, const torch::Tensor& campos, int64_t capacity, torch::Tensor& message,
+                   torch::Tensor& scratch)
+{
+	torch::NoGradGuard ng;
+	const int P = static_cast<int>(dL_dcolor_view.size(0));
+	if (dL_dcolor_view.dim() != 2 || dL_dcolor_view.size(1) != 3 || !dL_dcolor_view.is_contiguous() ||
+	    dL_dcolor_view.scalar_type() != torch::kFloat32)
+		throw std::runtime_error("packColorView: dL_dcolor_view must be a contiguous float32 (num_points, 3) tensor");
+	if (message.scalar_type() != torch::kInt32 || !message.is_contiguous() || message.numel() < packedViewWords(P, capacity) ||
+	    message.device() != dL_dcolor_view.device())
+		throw std::runtime_error("packColorView: message must be a contiguous int32 tensor of packedViewWords(P, capacity) words");
+	if (P == 0) return;
+	const int64_t need = static_cast<int64_t>(gsr_pack_scratch_bytes(P));
+	if (!scratch.defined() || scratch.numel() < need || scratch.device() != dL_dcolor_view.device())
+		scratch = torch::empty({need}, dL_dcolor_view.options().dtype(torch::kByte));
+	F32 c(campos);
+	check(gsr_pack_color_view(P, dL_dcolor_view.data_ptr<float>(), c.ptr, static_cast<int>(capacity),
+	                          reinterpret_cast<uint32_t*>(message.data_ptr<int32_t>()), scratch.data_ptr(), current_stream(dL_dcolor_view)),
+	      "packColorView");
+}
+
+torch::Tensor shGradFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
+                                    const int degree, const int M, const float scale)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	torch::Tensor out = torch::empty({P, M, 3}, means3D.options().dtype(torch::kFloat32));
+	if (P != 0) {
+		F32 m3(means3D);
+		check(gsr_sh_grad_from_packed_views(P, degree, M, static_cast<int>(n_views), m3.ptr,
+		                                    reinterpret_cast<const uint32_t*>(messages.data_ptr<int32_t>()), msg_stride, scale,
+		                                    out.data_ptr<float>(), current_stream(means3D)),
+		      "shGradFromPackedViews");
+	}
+	return out;
+}
+
+void shAdamFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
+                           const int degree, const float scale, torch::Tensor& sh, const ShAdamStep& sh_adam)
+{
+	const int P = static_cast<int>(means3D.size(0));
+	if (sh.dim() != 3 || !sh.is_contiguous() || sh.scalar_type() != torch::kFloat32 || !sh_adam.exp_avg.defined() ||
+	    !sh_adam.exp_avg.is_contiguous() || !sh_adam.exp_avg_sq.is_contiguous() || sh_adam.exp_avg.sizes() != sh.sizes() ||
+	    sh_adam.exp_avg_sq.sizes() != sh.sizes())
+		throw std::runtime_error("sh and its moments must be contiguous float32 (num_points, M, 3) tensors");
+	if (P == 0) return;
+	F32 m3(means3D);
+	gsr_sh_adam adam{};
+	gsr_sh_adam_lazy lazy{};
+	fill_sh_adam(sh_adam, sh.data_ptr<float>(), adam, lazy);
+	check(gsr_sh_adam_from_packed_views(P, degree, static_cast<int>(sh.size(1)), static_cast<int>(n_views), m3.ptr,
+	                                    reinterpret_cast<const uint32_t*>(messages.data_ptr<int32_t>()), msg_stride, scale,
+	                                    sh.data_ptr<float>(), &adam, current_stream(means3D)),
+	      "shAdamFromPackedViews");
+}
+
 void shAdamFlush(torch::Tensor& sh, const ShAdamStep& sh_adam)
 {
 	torch::NoGradGuard ng;

@@ -197,16 +197,32 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 		sh_send_ = torch::empty({P + 1, 3}, g->xyz_.options().requires_grad(false));
 		sh_grad_view_ = sh_send_.narrow(0, 0, P);
 		sh_send_.select(0, P).copy_(kf->camera_center_.detach().reshape({3}));
-		if (process_group_) {
+		// the packed form needs the fused [P,16,3] step of the views (the other layouts take the dense route)
+		packed_this_step_ = packed_exchange_ && process_group_ && g->features_.size(1) == 16 && g->groups_.size() > 1 &&
+		                    g->features_.is_contiguous() && !pipe_.convert_SHs_;
+		if (process_group_ && !packed_this_step_) {
 			const int64_t N = process_group_->getSize();
 			if (!sh_gathered_.defined() || sh_gathered_.size(0) != N || sh_gathered_.size(1) != P + 1 ||
 			    sh_gathered_.device() != sh_send_.device())
 				sh_gathered_ = torch::empty({N, P + 1, 3}, sh_send_.options());
 		}
+		if (packed_this_step_) {
+			// persistent message buffers sized for the worst case (every Gaussian visible), allocated HERE -- before the passes
+			// are enqueued, like sh_gathered_
+			const int64_t N = process_group_->getSize(), words = packedViewWords(P, (P + 3) / 4 * 4);
+			const auto io = sh_send_.options().dtype(torch::kInt32);
+			if (!sh_packed_send_.defined() || sh_packed_send_.numel() != words || sh_packed_send_.device() != sh_send_.device()) {
+				sh_packed_send_ = torch::empty({words}, io);
+				sh_packed_gathered_ = torch::empty({N * words}, io);
+				sh_gathered_ = torch::Tensor();
+			}
+			if (sh_packed_gathered_.numel() != N * words) sh_packed_gathered_ = torch::empty({N * words}, io);
+		}
 	} else {
 		sh_send_ = torch::Tensor();
 		sh_grad_view_ = torch::Tensor();
 		sh_gathered_ = torch::Tensor();
+		packed_this_step_ = false;
 	}
 	ShAdamStep sh_adam;
 	const auto& o = g->opt_;
@@ -316,6 +332,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats, geom_adam,
 	                                    cull_empty_tiles_);
 	g->in_lazy_step_ = false;
+	if (factored_exchange_ && packed_this_step_) beginCountExchange();   // (the forward pass has left this view's visible count)
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);
@@ -414,6 +431,29 @@ void TrainStep::stepFeaturesFromViews(torch::Tensor campos_views, torch::Tensor 
 	auto sh = g->features_.detach().narrow(0, row0, n);
 	shAdamFromViews(g->xyz_.detach().narrow(0, row0, n), campos_views, dL_dcolor_views, g->active_sh_degree_,
 	                1.0f / static_cast<float>(dL_dcolor_views.size(0)), sh, a);
+}
+
+void TrainStep::stepFeaturesFromPackedViews(torch::Tensor messages, int64_t msg_stride, int64_t n_views)
+{
+	torch::NoGradGuard ng;
+	auto& g = gaussians_;
+	if (iteration_ >= g->opt_.iterations_) return;
+	const float scale = 1.0f / static_cast<float>(n_views);
+	auto sh = g->features_.detach();
+	if (views_adam_pending_) {   // lazy rows: renderAndBackward() advanced the step counter and prepared the struct
+		shAdamFromPackedViews(g->xyz_.detach(), messages, msg_stride, n_views, g->active_sh_degree_, scale, sh, views_adam_);
+		return;
+	}
+	g->syncFeatures();
+	auto& grp = g->groups_[1];
+	grp.step++;
+	ShAdamStep a;
+	a.exp_avg = grp.exp_avg;
+	a.exp_avg_sq = grp.exp_avg_sq;
+	a.lr = grp.lr * g->lr_scale_;
+	a.lr_tail = grp.lr_tail * g->lr_scale_;
+	a.step = grp.step;
+	shAdamFromPackedViews(g->xyz_.detach(), messages, msg_stride, n_views, g->active_sh_degree_, scale, sh, a);
 }
 
 void TrainStep::finishFeaturesFromViews()

@@ -308,7 +308,9 @@ if mode == "densify":
     opts.update({"densify": 1.0, "densify_from_iter": 1.0, "densification_interval": 2.0, "densify_grad_threshold": 2e-5})
 ops.trainer_set_options(h, opts)
 # every collective of the step is issued by the C++ host from here on (host/src/keyframe_batch_exchange.cpp)
-ops.trainer_set_process_group(h, dist.group.WORLD.group_name, sys.argv[4] == "factored")
+ops.trainer_set_process_group(h, dist.group.WORLD.group_name, sys.argv[4] in ("factored", "packed"))
+if sys.argv[4] == "packed":   # the view-factored exchange in its packed form: only the rows a view sees travel
+    ops.trainer_set_options(h, {"packed_exchange": 1.0})
 cam = cl.cameras[rank]
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
@@ -334,13 +336,33 @@ def _launch_cpp(tmp_path, emu, n_ranks, port, *worker_args):
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(n_ranks)]
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+@pytest.mark.parametrize("exchange", ["factored", "allreduce", "packed"])
 def test_cpp_host_drives_the_exchange_itself_gloo(emu, tmp_path, exchange):
     """The C++ host's data-parallel step (TrainStep::trainForOneIterationDataParallel on c10d::ProcessGroup,
     host/src/keyframe_batch_exchange.cpp: no collective is issued from Python) on 2 gloo ranks: replicas bit-identical, equal to
     one process that accumulates both keyframes, per-rank statistics as in the Python host's run."""
-    ranks = _launch_cpp(tmp_path, emu, 2, 29531 if exchange == "factored" else 29533, exchange)
+    ranks = _launch_cpp(tmp_path, emu, 2, {"factored": 29531, "allreduce": 29533, "packed": 29539}[exchange], exchange)
     _check_batch(ranks, _single_process_batch(2), lr_units=2e-3)
+
+
+def test_packed_exchange_equals_the_dense_one_bit_for_bit_gloo(emu, tmp_path):
+    """The packed form of the view-factored exchange (only the rows a view sees travel; include/gsr.h: gsr_pack_color_view)
+    against the dense one, C++-driven: the same parameters and statistics BIT FOR BIT after the same iterations -- at 2 ranks,
+    at the EIGHT ranks of BASELINE config C4's batch, and with a densification in the sequence."""
+    for n, port in ((2, 29541), (8, 29545)):
+        dense = [{k: r[k].copy() for k in r.files} for r in _launch_cpp(tmp_path, emu, n, port, "factored")]
+        packed = _launch_cpp(tmp_path, emu, n, port + 2, "packed")
+        for r in range(n):
+            for k in ("xyz", "features", "opacity", "scaling", "rotation", "accum", "denom", "maxr"):
+                assert np.array_equal(dense[r][k], packed[r][k]), (n, r, k)
+        for k in ("xyz", "features", "opacity", "scaling", "rotation"):
+            assert np.array_equal(packed[0][k], packed[n - 1][k]), f"replicas diverged on {k}"
+    dense = [{k: r[k].copy() for k in r.files} for r in _launch_cpp(tmp_path, emu, 2, 29549, "factored", "densify")]
+    packed = _launch_cpp(tmp_path, emu, 2, 29551, "packed", "densify")
+    assert packed[0]["xyz"].shape[0] != 300
+    for r in range(2):
+        for k in ("xyz", "features", "opacity", "scaling", "rotation", "densify"):
+            assert np.array_equal(dense[r][k], packed[r][k]), (r, k)
 
 
 def test_cpp_host_data_parallel_densification_gloo(emu, tmp_path):

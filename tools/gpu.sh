@@ -162,14 +162,15 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
     pmc)    pmc_pass ${arg:-raster} ;;
     sq)     sq_pass ${arg:-full} ;;
     dp)     # dp | dp:allreduce | dp:py (view-factored, collectives issued from Python as in round 2) | dp:late (GSR_EARLY_GATHER=0)
-            ex=factored; pyx=0; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
+            ex=factored; pyx=0; form=auto; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
+            [ "$arg" = packed ] && form=packed; [ "$arg" = dense ] && form=dense   # dp:packed | dp:dense: the form of the view-factored exchange (default: the guarded trial)
             [ "$arg" = late ] && export GSR_EARLY_GATHER=0 || unset GSR_EARLY_GATHER
             for cfg in C3 C4; do
-              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex GSR_BENCH_PY_EXCHANGE=$pyx timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
+              GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex GSR_BENCH_PY_EXCHANGE=$pyx timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 --exchange-form $form > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
               f=$OUT/bench_${cfg}_dp_path_1rank_rccl_${arg:-factored}.json
               grep '^{"metric"' $OUT/dp_$cfg.log > $f   # (the RCCL banner precedes the JSON line)
               python -c "
-import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12])" || tail -5 $OUT/dp_err.log
+import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12], d['rccl'].get('exchange_form'), d.get('exposed_communication'))" || tail -5 $OUT/dp_err.log
             done ;;
     dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
     mapper) timeout 900 python bench.py --mapper-loop > $OUT/mapper_loop_C5.json 2>$OUT/mapper_err.log; cut -c1-1500 $OUT/mapper_loop_C5.json; tail -3 $OUT/mapper_err.log ;;
