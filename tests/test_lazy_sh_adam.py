@@ -77,7 +77,11 @@ def run_host_lazy_checks(ops, dev, lib_path, P=300, iterations=7):
         if dev.type == "cpu":
             assert torch.equal(a, b), what
         else:
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max())), what
+            # (two runs of the same program differ in the last bits of a gradient there; Adam turns a gradient whose SIGN is
+            # rounding noise -- the freshly inserted points of increasePcd, seen by a handful of pixels -- into a whole step of
+            # the learning rate: all but a few elements must agree)
+            off = (a - b).abs() > 1e-4 * b.abs() + 1e-5 * float(b.abs().max())
+            assert float(off.float().mean()) < 2e-3, (what, float(off.float().mean()))
 
     # C++ host
     results = {}
