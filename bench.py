@@ -163,7 +163,7 @@ def cpu_train_step_baseline(scene, args, W, H, quick=False, want_inputs=False):
     return out
 
 
-def dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, steps, stationary=True):
+def dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, steps, stationary=True, fused_loss=False):
     """What a maintainer gets from the API-only swap: the REFERENCE's own host code -- src/gaussian_trainer.cpp:45-133 calling
     src/gaussian_renderer.cpp / src/gaussian_rasterizer.cpp, ATen activations, cat(dc.clone(), rest.clone()), include/loss_utils.h
     through autograd (MIOpen convolutions), torch::optim::Adam, addDensificationStats -- compiled UNCHANGED
@@ -172,11 +172,14 @@ def dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, steps, stationa
     truth as `value`; a baseline beside it, never `value`.  Every iteration ends in torch::cuda::synchronize() + loss.item() as
     the reference's loop does (:86,92), so wall-clock differences are step times: two calls of GaussianTrainer::trainingOnce
     with n and n + steps iterations, (t2 - t1) / steps."""
-    path = os.path.join(ROOT, "oracle", "_ref", "libref_host_hip.so")
+    # fused_loss: the same unchanged sources compiled with ONE header swapped -- include/loss_utils.h -> this repository's
+    # host/include/loss_utils.h (same names and signatures; l1_loss / ssim on the fused HIP kernels): INTEGRATION.md section 5
+    name = "libref_host_hip_fused_loss.so" if fused_loss else "libref_host_hip.so"
+    path = os.path.join(ROOT, "oracle", "_ref", name)
     if not os.path.exists(path):
-        return {"skipped": "oracle/_ref/libref_host_hip.so was never built (python __graft_entry__.py where /root/reference exists)"}
+        return {"skipped": f"oracle/_ref/{name} was never built (python __graft_entry__.py where /root/reference exists)"}
     torch.ops.load_library(path)
-    rops = torch.ops.photoslam_reference_host
+    rops = torch.ops.photoslam_reference_host_fl if fused_loss else torch.ops.photoslam_reference_host
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     h = rops.create([t(cl.xyz), t(cl.features_dc), t(cl.features_rest), t(cl.opacity), t(cl.scaling), t(cl.rotation)], 3, 3,
                     float(cl.extent), float(cl.extent))
@@ -205,8 +208,10 @@ def dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, steps, stationa
             "method": f"GaussianTrainer::trainingOnce with {n0} and {n0 + steps} iterations after a warm-up call; "
                       f"({round(t2, 4)} s - {round(t1, 4)} s) / {steps}",
             "ema_loss_last": ema[-1] if ema else None, "peak_allocated_MB": int(peak // 2**20),
-            "host_code": "the reference's src/gaussian_trainer.cpp, gaussian_renderer.cpp, gaussian_rasterizer.cpp, loss_utils.h, "
-                         "GaussianModel members -- compiled unchanged (oracle/_ref/libref_host_hip.so)",
+            "host_code": "the reference's src/gaussian_trainer.cpp, gaussian_renderer.cpp, gaussian_rasterizer.cpp, "
+                         "GaussianModel members -- compiled unchanged (oracle/_ref/" + name + "); loss: " +
+                         ("this repository's host/include/loss_utils.h in place of the reference's header (fused HIP kernels)" if fused_loss
+                          else "the reference's include/loss_utils.h (MIOpen convolutions through autograd)"),
             "kernels": "lib/libcuda_rasterizer.so -> libgsr_hip.so through the reference's own signatures (no raw_params, no fused "
                        "loss / Adam / statistics: the reference contract)"}
 
@@ -475,6 +480,8 @@ def main():
     if args.dropin_only:
         print(json.dumps({"dropin_unfused": dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, max(args.dropin_steps, 1),
                                                                 stationary=not args.training_lr),
+                          "dropin_loss_header_swapped": dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, max(args.dropin_steps, 1),
+                                                                            stationary=not args.training_lr, fused_loss=True),
                           "config": {"workload": f"{args.config}: {cfg['note']}", "gaussians": P, "width": W, "height": H}}), flush=True)
         return
     if args.densify_interval:
@@ -778,9 +785,10 @@ def main():
                          "note": "training learning rates, fresh model, 100 timed steps (no densification)"}
 
     # ---- the reference's own host code on these kernels: what the API-only swap delivers (never `value`)
-    dropin_run = None
+    dropin_run = dropin_fl_run = None
     if rank == 0 and world == 1 and not dp and not args.raster_only and args.dropin_steps > 0:
         dropin_run = dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, args.dropin_steps)
+        dropin_fl_run = dropin_unfused_leg(torch, dev, cl, kf, fovx, fovy, H, W, gt, args.dropin_steps, fused_loss=True)
 
     # ---- BASELINE config C3 as stated ("with densify/prune + simple-knn"): the same program with the training learning rates and
     # densifyAndPrune every 100 steps (the reference's densification_interval_), on a fresh model; every step timed by its own
@@ -977,6 +985,8 @@ def main():
             out["densify_run"] = densify_run
         if dropin_run:
             out["dropin_unfused"] = dropin_run
+        if dropin_fl_run:
+            out["dropin_loss_header_swapped"] = dropin_fl_run
         # BASELINE.json's configuration AS STATED (C3 "with densify/prune") and the non-stationary figures, lifted next to `value`
         # (`value` itself is the stationary leg: lr x 0, one fixed view, lazy rows in steady state -- the most favourable one)
         out["stated_config"] = {
@@ -984,7 +994,8 @@ def main():
             "densify_every_100_training_lr_iters_per_s": densify_run["iters_per_s"] if densify_run else None,
             "training_lr_100_steps_iters_per_s": train_run_100["iters_per_s"] if train_run_100 else None,
             "changing_views_iters_per_s": views_run["iters_per_s"] if views_run else None,
-            "reference_host_code_on_these_kernels_iters_per_s": dropin_run.get("iters_per_s") if dropin_run else None}
+            "reference_host_code_on_these_kernels_iters_per_s": dropin_run.get("iters_per_s") if dropin_run else None,
+            "reference_host_code_with_this_loss_header_iters_per_s": dropin_fl_run.get("iters_per_s") if dropin_fl_run else None}
         if knn_run:
             out["knn"] = knn_run
         if dp:

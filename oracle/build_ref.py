@@ -228,7 +228,13 @@ def build_link_consumer(force=False):
 # ---------------------------------------------------------------------------------------------------------------------------
 # The reference's HOST code, unchanged, on this repository's kernels.
 
-HOST_OUT = {"emu": os.path.join(OUT_DIR, "libref_host_emu.so"), "hip": os.path.join(OUT_DIR, "libref_host_hip.so")}
+HOST_OUT = {"emu": os.path.join(OUT_DIR, "libref_host_emu.so"), "hip": os.path.join(OUT_DIR, "libref_host_hip.so"),
+            # the same sources with ONE header swapped: include/loss_utils.h -> this repository's host/include/loss_utils.h (same
+            # names and signatures, l1_loss / ssim on the fused HIP kernels) -- what a maintainer gets who also swaps that header
+            "emu_fused_loss": os.path.join(OUT_DIR, "libref_host_emu_fused_loss.so"),
+            "hip_fused_loss": os.path.join(OUT_DIR, "libref_host_hip_fused_loss.so")}
+HOST_OPS = {"emu": "photoslam_reference_host_emu", "hip": "photoslam_reference_host",
+            "emu_fused_loss": "photoslam_reference_host_emu_fl", "hip_fused_loss": "photoslam_reference_host_fl"}
 # compiled VERBATIM (the files themselves, through a tree of symbolic links -- no copy, no rewrite)
 HOST_SOURCES = ["gaussian_rasterizer.cpp", "gaussian_renderer.cpp", "gaussian_trainer.cpp", "gaussian_parameters.cpp"]
 HOST_HEADERS_REF = ["gaussian_renderer.h", "gaussian_rasterizer.h", "rasterize_points.h", "operate_points.h", "loss_utils.h",
@@ -255,7 +261,8 @@ def build_host_tree(force=False):
     the glue of oracle/ref_host.cpp.  `hip`: linked against photo-slam_amd/lib/libcuda_rasterizer.so + libsimple_knn.so (the
     CMake targets named like the reference's) and nothing else of this repository; `emu`: against
     tests/emu/libcuda_rasterizer_emu.so with oracle/ref_host/emu_device.h force-included.
-    Returns {"emu": path, "hip": path} (None where absent)."""
+    `*_fused_loss`: the same with include/loss_utils.h resolving to this repository's host/include/loss_utils.h.
+    Returns {flavour: path} (None where absent); torch op namespaces: HOST_OPS."""
     have = {k: (v if os.path.exists(v) else None) for k, v in HOST_OUT.items()}
     if not os.path.exists(MODEL_SRC):
         return have
@@ -274,58 +281,68 @@ def build_host_tree(force=False):
     compat = os.path.join(host_dir, "include", "compat")
     deps = [glue, MODEL_SRC, __file__] + [os.path.join(standin, f) for f in os.listdir(standin)] + \
         [os.path.join(REF, "src", f) for f in HOST_SOURCES] + [os.path.join(REF, "include", f) for f in HOST_HEADERS_REF] + \
-        [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs] + libs["emu"] + libs["hip"]
+        [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs] + libs["emu"] + libs["hip"] + [os.path.join(host_dir, "include", "loss_utils.h")]
     if not force and all(have.values()) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps for o in HOST_OUT.values()):
         return have
-    tree = os.path.join(GEN, "hosttree")
-    shutil.rmtree(tree, ignore_errors=True)
-    os.makedirs(os.path.join(tree, "include"))
-    os.makedirs(os.path.join(tree, "src"))
-    for f in HOST_HEADERS_REF:
-        os.symlink(os.path.join(REF, "include", f), os.path.join(tree, "include", f))
-    for f in HOST_HEADERS_STANDIN:
-        os.symlink(os.path.join(standin, f), os.path.join(tree, "include", f))
-    for f in HOST_SOURCES:
-        os.symlink(os.path.join(REF, "src", f), os.path.join(tree, "src", f))
-    os.symlink(os.path.join(REF, "third_party"), os.path.join(tree, "third_party"))
+    our_loss = os.path.join(host_dir, "include", "loss_utils.h")
     text = open(MODEL_SRC).read()
     body = "\n\n".join(_member_function(text, n) for n in HOST_MODEL_FUNCTIONS)
     assert body.count(ADAM_KEY) == 6, "the Adam state key idiom changed in the reference"
+    os.makedirs(GEN, exist_ok=True)
     with open(os.path.join(GEN, "ref_gaussian_model_functions.inc"), "w") as f:
         f.write(f'#line 1 "{MODEL_SRC} (extract)"\n' + body + "\n")
     base = os.path.dirname(torch.__file__)
     torch_inc = ["-I" + os.path.join(base, "include"), "-I" + os.path.join(base, "include", "torch", "csrc", "api", "include")]
     libdir = os.path.join(base, "lib")
     common = ["g++", "-std=c++17", "-O2", "-fPIC", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w"]
-    flavour = {
-        # the reference's sources with NO prefix and no definitions beyond what any ROCm LibTorch consumer sets
-        "hip": dict(flags=["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-I" + compat, "-I" + tree, "-I" + os.path.join(tree, "include")] +
-                    torch_inc + ["-I/opt/rocm/include"],
-                    glue_flags=["-include", os.path.join(compat, "optimizer_key.h")],
-                    link=["-ltorch_hip", "-lc10_hip"]),
-        "emu": dict(flags=["-DREF_HOST_EMU=1", "-include", os.path.join(standin, "emu_device.h"), "-I" + tree,
-                           "-I" + os.path.join(tree, "include")] + torch_inc,
-                    glue_flags=["-include", os.path.join(compat, "optimizer_key.h")], link=[]),
-    }
+
+    def make_tree(kind):
+        """the include tree of one flavour: symbolic links to the reference's files, the stand-ins of oracle/ref_host/ for the
+        four headers that need Sophus / Eigen / OpenCV / ORB-SLAM3, and -- *_fused_loss -- this repository's loss_utils.h"""
+        tree = os.path.join(GEN, "hosttree_" + kind)
+        shutil.rmtree(tree, ignore_errors=True)
+        os.makedirs(os.path.join(tree, "include"))
+        os.makedirs(os.path.join(tree, "src"))
+        for f in HOST_HEADERS_REF:
+            src = our_loss if (f == "loss_utils.h" and kind.endswith("fused_loss")) else os.path.join(REF, "include", f)
+            os.symlink(src, os.path.join(tree, "include", f))
+        for f in HOST_HEADERS_STANDIN:
+            os.symlink(os.path.join(standin, f), os.path.join(tree, "include", f))
+        for f in HOST_SOURCES:
+            os.symlink(os.path.join(REF, "src", f), os.path.join(tree, "src", f))
+        os.symlink(os.path.join(REF, "third_party"), os.path.join(tree, "third_party"))
+        return tree
+
     try:
         for kind, out in HOST_OUT.items():
-            fl = flavour[kind]
+            tree = make_tree(kind)
+            ops = "-DREF_HOST_OPS=" + HOST_OPS[kind]
+            if kind.startswith("hip"):
+                # the reference's sources with NO prefix and no definitions beyond what any ROCm LibTorch consumer sets
+                flags = ["-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", ops, "-I" + compat, "-I" + tree, "-I" + os.path.join(tree, "include")] + \
+                    torch_inc + ["-I/opt/rocm/include"]
+                link, lib_kind = ["-ltorch_hip", "-lc10_hip"], "hip"
+            else:
+                flags = ["-DREF_HOST_EMU=1", ops, "-include", os.path.join(standin, "emu_device.h"), "-I" + tree,
+                         "-I" + os.path.join(tree, "include")] + torch_inc
+                link, lib_kind = [], "emu"
+            glue_flags = ["-include", os.path.join(compat, "optimizer_key.h")]
             odir = os.path.join(GEN, "obj_" + kind)
             os.makedirs(odir, exist_ok=True)
             procs, objs = [], []
             for f in HOST_SOURCES:
                 o = os.path.join(odir, f + ".o")
-                procs.append(subprocess.Popen(common + fl["flags"] + ["-c", os.path.join(tree, "src", f), "-o", o]))
+                procs.append(subprocess.Popen(common + flags + ["-c", os.path.join(tree, "src", f), "-o", o]))
                 objs.append(o)
             o = os.path.join(odir, "ref_host.cpp.o")
-            procs.append(subprocess.Popen(common + fl["flags"] + fl["glue_flags"] + ["-I" + GEN, "-c", glue, "-o", o]))
+            procs.append(subprocess.Popen(common + flags + glue_flags + ["-I" + GEN, "-c", glue, "-o", o]))
             objs.append(o)
             if any(p.wait() != 0 for p in procs):
                 raise RuntimeError(f"the reference's host sources did not compile ({kind})")
-            link_dirs = sorted({os.path.dirname(l) for l in libs[kind]})
+            link_dirs = sorted({os.path.dirname(l) for l in libs[lib_kind]})
             subprocess.check_call(["g++", "-shared", "-o", out] + objs + ["-L" + d for d in link_dirs] +
-                                  ["-l" + os.path.basename(l)[3:-3] for l in libs[kind]] +
-                                  ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + fl["link"] +
+                                  ["-l" + os.path.basename(l)[3:-3] for l in libs[lib_kind]] +
+                                  ["-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10"] + link +
                                   # --wrap=rand: the reference loop's std::rand() draws from the harness (oracle/ref_host.cpp)
                                   ["-Wl,--no-undefined", "-Wl,--wrap=rand", "-Wl,-rpath," + libdir] + ["-Wl,-rpath," + d for d in link_dirs])
     finally:

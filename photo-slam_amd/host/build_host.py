@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 # the link-level boundary of the reference (its `cuda_rasterizer` + `simple_knn` libraries) and what this repository adds on top
-BOUNDARY_SRCS = ["rasterize_points.cpp", "operate_points.cpp", "spatial.cpp"]
+BOUNDARY_SRCS = ["rasterize_points.cpp", "operate_points.cpp", "spatial.cpp", "loss_utils.cpp"]
 HOST_SRCS = ["gaussian_rasterizer.cpp", "train_step.cpp", "gaussian_model_densify.cpp", "ply_io.cpp", "keyframe_batch_exchange.cpp",
              "ops_register.cpp"]
 HIP_OUT = {"cuda_rasterizer": os.path.join(PKG, "lib", "libcuda_rasterizer.so"), "simple_knn": os.path.join(PKG, "lib", "libsimple_knn.so"),

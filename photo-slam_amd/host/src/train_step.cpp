@@ -6,6 +6,7 @@
 #include "../../../include/gsr.h"
 #include "gaussian_model_lite.h"
 #include "gaussian_renderer.h"
+#include "loss_utils.h"
 
 #ifndef GSR_HOST_NO_HIP
 #include <c10/hip/HIPStream.h>
@@ -24,37 +25,11 @@ void check(int status, const char* where)
 	if (status != GSR_OK) throw std::runtime_error(std::string(where) + ": " + gsr_strerror(status));
 }
 
-class FusedL1SSIMFunction : public torch::autograd::Function<FusedL1SSIMFunction> {
-public:
-	static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor rendered, torch::Tensor gt,
-	                             torch::Tensor mask, double lambda_dssim, bool is_root)
-	{
-		ctx->saved_data["is_root"] = is_root;
-		auto r = rendered.contiguous(), g = gt.contiguous();
-		torch::Tensor m = mask.defined() && mask.numel() ? mask.contiguous() : torch::Tensor();
-		const int H = static_cast<int>(r.size(1)), W = static_cast<int>(r.size(2));
-		auto grad = torch::empty_like(r);
-		auto loss = torch::empty({1}, r.options());
-		auto scratch = torch::empty({static_cast<int64_t>(gsr_loss_scratch_bytes(W, H))}, r.options().dtype(torch::kByte));
-		check(gsr_l1_ssim_loss(r.data_ptr<float>(), g.data_ptr<float>(), m.defined() ? m.data_ptr<float>() : nullptr, W,
-		                       H, static_cast<float>(lambda_dssim), grad.data_ptr<float>(), loss.data_ptr<float>(),
-		                       reinterpret_cast<char*>(scratch.data_ptr()), stream_of(r)),
-		      "gsr_l1_ssim_loss");
-		ctx->save_for_backward({grad});
-		return loss[0];
-	}
-	static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list go)
-	{
-		auto grad = ctx->get_saved_variables()[0];
-		if (ctx->saved_data["is_root"].toBool()) return {grad, torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
-		return {grad * go[0], torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
-	}
-};
 }  // namespace
 
 torch::Tensor fusedL1SSIMLoss(torch::Tensor rendered, torch::Tensor gt, torch::Tensor mask, float lambda_dssim, bool is_root)
 {
-	return FusedL1SSIMFunction::apply(rendered, gt, mask, static_cast<double>(lambda_dssim), is_root);
+	return loss_utils::fused_l1_ssim(rendered, gt, mask, lambda_dssim, is_root);   // (lib cuda_rasterizer: host/src/loss_utils.cpp)
 }
 
 GaussianModel::GaussianModel(int sh_degree, torch::Tensor xyz, torch::Tensor features, torch::Tensor opacity,

@@ -29,7 +29,7 @@ def _ref_ops(kind):
     if path is None or not os.path.exists(path):
         pytest.skip("oracle/_ref/libref_host_*.so was never built (no reference tree, no prebuilt library)")
     torch.ops.load_library(path)
-    return torch.ops.photoslam_reference_host_emu if kind == "emu" else torch.ops.photoslam_reference_host
+    return getattr(torch.ops, build_ref.HOST_OPS[kind])
 
 
 def _host(variant):

@@ -41,7 +41,7 @@ def _ops(kind):
     if path is None or not os.path.exists(path):
         pytest.skip("oracle/_ref/libref_host_*.so was never built (no reference tree, no prebuilt library)")
     torch.ops.load_library(path)
-    return (torch.ops.photoslam_reference_host_emu if kind == "emu" else torch.ops.photoslam_reference_host), path
+    return getattr(torch.ops, build_ref.HOST_OPS[kind]), path
 
 
 def _keyframe_order(draws, n_keyframes):
@@ -213,13 +213,16 @@ def test_reference_renderer_on_the_emulated_kernels():
     check_render(ops, torch.device("cpu"), cl)
 
 
-def test_reference_training_loop_on_the_emulated_kernels():
+@pytest.mark.parametrize("flavour", ["emu", "emu_fused_loss"])
+def test_reference_training_loop_on_the_emulated_kernels(flavour):
+    """emu_fused_loss: the same unchanged sources with include/loss_utils.h resolving to this repository's
+    host/include/loss_utils.h (l1_loss / ssim on the fused HIP kernels): the header swap of INTEGRATION.md section 5"""
     from oracle import ref_model
     if ref_model.load("cpu") is None:
         pytest.skip("oracle/_ref/libref_densify.so was never built")
-    ops, _ = _ops("emu")
+    ops, _ = _ops(flavour)
     cl = scene.make_cloud(320, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35, n_views=3)
-    run_training_once(ops, torch.device("cpu"), cl, "cpu")
+    run_training_once(ops, torch.device("cpu"), cl, "cpu", " " + flavour)
 
 
 @pytest.mark.gpu
@@ -230,11 +233,13 @@ def test_reference_renderer_on_the_gpu():
 
 
 @pytest.mark.gpu
-def test_reference_training_loop_at_C1_on_the_gpu():
-    """BASELINE config C1: the reference's own trainingOnce, unchanged, on the MI355X kernels against the same loop on the CPU oracle."""
+@pytest.mark.parametrize("flavour", ["hip", "hip_fused_loss"])
+def test_reference_training_loop_at_C1_on_the_gpu(flavour):
+    """BASELINE config C1: the reference's own trainingOnce, unchanged, on the MI355X kernels against the same loop on the CPU
+    oracle; hip_fused_loss: with this repository's loss_utils.h in place of the reference's (the header swap)."""
     from oracle import ref_model
     if ref_model.load("cuda") is None:
         pytest.skip("oracle/_ref/libref_densify_cuda.so was never built")
-    ops, _ = _ops("hip")
+    ops, _ = _ops(flavour)
     cl = scene.make_config("C1", seed=0, n_views=3)
-    run_training_once(ops, torch.device("cuda:0"), cl, "cuda", " @C1")
+    run_training_once(ops, torch.device("cuda:0"), cl, "cuda", f" @C1 {flavour}")
