@@ -502,7 +502,9 @@ def main():
                                          "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
         # GSR_BENCH_PY_EXCHANGE=1: the collectives issued from Python around the C++ pieces (the round-2 arrangement, kept for
         # comparison); default: the C++ host drives the exchange itself on the c10d process group (keyframe_batch_exchange.cpp)
-        py_exchange = os.environ.get("GSR_BENCH_PY_EXCHANGE") == "1" or (dp and backend != "nccl")
+        # (GSR_BENCH_CPP_EXCHANGE=1 keeps the C++ exchange on a backend other than RCCL: the two-ranks-on-one-GPU functional check)
+        py_exchange = os.environ.get("GSR_BENCH_PY_EXCHANGE") == "1" or (dp and backend != "nccl"
+                                                                          and os.environ.get("GSR_BENCH_CPP_EXCHANGE") != "1")
         if dp:
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and not py_exchange:

@@ -2,6 +2,7 @@
 #include "keyframe_batch_exchange.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 
@@ -33,6 +34,14 @@ torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
 	auto flat = torch::empty({0}, tensors[0].options().requires_grad(false));
 	flat.set_(storage, 0, {end}, {1});
 	return flat;
+}
+
+// Device tensors over gloo travel through the host and block the calling thread in Work::wait(): refused, except for the
+// functional check that runs several ranks on ONE GPU (tools/gpu.sh share2 sets GSR_EXCHANGE_ALLOW_GLOO_DEVICE=1).
+static bool glooDeviceTensorsAllowed()
+{
+	const char* e = std::getenv("GSR_EXCHANGE_ALLOW_GLOO_DEVICE");
+	return e && e[0] == '1';
 }
 
 GradientReduction::GradientReduction(c10::intrusive_ptr<c10d::ProcessGroup> pg, std::vector<torch::Tensor> tensors, bool sum_only)
@@ -98,7 +107,7 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 {
 	const int64_t N = pg_->getSize(), P = send.size(0) - 1;
 	const auto o = send.options().requires_grad(false);
-	if (pg_->getBackendName() == "gloo" && send.is_cuda())
+	if (pg_->getBackendName() == "gloo" && send.is_cuda() && !glooDeviceTensorsAllowed())
 		throw std::runtime_error("ViewFactoredExchange: gloo moves host tensors; use the RCCL backend for device tensors");
 	// ONE all-gather: rows 0 .. P-1 of `send` are this view's colour gradients, row P its camera centre -- every collective
 	// costs a launch on RCCL's stream and two cross-stream hand-offs (measured at one rank: four collectives per step cost
@@ -148,7 +157,7 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
     : pg_(std::move(pg))
 {
 	const int64_t N = pg_->getSize(), P = pk.color_view.size(0);
-	if (pg_->getBackendName() == "gloo" && pk.color_view.is_cuda())
+	if (pg_->getBackendName() == "gloo" && pk.color_view.is_cuda() && !glooDeviceTensorsAllowed())
 		throw std::runtime_error("ViewFactoredExchange: gloo moves host tensors; use the RCCL backend for device tensors");
 	const int64_t words = packedViewWords(P, pk.capacity);
 	if (pk.send.numel() < words || pk.gathered.numel() < N * words)

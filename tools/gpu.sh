@@ -16,6 +16,7 @@
 #   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
 #   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
 #   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
+#   share2       N ranks on the box's one GPU over gloo, C++ exchange (share2 | share2:packed | share2:dense | share2:4): functional check of the multi-rank glue
 #   mapper       bench.py --mapper-loop: the C5-shaped mapper loop on one GPU (4 M @ 752x480, eight keyframes, map maintenance) -> mapper_loop_C5.json
 #   dropin       bench.py --dropin-only: the reference's own host code (oracle/_ref/libref_host_hip.so) on these kernels, 20 steps at C3
 #   dropinstats  rocprofv3 --kernel-trace --stats of that leg -> kernel_stats_dropin_unfused_C3.csv
@@ -172,7 +173,18 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
               python -c "
 import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12], d['rccl'].get('exchange_form'), d.get('exposed_communication'))" || tail -5 $OUT/dp_err.log
             done ;;
-    dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 ;;
+    dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3${arg:+_$arg}.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 --dropin-steps 0 --exchange-form ${arg:-dense} ;;   # dpstats | dpstats:packed
+    share2) # share2 | share2:packed | share2:dense | share2:4 -- TWO (or N) ranks on the ONE GPU of the box over gloo, the exchange driven
+            # by the C++ host: a functional check of bench.py's multi-rank glue (trial of the exchange forms, per-rank tables, replica
+            # checksum) -- not a rate: the ranks share the device and gloo moves the bytes through the host
+            n=2; form=auto; case "$arg" in packed|dense) form=$arg ;; [0-9]*) n=$arg ;; esac
+            GSR_BENCH_SHARE_GPU=1 GSR_BENCH_BACKEND=gloo GSR_BENCH_CPP_EXCHANGE=1 GSR_EXCHANGE_ALLOW_GLOO_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
+              --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus $n --steps 10 --warmup 3 --config C2 --no-cpu-baseline --no-knn-leg \
+              --densify-leg-steps 0 --dropin-steps 0 --median-steps 20 --exchange-form $form > $OUT/share_${n}_$form.log 2>$OUT/share_err.log
+            f=$OUT/bench_C2_${n}ranks_one_gpu_gloo_cpp_exchange_$form.json
+            grep '^{"metric"' $OUT/share_${n}_$form.log > $f
+            python -c "
+import json; d=json.load(open('$f')); print('C2 $n ranks one GPU gloo', d['n_gpus'], d['ms_per_step'], d['rccl'], 'replicas_identical', d.get('replicas_identical'), d.get('exposed_communication'), 'per_rank', len(d.get('per_rank') or []))" || tail -20 $OUT/share_err.log ;;
     mapper) timeout 900 python bench.py --mapper-loop > $OUT/mapper_loop_C5.json 2>$OUT/mapper_err.log; cut -c1-1500 $OUT/mapper_loop_C5.json; tail -3 $OUT/mapper_err.log ;;
     dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
     dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
