@@ -621,17 +621,31 @@ class GaussianModel:
             act = self.getOpacityActivation()
             bound = torch.ones_like(act * 0.01) if clamp_to is None else torch.ones_like(act) * clamp_to
             new = inverse_sigmoid(torch.min(act, bound))
-        new = new.clone().requires_grad_(True)
-        old = self.opacity_
-        self.opacity_ = new
-        if self.optimizer_ is not None:
-            self.optimizer_.replace_param(old, new)
+        self._replace_leaf("opacity_", new)
 
     # ---- loop closure (src/gaussian_model.cpp:379-475) ------------------------------------------------------------------------
     def _replace_leaf(self, name, values):
-        """replaceTensorToOptimizer (:567-586): a fresh leaf, zero Adam moments, the step counter carried"""
-        new = values.detach().contiguous().clone().requires_grad_(True)
+        """replaceTensorToOptimizer (:567-586) with a tensor of the same shape: a fresh leaf, zero Adam moments, the step counter
+        carried.  While the leaf is a view of the arena the values are written into its rows and the moment rows zeroed in place,
+        so that the next increasePcd / densifyAndPrune still finds the tensor where it expects it (re-seated outside, the next
+        append rebuilt the whole arena: +25 ms after a resetOpacity at 4 M Gaussians in the C++ host's mapper-loop leg)."""
         old = getattr(self, name)
+        arena = getattr(self, "_arena", None)
+        slot = arena["sets"][arena["cur"]]["params"][name] if arena is not None else None
+        if (slot is not None and old.data_ptr() == slot[0].data_ptr() and values.shape == old.shape and values.device == old.device
+                and values.data_ptr() != old.data_ptr()):
+            P = old.shape[0]
+            with torch.no_grad():
+                bufs = [b.narrow(0, 0, P) for b in slot]
+                bufs[0].copy_(values.detach())
+                bufs[1].zero_()
+                bufs[2].zero_()
+            new = bufs[0].detach().requires_grad_(True)
+            setattr(self, name, new)
+            if self.optimizer_ is not None:
+                self.optimizer_.replace_param(old, new, bufs[1], bufs[2])
+            return
+        new = values.detach().contiguous().clone().requires_grad_(True)
         setattr(self, name, new)
         if self.optimizer_ is not None:
             self.optimizer_.replace_param(old, new)

@@ -156,6 +156,8 @@ public:
 private:
 	torch::Tensor& paramByIndex(int i);
 	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq, bool rows_kept = false);
+	void preloadMaintenanceKernels();   // first-use code-object loads of the ATen kernels behind resetOpacity / loop closure, paid in trainingSetup
+	void replaceParamValues(int group, torch::Tensor fresh);   // same shape, zero moments: in place while the leaf lives in the arena
 	// gsr_densify_select + one host read + gsr_densify_gather; returns kept, clones, child parents, split, clone-selected, rows
 	std::array<int64_t, 6> compact(struct gsr_densify_select_args& sel, c10::optional<at::Generator> generator);
 	static void* hostStream(const torch::Tensor& t);   // the current HIP stream of the tensor's device (null on the host)

@@ -206,6 +206,30 @@ void GaussianModel::replaceParam(int group, torch::Tensor fresh, torch::Tensor e
 	}
 }
 
+// A leaf whose VALUES are replaced and whose moments start again from zero (resetOpacity, the loop-closure transforms: the
+// reference's replaceTensorToOptimizer with a tensor of the same shape).  While the leaf is a view of the arena the new values
+// are written into its rows and the moment rows are zeroed in place: the tensor stays where increasePcd / densifyAndPrune
+// expect it.  (Re-seating it outside made the next increasePcd take the "not live" path: a fresh arena of 2 x 840 B per
+// Gaussian and a copy of everything -- +25 ms on the iteration after a resetOpacity at 4 M Gaussians, bench.py --mapper-loop.)
+void GaussianModel::replaceParamValues(int group, torch::Tensor fresh)
+{
+	auto& leaf = paramByIndex(group);
+	const bool have_state = static_cast<size_t>(group) < groups_.size();
+	bool in_arena = arena_.capacity > 0 && arena_.params[arena_.cur][group][0].defined() && leaf.defined() &&
+	                leaf.data_ptr() == arena_.params[arena_.cur][group][0].data_ptr() && fresh.sizes() == leaf.sizes() &&
+	                fresh.device() == leaf.device() && fresh.data_ptr() != leaf.data_ptr();
+	if (!in_arena) {
+		replaceParam(group, fresh, torch::Tensor(), torch::Tensor());
+		return;
+	}
+	const int64_t P = leaf.size(0);
+	auto& slot = arena_.params[arena_.cur][group];
+	auto value = slot[0].narrow(0, 0, P);
+	value.copy_(fresh.detach());
+	if (have_state) replaceParam(group, value, slot[1].narrow(0, 0, P).zero_(), slot[2].narrow(0, 0, P).zero_());
+	else replaceParam(group, value, torch::Tensor(), torch::Tensor());
+}
+
 // src/gaussian_model.cpp:556-565 exactly as shipped: inverse_sigmoid(min(sigmoid(o), ones_like(sigmoid(o) * 0.01))) -- the
 // 0.01 sits INSIDE ones_like, so the clamp is against 1 and never binds: the values survive (up to the sigmoid / logit round
 // trip) and only the Adam moments of the opacity group are zeroed.  intended_opacity_reset_ (default off) selects the reset
@@ -215,8 +239,8 @@ void GaussianModel::resetOpacity()
 	torch::NoGradGuard ng;
 	auto act = getOpacityActivation();
 	auto bound = intended_opacity_reset_ ? torch::ones_like(act) * 0.01 : torch::ones_like(act * 0.01);
-	auto fresh = inverse_sigmoid(torch::min(act, bound)).detach().clone();
-	replaceParam(2, fresh, torch::Tensor(), torch::Tensor());
+	auto fresh = inverse_sigmoid(torch::min(act, bound)).detach();
+	replaceParamValues(2, fresh);
 }
 
 // ---- loop closure (src/gaussian_model.cpp:379-475) -------------------------------------------------------------------------
@@ -233,8 +257,8 @@ void GaussianModel::applyScaledTransformation(const float s, torch::Tensor T)
 	auto scl = (scaling_.detach() * s).contiguous();
 	// scaledTransformationPostfix (:398-411): fresh leaves in groups 0 (xyz) and 4 (scaling; group 3 of the five here), zero
 	// moments, the step counters stay
-	replaceParam(0, pts, torch::Tensor(), torch::Tensor());
-	replaceParam(3, scl, torch::Tensor(), torch::Tensor());
+	replaceParamValues(0, pts);
+	replaceParamValues(3, scl);
 }
 
 void GaussianModel::scaledTransformVisiblePointsOfKeyframe(torch::Tensor& point_not_transformed_flags, torch::Tensor& diff_pose,
@@ -248,8 +272,8 @@ void GaussianModel::scaledTransformVisiblePointsOfKeyframe(torch::Tensor& point_
 	auto point_unstable_flags = torch::abs(exist_since_iter_ - kf_creation_iter) < stable_num_iter_existence;   // :433-436
 	scaleAndTransformThenMarkVisiblePoints(points, rots, point_not_transformed_flags, point_unstable_flags, diff_pose,
 	                                       kf_world_view_transform, kf_full_proj_transform, num_transformed, scale);
-	replaceParam(0, points, torch::Tensor(), torch::Tensor());   // :463  param_groups[0] = xyz_
-	replaceParam(4, rots, torch::Tensor(), torch::Tensor());     // :465  param_groups[5] = rotation_ (group 4 of the five here)
+	replaceParamValues(0, points);   // :463  param_groups[0] = xyz_
+	replaceParamValues(4, rots);     // :465  param_groups[5] = rotation_ (group 4 of the five here)
 }
 
 // ---- rebuilds as stream compaction (csrc/densify.hip, include/gsr.h) ------------------------------------------------

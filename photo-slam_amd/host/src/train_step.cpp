@@ -85,6 +85,27 @@ void GaussianModel::trainingSetup(const GaussianOptimizationParams& opt)
 	add(opacity_, opt.opacity_lr_);
 	add(scaling_, opt.scaling_lr_);
 	add(rotation_, opt.rotation_lr_);
+	preloadMaintenanceKernels();
+}
+
+// The HIP runtime loads a code object of LibTorch the first time one of its kernels is launched.  The train step itself uses
+// none of ATen's elementwise kernels, so the first resetOpacity (sigmoid, minimum) or loop-closure call (integer abs / compare)
+// in the middle of a mapping session would pay for that: 25 ms on a warm box, 110 ms on a cold one, measured as ONE iteration of
+// bench.py --mapper-loop (the second reset of the same run costs nothing measurable).  They are touched here, on four elements,
+// when the optimizer is set up -- a session pays at its start, not at iteration opacity_reset_interval.
+void GaussianModel::preloadMaintenanceKernels()
+{
+	if (!xyz_.defined() || !xyz_.is_cuda()) return;
+	torch::NoGradGuard ng;
+	const auto o = xyz_.options().requires_grad(false);
+	auto x = torch::full({4, 1}, 0.25f, o);
+	auto act = torch::sigmoid(x);
+	auto bound = torch::ones_like(act * 0.01);
+	auto y = torch::log(torch::min(act, bound) / (1 - torch::min(act, torch::ones_like(act) * 0.01)));   // resetOpacity, both forms
+	auto age = torch::zeros({4}, o.dtype(torch::kInt32));
+	auto young = torch::abs(age - 3) < 2;                                                               // scaledTransformVisiblePointsOfKeyframe
+	auto z = (x * 1.5f).contiguous().clone().zero_();
+	(void)y; (void)young; (void)z;
 }
 
 float GaussianModel::updateLearningRate(int step)

@@ -155,6 +155,85 @@ def run(dev, lib_path, kind, variant, cl):
     print(f"[loop closure, {kind}] {moved_ref} of {cl.xyz.shape[0]} points moved by the keyframe correction")
 
 
+def run_in_arena(dev, lib_path, variant, cl):
+    """The same calls + resetOpacity on leaves that LIVE IN THE ARENA (after an increasePcd): the values are replaced in place, the
+    results equal those of a model whose leaves were moved out of the arena first (release: the path the reference comparison
+    above pins), and the next increasePcd still appends in place -- it used to rebuild the whole arena (+25 ms at 4 M Gaussians)."""
+    ops = _host(variant)
+    state = _state(cl, dev, 5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = cl.cameras[0]
+    view, proj = t(cam.viewmatrix), t(cam.projmatrix)
+    T, diff_pose = t(_rigid(1)), t(np.ascontiguousarray(_rigid(2).T))
+    gen = torch.Generator().manual_seed(11)
+    new_pts = (torch.rand(40, 3, generator=gen) * 2.0 - 1.0).to(dev)
+    new_cols = torch.rand(40, 3, generator=gen).to(dev)
+    more_pts, more_cols = new_pts[:7] + 0.01, new_cols[:7]
+    flags0 = (torch.rand(cl.xyz.shape[0] + 40, generator=torch.Generator().manual_seed(3)) < 0.8).to(dev)
+    ptrs = lambda ts: [x.data_ptr() for x in ts]
+    rp._LIB_OVERRIDE = lib_path
+    try:
+        def cpp(release):
+            h = _cpp_session(ops, cl, dev, state)
+            ops.trainer_increase_pcd(h, new_pts, new_cols, 12, False)      # the leaves move into the arena
+            if release:
+                ops.trainer_release_arena(h)
+            before = ptrs(ops.trainer_params(h)) + ptrs(ops.trainer_moments(h))
+            ops.trainer_apply_scaled_transformation(h, 1.25, T)
+            flags, moved = ops.trainer_scaled_transform_visible(h, flags0, diff_pose, view, proj, 20, 15, 1.1)
+            ops.trainer_reset_opacity(h)
+            after = ptrs(ops.trainer_params(h)) + ptrs(ops.trainer_moments(h))
+            out = [x.detach().clone() for x in list(ops.trainer_params(h)) + list(ops.trainer_moments(h))] + [flags.clone()]
+            if not release:
+                assert after == before, "a leaf or a moment left the arena"
+                ops.trainer_increase_pcd(h, more_pts, more_cols, 13, False)
+                assert ptrs(ops.trainer_params(h)) + ptrs(ops.trainer_moments(h)) == before, "the append behind the calls rebuilt the arena"
+            ops.trainer_destroy(h)
+            return out, moved
+
+        def py(release):
+            g = _py_model(cl, dev, state)
+            leaves = lambda: [g.xyz_, g.features_, g.opacity_, g.scaling_, g.rotation_]
+            mom = lambda: [g.optimizer_.state[id(p)]["exp_avg"] for p in leaves()] + [g.optimizer_.state[id(p)]["exp_avg_sq"] for p in leaves()]
+            g.increasePcd(new_pts, new_cols, 12)
+            if release:
+                g.release_arena()
+            before = ptrs(leaves()) + ptrs(mom())
+            g.applyScaledTransformation(1.25, T)
+            flags = flags0.clone()
+            moved = g.scaledTransformVisiblePointsOfKeyframe(flags, diff_pose, view, proj, 20, 15, 0, 1.1)
+            g.resetOpacity()
+            out = [x.detach().clone() for x in leaves() + mom()] + [flags]
+            if not release:
+                assert ptrs(leaves()) + ptrs(mom()) == before, "a leaf or a moment left the arena"
+                g.increasePcd(more_pts, more_cols, 13)
+                assert ptrs(leaves()) + ptrs(mom()) == before, "the append behind the calls rebuilt the arena"
+            return out, moved
+
+        for name, host in (("c++", cpp), ("python", py)):
+            (a, moved_a), (b, moved_b) = host(False), host(True)
+            assert moved_a == moved_b and moved_a > 0
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x.cpu(), y.cpu()), (name, k)
+            # the replaced groups' moments are zero, the others' are not (xyz, opacity, scaling, rotation: 0, 2, 3, 4)
+            for k in (0, 2, 3, 4):
+                assert not a[5 + k].any() and not a[10 + k].any(), (name, k)
+            assert a[5 + 1][: cl.xyz.shape[0]].any()
+    finally:
+        rp._LIB_OVERRIDE = None
+
+
+def test_loop_closure_and_reset_keep_the_leaves_in_the_arena_on_the_emulator(emu_lib_path):
+    cl = scene.make_cloud(500, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35)
+    run_in_arena(torch.device("cpu"), emu_lib_path, "emu", cl)
+
+
+@pytest.mark.gpu
+def test_loop_closure_and_reset_keep_the_leaves_in_the_arena_on_gpu():
+    cl = scene.make_config("C1", seed=0)
+    run_in_arena(torch.device("cuda:0"), None, "hip", cl)
+
+
 def test_loop_closure_methods_match_the_reference_on_the_emulator(emu_lib_path):
     cl = scene.make_cloud(500, 48, 32, 40.0, 40.0, seed=3, scale_k=0.35)
     run(torch.device("cpu"), emu_lib_path, "emu", "emu", cl)
