@@ -88,6 +88,20 @@ static bool cov3D_stored()
 	static const int env = env_int("GSR_COV3D_STORED", 0);
 	return env != 0;
 }
+#ifndef GSR_EMU   // (the emulator has no graph API)
+static bool graph_sort()
+{
+	static const int env = env_int("GSR_GRAPH_SORT", 0);
+	return env != 0;
+}
+struct SortGraph {
+	static constexpr int KEYS = 12;
+	hipGraphExec_t exec = nullptr;
+	hipStream_t capture = nullptr;
+	const void* key[KEYS] = {};
+};
+static thread_local SortGraph t_sort_graph;
+#endif
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -272,6 +286,37 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// V visible ones only (V = 0.47 P at C3).  order[V..P) is undefined, offsets[V..P) = R: the culled Gaussians used to sort
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
+#ifndef GSR_EMU
+	if (graph_sort() && t_prof.on != 1) {
+		// experiment (GSR_GRAPH_SORT=1): the 14 launches of the depth sort and the offset scan -- fixed grids, counts on the device --
+		// replayed from a hipGraph captured once per (buffers, P)
+		const void* key[SortGraph::KEYS] = {g.depth_key, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, g.sort_scratch, g.visible,
+		                                    g.rect, g.offsets, g.rect_sorted, g.scan_scratch, (const void*)(size_t)P};
+		if (!t_sort_graph.exec || memcmp(key, t_sort_graph.key, sizeof(key)) != 0) {
+			if (t_sort_graph.exec) (void)hipGraphExecDestroy(t_sort_graph.exec);
+			t_sort_graph.exec = nullptr;
+			hipGraph_t graph = nullptr;
+			// (captured on a stream of its own: nothing runs during a capture, and the caller's stream may be the legacy default
+			// stream, which cannot capture)
+			if (!t_sort_graph.capture) GSR_HIP(hipStreamCreateWithFlags(&t_sort_graph.capture, hipStreamNonBlocking));
+			hipStream_t cs = t_sort_graph.capture;
+			GSR_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+			st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32, g.sort_scratch,
+			                       cs, &kres, &vres, g.visible);
+			if (st == GSR_OK)
+				st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch,
+				                            cs, g.visible);
+			const hipError_t ce = hipStreamEndCapture(cs, &graph);
+			if (st != GSR_OK) return st;
+			GSR_HIP(ce);
+			GSR_HIP(hipGraphInstantiate(&t_sort_graph.exec, graph, nullptr, nullptr, 0));
+			(void)hipGraphDestroy(graph);
+			memcpy(t_sort_graph.key, key, sizeof(key));
+		}
+		GSR_HIP(hipGraphLaunch(t_sort_graph.exec, stream));
+	} else
+#endif
+	{
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
 	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
 		return st;
@@ -280,6 +325,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
 	                                 g.visible)) != GSR_OK)
 		return st;
+	}
 	PROF_FWD(3);
 
 	GSR_HIP(hipEventSynchronize(t_sync.ev));

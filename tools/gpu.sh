@@ -46,25 +46,35 @@ rows.sort()
 # a step = from one preprocess_fwd to the next
 starts = [i for i, r in enumerate(rows) if "preprocess_fwd_kernel" in r[2]]
 steps = []
+short = lambda n: n.replace("gsr::", "").replace("void ", "").split("(")[0][:40]
+pairs = []   # per step: {(kernel before the gap, kernel behind it): idle ns}
 for a, b in zip(starts[:-1], starts[1:]):
     ks = rows[a:b]
     span = ks[-1][1] - ks[0][0]
-    busy_end, idle, sync_gap = ks[0][1], 0, None
+    busy_end, idle, sync_gap, last, where = ks[0][1], 0, None, ks[0][2], {}
     for i in range(1, len(ks)):
         gap = ks[i][0] - busy_end
         if gap > 0:
             idle += gap
+            k = (short(last), short(ks[i][2]))
+            where[k] = where.get(k, 0) + gap
             if "emit_instances" in ks[i][2]:
                 sync_gap = gap
-        busy_end = max(busy_end, ks[i][1])
+        if ks[i][1] >= busy_end:
+            busy_end, last = ks[i][1], ks[i][2]
     steps.append((span, idle, sync_gap, len(ks)))
+    pairs.append(where)
 steps = steps[len(steps) // 3:]   # (the warm-up third of the run is dropped)
+pairs = pairs[len(pairs) - len(steps):]
 if steps:
     med = lambda k: st.median(s[k] for s in steps if s[k] is not None) / 1e3
     out = {"steps": len(steps), "kernels_per_step_median": st.median(s[3] for s in steps),
            "step_span_us_median": round(med(0), 1), "device_idle_us_per_step_median": round(med(1), 1),
            "idle_before_emit_instances_us_median (the mid-forward host wait)": round(med(2), 1),
            "note": "from rocprofv3 --kernel-trace timestamps of the same run; concurrent kernels (second stream) count as busy"}
+    keys = set(k for w in pairs for k in w)
+    top = sorted(((st.median(w.get(k, 0) for w in pairs) / 1e3, k) for k in keys), reverse=True)[:12]
+    out["largest_gaps_us_per_step_median"] = [{"after": k[0], "before": k[1], "us": round(v, 1)} for v, k in top if v > 0]
     json.dump(out, open(sys.argv[2], "w"), indent=1)
     print(json.dumps(out))
 PY
