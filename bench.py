@@ -518,6 +518,11 @@ def main():
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
         if dp and not py_exchange:
             ops.trainer_set_process_group(handle, dist.group.WORLD.group_name, factored)
+            if world > 1:
+                # the packed exchange agrees on its message capacity host-side: one int per rank over gloo (the visible counts are on
+                # the host anyway; through RCCL their two pinned copies cost the compute stream +42 us per step: profiles/r04_r)
+                count_group = dist.new_group(backend="gloo")
+                ops.trainer_set_count_group(handle, count_group.group_name)
         elif dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
         if args.densify_interval:
@@ -662,7 +667,11 @@ def main():
     # Timed region: HIP events only around the backward blend, the dominant kernel (gsr_profile_enable(2)): every event
     # record is a ~5 us bubble in the stream, and eleven of them per step cost 2 % of the step they are meant to measure.
     capi.profile_enable(lib, 2)
+    capi.host_wait_stats(lib)                       # (reset)
     elapsed, dom_ms = timed(args.steps, read_dominant=True)
+    # how long the host was blocked in the forward pass's one synchronisation: a host that runs ahead of the device waits there
+    # for most of a step; near zero = the device waits for the host (include/gsr.h: gsr_host_wait_stats)
+    host_wait_us, host_waits = capi.host_wait_stats(lib)
     capi.profile_enable(lib, 0)
 
     # ---- per-step times from HIP events on the stream: 20 warm-up + median of >= 100
@@ -700,6 +709,9 @@ def main():
         ops.trainer_set_options(handle, {"profile_exchange": 0.0})
         mine = {"rank": rank, "all_gather_wait_ms_median": round(float(np.median([w[0] for w in waits])), 4),
                 "all_reduce_wait_ms_median": round(float(np.median([w[1] for w in waits])), 4),
+                "segments_ms_median": {name: round(float(np.median([w[k] for w in waits])), 4) for k, name in
+                                       ((2, "forward_loss_backward"), (0, "all_gather_wait"), (3, "sh_step_from_views"),
+                                        (1, "all_reduce_wait"), (4, "geometry_adam_and_finish")) if len(waits[0]) > k},
                 "stage_ms_median": {k: round(float(np.median([m for m in v if m >= 0])), 4) for k, v in stage_ms.items() if any(m >= 0 for m in v)}}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -986,6 +998,10 @@ def main():
                                "source": "one HIP event per step on the compute stream of rank 0"}
             if args.dump_steps:
                 out["protocol"]["step_ms"] = [round(float(x), 3) for x in step_ms]
+        if host_waits:
+            out["host"] = {"blocked_in_forward_sync_us_per_step": round(host_wait_us / max(args.steps, 1), 1), "syncs": host_waits,
+                           "note": "time the host thread spent blocked in gsr_forward's one synchronisation during the timed steps "
+                                   "(gsr_host_wait_stats): large = the host runs ahead of the device; near zero = the device waits for the host"}
         if views_run:
             out["changing_views_run"] = views_run
         if train_run:

@@ -244,6 +244,14 @@ typedef struct gsr_backward_args {
 	 * all-gather of the exchange -- overlaps that last kernel instead of following the whole pass.  The stream must not be the
 	 * one gsr_backward is called with. */
 	void* color_view_ready_stream;
+	/* Extension for the PACKED view-factored exchange (NULL = off; consulted only with dL_dcolor_view): a message whose prefix and
+	 * mask sections gsr_pack_view_plan has filled from this view's radii.  The backward pass writes the seen rows and the header
+	 * into it next to dL_dcolor_view -- the message is complete at the same point as the dense view (color_view_ready_stream),
+	 * with no pack launch between the backward pass and the gather.  packed_capacity_rows = the rows the buffer has room for
+	 * (>= this view's visible count, e.g. P rounded up to 4: the ranks then send the first gsr_packed_view_words(P, max_v K_v)
+	 * words).  The same bits as gsr_pack_color_view(P, dL_dcolor_view, campos, packed_capacity_rows, ...). */
+	uint32_t* packed_view;
+	int packed_capacity_rows;
 } gsr_backward_args;
 
 /* Rasterizer::backward, cuda_rasterizer/rasterizer_impl.cu:340-433.
@@ -303,8 +311,12 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
  * max_v K_v beforehand -- K of a view is its number of visible Gaussians, which gsr_forward leaves for the calling thread in
  * gsr_last_visible_count().  gsr_sh_grad_from_packed_views / gsr_sh_adam_from_packed_views are gsr_sh_grad_from_views /
  * gsr_sh_adam_from_views on n_views such messages, msg_stride words apart: bit-identical results (the same rows, the same
- * order of the views).  At 2 M Gaussians, 47 % seen: 11.7 MB instead of 24 MB per rank on every link. */
+ * order of the views).  At 2 M Gaussians, 47 % seen: 11.7 MB instead of 24 MB per rank on every link.
+ * gsr_pack_view_plan writes the sections that do not depend on the gradient -- masks and prefix, from the radii of the forward
+ * pass (seen = radii > 0; three launches, any stream once gsr_forward has returned) -- so that gsr_backward can write rows and
+ * header itself (gsr_backward_args.packed_view). */
 size_t gsr_packed_view_words(int P, int capacity_rows);
+int gsr_pack_view_plan(int P, const int* radii, uint32_t* message, void* scratch, void* stream);
 size_t gsr_pack_scratch_bytes(int P);
 int gsr_pack_color_view(int P, const float* dL_dcolor_view, const float* campos, int capacity_rows, uint32_t* message, void* scratch,
                         void* stream);
@@ -314,6 +326,11 @@ int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float*
                                   long long msg_stride, float scale, float* shs, const gsr_sh_adam* sh_adam, void* stream);
 /* Gaussians with radii > 0 in the last gsr_forward of the calling thread (-1 before the first) */
 int gsr_last_visible_count(void);
+/* Diagnostic: the time the calling thread has spent BLOCKED in gsr_forward's one host synchronisation (the read of the instance
+ * count behind the projection kernel) and the number of such waits, since the last reset.  A host that runs ahead of the device
+ * waits there for most of a step; a wait near zero means the device is waiting for the HOST (launch-bound step: the gaps
+ * between kernels are then host time, and every host-side call of the step costs step time). */
+int gsr_host_wait_stats(double* total_us, long long* calls, int reset);
 
 /* ahead == 0: after the last gsr_sh_adam_from_views range of the step -- row blocks b with b % window == step % window, every
  * row that is behind catches up to `step`.  ahead != 0 (window >= 3): BEFORE the step's gsr_sh_adam_from_views calls (what

@@ -108,7 +108,8 @@ class BackwardArgs(C.Structure):
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p), ("raw_params", C.c_int),
                 ("dL_dcolor_view", C.c_void_p), ("sh_adam", C.POINTER(ShAdam)),
                 ("stat_grad_accum", C.c_void_p), ("stat_denom", C.c_void_p), ("stat_max_radii", C.c_void_p),
-                ("geom_adam", C.POINTER(GeomAdam)), ("color_view_ready_stream", C.c_void_p)]
+                ("geom_adam", C.POINTER(GeomAdam)), ("color_view_ready_stream", C.c_void_p),
+                ("packed_view", C.c_void_p), ("packed_capacity_rows", C.c_int)]
 
 class DensifySelectArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("scaling", C.c_void_p),
@@ -135,8 +136,9 @@ EXPORTED_SYMBOLS = [
     "gsr_backend", "gsr_profile_enable", "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read",
     "gsr_loss_scratch_bytes", "gsr_l1_ssim_loss", "gsr_adam_step", "gsr_densify_stats", "gsr_densify_scratch_bytes",
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
-    "gsr_neighborhood_depth_pinhole", "gsr_packed_view_words", "gsr_pack_scratch_bytes", "gsr_pack_color_view",
+    "gsr_neighborhood_depth_pinhole", "gsr_packed_view_words", "gsr_pack_scratch_bytes", "gsr_pack_color_view", "gsr_pack_view_plan",
     "gsr_sh_grad_from_packed_views", "gsr_sh_adam_from_packed_views", "gsr_last_visible_count",
+    "gsr_host_wait_stats",
 ]
 
 _libs = {}
@@ -231,3 +233,10 @@ def profile_read(lib):
     ms = (C.c_float * n)()
     check(lib, lib.gsr_profile_read(ms, n), "gsr_profile_read")
     return {lib.gsr_profile_stage_name(i).decode(): float(ms[i]) for i in range(n)}
+
+
+def host_wait_stats(lib, reset=True):
+    """gsr_host_wait_stats: (microseconds the calling thread was blocked in gsr_forward's host synchronisation, number of waits)"""
+    us, n = C.c_double(0.0), C.c_longlong(0)
+    lib.gsr_host_wait_stats(C.byref(us), C.byref(n), 1 if reset else 0)
+    return float(us.value), int(n.value)

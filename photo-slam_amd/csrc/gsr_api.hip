@@ -8,6 +8,7 @@
 //   -> depth sort of the P Gaussians (4 x 8-bit passes) -> exclusive scan in depth order
 //   -> host waits for the event only now, sizes the binning buffer
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
+#include <chrono>
 #include <cmath>
 #include "kernels.h"
 #include "shrows.h"
@@ -63,6 +64,9 @@ struct HostSync {
 };
 static thread_local HostSync t_sync;
 static thread_local int t_last_visible = -1;   // gsr_last_visible_count()
+// gsr_host_wait_stats(): how long the calling thread was blocked in gsr_forward's ONE host synchronisation (the instance count)
+static thread_local double t_sync_wait_us = 0.0;
+static thread_local long long t_sync_waits = 0;
 // Scheduling switches live in the caller's struct (gsr_sh_adam: no_side_stream, lazy_slice_late, side_blocks; zero = the
 // measured-best arrangement).  The environment variable of a switch, when SET, overrides the field -- the A/B handle of the
 // bench sessions; read once per process.
@@ -328,7 +332,12 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	}
 	PROF_FWD(3);
 
-	GSR_HIP(hipEventSynchronize(t_sync.ev));
+	{
+		const auto w0 = std::chrono::steady_clock::now();
+		GSR_HIP(hipEventSynchronize(t_sync.ev));
+		t_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+		t_sync_waits++;
+	}
 	unsigned long long R64 = 0, V64 = 0;
 	for (int i = 0; i < NUM_COUNTERS; i += 2) {   // (even words: tiles; odd words: visible Gaussians -- preprocess_fwd)
 		R64 += t_sync.pinned[i];
@@ -401,6 +410,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	// (a stream cannot be made to wait for an event of its own future: refused HERE, before anything is enqueued and before the
 	// lazy rows' catch-up has advanced a step counter)
 	if (a->color_view_ready_stream && a->dL_dcolor_view && a->color_view_ready_stream == stream_) return GSR_ERR_INVALID_ARG;
+	if (a->packed_view && a->dL_dcolor_view && (a->packed_capacity_rows < 0 || (a->packed_capacity_rows & 3))) return GSR_ERR_INVALID_ARG;
 	hipStream_t stream = (hipStream_t)stream_;
 	const int P = a->P, W = a->width, H = a->height, R = a->R;
 	const int grid_x = div_up(W, TILE), grid_y = div_up(H, TILE), tiles = grid_x * grid_y;
@@ -540,6 +550,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.dL_dmean3D = a->dL_dmean3D; pb.dL_dcov3D = a->dL_dcov3D; pb.dL_dsh = a->dL_dsh; pb.dL_dscale = a->dL_dscale;
 	pb.dL_drot = a->dL_drot;
 	pb.dL_dcolor_view = a->dL_dcolor_view;
+	pb.packed_msg = a->dL_dcolor_view ? a->packed_view : nullptr;
+	pb.packed_capacity = a->packed_capacity_rows;
 	pb.stat_accum = a->stat_grad_accum; pb.stat_denom = a->stat_denom; pb.stat_max_radii = a->stat_max_radii;
 	pb.adam_param = nullptr; pb.adam_exp_avg = nullptr; pb.adam_exp_avg_sq = nullptr;
 	pb.adam = AdamScalars{};
@@ -616,6 +628,14 @@ int gsr_sh_adam_from_views(int P, int D, int M, int n_views, const float* means3
 size_t gsr_packed_view_words(int P, int capacity_rows) { return (P < 0 || capacity_rows < 0) ? 0 : packed_view_words(P, capacity_rows); }
 size_t gsr_pack_scratch_bytes(int P) { return P <= 0 ? 0 : (scan_scratch_elems((int)pack_groups(P)) + 64) * sizeof(uint32_t); }
 
+int gsr_pack_view_plan(int P, const int* radii, uint32_t* message, void* scratch, void* stream_)
+{
+	if (P < 0) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!radii || !message || !scratch) return GSR_ERR_INVALID_ARG;
+	return launch_pack_view_plan(P, radii, message, static_cast<uint32_t*>(scratch), (hipStream_t)stream_);
+}
+
 int gsr_pack_color_view(int P, const float* dL_dcolor_view, const float* campos, int capacity_rows, uint32_t* message, void* scratch,
                         void* stream_)
 {
@@ -662,6 +682,17 @@ int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float*
 }
 
 int gsr_last_visible_count(void) { return t_last_visible; }
+
+int gsr_host_wait_stats(double* total_us, long long* calls, int reset)
+{
+	if (total_us) *total_us = t_sync_wait_us;
+	if (calls) *calls = t_sync_waits;
+	if (reset) {
+		t_sync_wait_us = 0.0;
+		t_sync_waits = 0;
+	}
+	return GSR_OK;
+}
 
 int gsr_sh_adam_lazy_slice(int P, const gsr_sh_adam* adam, int ahead, void* stream_)
 {

@@ -171,6 +171,10 @@ struct PreprocessBwdParams {
 	// gather issued on it overlaps sh_bwd_rows_kernel.  Host-side only; null = off.
 	void* notify_stream;
 	void* notify_event;
+	// view-factored mode, packed (gsr_backward_args.packed_view): the view's message with its prefix and mask sections filled by
+	// gsr_pack_view_plan -- preprocess_bwd_kernel writes the seen rows and the header next to dL_dcolor_view; null = off
+	uint32_t* packed_msg;
+	int packed_capacity;      // rows the message has room for
 };
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream);
 // does the backward preprocess take the two-kernel path of the reference's SH layout (preprocess_bwd_kernel<true> +
@@ -187,6 +191,8 @@ static inline size_t pack_prefix_words(int P) { return (pack_groups(P) + 3) & ~(
 static inline size_t pack_mask_words(int P) { return (2 * pack_groups(P) + 3) & ~(size_t)3; }
 static inline size_t packed_view_words(int P, int capacity) { return PACK_HEADER + pack_prefix_words(P) + pack_mask_words(P) + 3 * (size_t)capacity + 4; }
 int launch_pack_color_view(int P, const float* view, const float* campos, int capacity, uint32_t* msg, uint32_t* scratch, hipStream_t stream);
+// the capacity-independent part of a view's message from the forward pass's radii (seen = radii > 0): masks + prefix
+int launch_pack_view_plan(int P, const int* radii, uint32_t* msg, uint32_t* scratch, hipStream_t stream);
 struct PackedViews {   // n_views messages, `stride` words apart; null msgs = the dense [n_views, P, 3] form
 	const uint32_t* msgs = nullptr;
 	long long stride = 0;

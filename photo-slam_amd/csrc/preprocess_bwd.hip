@@ -188,6 +188,39 @@ sh_bwd_rows_kernel(const PreprocessBwdParams p)
 	if (p.geom.on && in_range) geom_adam_row<3>(p.geom.xyz, (size_t)idx, gm);
 }
 
+// The row of Gaussian idx of the view's packed message (include/gsr.h: gsr_backward_args.packed_view).  seen_mask = the ballot of
+// "visible" over the wave = the 64-row group idx >> 6; the rows in front of the group come from the prefix section that
+// gsr_pack_view_plan computed from the forward pass's radii.  The last group's first lane writes the header.
+__device__ __forceinline__ void pack_view_row(const PreprocessBwdParams& p, int idx, bool vis, unsigned long long seen_mask, float v0, float v1,
+                                              float v2)
+{
+	const size_t groups = ((size_t)p.P + 63) >> 6;
+	const size_t prefix_words = (groups + 3) & ~(size_t)3, mask_words = (2 * groups + 3) & ~(size_t)3;
+	uint32_t* msg = p.packed_msg;
+	const size_t group = (size_t)idx >> 6;
+	const uint32_t first = msg[PACK_HEADER + group];
+	if (vis) {
+		const uint32_t rank = first + (uint32_t)__popcll(seen_mask & lanemask_lt());
+		if (rank < (uint32_t)p.packed_capacity) {
+			float* rows = reinterpret_cast<float*>(msg + PACK_HEADER + prefix_words + mask_words);
+			rows[3 * (size_t)rank] = v0;
+			rows[3 * (size_t)rank + 1] = v1;
+			rows[3 * (size_t)rank + 2] = v2;
+		}
+	}
+	if (idx == p.P - 1) {   // (the last Gaussian: its group knows the total)
+		const uint32_t K = first + (uint32_t)__popcll(seen_mask);
+		msg[0] = K;
+		msg[1] = (uint32_t)p.P;
+		msg[2] = (uint32_t)p.packed_capacity;
+		msg[3] = K > (uint32_t)p.packed_capacity ? 1u : 0u;
+		msg[4] = __float_as_uint(p.campos[0]);
+		msg[5] = __float_as_uint(p.campos[1]);
+		msg[6] = __float_as_uint(p.campos[2]);
+		msg[7] = 0u;
+	}
+}
+
 // ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel
 // follows and adds the SH term; otherwise the SH backward happens here with per-lane scalar row access.
 template <bool ROWS_OK>
@@ -200,6 +233,8 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	const bool vis = in_range && (p.radii[idx] > 0);
 	const int M3 = 3 * p.M;
 	constexpr bool rows_ok = ROWS_OK;
+	// packed view (kernel-uniform): the lanes of this wave are one 64-row group of the message
+	const unsigned long long seen_mask = p.packed_msg ? wave_ballot(vis) : 0ull;
 
 	// ------------------------------------------------------------------ gradients of the blend stage (partials.h)
 	// the per-instance slots of this Gaussian's tiles are summed here, in registers: colour 0..2, mean2D moments 3..4,
@@ -269,6 +304,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			p.dL_dcolor_view[3 * (size_t)idx + 0] = v0;
 			p.dL_dcolor_view[3 * (size_t)idx + 1] = v1;
 			p.dL_dcolor_view[3 * (size_t)idx + 2] = v2;
+			if (p.packed_msg) pack_view_row(p, idx, vis, seen_mask, v0, v1, v2);
 		}
 		if (p.geom.on) {
 			const float go[1] = {g_opacity};
@@ -333,6 +369,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 				p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
 				p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
 				p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
+				if (p.packed_msg) pack_view_row(p, idx, vis, seen_mask, dRGB[0], dRGB[1], dRGB[2]);
 			}
 		}
 	}
@@ -923,6 +960,22 @@ pack_mask_kernel(int P, const float* __restrict__ view, uint32_t* __restrict__ c
 	}
 }
 
+// the same two sections from the forward pass's radii (gsr_pack_view_plan): a Gaussian is seen when its radius is positive --
+// exactly the rows preprocess_bwd_kernel leaves non-zero in the view (a lit row or the -0.0f marker)
+__global__ void __launch_bounds__(256)
+pack_plan_kernel(int P, const int* __restrict__ radii, uint32_t* __restrict__ counts, uint32_t* __restrict__ mask)
+{
+	const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const bool seen = idx < P && radii[idx] > 0;
+	const unsigned long long m = wave_ballot(seen);
+	const int group = idx >> 6;
+	if (lane_id() == 0 && (size_t)group < (((size_t)P + 63) >> 6)) {
+		counts[group] = (uint32_t)__popcll(m);
+		mask[2 * (size_t)group] = (uint32_t)m;
+		mask[2 * (size_t)group + 1] = (uint32_t)(m >> 32);
+	}
+}
+
 __global__ void __launch_bounds__(256)
 pack_rows_kernel(int P, const float* __restrict__ view, const float* __restrict__ campos, int capacity, uint32_t* __restrict__ msg,
                  int prefix_words, int mask_words)
@@ -973,6 +1026,18 @@ int launch_pack_color_view(int P, const float* view, const float* campos, int ca
 	int st = launch_scan_u32(prefix, nullptr, prefix, groups, false, scratch, stream);
 	if (st != GSR_OK) return st;
 	GSR_LAUNCH(pack_rows_kernel, div_up(P, 256), 256, stream, P, view, campos, capacity, msg, pw, mw);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+int launch_pack_view_plan(int P, const int* radii, uint32_t* msg, uint32_t* scratch, hipStream_t stream)
+{
+	if (P <= 0) return GSR_OK;
+	const int groups = (int)pack_groups(P), pw = (int)pack_prefix_words(P);
+	uint32_t* prefix = msg + PACK_HEADER;
+	GSR_LAUNCH(pack_plan_kernel, div_up(P, 256), 256, stream, P, radii, prefix, prefix + pw);
+	int st = launch_scan_u32(prefix, nullptr, prefix, groups, false, scratch, stream);
+	if (st != GSR_OK) return st;
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

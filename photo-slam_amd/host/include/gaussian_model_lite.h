@@ -278,13 +278,29 @@ public:
 	torch::Tensor sh_gathered_;
 	// packed form: the message buffers (int32; persistent like sh_gathered_), the pack kernels' scratch and the count exchange
 	torch::Tensor sh_packed_send_, sh_packed_gathered_, sh_pack_scratch_;
-	torch::Tensor count_own_pinned_, count_own_dev_, counts_dev_, counts_pinned_;
+	torch::Tensor count_own_pinned_, count_own_dev_, counts_dev_, counts_pinned_, count_own_host_;
+	// the visible counts travel host-side over this group when it is set (gloo next to the RCCL group of the gradients):
+	// keyframe_batch_exchange.cpp: beginCountExchange
+	c10::intrusive_ptr<c10d::ProcessGroup> count_group_;
+	void setCountGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg) { count_group_ = std::move(pg); }
+	c10::intrusive_ptr<c10d::Work> count_work_;
+	bool counts_on_device_route_ = false;
 	void* counts_event_ = nullptr;     // hipEvent_t behind the counts' copy to the host
 	bool packed_this_step_ = false;
+	// On = the backward pass writes the message itself (gsr_backward_args.packed_view; mask + prefix planned from the radii on the
+	// gather stream behind the forward pass): no pack launches between the backward pass and the gather.  Off (default) = the
+	// message is packed from the dense view behind the backward pass (gsr_pack_color_view, four launches on the gather stream next
+	// to the SH backward kernel).  Measured on one box at one rank (profiles/r04_r): writing the message inside the backward pass
+	// costs the compute stream +26 us, packing behind it costs +3 us there (it hides next to the SH kernel) -- the same step time
+	// either way, so the simpler arrangement is the default.  GSR_PACK_IN_BACKWARD overrides.
+	bool pack_in_backward_ = false;
+	bool prepacked_this_step_ = false;
+	void planPackedView(const torch::Tensor& radii);
 	void beginCountExchange();         // behind the forward pass: this view's visible count to every rank
 	int64_t finishCountExchange();     // -> the capacity every rank uses (max count, rounded up to 4 rows)
 	void stepFeaturesFromPackedViews(torch::Tensor messages, int64_t msg_stride, int64_t n_views);
-	void* wait_events_[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: before / after the gather wait, before / after the reduce wait
+	// hipEvent_t: before / after the gather wait, before / after the reduce wait, start and end of the data-parallel step
+	void* wait_events_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	torch::Tensor sh_grad_view_;
 	void setFeaturesGradFromViews(torch::Tensor campos_views, torch::Tensor dL_dcolor_views);
 	// ... or rebuilds it and takes the Adam step of features_ in the same pass (gsr_sh_adam_from_views): the mean gradient

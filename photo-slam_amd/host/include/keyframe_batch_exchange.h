@@ -72,6 +72,7 @@ public:
 	struct Packed {
 		torch::Tensor color_view, send, gathered, scratch;
 		int64_t capacity = 0;
+		bool prepacked = false;   // the backward pass has written the message into `send` (ShAdamStep::packed_view): nothing to pack
 	};
 	ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup> pg, Packed packed, torch::Tensor camera_center,
 	                     std::vector<torch::Tensor> others, void* gather_stream = nullptr);

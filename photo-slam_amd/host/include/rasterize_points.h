@@ -26,6 +26,10 @@ struct ShAdamStep {
 	// above): a hipStream_t that is made to wait for the point inside backward at which dL_dcolor_view is complete -- the
 	// exchange issues its all-gather there and overlaps the last kernel of the pass
 	void* color_view_ready_stream = nullptr;
+	// view-factored mode, packed exchange (gsr_backward_args.packed_view): an int32 message whose mask / prefix sections
+	// packViewPlan() fills between the forward and the backward pass; backward writes rows and header next to dL_dcolor_view
+	torch::Tensor packed_view;
+	int64_t packed_capacity = 0;
 	// scheduling of the optimizer work the library forks next to its own kernels (gsr_sh_adam: zero = the measured-best
 	// arrangement; the environment variables GSR_SH_ADAM_SIDE_STREAM / GSR_LAZY_SLICE_EARLY / GSR_SH_ADAM_SIDE_BLOCKS override)
 	bool no_side_stream = false, lazy_slice_late = false;
@@ -129,6 +133,9 @@ int lastVisibleCount();
 int64_t packedViewWords(int64_t P, int64_t capacity);
 void packColorView(const torch::Tensor& dL_dcolor_view, const torch::Tensor& campos, int64_t capacity, torch::Tensor& message,
                    torch::Tensor& scratch);
+// gsr_pack_view_plan: the mask and prefix sections of a view's message from the forward pass's radii (CURRENT stream); the
+// backward pass writes rows and header itself when ShAdamStep::packed_view names the message
+void packViewPlan(const torch::Tensor& radii, int64_t capacity, torch::Tensor& message, torch::Tensor& scratch);
 torch::Tensor shGradFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
                                     const int degree, const int M, const float scale);
 void shAdamFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,

@@ -33,6 +33,10 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 	if (e.sh_grad_view_.defined()) ctx->saved_data["sh_grad_view"] = e.sh_grad_view_;
 	if (e.sh_adam_.color_view_ready_stream)
 		ctx->saved_data["color_view_ready_stream"] = static_cast<int64_t>(reinterpret_cast<intptr_t>(e.sh_adam_.color_view_ready_stream));
+	if (e.sh_adam_.packed_view.defined()) {
+		ctx->saved_data["packed_view"] = e.sh_adam_.packed_view;
+		ctx->saved_data["packed_capacity"] = e.sh_adam_.packed_capacity;
+	}
 	if (!e.view_stats_.empty()) ctx->saved_data["view_stats"] = e.view_stats_;
 	if (e.sh_adam_.exp_avg.defined()) {
 		ctx->saved_data["sh_adam_m"] = e.sh_adam_.exp_avg;
@@ -111,6 +115,10 @@ torch::autograd::tensor_list backward_impl(torch::autograd::AutogradContext* ctx
 	ShAdamStep bwd_adam = (sh_grad_view.defined() && !sh_adam.row_step.defined()) ? ShAdamStep() : sh_adam;
 	if (ctx->saved_data.count("color_view_ready_stream"))
 		bwd_adam.color_view_ready_stream = reinterpret_cast<void*>(static_cast<intptr_t>(ctx->saved_data["color_view_ready_stream"].toInt()));
+	if (ctx->saved_data.count("packed_view")) {
+		bwd_adam.packed_view = ctx->saved_data["packed_view"].toTensor();
+		bwd_adam.packed_capacity = ctx->saved_data["packed_capacity"].toInt();
+	}
 	auto v = ctx->get_saved_variables();
 	auto g = RasterizeGaussiansBackwardCUDA(v[0] /*bg*/, v[5] /*means3D*/, v[9] /*radii*/, v[4] /*colors_precomp*/,
 	                                        v[6] /*scales*/, v[7] /*rotations*/, scale_modifier, v[8] /*cov3Ds*/,

@@ -168,7 +168,8 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	p.msg_stride = words;
 	p.messages = gathered_;
 	auto issue = [&]() {
-		packColorView(pk.color_view, camera_center.detach().reshape({3}), pk.capacity, send, pk.scratch);   // four launches, current stream
+		// (four launches on the current stream -- or none: the backward pass wrote the message itself, ShAdamStep::packed_view)
+		if (!pk.prepacked) packColorView(pk.color_view, camera_center.detach().reshape({3}), pk.capacity, send, pk.scratch);
 		p.work = pg_->_allgather_base(gathered_, send);
 	};
 #ifndef GSR_HOST_NO_HIP
@@ -232,10 +233,12 @@ void TrainStep::markWait(int k)
 
 std::vector<double> TrainStep::exchangeWaitMs()
 {
-	std::vector<double> out{-1.0, -1.0};
+	// {gather wait, reduce wait, start -> gather wait (forward, loss, backward), SH step between the two waits, reduce wait -> end}
+	std::vector<double> out{-1.0, -1.0, -1.0, -1.0, -1.0};
 #ifndef GSR_HOST_NO_HIP
-	for (int j = 0; j < 2; j++) {
-		auto a = static_cast<hipEvent_t>(wait_events_[2 * j]), b = static_cast<hipEvent_t>(wait_events_[2 * j + 1]);
+	const int pairs[5][2] = {{0, 1}, {2, 3}, {4, 0}, {1, 2}, {3, 5}};
+	for (int j = 0; j < 5; j++) {
+		auto a = static_cast<hipEvent_t>(wait_events_[pairs[j][0]]), b = static_cast<hipEvent_t>(wait_events_[pairs[j][1]]);
 		float ms = 0.f;
 		if (a && b && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) out[static_cast<size_t>(j)] = ms;
 	}
@@ -244,26 +247,38 @@ std::vector<double> TrainStep::exchangeWaitMs()
 }
 
 // The packed exchange: every rank's message must have room for the LARGEST view of the batch.  A view's row count is its
-// number of visible Gaussians, which the forward pass leaves on the host (gsr_last_visible_count); the ranks all-gather the
-// counts -- one int each -- on the gather stream right behind the forward pass, i.e. next to the forward blend, the loss and
-// the whole backward pass, and the host picks the result up after it has queued those (no bubble: the device has ~1 ms of
-// work in front of it; the host waits at most for a collective of N ints that was issued long before).
+// number of visible Gaussians, which the forward pass leaves on the HOST (gsr_last_visible_count) -- so the ranks agree on the
+// maximum host-side: one int per rank over a host process group (setCountGroup: gloo), issued right behind the forward pass
+// and picked up after the host has queued the loss and the backward pass.  The host runs ~0.6 ms ahead of the device there
+// (bench.py: host.blocked_in_forward_sync_us_per_step), a gloo all-gather of N ints on one node takes a fraction of that, and
+// the device is not involved at all.  (Round 4 first sent the counts through RCCL on the gather stream -- pinned copy in, gather,
+// pinned copy out: measured +42 us per step ON THE COMPUTE STREAM at one rank, profiles/r04_r: the two host<->device copies cost the
+// kernels running next to them more than the 12 MB they save on the links.  That route remains for a caller without a host group.)
+// One rank needs no exchange.
 void TrainStep::beginCountExchange()
 {
 	torch::NoGradGuard ng;
 	const int64_t N = process_group_->getSize();
 	const int V = lastVisibleCount();
+	count_work_ = nullptr;
+	counts_on_device_route_ = false;
+	if (N == 1) {
+		counts_pinned_ = torch::full({1}, V, torch::kInt32);
+		return;
+	}
 	const auto& xyz = gaussians_->xyz_;
-	if (!xyz.is_cuda()) {   // gloo, host tensors: synchronous
-		auto own = torch::full({1}, V, torch::kInt32);
+	if (count_group_ || !xyz.is_cuda()) {   // host tensors over a host group (gloo); in flight until finishCountExchange()
+		auto& pg = count_group_ ? count_group_ : process_group_;
+		count_own_host_ = torch::full({1}, V, torch::kInt32);
 		counts_pinned_ = torch::empty({N}, torch::kInt32);
-		process_group_->_allgather_base(counts_pinned_, own)->wait();
+		count_work_ = pg->_allgather_base(counts_pinned_, count_own_host_);
 		return;
 	}
 #ifndef GSR_HOST_NO_HIP
+	counts_on_device_route_ = true;
 	const auto idx = xyz.device().index();
 	if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, idx).stream();
-	if (!count_own_pinned_.defined() || counts_pinned_.numel() != N) {
+	if (!count_own_pinned_.defined() || !counts_pinned_.defined() || counts_pinned_.numel() != N || !counts_pinned_.is_pinned()) {
 		count_own_pinned_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
 		counts_pinned_ = torch::empty({N}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
 		count_own_dev_ = torch::empty({1}, xyz.options().dtype(torch::kInt32).requires_grad(false));
@@ -286,10 +301,46 @@ void TrainStep::beginCountExchange()
 #endif
 }
 
+// The mask and prefix sections of this view's message from the radii the forward pass has just left (gsr_forward returns
+// behind preprocess_fwd: they are complete) -- three small launches on the gather stream, next to the forward blend; the compute
+// stream waits for them in front of the backward pass, which writes rows and header (ShAdamStep::packed_view).
+void TrainStep::planPackedView(const torch::Tensor& radii)
+{
+	torch::NoGradGuard ng;
+	const int64_t cap = (radii.size(0) + 3) / 4 * 4;
+#ifndef GSR_HOST_NO_HIP
+	if (radii.is_cuda()) {
+		const auto idx = radii.device().index();
+		if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, idx).stream();
+		auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream_), idx);
+		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+		radii.record_stream(side.unwrap());
+		sh_packed_send_.record_stream(side.unwrap());
+		if (!sh_pack_scratch_.defined()) {   // (allocated on the compute stream, used on the gather stream from here on)
+			packViewPlan(radii, cap, sh_packed_send_, sh_pack_scratch_);   // first step: on the compute stream, allocates the scratch
+			sh_pack_scratch_.record_stream(side.unwrap());
+			return;
+		}
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+		packViewPlan(radii, cap, sh_packed_send_, sh_pack_scratch_);
+		at::cuda::CUDAEvent planned;
+		planned.record(side);
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
+		planned.block(prev);
+		return;
+	}
+#endif
+	packViewPlan(radii, cap, sh_packed_send_, sh_pack_scratch_);
+}
+
 int64_t TrainStep::finishCountExchange()
 {
+	if (count_work_) {   // the host group's all-gather: issued behind the forward pass, long landed
+		count_work_->wait();
+		count_work_ = nullptr;
+	}
 #ifndef GSR_HOST_NO_HIP
-	if (gaussians_->xyz_.is_cuda() && counts_event_ && hipEventSynchronize(static_cast<hipEvent_t>(counts_event_)) != hipSuccess)
+	if (counts_on_device_route_ && counts_event_ && hipEventSynchronize(static_cast<hipEvent_t>(counts_event_)) != hipSuccess)
 		throw std::runtime_error("finishCountExchange: waiting for the visible counts failed");
 #endif
 	int64_t most = 0;
@@ -308,6 +359,7 @@ void TrainStep::setProcessGroup(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool 
 torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask)
 {
 	if (!process_group_) throw std::runtime_error("trainForOneIterationDataParallel: setProcessGroup() first");
+	markWait(4);
 	auto loss = renderAndBackward(kf, gt_image, mask);
 	torch::NoGradGuard ng;
 	auto& g = gaussians_;
@@ -326,6 +378,7 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 			pk.gathered = sh_packed_gathered_;
 			pk.scratch = sh_pack_scratch_;
 			pk.capacity = finishCountExchange();
+			pk.prepacked = prepacked_this_step_;
 			vf = std::make_unique<ViewFactoredExchange>(process_group_, pk, kf->camera_center_, others,
 			                                            gather_stream_in_use_ ? gather_stream_ : nullptr);
 			sh_pack_scratch_ = pk.scratch;   // (grown on first use: kept)
@@ -393,5 +446,6 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 		wait_all();
 	}
 	finishEnd();
+	markWait(5);
 	return loss;
 }

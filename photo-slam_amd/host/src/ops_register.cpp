@@ -170,6 +170,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "cull_empty_tiles") t->cull_empty_tiles_ = v != 0.0;
 		else if (k == "early_gather") t->early_gather_ = v != 0.0;
 		else if (k == "packed_exchange") t->packed_exchange_ = v != 0.0;
+		else if (k == "pack_in_backward") t->pack_in_backward_ = v != 0.0;
 		else if (k == "lazy_slice_late") t->lazy_slice_late_ = v != 0.0;
 		else if (k == "no_side_stream") t->no_side_stream_ = v != 0.0;
 		else if (k == "profile_exchange") t->profile_exchange_ = v != 0.0;
@@ -291,6 +292,12 @@ void trainer_set_exist_since_iter(int64_t h, torch::Tensor v)
 void trainer_release_arena(int64_t h) { get(h)->gaussians_->releaseArena(); }
 // Data-parallel keyframe batches driven from C++: the process group Python created (torch.distributed's default group, or any
 // other) is resolved by its registered name; from then on trainer_train_one_iteration() issues every collective itself.
+// the host-side group (gloo) over which the packed exchange agrees on its message capacity; empty name = none
+void trainer_set_count_group(int64_t h, std::string group_name)
+{
+	if (group_name.empty()) get(h)->setCountGroup(nullptr);
+	else get(h)->setCountGroup(c10d::resolve_process_group(group_name));
+}
 void trainer_set_process_group(int64_t h, std::string group_name, bool factored)
 {
 	if (group_name.empty()) get(h)->setProcessGroup(nullptr, factored);
@@ -367,6 +374,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_set_exist_since_iter", &trainer_set_exist_since_iter);
 	m.def("trainer_release_arena", &trainer_release_arena);
 	m.def("trainer_set_process_group", &trainer_set_process_group);
+	m.def("trainer_set_count_group", &trainer_set_count_group);
 	m.def("trainer_train_one_iteration", &trainer_train_one_iteration);
 	m.def("trainer_features_finish_from_views", &trainer_features_finish_from_views);
 	m.def("trainer_geom_adam", &trainer_geom_adam);

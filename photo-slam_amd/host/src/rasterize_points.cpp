@@ -336,6 +336,15 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 		}
 		a.dL_dcolor_view = factored ? dL_dcolor_view.data_ptr<float>() : nullptr;
 		a.color_view_ready_stream = factored ? sh_adam.color_view_ready_stream : nullptr;
+		if (factored && sh_adam.packed_view.defined()) {
+			const auto& m = sh_adam.packed_view;
+			if (m.scalar_type() != torch::kInt32 || !m.is_contiguous() || m.device() != means3D.device() ||
+			    m.numel() < packedViewWords(P, sh_adam.packed_capacity))
+				throw std::runtime_error("RasterizeGaussiansBackwardCUDA: packed_view must be a contiguous int32 message of "
+				                         "packedViewWords(P, packed_capacity) words on the device of means3D");
+			a.packed_view = reinterpret_cast<uint32_t*>(m.data_ptr<int32_t>());
+			a.packed_capacity_rows = static_cast<int>(sh_adam.packed_capacity);
+		}
 		a.dL_dscale = (has_scales && !geom) ? dL_dscales.data_ptr<float>() : nullptr;
 		a.dL_drot = (has_scales && !geom) ? dL_drotations.data_ptr<float>() : nullptr;
 		a.raw_params = raw_params;
@@ -448,6 +457,24 @@ void packColorView(const torch::Tensor& dL_dcolor_view, const torch::Tensor& cam
 	check(gsr_pack_color_view(P, dL_dcolor_view.data_ptr<float>(), c.ptr, static_cast<int>(capacity),
 	                          reinterpret_cast<uint32_t*>(message.data_ptr<int32_t>()), scratch.data_ptr(), current_stream(dL_dcolor_view)),
 	      "packColorView");
+}
+
+void packViewPlan(const torch::Tensor& radii, int64_t capacity, torch::Tensor& message, torch::Tensor& scratch)
+{
+	torch::NoGradGuard ng;
+	const int P = static_cast<int>(radii.size(0));
+	if (radii.dim() != 1 || !radii.is_contiguous() || radii.scalar_type() != torch::kInt32)
+		throw std::runtime_error("packViewPlan: radii must be a contiguous int32 (num_points) tensor");
+	if (message.scalar_type() != torch::kInt32 || !message.is_contiguous() || message.numel() < packedViewWords(P, capacity) ||
+	    message.device() != radii.device())
+		throw std::runtime_error("packViewPlan: message must be a contiguous int32 tensor of packedViewWords(P, capacity) words");
+	if (P == 0) return;
+	const int64_t need = static_cast<int64_t>(gsr_pack_scratch_bytes(P));
+	if (!scratch.defined() || scratch.numel() < need || scratch.device() != radii.device())
+		scratch = torch::empty({need}, radii.options().dtype(torch::kByte));
+	check(gsr_pack_view_plan(P, radii.data_ptr<int32_t>(), reinterpret_cast<uint32_t*>(message.data_ptr<int32_t>()), scratch.data_ptr(),
+	                         current_stream(radii)),
+	      "packViewPlan");
 }
 
 torch::Tensor shGradFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,

@@ -299,6 +299,14 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 #endif
 	sh_adam.no_side_stream = no_side_stream_;
 	sh_adam.lazy_slice_late = lazy_slice_late_;
+	// packed exchange: the backward pass writes this view's message itself (rows + header; the mask / prefix sections are
+	// planned from the radii right behind the forward pass, below) -- no pack launches between the backward pass and the gather
+	static const int pack_env = [] { const char* e = getenv("GSR_PACK_IN_BACKWARD"); return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+	prepacked_this_step_ = packed_this_step_ && (pack_env >= 0 ? pack_env != 0 : pack_in_backward_);
+	if (prepacked_this_step_) {
+		sh_adam.packed_view = sh_packed_send_;
+		sh_adam.packed_capacity = (g->xyz_.size(0) + 3) / 4 * 4;
+	}
 	GeomAdamStep geom_adam;
 	// (an iteration that resets the opacity replaces that leaf AFTER backward: the reference's optimizer step then skips it -- no
 	// gradient -- while a step fused into backward would already have been taken: src/gaussian_mapper.cpp:732-735)
@@ -329,6 +337,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	                                    cull_empty_tiles_);
 	g->in_lazy_step_ = false;
 	if (factored_exchange_ && packed_this_step_) beginCountExchange();   // (the forward pass has left this view's visible count)
+	if (prepacked_this_step_) planPackedView(std::get<3>(pkg));
 	auto rendered = std::get<0>(pkg);
 	last_viewspace_ = std::get<1>(pkg);
 	last_visibility_ = std::get<2>(pkg);

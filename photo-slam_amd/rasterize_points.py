@@ -118,7 +118,7 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
 def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                    viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                    geomBuffer, R, binningBuffer, imageBuffer, raw_params=0, dL_dcolor_view=None, sh_adam=None,
-                                   view_stats=None, geom_adam=None, training_outputs_only=False):
+                                   view_stats=None, geom_adam=None, training_outputs_only=False, packed_view=None):
     """dL_dcolor_view (extension, default None = reference contract): a [P,3] float tensor that receives the clamp-masked
     colour gradient; dL_dsh is then NOT computed and None is returned in its place (view-factored gradient exchange,
     shGradFromViews below).
@@ -197,6 +197,14 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
             adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
             a.sh_adam = C.pointer(adam)
         a.dL_dcolor_view = dL_dcolor_view.data_ptr() if factored else None
+        if packed_view is not None:
+            # (message, capacity_rows): a message packViewPlan() prepared -- backward writes its rows and header (gsr_backward_args.packed_view)
+            msg, cap = packed_view
+            if not factored:
+                raise RuntimeError("packed_view needs dL_dcolor_view")
+            if msg.dtype != torch.int32 or not msg.is_contiguous() or msg.device != dev or msg.numel() < packedViewWords(P, int(cap)):
+                raise RuntimeError("packed_view: a contiguous int32 message of packedViewWords(P, capacity) words on the device of means3D")
+            a.packed_view, a.packed_capacity_rows = msg.data_ptr(), int(cap)
         a.dL_dscale = dL_dscales.data_ptr() if has_scales else None
         a.dL_drot = dL_drotations.data_ptr() if has_scales else None
         if training_outputs_only:
@@ -285,6 +293,26 @@ def packedViewWords(P, capacity):
     lib = _lib()
     lib.gsr_packed_view_words.restype = C.c_size_t
     return int(lib.gsr_packed_view_words(int(P), int(capacity)))
+
+
+def packViewPlan(radii, capacity, message=None):
+    """gsr_pack_view_plan (include/gsr.h): the mask and prefix sections of a view's message from the forward pass's radii; the
+    backward pass then writes rows and header itself (RasterizeGaussiansBackwardCUDA(packed_view=(message, capacity)))."""
+    lib = _lib()
+    P = radii.size(0)
+    _check_device(lib, radii)
+    words = packedViewWords(P, capacity)
+    if message is None:
+        message = torch.empty(words, dtype=torch.int32, device=radii.device)
+    if message.numel() < words or message.dtype != torch.int32 or not message.is_contiguous() or radii.dtype != torch.int32:
+        raise RuntimeError("message must be a contiguous int32 tensor of packedViewWords(P, capacity) words, radii int32")
+    if P != 0:
+        lib.gsr_pack_scratch_bytes.restype = C.c_size_t
+        scratch = torch.empty(int(lib.gsr_pack_scratch_bytes(int(P))), dtype=torch.uint8, device=radii.device)
+        r = radii.contiguous()
+        capi.check(lib, lib.gsr_pack_view_plan(int(P), C.c_void_p(r.data_ptr()), C.c_void_p(message.data_ptr()),
+                                               C.c_void_p(scratch.data_ptr()), _stream_ptr(r)), "packViewPlan")
+    return message
 
 
 def packColorView(dL_dcolor_view, campos, capacity, message=None):

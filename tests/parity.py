@@ -53,7 +53,8 @@ def _features(cl, sh_coeffs):
 
 
 def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_colors_precomp=False, use_cov3D_precomp=False,
-                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None, view_stats=None, flags=0):
+                colors=None, cov3D=None, do_backward=True, sh_coeffs=None, factored=False, sh_adam=None, view_stats=None, flags=0,
+                packed=False):
     """cl: scene.Cloud, cam: scene.Camera.  lib_path None = product HIP library.  flags: extension bits of raw_params
     that do not concern the inputs (GSR_CULL_EMPTY_TILES = 8).  factored: backward in the
     view-factored mode (dL_dcolor_view instead of dL_dsh, include/gsr.h)."""
@@ -102,11 +103,18 @@ def run_backend(lib_path, dev, cl, cam, bg, sh_degree=3, dL_dpix=None, use_color
         if do_backward:
             dpix = _t(dL_dpix if dL_dpix is not None else np.ones((3, cam.H, cam.W), np.float32), dev)
             view = torch.full((P, 3), float("nan"), device=dev) if factored else None
+            packed_view = None
+            if packed:   # the backward pass writes the view's packed message too (gsr_backward_args.packed_view)
+                cap = (P + 3) // 4 * 4
+                msg = torch.full((rp.packedViewWords(P, cap),), -1, dtype=torch.int32, device=dev)
+                packed_view = (rp.packViewPlan(radii, cap, msg), cap)
             g = rp.RasterizeGaussiansBackwardCUDA(a["background"], a["means3D"], radii, a["colors"], a["scales"],
                                                   a["rotations"], 1.0, a["cov3D_precomp"], a["viewmatrix"],
                                                   a["projmatrix"], cam.tanfovx, cam.tanfovy, dpix, a["sh"], sh_degree,
                                                   a["campos"], geom, R, binning, img,
-                                                  dL_dcolor_view=view, sh_adam=sh_adam, view_stats=view_stats)
+                                                  dL_dcolor_view=view, sh_adam=sh_adam, view_stats=view_stats, packed_view=packed_view)
+            if packed:
+                r.packed_msg, r.packed_capacity = packed_view[0].cpu(), packed_view[1]
             if sh_adam is not None:
                 r.sh_after = a["sh"].cpu().numpy()
             names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")

@@ -84,6 +84,48 @@ def run_visible_count_check(dev, lib_path):
         rp._LIB_OVERRIDE = None
 
 
+def run_backward_packs_check(dev, lib_path, cl, sh_degree=3):
+    """gsr_backward_args.packed_view: the backward pass writes the view's message itself (mask + prefix planned from the radii by
+    gsr_pack_view_plan) -- the same words as gsr_pack_color_view on the dense view it leaves next to it, and nothing else changes."""
+    import parity
+    bg = np.zeros(3, np.float32)
+    for k, cam in enumerate(cl.cameras):
+        dpix = np.random.default_rng(k).standard_normal((3, cam.H, cam.W)).astype(np.float32)
+        a = parity.run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix, factored=True)
+        b = parity.run_backend(lib_path, dev, cl, cam, bg, sh_degree=sh_degree, dL_dpix=dpix, factored=True, packed=True)
+        for n in a.grads:
+            if dev.type == "cpu":
+                assert np.array_equal(a.grads[n], b.grads[n], equal_nan=True), n
+            else:   # (two passes on the GPU differ by the order of the four LDS adds that merge a tile's quads)
+                d = np.abs(a.grads[n].astype(np.float64) - b.grads[n]).sum() / max(np.abs(a.grads[n]).sum(), 1e-30)
+                assert d < 1e-5, (n, d)
+        view = torch.from_numpy(b.grads["dL_dcolor_view"]).to(dev)
+        P, cap = view.shape[0], b.packed_capacity
+        rp._LIB_OVERRIDE = lib_path
+        try:
+            blank = torch.full((rp.packedViewWords(P, cap),), -1, dtype=torch.int32, device=dev)   # (as parity.run_backend: padding words stay)
+            want = rp.packColorView(view, torch.from_numpy(np.ascontiguousarray(cam.campos)).to(dev), cap, blank).cpu()
+        finally:
+            rp._LIB_OVERRIDE = None
+        K = int(want[0])
+        assert K == int((b.radii > 0).sum()) > 0 and int(want[3]) == 0
+        used = rp.packedViewWords(P, (K + 3) // 4 * 4) - 4 - 3 * ((K + 3) // 4 * 4 - K)     # header + prefix + masks + K rows
+        assert torch.equal(b.packed_msg[:used], want[:used]), f"camera {k}: the message of the backward pass differs"
+
+
+def test_backward_writes_the_packed_message_on_the_emulator(emu_lib_path):
+    cl = scene.make_cloud(3000, 96, 64, 80.0, 80.0, seed=4, scale_k=0.3, n_views=2)
+    run_backward_packs_check(torch.device("cpu"), emu_lib_path, cl)
+    cl = scene.make_cloud(130, 48, 32, 40.0, 40.0, seed=5, scale_k=0.4)      # P not a multiple of 64, a last group of 2 rows
+    run_backward_packs_check(torch.device("cpu"), emu_lib_path, cl, sh_degree=1)
+
+
+@pytest.mark.gpu
+def test_backward_writes_the_packed_message_on_gpu():
+    run_backward_packs_check(torch.device("cuda:0"), None, scene.make_config("C1", seed=0, n_views=2))
+    run_backward_packs_check(torch.device("cuda:0"), None, scene.make_config("C2", seed=1))
+
+
 def test_packed_views_equal_the_dense_exchange_on_the_emulator(emu_lib_path):
     dev = torch.device("cpu")
     run_packed_checks(dev, emu_lib_path)

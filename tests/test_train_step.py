@@ -308,9 +308,13 @@ if mode == "densify":
     opts.update({"densify": 1.0, "densify_from_iter": 1.0, "densification_interval": 2.0, "densify_grad_threshold": 2e-5})
 ops.trainer_set_options(h, opts)
 # every collective of the step is issued by the C++ host from here on (host/src/keyframe_batch_exchange.cpp)
-ops.trainer_set_process_group(h, dist.group.WORLD.group_name, sys.argv[4] in ("factored", "packed"))
-if sys.argv[4] == "packed":   # the view-factored exchange in its packed form: only the rows a view sees travel
-    ops.trainer_set_options(h, {"packed_exchange": 1.0})
+ops.trainer_set_process_group(h, dist.group.WORLD.group_name, sys.argv[4] in ("factored", "packed", "packed_late"))
+if sys.argv[4] in ("packed", "packed_late"):   # the view-factored exchange in its packed form: only the rows a view sees travel
+    # packed: the backward pass writes the message itself; packed_late: it is packed from the dense view behind the pass
+    ops.trainer_set_options(h, {"packed_exchange": 1.0, "pack_in_backward": 1.0 if sys.argv[4] == "packed" else 0.0})
+    if sys.argv[4] == "packed":   # the visible counts over a host group of their own (what bench.py does next to RCCL); packed_late: the main group
+        count_group = dist.new_group(backend="gloo")
+        ops.trainer_set_count_group(h, count_group.group_name)
 cam = cl.cameras[rank]
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
@@ -357,6 +361,11 @@ def test_packed_exchange_equals_the_dense_one_bit_for_bit_gloo(emu, tmp_path):
                 assert np.array_equal(dense[r][k], packed[r][k]), (n, r, k)
         for k in ("xyz", "features", "opacity", "scaling", "rotation"):
             assert np.array_equal(packed[0][k], packed[n - 1][k]), f"replicas diverged on {k}"
+    late = _launch_cpp(tmp_path, emu, 2, 29553, "packed_late")          # the message packed behind the backward pass (gsr_pack_color_view)
+    dense2 = _launch_cpp(tmp_path, emu, 2, 29555, "factored")
+    for r in range(2):
+        for k in ("xyz", "features", "opacity", "scaling", "rotation", "accum", "denom", "maxr"):
+            assert np.array_equal(late[r][k], dense2[r][k]), (r, k)
     dense = [{k: r[k].copy() for k in r.files} for r in _launch_cpp(tmp_path, emu, 2, 29549, "factored", "densify")]
     packed = _launch_cpp(tmp_path, emu, 2, 29551, "packed", "densify")
     assert packed[0]["xyz"].shape[0] != 300

@@ -166,7 +166,7 @@ PY
 import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'raster', d.get('rasterizer_only', {}).get('fwd_bwd_ms'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
     benchq) cfg=${arg:-C3}; timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_$cfg$SUF.json 2>$OUT/bench_err.log   # quick A/B form: no densify leg
             python -c "
-import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
+import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'host blocked us/step', d.get('host', {}).get('blocked_in_forward_sync_us_per_step'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
     kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
@@ -176,14 +176,14 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
             ex=factored; pyx=0; form=auto; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
             [ "$arg" = packed ] && form=packed; [ "$arg" = dense ] && form=dense   # dp:packed | dp:dense: the form of the view-factored exchange (default: the guarded trial)
             [ "$arg" = late ] && export GSR_EARLY_GATHER=0 || unset GSR_EARLY_GATHER
-            for cfg in C3 C4; do
+            for cfg in ${DP_CONFIGS:-C3 C4}; do
               GSR_BENCH_FORCE_DP=1 GSR_BENCH_EXCHANGE=$ex GSR_BENCH_PY_EXCHANGE=$pyx timeout 400 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 --exchange-form $form > $OUT/dp_$cfg.log 2>$OUT/dp_err.log
-              f=$OUT/bench_${cfg}_dp_path_1rank_rccl_${arg:-factored}.json
+              f=$OUT/bench_${cfg}_dp_path_1rank_rccl_${arg:-factored}$SUF.json
               grep '^{"metric"' $OUT/dp_$cfg.log > $f   # (the RCCL banner precedes the JSON line)
               python -c "
-import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12], d['rccl'].get('exchange_form'), d.get('exposed_communication'))" || tail -5 $OUT/dp_err.log
+import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], d['rccl']['collectives_issued_by'][:12], d['rccl'].get('exchange_form'), d.get('host', {}).get('blocked_in_forward_sync_us_per_step'), (d.get('per_rank') or [{}])[0].get('segments_ms_median'))" || tail -5 $OUT/dp_err.log
             done ;;
-    dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3${arg:+_$arg}.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 --dropin-steps 0 --exchange-form ${arg:-dense} ;;   # dpstats | dpstats:packed
+    dpstats) GSR_BENCH_FORCE_DP=1 kernel_stats $OUT/kernel_stats_dp_path_1rank_C3${arg:+_$arg}$SUF.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --median-steps 0 --dropin-steps 0 --exchange-form ${arg:-dense} ;;   # dpstats | dpstats:packed
     share2) # share2 | share2:packed | share2:dense | share2:4 -- TWO (or N) ranks on the ONE GPU of the box over gloo, the exchange driven
             # by the C++ host: a functional check of bench.py's multi-rank glue (trial of the exchange forms, per-rank tables, replica
             # checksum) -- not a rate: the ranks share the device and gloo moves the bytes through the host
