@@ -543,7 +543,11 @@ def main():
     loss_state = {"n": 0, "ema": 0.0}
     comm_ms = {"gather": [], "reduce": []}
 
+    no_loss_read = os.environ.get("GSR_BENCH_NO_LOSS_READ") == "1"   # (A/B: what does the per-iteration host read of the loss cost?)
+
     def read_loss_deferred(loss):
+        if no_loss_read:
+            return
         k = loss_state["n"] & 1
         if loss_state["n"] >= 1:
             loss_ready[k ^ 1].synchronize()                       # step n-1: finished long ago, or being finished now
