@@ -520,9 +520,22 @@ def main():
             ops.trainer_set_process_group(handle, dist.group.WORLD.group_name, factored)
             if world > 1:
                 # the packed exchange agrees on its message capacity host-side: one int per rank over gloo (the visible counts are on
-                # the host anyway; through RCCL their two pinned copies cost the compute stream +42 us per step: profiles/r04_r)
-                count_group = dist.new_group(backend="gloo")
-                ops.trainer_set_count_group(handle, count_group.group_name)
+                # the host anyway; through RCCL their two pinned copies cost the compute stream +42 us per step: profiles/r04_r).
+                # Every rank takes the same route: a gloo group that does not come up on ANY rank leaves the RCCL route on all.
+                count_group, ok = None, 1.0
+                try:
+                    import datetime
+                    count_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+                    probe = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+                    dist.all_gather(probe, torch.full((1,), rank, dtype=torch.int32), group=count_group)
+                    ok = 1.0 if [int(p) for p in probe] == list(range(world)) else 0.0
+                except Exception as e:                        # noqa: BLE001
+                    ok = 0.0
+                    print(f"bench.py: no gloo group for the visible counts on rank {rank} ({e!r}); they travel through {backend}", file=sys.stderr)
+                flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) > 0:
+                    ops.trainer_set_count_group(handle, count_group.group_name)
         elif dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
         if args.densify_interval:
