@@ -462,14 +462,15 @@ def test_cpp_data_parallel_step_over_rccl_with_one_rank_on_gpu():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=dev)
     try:
         results = {}
-        # ("packed": the view-factored exchange sending only the rows the view sees -- the count exchange on the gather stream, the
-        # message packed there, the decoder inside the SH step; include/gsr.h gsr_pack_color_view)
-        for factored in (True, False, "packed"):
+        # ("packed": the view-factored exchange sending only the rows the view sees -- the message packed on the gather stream behind
+        # the backward pass, the decoder inside the SH step; include/gsr.h gsr_pack_color_view.  "packed_in_backward": the backward
+        # pass writes the message itself, gsr_backward_args.packed_view)
+        for factored in (True, False, "packed", "packed_in_backward"):
             h = make()
             ops.trainer_set_options(h, {"lazy_sh_adam_window": 4.0})   # (window 4: rows fall behind and catch up within six steps)
             ops.trainer_set_process_group(h, dist.group.WORLD.group_name, bool(factored))
-            if factored == "packed":
-                ops.trainer_set_options(h, {"packed_exchange": 1.0})
+            if factored in ("packed", "packed_in_backward"):
+                ops.trainer_set_options(h, {"packed_exchange": 1.0, "pack_in_backward": 1.0 if factored == "packed_in_backward" else 0.0})
             losses = [step(h) for _ in range(n_it)]
             results[factored] = (losses, [p.detach().clone() for p in ops.trainer_params(h)], list(ops.trainer_steps(h)))
             ops.trainer_destroy(h)
@@ -488,8 +489,9 @@ def test_cpp_data_parallel_step_over_rccl_with_one_rank_on_gpu():
             assert float((err > 1e-2).float().mean()) < 2e-3, (factored, float(err.max()))
     # the packed form against the dense one: the same rows in the same order -- differences only where two runs of the same
     # backward pass differ (the blend's LDS add order)
-    for a, b, lr in zip(results["packed"][1], results[True][1], lrs):
-        assert float((((a - b).abs() / lr) > 1e-2).float().mean()) < 2e-3
+    for form in ("packed", "packed_in_backward"):
+        for a, b, lr in zip(results[form][1], results[True][1], lrs):
+            assert float((((a - b).abs() / lr) > 1e-2).float().mean()) < 2e-3, form
     ops.trainer_destroy(h_fused)
 
 
