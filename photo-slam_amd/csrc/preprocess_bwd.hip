@@ -223,7 +223,9 @@ __device__ __forceinline__ void pack_view_row(const PreprocessBwdParams& p, int 
 
 // ROWS_OK: dL_dsh / shs rows are 48 floats and 16-byte aligned (the layout of the reference model): sh_bwd_rows_kernel
 // follows and adds the SH term; otherwise the SH backward happens here with per-lane scalar row access.
-template <bool ROWS_OK>
+// PACKED: the view's packed message is written next to dL_dcolor_view (gsr_backward_args.packed_view) -- an instantiation of its
+// own: as a run-time branch it cost the kernel of the single-GPU step 8 us (181 -> 189 us at C3, profiles/r04_v) with the option off.
+template <bool ROWS_OK, bool PACKED = false>
 __global__ void __launch_bounds__(PRB_THREADS)
 preprocess_bwd_kernel(const PreprocessBwdParams p)
 {
@@ -234,7 +236,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	const int M3 = 3 * p.M;
 	constexpr bool rows_ok = ROWS_OK;
 	// packed view (kernel-uniform): the lanes of this wave are one 64-row group of the message
-	const unsigned long long seen_mask = p.packed_msg ? wave_ballot(vis) : 0ull;
+	const unsigned long long seen_mask = PACKED ? wave_ballot(vis) : 0ull;
 
 	// ------------------------------------------------------------------ gradients of the blend stage (partials.h)
 	// the per-instance slots of this Gaussian's tiles are summed here, in registers: colour 0..2, mean2D moments 3..4,
@@ -304,7 +306,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 			p.dL_dcolor_view[3 * (size_t)idx + 0] = v0;
 			p.dL_dcolor_view[3 * (size_t)idx + 1] = v1;
 			p.dL_dcolor_view[3 * (size_t)idx + 2] = v2;
-			if (p.packed_msg) pack_view_row(p, idx, vis, seen_mask, v0, v1, v2);
+			if (PACKED) pack_view_row(p, idx, vis, seen_mask, v0, v1, v2);
 		}
 		if (p.geom.on) {
 			const float go[1] = {g_opacity};
@@ -369,7 +371,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 				p.dL_dcolor_view[3 * (size_t)idx + 0] = dRGB[0];
 				p.dL_dcolor_view[3 * (size_t)idx + 1] = dRGB[1];
 				p.dL_dcolor_view[3 * (size_t)idx + 2] = dRGB[2];
-				if (p.packed_msg) pack_view_row(p, idx, vis, seen_mask, dRGB[0], dRGB[1], dRGB[2]);
+				if (PACKED) pack_view_row(p, idx, vis, seen_mask, dRGB[0], dRGB[1], dRGB[2]);
 			}
 		}
 	}
@@ -700,7 +702,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 		return GSR_ERR_UNSUPPORTED;   // the fused geometry step lives in the two-kernel path of the reference's SH layout
 	const int grid = div_up(p.P, PRB_THREADS);
 	if (rows_ok && p.D >= 0 && p.D <= 3) {
-		GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
+		if (p.packed_msg) GSR_LAUNCH((preprocess_bwd_kernel<true, true>), grid, PRB_THREADS, stream, p);
+		else GSR_LAUNCH(preprocess_bwd_kernel<true>, grid, PRB_THREADS, stream, p);
 		GSR_CHECK_LAUNCH();
 		if (p.notify_stream && p.notify_event) {   // dL_dcolor_view is complete: whoever gathers it need not wait for the SH kernel
 			GSR_HIP(hipEventRecord((hipEvent_t)p.notify_event, stream));
@@ -726,7 +729,8 @@ int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 			GSR_SHB(0);
 #undef GSR_SHB
 	} else {
-		GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
+		if (p.packed_msg) GSR_LAUNCH((preprocess_bwd_kernel<false, true>), grid, PRB_THREADS, stream, p);
+		else GSR_LAUNCH(preprocess_bwd_kernel<false>, grid, PRB_THREADS, stream, p);
 		if (p.notify_stream && p.notify_event) {
 			GSR_HIP(hipEventRecord((hipEvent_t)p.notify_event, stream));
 			GSR_HIP(hipStreamWaitEvent((hipStream_t)p.notify_stream, (hipEvent_t)p.notify_event, 0));
