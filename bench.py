@@ -344,6 +344,18 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
         if len(v) <= 4:
             events[k]["ms_each"] = [round(x, 3) for x in v]     # (the first use of an ATen kernel loads its code object: a one-off)
     plain_steps = sorted(((float(per[i]), 8 + i + 1) for i in range(steps) if kinds[i] == "plain"), reverse=True)
+    # where a plain step of this loop spends its time: 16 more steps (no maintenance falls on them) with the stage events on
+    from photo_slam_amd import capi
+    lib = capi.load()
+    capi.profile_enable(lib, 1)
+    stage = {}
+    for i in range(16):
+        step(8 + steps + i)
+        for k, v in capi.profile_read(lib).items():
+            if v >= 0:
+                stage.setdefault(k, []).append(v)
+    capi.profile_enable(lib, 0)
+    torch.cuda.synchronize()
     P_end = int(ops.trainer_params(h)[0].shape[0])
     ops.trainer_destroy(h)
     torch.cuda.empty_cache()
@@ -351,7 +363,10 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
             "steps": steps, "iters_per_s": round(steps / el, 3), "ms_per_step_mean": round(el / steps * 1e3, 3),
             "ms_first_to_last_event": round(float(ev[0].elapsed_time(ev[steps])), 3), "ms_sum_of_steps": round(float(per.sum()), 3), "ms_wall": round(el * 1e3, 3),
             "ms_plain_step_median": round(plain, 3), "ms_plain_step_mean": round(float(np.mean([p for p, _ in plain_steps])), 3),
-            "slowest_plain_steps": [{"iteration": it, "ms": round(ms, 3)} for ms, it in plain_steps[:10]], "events": events, "gaussians_start": P, "gaussians_end": P_end,
+            "slowest_plain_steps": [{"iteration": it, "ms": round(ms, 3)} for ms, it in plain_steps[:10]], "events": events,
+            "stage_ms_median_of_a_plain_step": {k: round(float(np.median(v)), 4) for k, v in stage.items()},
+            "stage_note": "16 plain steps behind the timed loop with the stage events on: after 300 training-lr steps the synthetic scene has "
+                          "inflated (DESIGN.md section 7) -- the instance-bound stages (emit_instances, tile_sort) carry ~3x the instances of step 1", "gaussians_start": P, "gaussians_end": P_end,
             "learning_rates": "training", "sh_degree": "2, then 3 from iteration 200 (oneUpShDegree)",
             "schedule": "increasePcd(5 k) every 10 iterations, densifyAndPrune every 100, resetOpacity every 150, oneUpShDegree at 200",
             "note": "one HIP event per iteration; an iteration's time includes the maintenance calls that follow its optimizer step"}
