@@ -531,6 +531,7 @@ def main():
                                                                           and os.environ.get("GSR_BENCH_CPP_EXCHANGE") != "1")
         if dp:
             ops.trainer_set_options(handle, {"fused_sh_adam": 0.0})   # the optimizer follows the gradient exchange
+        counts_over = "nothing to exchange (one rank)" if world == 1 else f"{backend}, on the gather stream"
         if dp and not py_exchange:
             ops.trainer_set_process_group(handle, dist.group.WORLD.group_name, factored)
             if world > 1:
@@ -538,6 +539,8 @@ def main():
                 # the host anyway; through RCCL their two pinned copies cost the compute stream +42 us per step: profiles/r04_r).
                 # Every rank takes the same route: a gloo group that does not come up on ANY rank leaves the RCCL route on all.
                 count_group, ok = None, 1.0
+                if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost"):
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # (one node: gloo need not resolve the container's hostname)
                 try:
                     import datetime
                     count_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
@@ -551,6 +554,7 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if float(flag.item()) > 0:
                     ops.trainer_set_count_group(handle, count_group.group_name)
+                    counts_over = "a gloo group next to the gradients' group (host-side)"
         elif dp and factored:
             ops.trainer_set_factored_exchange(handle, True)
         if args.densify_interval:
@@ -1068,6 +1072,8 @@ def main():
                                                     "the C++ host (host/src/keyframe_batch_exchange.cpp on c10d::ProcessGroup)",
                            "NCCL_ALGO": os.environ.get("NCCL_ALGO", "default"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "default"),
                            "exchange": "view-factored" if factored else "all-reduce", "exchange_form": exchange_form}
+            if exchange_form:
+                out["rccl"]["packed_form_visible_counts_over"] = counts_over
         traffic = traffic_src = None
         # HBM bytes per launch from rocprofv3 TCC counters (separate --pmc passes, tools/gpu_pmc.sh), corrected as
         # MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Measured for C3 only, on the
