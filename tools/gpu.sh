@@ -8,6 +8,7 @@
 #   smoke        __graft_entry__.smoke()
 #   driver       the driver's command `bench.py --gpus 1 --steps 20 --warmup 5` (with the CPU baseline, timed)
 #   bench        `bench.py --no-cpu-baseline` (100 steps + median of 100)      bench:C2 | bench:C4 | bench:C5  other configs
+#   big:<points> the C3 view with <points> Gaussians (default 16 M): the path at 8x the stated model size
 #   raster       `bench.py --raster-only --no-cpu-baseline`
 #   kstats       rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline) -> kernel_stats_bench_full_C3.csv
 #   knnstats     rocprofv3 --kernel-trace --stats of distCUDA2 at 100 k and 1 M points -> knn_kernel_stats_<points>.csv
@@ -167,6 +168,10 @@ import json; d=json.load(open('$OUT/bench_full_$cfg$SUF.json')); print('$cfg$SUF
     benchq) cfg=${arg:-C3}; timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_$cfg$SUF.json 2>$OUT/bench_err.log   # quick A/B form: no densify leg
             python -c "
 import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d['ms_per_step'], 'median', d['protocol']['median_ms_per_step'], 'host blocked us/step', d.get('host', {}).get('blocked_in_forward_sync_us_per_step'), {k: v['ms'] for k, v in d['roofline']['stages'].items()})" ;;
+    big)    # big:<points>: the C3 view with <points> Gaussians (default 16 M) -- does the path hold at 8x / 16x the stated model size?
+            n=${arg:-16000000}; timeout 900 python bench.py --points $n --steps 20 --warmup 5 --median-steps 20 --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/bench_C3_${n}_points.json 2>$OUT/big_err.log
+            python -c "
+import json; d=json.load(open('$OUT/bench_C3_${n}_points.json')); print('C3 view,', d['config']['gaussians'], 'Gaussians:', d['ms_per_step'], 'ms', d['value'], 'it/s', 'visible', d['config']['visible'], 'instances', d['config']['instances'], {k: v['ms'] for k, v in d['roofline']['stages'].items()})" || tail -5 $OUT/big_err.log ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
     kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
