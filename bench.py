@@ -1082,7 +1082,8 @@ def main():
                      "preprocess_fwd": "gsr::preprocess_fwd_kernel", "preprocess_bwd": "gsr::preprocess_bwd_kernel"}
         for f in PMC_FILES:
             if dom and args.config == "C3" and args.points is None and dom in kernel_of and os.path.exists(os.path.join(ROOT, f)):
-                pm = json.load(open(os.path.join(ROOT, f))).get(kernel_of[dom])
+                table = json.load(open(os.path.join(ROOT, f)))
+                pm = table.get(kernel_of[dom]) or next((v for k, v in table.items() if k.startswith(kernel_of[dom])), None)   # (template arguments follow the name)
                 if pm:
                     traffic = int((2 * pm.get("FETCH_SIZE", 0) + pm.get("WRITE_SIZE", 0)) * 1024)
                     traffic_src = f
