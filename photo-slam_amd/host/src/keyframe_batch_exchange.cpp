@@ -179,6 +179,10 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 		const auto idx = pk.color_view.device().index();
 		auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream), idx);
 		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
+		// (allocated on the compute stream, read and written on this one: the caching allocator is told, as for the dense buffers)
+		pk.color_view.record_stream(side.unwrap());
+		pk.send.record_stream(side.unwrap());
+		pk.gathered.record_stream(side.unwrap());
 		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
 		issue();
 		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
