@@ -255,9 +255,10 @@ public:
 	bool early_gather_ = true;        // the exchange's all-gather waits for the colour gradients only, not for the whole backward pass
 	// The view-factored exchange in its PACKED form (include/gsr.h: gsr_pack_color_view): every rank sends only the rows its
 	// view sees -- 11.7 MB instead of 24 MB per rank and link at 2 M Gaussians.  The ranks agree on the message capacity by
-	// exchanging their views' visible counts (one int each) on the gather stream right behind the forward pass; the host reads
-	// them after it has queued the backward pass.  Off by default until a multi-GPU node has measured it (bench.py picks the
-	// faster form in a guarded trial); bit-identical results (tests/test_packed_views.py, tests/test_train_step.py).
+	// exchanging their views' visible counts (one int each, host values) over a host-side group (setCountGroup: gloo) right behind
+	// the forward pass; the host picks the result up after it has queued the backward pass (keyframe_batch_exchange.cpp:
+	// beginCountExchange).  Off by default until a multi-GPU node has measured it (bench.py picks the faster form in a guarded
+	// trial); bit-identical results (tests/test_packed_views.py, tests/test_train_step.py).
 	bool packed_exchange_ = false;
 	bool lazy_slice_late_ = false;    // the lazy SH rows' slice behind the backward blend instead of next to it
 	bool no_side_stream_ = false;     // no second stream inside gsr_forward / gsr_backward
