@@ -279,7 +279,8 @@ public:
 	torch::Tensor sh_gathered_;
 	// packed form: the message buffers (int32; persistent like sh_gathered_), the pack kernels' scratch and the count exchange
 	torch::Tensor sh_packed_send_, sh_packed_gathered_, sh_pack_scratch_;
-	torch::Tensor count_own_pinned_, count_own_dev_, counts_dev_, counts_pinned_, count_own_host_;
+	// counts_host_: every rank's visible count, on the host (pinned only on the RCCL route, whose copies need it)
+	torch::Tensor count_own_pinned_, count_own_dev_, counts_dev_, counts_host_, count_own_host_;
 	// the visible counts travel host-side over this group when it is set (gloo next to the RCCL group of the gradients):
 	// keyframe_batch_exchange.cpp: beginCountExchange
 	c10::intrusive_ptr<c10d::ProcessGroup> count_group_;

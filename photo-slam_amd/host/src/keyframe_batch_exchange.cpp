@@ -267,24 +267,24 @@ void TrainStep::beginCountExchange()
 	count_work_ = nullptr;
 	counts_on_device_route_ = false;
 	if (N == 1) {
-		counts_pinned_ = torch::full({1}, V, torch::kInt32);
+		counts_host_ = torch::full({1}, V, torch::kInt32);
 		return;
 	}
 	const auto& xyz = gaussians_->xyz_;
 	if (count_group_ || !xyz.is_cuda()) {   // host tensors over a host group (gloo); in flight until finishCountExchange()
 		auto& pg = count_group_ ? count_group_ : process_group_;
 		count_own_host_ = torch::full({1}, V, torch::kInt32);
-		counts_pinned_ = torch::empty({N}, torch::kInt32);
-		count_work_ = pg->_allgather_base(counts_pinned_, count_own_host_);
+		counts_host_ = torch::empty({N}, torch::kInt32);
+		count_work_ = pg->_allgather_base(counts_host_, count_own_host_);
 		return;
 	}
 #ifndef GSR_HOST_NO_HIP
 	counts_on_device_route_ = true;
 	const auto idx = xyz.device().index();
 	if (!gather_stream_) gather_stream_ = c10::hip::getStreamFromPool(/*isHighPriority=*/false, idx).stream();
-	if (!count_own_pinned_.defined() || !counts_pinned_.defined() || counts_pinned_.numel() != N || !counts_pinned_.is_pinned()) {
+	if (!count_own_pinned_.defined() || !counts_host_.defined() || counts_host_.numel() != N || !counts_host_.is_pinned()) {
 		count_own_pinned_ = torch::empty({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-		counts_pinned_ = torch::empty({N}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+		counts_host_ = torch::empty({N}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
 		count_own_dev_ = torch::empty({1}, xyz.options().dtype(torch::kInt32).requires_grad(false));
 		counts_dev_ = torch::empty({N}, xyz.options().dtype(torch::kInt32).requires_grad(false));
 	}
@@ -299,7 +299,7 @@ void TrainStep::beginCountExchange()
 	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
 	count_own_dev_.copy_(count_own_pinned_, /*non_blocking=*/true);
 	process_group_->_allgather_base(counts_dev_, count_own_dev_)->wait();   // (stream-side: the gather stream waits, not the host)
-	counts_pinned_.copy_(counts_dev_, /*non_blocking=*/true);
+	counts_host_.copy_(counts_dev_, /*non_blocking=*/true);
 	(void)hipEventRecord(static_cast<hipEvent_t>(counts_event_), side.stream());
 	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
 #endif
@@ -348,8 +348,8 @@ int64_t TrainStep::finishCountExchange()
 		throw std::runtime_error("finishCountExchange: waiting for the visible counts failed");
 #endif
 	int64_t most = 0;
-	const int32_t* c = counts_pinned_.data_ptr<int32_t>();
-	for (int64_t i = 0; i < counts_pinned_.numel(); i++) most = std::max<int64_t>(most, c[i]);
+	const int32_t* c = counts_host_.data_ptr<int32_t>();
+	for (int64_t i = 0; i < counts_host_.numel(); i++) most = std::max<int64_t>(most, c[i]);
 	return (most + 3) / 4 * 4;   // (a multiple of 4 rows: the messages stay 16-byte aligned)
 }
 
