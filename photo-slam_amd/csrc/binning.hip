@@ -24,12 +24,13 @@ namespace gsr {
 // offset == R and are never selected), and each lane locates its slot's Gaussian with an 8-step LDS binary
 // search.  Screen-filling splats near the camera are consecutive in depth order; a per-Gaussian decomposition
 // left a single wave with >100 k instances of them (the kernel's tail was 80 % of its time).
-constexpr int EMIT_SLOTS = 256;
+constexpr int EMIT_SLOTS = (int)EMIT_SEED_STRIDE;
 
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                      float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull)
+                      float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull,
+                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity)
 {
 	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
 	const int w = wave_id(), l = lane_id();
@@ -44,8 +45,12 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		const uint32_t c_end = (s0 + (uint32_t)EMIT_SLOTS >= R) ? touched_bytes : s0 + (uint32_t)EMIT_SLOTS;
 		for (uint32_t o = s0 + 4u * (uint32_t)l; o < c_end; o += 256u) *reinterpret_cast<uint32_t*>(touched + o) = 0u;
 	}
-	// r0 = last depth rank whose offset is <= s0 (offsets[0] == 0 keeps the invariant offsets[lo] <= s0)
-	uint32_t lo = 0, hi = (uint32_t)P;
+	// r0 = last depth rank whose offset is <= s0 (offsets[0] == 0 keeps the invariant offsets[lo] <= s0): left by the offset
+	// scan for this window (one load instead of four dependent probes of the offsets per wave), searched for only beyond the
+	// seed table's capacity
+	const uint32_t window = s0 / (uint32_t)EMIT_SLOTS;
+	const bool seeded = seeds != nullptr && window < seed_capacity;   // wave-uniform
+	uint32_t lo = seeded ? wave_uniform_u32(seeds[window]) : 0u, hi = seeded ? lo + 1u : (uint32_t)P;
 	while (hi - lo > 1u) {
 		const uint32_t step = (hi - lo + 63u) >> 6;
 		const uint32_t probe = lo + (uint32_t)l * step;
@@ -105,12 +110,12 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          hipStream_t stream, int cull)
+                          hipStream_t stream, int cull, bool seeded)
 {
 	if (R <= 0) return GSR_OK;
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
 	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
-	           (uint32_t)touched_clear_bytes((size_t)R), cull);
+	           (uint32_t)touched_clear_bytes((size_t)R), cull, seeded ? (const uint32_t*)g.sort_keys_b : (const uint32_t*)nullptr, (uint32_t)P);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

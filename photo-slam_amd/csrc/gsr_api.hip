@@ -92,6 +92,13 @@ static bool cov3D_stored()
 	static const int env = env_int("GSR_COV3D_STORED", 0);
 	return env != 0;
 }
+// GSR_EMIT_SEEDS=0 (A/B handle): the instance emission searches the offsets for every window instead of starting from the seeds
+// the offset scan left (binning.hip); same instances either way
+static bool emit_seeded()
+{
+	static const int env = env_int("GSR_EMIT_SEEDS", 1);
+	return env != 0;
+}
 #ifndef GSR_EMU   // (the emulator has no graph API)
 static bool graph_sort()
 {
@@ -309,7 +316,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 			                       cs, &kres, &vres, g.visible);
 			if (st == GSR_OK)
 				st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch,
-				                            cs, g.visible);
+				                            cs, g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P);
 			const hipError_t ce = hipStreamEndCapture(cs, &graph);
 			if (st != GSR_OK) return st;
 			GSR_HIP(ce);
@@ -326,8 +333,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);
+	// (g.sort_keys_b, the depth sort's pong buffer, is free again: it receives the emission's seeds -- binning.hip)
 	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
-	                                 g.visible)) != GSR_OK)
+	                                 g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P)) != GSR_OK)
 		return st;
 	}
 	PROF_FWD(3);
@@ -359,7 +367,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		// (a sort of zero passes -- a one-tile image -- cannot drop anything: the flag is ignored there)
 		const bool cull = (a->raw_params & GSR_CULL_EMPTY_TILES) != 0 && bits > 0;
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0)) != GSR_OK) return st;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded())) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,

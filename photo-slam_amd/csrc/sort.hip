@@ -83,9 +83,12 @@ scan_reduce_rect_kernel(const uint2* __restrict__ rect, const uint32_t* __restri
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// seeds (nullable; exclusive scans of counts only): seeds[k] = the element whose run [out[i], out[i] + v) holds position
+// k * seed_stride -- the instance emission starts its walk there instead of searching the offsets (binning.hip).
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint32_t* out,   // in may alias out (staged input)
-                  const uint32_t* __restrict__ block_sums, int n, int items_per_block, int inclusive)
+                  const uint32_t* __restrict__ block_sums, int n, int items_per_block, int inclusive,
+                  uint32_t* __restrict__ seeds, uint32_t seed_stride, uint32_t seed_capacity)
 {
 	__shared__ uint32_t s_wave[4];
 	const int base = blockIdx.x * items_per_block;
@@ -104,12 +107,17 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 		uint32_t tot;
 		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
 		if (i < end) out[i] = carry + ex + (inclusive ? v : 0u);
+		if (seeds && i < end && v != 0u) {
+			const uint32_t first = carry + ex;
+			// (one element in seed_stride / mean count holds a seed position; a screen-filling splat holds a few dozen)
+			for (uint32_t k = (first + seed_stride - 1u) / seed_stride; k < seed_capacity && k * seed_stride < first + v; k++) seeds[k] = (uint32_t)i;
+		}
 		carry += tot;
 	}
 }
 
 int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
-                           hipStream_t stream, const uint32_t* n_dev)
+                           hipStream_t stream, const uint32_t* n_dev, uint32_t* seeds, uint32_t seed_stride, uint32_t seed_capacity)
 {
 	if (!rect || !gather || !out || !rect_sorted) return GSR_ERR_INVALID_ARG;
 	if (n <= 0) return GSR_OK;
@@ -117,7 +125,7 @@ int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* 
 	const int nb = div_up(n, ipb);
 	GSR_LAUNCH(scan_reduce_rect_kernel, nb, SCAN_THREADS, stream, rect, gather, out, rect_sorted, scratch, n, ipb, n_dev);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, (const uint32_t*)out, (const uint32_t*)nullptr, out,
-	           (const uint32_t*)scratch, n, ipb, 0);
+	           (const uint32_t*)scratch, n, ipb, 0, seeds, seed_stride, seed_capacity);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
@@ -133,7 +141,7 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 	uint32_t* staged = gather ? out : nullptr;
 	GSR_LAUNCH(scan_reduce_kernel, nb, SCAN_THREADS, stream, in, gather, staged, scratch, n, ipb, n_dev);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, gather ? (const uint32_t*)out : in, (const uint32_t*)nullptr, out,
-	           (const uint32_t*)scratch, n, ipb, inclusive ? 1 : 0);
+	           (const uint32_t*)scratch, n, ipb, inclusive ? 1 : 0, (uint32_t*)nullptr, 1u, 0u);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

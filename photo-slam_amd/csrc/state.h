@@ -190,8 +190,10 @@ static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((u
 // n_dev (nullable, with gather only): a device word; elements from *n_dev on count as zeros (their gather indices are undefined)
 // exclusive scan of the tile counts of rect[gather[i]] ((maxx - minx) * (maxy - miny), packed as preprocess_fwd writes them) into
 // out, with the gathered rectangles left in rect_sorted; elements from *n_dev on count as zeros
+// seeds (nullable): seeds[k] = the element whose instances hold instance slot k * seed_stride, for k < seed_capacity
 int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
-                           hipStream_t stream, const uint32_t* n_dev);
+                           hipStream_t stream, const uint32_t* n_dev, uint32_t* seeds = nullptr, uint32_t seed_stride = 1,
+                           uint32_t seed_capacity = 0);
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
                     uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
