@@ -89,24 +89,37 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 	}
 }
 
-// identifyTileRanges, rasterizer_impl.cu:116-138, on 32-bit tile keys.
+// identifyTileRanges, rasterizer_impl.cu:116-138, on 32-bit tile keys.  Four consecutive keys per thread (one 16-byte load + the
+// key in front of them): a quarter of the threads and loads of the one-key-per-thread form for the same 25 MB.
 __global__ void __launch_bounds__(256)
 tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev)
 {
 	if (n_dev) R = min(R, (int)*n_dev);   // (the list was compacted by the tile sort: GSR_CULL_EMPTY_TILES)
-	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	if (i >= R) return;
-	const uint32_t cur = tile_keys[i];
-	if (i == 0)
-		ranges[cur].x = 0;
-	else {
-		const uint32_t prev = tile_keys[i - 1];
-		if (cur != prev) {
+	const int i0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i0 >= R) return;
+	uint32_t k[4];
+	if (i0 + 3 < R) {
+		const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);   // (the key arrays are 16-byte aligned: state.h)
+		k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+	} else {
+#pragma unroll
+		for (int j = 0; j < 4; j++) k[j] = i0 + j < R ? tile_keys[i0 + j] : 0u;
+	}
+	uint32_t prev = i0 > 0 ? tile_keys[i0 - 1] : 0u;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int i = i0 + j;
+		if (i >= R) break;
+		const uint32_t cur = k[j];
+		if (i == 0)
+			ranges[cur].x = 0;
+		else if (cur != prev) {
 			ranges[prev].y = (uint32_t)i;
 			ranges[cur].x = (uint32_t)i;
 		}
+		if (i == R - 1) ranges[cur].y = (uint32_t)R;
+		prev = cur;
 	}
-	if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
@@ -123,7 +136,7 @@ int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream, const uint32_t* n_dev)
 {
 	if (R <= 0) return GSR_OK;
-	GSR_LAUNCH(tile_ranges_kernel, div_up(R, 256), 256, stream, R, tile_keys, ranges, n_dev);
+	GSR_LAUNCH(tile_ranges_kernel, div_up(R, 4 * 256), 256, stream, R, tile_keys, ranges, n_dev);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }
