@@ -37,3 +37,31 @@ def test_cull_empty_tiles_keeps_image_and_gradients(emu_lib_path, P, W, H, seed,
     kept, listed = parity.check_cull_empty_tiles(emu_lib_path, CPU, cl, cl.cameras[0], np.array([0.2, 0.5, 0.1], np.float32), seed=seed)
     print(f"instances listed {listed} -> {kept}")
     assert kept < listed or W * H <= 256
+
+
+def test_emission_without_seeds_gives_the_same_instance_list(emu_lib_path, tmp_path):
+    """GSR_EMIT_SEEDS=0: emit_instances searches the offsets for every 256-slot window (the path windows beyond the seed table's
+    capacity take) instead of starting from the seeds the offset scan leaves -- the same instance list, ranges and image.  The
+    switch is read once per process: the run happens in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import conftest, parity
+from photo_slam_amd import scene
+cl = scene.make_cloud(1500, 80, 70, 64.0, 64.0, seed=2, scale_k=0.35)
+r = parity.run_backend({emu_lib_path!r}, torch.device('cpu'), cl, cl.cameras[0], np.array([0.2, 0.5, 0.1], np.float32), do_backward=False)
+np.savez(sys.argv[1], point_list=r.point_list, tile_keys=r.tile_keys, ranges=r.ranges, color=r.out_color, R=r.R)
+"""
+    outs = []
+    for seeds in ("1", "0"):
+        out = str(tmp_path / f"emit_{seeds}.npz")
+        env = dict(os.environ, GSR_EMIT_SEEDS=seeds, PYTEST_CURRENT_TEST="emit")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    assert int(outs[0]["R"]) > 256 * 4      # (several windows)
+    for k in ("point_list", "tile_keys", "ranges", "color"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
