@@ -36,6 +36,22 @@ torch::Tensor oneBuffer(const std::vector<torch::Tensor>& tensors)
 	return flat;
 }
 
+#ifndef GSR_HOST_NO_HIP
+// The current stream of this thread switched to `side` for a scope -- restored on every way out, an exception included (a
+// collective or a pack launch that throws must not leave the caller's later torch ops on the gather stream).
+struct CurrentStreamScope {
+	c10::hip::HIPStreamMasqueradingAsCUDA prev;
+	explicit CurrentStreamScope(const c10::hip::HIPStreamMasqueradingAsCUDA& side)
+	    : prev(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(side.device_index()))
+	{
+		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+	}
+	~CurrentStreamScope() { c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev); }
+	CurrentStreamScope(const CurrentStreamScope&) = delete;
+	CurrentStreamScope& operator=(const CurrentStreamScope&) = delete;
+};
+#endif
+
 // Device tensors over gloo travel through the host and block the calling thread in Work::wait(): refused, except for the
 // functional check that runs several ranks on ONE GPU (tools/gpu.sh share2 sets GSR_EXCHANGE_ALLOW_GLOO_DEVICE=1).
 static bool glooDeviceTensorsAllowed()
@@ -140,9 +156,8 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 			tail.record(prev);
 			tail.block(side);
 		}
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+		CurrentStreamScope on_side(side);
 		p.work = pg_->_allgather_base(gathered_, in);
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
 	} else
 #endif
 		p.work = pg_->_allgather_base(gathered_, in);
@@ -178,14 +193,12 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 		// built there and ProcessGroupNCCL orders the gather behind it)
 		const auto idx = pk.color_view.device().index();
 		auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream), idx);
-		const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
 		// (allocated on the compute stream, read and written on this one: the caching allocator is told, as for the dense buffers)
 		pk.color_view.record_stream(side.unwrap());
 		pk.send.record_stream(side.unwrap());
 		pk.gathered.record_stream(side.unwrap());
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+		CurrentStreamScope on_side(side);
 		issue();
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
 	} else
 #endif
 		issue();
@@ -295,13 +308,11 @@ void TrainStep::beginCountExchange()
 	}
 	count_own_pinned_.data_ptr<int32_t>()[0] = V;   // (the previous step's copy was waited for in finishCountExchange)
 	auto side = c10::hip::getStreamFromExternalMasqueradingAsCUDA(static_cast<hipStream_t>(gather_stream_), idx);
-	const auto prev = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(idx);
-	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
+	CurrentStreamScope on_side(side);
 	count_own_dev_.copy_(count_own_pinned_, /*non_blocking=*/true);
 	process_group_->_allgather_base(counts_dev_, count_own_dev_)->wait();   // (stream-side: the gather stream waits, not the host)
 	counts_host_.copy_(counts_dev_, /*non_blocking=*/true);
 	(void)hipEventRecord(static_cast<hipEvent_t>(counts_event_), side.stream());
-	c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
 #endif
 }
 
@@ -325,11 +336,12 @@ void TrainStep::planPackedView(const torch::Tensor& radii)
 			sh_pack_scratch_.record_stream(side.unwrap());
 			return;
 		}
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(side);
-		packViewPlan(radii, cap, sh_packed_send_, sh_pack_scratch_);
 		at::cuda::CUDAEvent planned;
-		planned.record(side);
-		c10::hip::setCurrentHIPStreamMasqueradingAsCUDA(prev);
+		{
+			CurrentStreamScope on_side(side);
+			packViewPlan(radii, cap, sh_packed_send_, sh_pack_scratch_);
+			planned.record(side);
+		}
 		planned.block(prev);
 		return;
 	}
