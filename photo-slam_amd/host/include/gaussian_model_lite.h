@@ -187,6 +187,9 @@ private:
 class TrainStep {
 public:
 	TrainStep(std::shared_ptr<GaussianModel> g, torch::Tensor background) : gaussians_(g), background_(background) {}
+	~TrainStep();                                  // releases the HIP events of the data-parallel step (keyframe_batch_exchange.cpp)
+	TrainStep(const TrainStep&) = delete;          // (it owns them)
+	TrainStep& operator=(const TrainStep&) = delete;
 	// forward + backward only (gradients left on the leaves, statistics gathered): lets a data-parallel
 	// driver all-reduce before finishOneIteration()
 	torch::Tensor renderAndBackward(std::shared_ptr<GaussianKeyframe> kf, torch::Tensor gt_image, torch::Tensor mask);

@@ -230,6 +230,15 @@ void ViewFactoredExchange::waitAll()
 
 // ---- TrainStep: the data-parallel step --------------------------------------------------------------------------------------
 
+TrainStep::~TrainStep()
+{
+#ifndef GSR_HOST_NO_HIP
+	if (counts_event_) (void)hipEventDestroy(static_cast<hipEvent_t>(counts_event_));
+	for (auto& e : wait_events_)
+		if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+#endif
+}
+
 // profile_exchange_: HIP events on the compute stream in front of and behind a Work::wait() -- the elapsed time between the two
 // is the time the stream idled for the collective (0 when it had landed already): the EXPOSED communication of the step.
 void TrainStep::markWait(int k)
