@@ -324,8 +324,13 @@ int gsr_sh_grad_from_packed_views(int P, int D, int M, int n_views, const float*
                                   long long msg_stride, float scale, float* dL_dsh, void* stream);
 int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float* means3D, const uint32_t* messages,
                                   long long msg_stride, float scale, float* shs, const gsr_sh_adam* sh_adam, void* stream);
-/* Gaussians with radii > 0 in the last gsr_forward of the calling thread (-1 before the first) */
+/* Gaussians with radii > 0 in the last gsr_forward of the calling thread (-1 before the first; 0 after a call with P == 0) */
 int gsr_last_visible_count(void);
+/* The loud form of the decoders' silent guards (they decode nothing from a message whose P differs and read no row beyond the
+ * rows a message holds): copies the n_views headers to the host, WAITS for `stream`, and returns GSR_ERR_INVALID_ARG unless
+ * every message says P rows total, K <= min(its own capacity, `capacity_rows` = the rows that travelled) and "nothing dropped".  A synchronisation: for
+ * tests, the first steps of a session and a debugging run -- not for every step. */
+int gsr_check_packed_views(int P, int n_views, const uint32_t* messages, long long msg_stride, int capacity_rows, void* stream);
 /* Diagnostic: the time the calling thread has spent BLOCKED in gsr_forward's one host synchronisation (the read of the instance
  * count behind the projection kernel) and the number of such waits, since the last reset.  A host that runs ahead of the device
  * waits there for most of a step; a wait near zero means the device is waiting for the HOST (launch-bound step: the gaps

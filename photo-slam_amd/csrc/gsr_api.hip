@@ -10,6 +10,7 @@
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
 #include <chrono>
 #include <cmath>
+#include <vector>
 #include "kernels.h"
 #include "shrows.h"
 
@@ -99,20 +100,6 @@ static bool emit_seeded()
 	static const int env = env_int("GSR_EMIT_SEEDS", 1);
 	return env != 0;
 }
-#ifndef GSR_EMU   // (the emulator has no graph API)
-static bool graph_sort()
-{
-	static const int env = env_int("GSR_GRAPH_SORT", 0);
-	return env != 0;
-}
-struct SortGraph {
-	static constexpr int KEYS = 12;
-	hipGraphExec_t exec = nullptr;
-	hipStream_t capture = nullptr;
-	const void* key[KEYS] = {};
-};
-static thread_local SortGraph t_sort_graph;
-#endif
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -248,7 +235,10 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	*num_rendered = 0;
 	int st = validate_common(a->P, a->D, a->M, a->width, a->height, a->shs, a->colors_precomp, a->scales, a->rotations,
 	                         a->cov3D_precomp);
-	if (a->P == 0) return GSR_OK;  // src/rasterize_points.cu:81
+	if (a->P == 0) {   // src/rasterize_points.cu:81
+		t_last_visible = 0;   // (an empty model sees nothing: gsr_last_visible_count() must not keep the previous view's count)
+		return GSR_OK;
+	}
 	if (st != GSR_OK) return st;
 	if (!a->background || !a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->cam_pos || !a->out_color)
 		return GSR_ERR_INVALID_ARG;
@@ -297,37 +287,6 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// V visible ones only (V = 0.47 P at C3).  order[V..P) is undefined, offsets[V..P) = R: the culled Gaussians used to sort
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
-#ifndef GSR_EMU
-	if (graph_sort() && t_prof.on != 1) {
-		// experiment (GSR_GRAPH_SORT=1): the 14 launches of the depth sort and the offset scan -- fixed grids, counts on the device --
-		// replayed from a hipGraph captured once per (buffers, P)
-		const void* key[SortGraph::KEYS] = {g.depth_key, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, g.sort_scratch, g.visible,
-		                                    g.rect, g.offsets, g.rect_sorted, g.scan_scratch, (const void*)(size_t)P};
-		if (!t_sort_graph.exec || memcmp(key, t_sort_graph.key, sizeof(key)) != 0) {
-			if (t_sort_graph.exec) (void)hipGraphExecDestroy(t_sort_graph.exec);
-			t_sort_graph.exec = nullptr;
-			hipGraph_t graph = nullptr;
-			// (captured on a stream of its own: nothing runs during a capture, and the caller's stream may be the legacy default
-			// stream, which cannot capture)
-			if (!t_sort_graph.capture) GSR_HIP(hipStreamCreateWithFlags(&t_sort_graph.capture, hipStreamNonBlocking));
-			hipStream_t cs = t_sort_graph.capture;
-			GSR_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-			st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32, g.sort_scratch,
-			                       cs, &kres, &vres, g.visible);
-			if (st == GSR_OK)
-				st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch,
-				                            cs, g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P);
-			const hipError_t ce = hipStreamEndCapture(cs, &graph);
-			if (st != GSR_OK) return st;
-			GSR_HIP(ce);
-			GSR_HIP(hipGraphInstantiate(&t_sort_graph.exec, graph, nullptr, nullptr, 0));
-			(void)hipGraphDestroy(graph);
-			memcpy(t_sort_graph.key, key, sizeof(key));
-		}
-		GSR_HIP(hipGraphLaunch(t_sort_graph.exec, stream));
-	} else
-#endif
-	{
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
 	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
 		return st;
@@ -337,7 +296,6 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
 	                                 g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P)) != GSR_OK)
 		return st;
-	}
 	PROF_FWD(3);
 
 	{
@@ -690,6 +648,26 @@ int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float*
 }
 
 int gsr_last_visible_count(void) { return t_last_visible; }
+
+int gsr_check_packed_views(int P, int n_views, const uint32_t* messages, long long msg_stride, int capacity_rows, void* stream_)
+{
+	if (P < 0 || n_views < 1 || msg_stride < PACK_HEADER || capacity_rows < 0) return GSR_ERR_INVALID_ARG;
+	if (P == 0) return GSR_OK;
+	if (!messages) return GSR_ERR_INVALID_ARG;
+	hipStream_t stream = (hipStream_t)stream_;
+	std::vector<uint32_t> head((size_t)n_views * PACK_HEADER);
+	GSR_HIP(hipMemcpy2DAsync(head.data(), PACK_HEADER * sizeof(uint32_t), messages, (size_t)msg_stride * sizeof(uint32_t),
+	                         PACK_HEADER * sizeof(uint32_t), (size_t)n_views, hipMemcpyDeviceToHost, stream));
+	GSR_HIP(hipStreamSynchronize(stream));
+	for (int v = 0; v < n_views; v++) {
+		const uint32_t* h = &head[(size_t)v * PACK_HEADER];
+		// K rows of a P-row view, all of them inside the `capacity_rows` rows that travelled: anything else was written for another
+		// exchange, or the sender's capacity was too small and rows were dropped (h[3]).  (h[2] is the capacity the SENDER's buffer
+		// had: gsr_backward writes its message before the ranks have agreed, into a buffer with room for every row.)
+		if (h[1] != (uint32_t)P || h[3] != 0u || h[0] > h[2] || h[0] > (uint32_t)capacity_rows || h[0] > (uint32_t)P) return GSR_ERR_INVALID_ARG;
+	}
+	return GSR_OK;
+}
 
 int gsr_host_wait_stats(double* total_us, long long* calls, int reset)
 {

@@ -786,13 +786,19 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 		const uint32_t* msg = nullptr;
 		if (PACKED) {
 			msg = pk.msgs + (size_t)v * (size_t)pk.stride;
+			// (wave-uniform header words.  A message written for another P is not decoded at all, and no row beyond the rows the
+			// message HOLDS is read -- a sender whose capacity was too small has set msg[3] and dropped them; gsr_check_packed_views
+			// is the loud form of the same test)
+			const uint32_t held = msg[1] == (uint32_t)P ? (msg[0] < msg[2] ? msg[0] : msg[2]) : 0u;
 			if (in_range) {
 				const uint32_t* prefix = msg + PACK_HEADER;
 				const unsigned long long mw = reinterpret_cast<const unsigned long long*>(prefix + pk_prefix_words)[idx >> 6];
 				if ((mw >> (idx & 63)) & 1ull) {
 					const uint32_t rank = prefix[idx >> 6] + (uint32_t)__popcll(mw & ((1ull << (idx & 63)) - 1ull));
-					const float* c = reinterpret_cast<const float*>(prefix + pk_prefix_words + pk_mask_words) + 3 * (size_t)rank;
-					r = c[0]; g = c[1]; b = c[2];
+					if (rank < held) {
+						const float* c = reinterpret_cast<const float*>(prefix + pk_prefix_words + pk_mask_words) + 3 * (size_t)rank;
+						r = c[0]; g = c[1]; b = c[2];
+					}
 				}
 			}
 		} else if (in_range) {

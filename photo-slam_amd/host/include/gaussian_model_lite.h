@@ -292,6 +292,10 @@ public:
 	bool counts_on_device_route_ = false;
 	void* counts_event_ = nullptr;     // hipEvent_t behind the counts' copy to the host
 	bool packed_this_step_ = false;
+	// the gathered messages' headers are read back and verified (checkPackedViews: a host wait) on the first packed steps of this
+	// object -- a capacity the ranks did not agree on shows there, loudly, instead of as rows silently read as zero
+	int check_packed_first_steps_ = 3;
+	int packed_steps_checked_ = 0;
 	// On = the backward pass writes the message itself (gsr_backward_args.packed_view; mask + prefix planned from the radii on the
 	// gather stream behind the forward pass): no pack launches between the backward pass and the gather.  Off (default) = the
 	// message is packed from the dense view behind the backward pass (gsr_pack_color_view, four launches on the gather stream next

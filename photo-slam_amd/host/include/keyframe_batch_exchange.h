@@ -81,6 +81,7 @@ public:
 		torch::Tensor views;   // [N, rows, 3]
 		torch::Tensor messages;   // packed form: int32 [N * msg_stride], the N messages
 		int64_t msg_stride = 0;   // words between two messages (0 = the dense form above)
+		int64_t capacity = 0;     // rows every message has room for (packed form)
 		c10::intrusive_ptr<c10d::Work> work;
 	};
 	int parts() const { return static_cast<int>(parts_.size()); }

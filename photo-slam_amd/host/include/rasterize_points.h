@@ -131,6 +131,9 @@ void shAdamFromViews(const torch::Tensor& means3D, const torch::Tensor& campos_v
 // needed) on the CURRENT stream; the two consumers are shGradFromViews / shAdamFromViews on n_views messages msg_stride words apart.
 int lastVisibleCount();
 int64_t packedViewWords(int64_t P, int64_t capacity);
+// throws unless each of the n_views gathered messages says "P rows, this capacity, nothing dropped" (gsr_check_packed_views; WAITS
+// for the current stream: tests, the first steps of a session, debugging runs)
+void checkPackedViews(const torch::Tensor& messages, int64_t msg_stride, int64_t n_views, int64_t P, int64_t capacity);
 void packColorView(const torch::Tensor& dL_dcolor_view, const torch::Tensor& campos, int64_t capacity, torch::Tensor& message,
                    torch::Tensor& scratch);
 // gsr_pack_view_plan: the mask and prefix sections of a view's message from the forward pass's radii (CURRENT stream); the

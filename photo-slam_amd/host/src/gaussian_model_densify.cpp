@@ -217,7 +217,7 @@ void GaussianModel::replaceParamValues(int group, torch::Tensor fresh)
 	const bool have_state = static_cast<size_t>(group) < groups_.size();
 	bool in_arena = arena_.capacity > 0 && arena_.params[arena_.cur][group][0].defined() && leaf.defined() &&
 	                leaf.data_ptr() == arena_.params[arena_.cur][group][0].data_ptr() && fresh.sizes() == leaf.sizes() &&
-	                fresh.device() == leaf.device() && fresh.data_ptr() != leaf.data_ptr();
+	                fresh.device() == leaf.device();
 	if (!in_arena) {
 		replaceParam(group, fresh, torch::Tensor(), torch::Tensor());
 		return;
@@ -225,7 +225,10 @@ void GaussianModel::replaceParamValues(int group, torch::Tensor fresh)
 	const int64_t P = leaf.size(0);
 	auto& slot = arena_.params[arena_.cur][group];
 	auto value = slot[0].narrow(0, 0, P);
-	value.copy_(fresh.detach());
+	// (`fresh` may BE the leaf's rows -- a caller that edited them in place: nothing to copy, but the moment rows of the arena
+	// are still zeroed below.  Installing zero moments OUTSIDE the arena there would leave the old ones in slot[1] / slot[2] for
+	// the next in-place append to re-adopt, undoing the reset.)
+	if (fresh.data_ptr() != value.data_ptr()) value.copy_(fresh.detach());
 	if (have_state) replaceParam(group, value, slot[1].narrow(0, 0, P).zero_(), slot[2].narrow(0, 0, P).zero_());
 	else replaceParam(group, value, torch::Tensor(), torch::Tensor());
 }

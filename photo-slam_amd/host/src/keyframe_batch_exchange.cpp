@@ -181,6 +181,7 @@ ViewFactoredExchange::ViewFactoredExchange(c10::intrusive_ptr<c10d::ProcessGroup
 	gathered_ = pk.gathered.narrow(0, 0, N * words);
 	Part p;
 	p.msg_stride = words;
+	p.capacity = pk.capacity;
 	p.messages = gathered_;
 	auto issue = [&]() {
 		// (four launches on the current stream -- or none: the backward pass wrote the message itself, ShAdamStep::packed_view)
@@ -286,6 +287,12 @@ void TrainStep::beginCountExchange()
 	torch::NoGradGuard ng;
 	const int64_t N = process_group_->getSize();
 	const int V = lastVisibleCount();
+	// (-1: no forward pass has run on this thread -- a capacity agreed on from it would drop every row of this view's message)
+	if (V < 0) throw std::runtime_error("beginCountExchange: no forward pass on this thread has left a visible count (gsr_last_visible_count() < 0)");
+	// a caller that drives renderAndBackward() / finishOneIteration() itself never reaches finishCountExchange(): the previous
+	// step's exchange is finished here before the next collective is issued on the same group (and before the pinned word of the
+	// device route is rewritten under its copy)
+	if (count_work_ || counts_on_device_route_) (void)finishCountExchange();
 	count_work_ = nullptr;
 	counts_on_device_route_ = false;
 	if (N == 1) {
@@ -368,6 +375,7 @@ int64_t TrainStep::finishCountExchange()
 	if (counts_on_device_route_ && counts_event_ && hipEventSynchronize(static_cast<hipEvent_t>(counts_event_)) != hipSuccess)
 		throw std::runtime_error("finishCountExchange: waiting for the visible counts failed");
 #endif
+	counts_on_device_route_ = false;   // (landed: nothing in flight any more)
 	int64_t most = 0;
 	const int32_t* c = counts_host_.data_ptr<int32_t>();
 	for (int64_t i = 0; i < counts_host_.numel(); i++) most = std::max<int64_t>(most, c[i]);
@@ -446,7 +454,16 @@ torch::Tensor TrainStep::trainForOneIterationDataParallel(std::shared_ptr<Gaussi
 					markWait(0);   // (profile_exchange_: how long does the compute stream wait for the all-gather?)
 					const auto& p = vf->part(k);
 					markWait(1);
-					if (p.msg_stride) stepFeaturesFromPackedViews(p.messages, p.msg_stride, process_group_->getSize());
+					if (p.msg_stride) {
+						// the first packed steps of this object (and every one under GSR_CHECK_PACKED=1) read the gathered headers back:
+						// a rank whose message was written for another P / capacity, or that dropped rows, stops the run here
+						static const int check_env = [] { const char* e = getenv("GSR_CHECK_PACKED"); return (e && *e) ? atoi(e) : -1; }();
+						if (check_env > 0 || (check_env < 0 && packed_steps_checked_ < check_packed_first_steps_)) {
+							checkPackedViews(p.messages, p.msg_stride, process_group_->getSize(), g->xyz_.size(0), p.capacity);
+							packed_steps_checked_++;
+						}
+						stepFeaturesFromPackedViews(p.messages, p.msg_stride, process_group_->getSize());
+					}
 					else stepFeaturesFromViews(vf->centres(), p.views, p.row0, k == 0);
 				}
 				finishFeaturesFromViews();

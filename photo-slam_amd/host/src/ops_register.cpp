@@ -241,6 +241,13 @@ std::vector<torch::Tensor> trainer_moments(int64_t h)   // exp_avg of the five g
 	return out;
 }
 
+// lazy SH Adam: the step every row of the SH tensor has taken (empty = every row is up to date), WITHOUT bringing them up to date
+torch::Tensor trainer_features_row_step(int64_t h)
+{
+	auto& r = get(h)->gaussians_->features_row_step_;
+	return r.defined() ? r.clone() : torch::empty({0}, torch::kInt32);
+}
+
 // Adam step counters of the five groups (torch::optim::AdamParamState::step of the reference's six: features_dc and
 // features_rest share one counter here, as they always carry a gradient together)
 std::vector<int64_t> trainer_steps(int64_t h)
@@ -361,6 +368,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_one_up_sh_degree", &trainer_one_up_sh_degree);
 	m.def("trainer_moments", &trainer_moments);
 	m.def("trainer_steps", &trainer_steps);
+	m.def("trainer_features_row_step", &trainer_features_row_step);
 	m.def("trainer_set_steps", &trainer_set_steps);
 	m.def("trainer_densify_due", &trainer_densify_due);
 	m.def("trainer_set_factored_exchange", &trainer_set_factored_exchange);

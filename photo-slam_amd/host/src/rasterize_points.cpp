@@ -477,6 +477,19 @@ void packViewPlan(const torch::Tensor& radii, int64_t capacity, torch::Tensor& m
 	      "packViewPlan");
 }
 
+void checkPackedViews(const torch::Tensor& messages, int64_t msg_stride, int64_t n_views, int64_t P, int64_t capacity)
+{
+	if (messages.scalar_type() != torch::kInt32 || !messages.is_contiguous() || messages.numel() < (n_views - 1) * msg_stride + 8)
+		throw std::runtime_error("checkPackedViews: messages must be a contiguous int32 tensor of n_views messages, msg_stride words apart");
+	const int st = gsr_check_packed_views(static_cast<int>(P), static_cast<int>(n_views),
+	                                      reinterpret_cast<const uint32_t*>(messages.data_ptr<int32_t>()), msg_stride,
+	                                      static_cast<int>(capacity), current_stream(messages));
+	if (st == GSR_ERR_INVALID_ARG)
+		throw std::runtime_error("checkPackedViews: a gathered message does not describe " + std::to_string(P) + " rows with capacity " +
+		                         std::to_string(capacity) + ", or its sender dropped rows (include/gsr.h: message word [3])");
+	check(st, "checkPackedViews");
+}
+
 torch::Tensor shGradFromPackedViews(const torch::Tensor& means3D, const torch::Tensor& messages, int64_t msg_stride, int64_t n_views,
                                     const int degree, const int M, const float scale)
 {

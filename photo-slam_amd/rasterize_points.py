@@ -336,6 +336,22 @@ def packColorView(dL_dcolor_view, campos, capacity, message=None):
     return message
 
 
+def checkPackedViews(messages, msg_stride, n_views, P, capacity):
+    """gsr_check_packed_views: raises unless every gathered message says "P rows, this capacity, nothing dropped" (waits for the
+    current stream: tests, first steps, debugging runs)"""
+    lib = _lib()
+    _check_device(lib, messages)
+    if messages.dtype != torch.int32 or not messages.is_contiguous() or messages.numel() < (int(n_views) - 1) * int(msg_stride) + 8:
+        raise RuntimeError("messages must be a contiguous int32 tensor of n_views messages, msg_stride words apart")
+    lib.gsr_check_packed_views.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    st = lib.gsr_check_packed_views(int(P), int(n_views), C.c_void_p(messages.data_ptr()), int(msg_stride), int(capacity),
+                                    _stream_ptr(messages))
+    if st == -1:   # GSR_ERR_INVALID_ARG
+        raise RuntimeError(f"checkPackedViews: a gathered message does not describe {int(P)} rows with capacity {int(capacity)}, "
+                           "or its sender dropped rows (include/gsr.h: message word [3])")
+    capi.check(lib, st, "checkPackedViews")
+
+
 def shGradFromPackedViews(means3D, messages, msg_stride, n_views, degree, M, scale):
     """gsr_sh_grad_from_packed_views: shGradFromViews on n_views messages of packColorView, msg_stride words apart"""
     lib = _lib()

@@ -65,10 +65,34 @@ def run_packed_checks(dev, lib_path, P=1000, n_views=3, fractions=(0.5, 0.45, 0.
                 if a is not None:
                     assert torch.equal(a, b)
             assert not torch.equal(out[0][0], sh0)
+        # the gathered headers read back: these messages describe P rows at this capacity, nothing dropped
+        rp.checkPackedViews(msgs, words, n_views, P, capacity)
         # a capacity below K: the overflow flag is raised (a caller's bug made visible, never a silent truncation)
         small = max(capacity - 8, 0)
-        over = rp.packColorView(views[int(np.argmax(counts))], centres[0], small)
+        worst = int(np.argmax(counts))
+        over = rp.packColorView(views[worst], centres[0], small)
         assert int(over[3].cpu()) == 1 and int(over[0].cpu()) == max(counts)
+        if max(counts) > small:
+            # ... the check refuses such a message, and the decoder reads no row beyond the ones it holds (rows past `small`
+            # decode as zero instead of as the words behind the message)
+            with pytest.raises(RuntimeError, match="dropped rows"):
+                rp.checkPackedViews(over, over.numel(), 1, P, small)
+            got = rp.shGradFromPackedViews(means, over, over.numel(), 1, 3, 16, 1.0)
+            seen = (views[worst].view(torch.int32) != 0).any(1)
+            rank = torch.cumsum(seen.to(torch.int64), 0) - 1
+            held = seen & (rank < small)
+            cut = views[worst].clone()
+            cut[~held] = 0.0
+            cut_msg = rp.packColorView(cut, centres[0], small)
+            assert torch.equal(got, rp.shGradFromPackedViews(means, cut_msg, cut_msg.numel(), 1, 3, 16, 1.0))
+        # a message written for another P is not decoded at all, and the check says so
+        alien = msgs.clone()
+        alien[0][1] = P + 64
+        with pytest.raises(RuntimeError, match="does not describe"):
+            rp.checkPackedViews(alien, words, n_views, P, capacity)
+        if n_views > 1:
+            rest = rp.shGradFromPackedViews(means, msgs[1:].contiguous(), words, n_views - 1, 3, 16, 1.0 / n_views)
+            assert torch.equal(rp.shGradFromPackedViews(means, alien, words, n_views, 3, 16, 1.0 / n_views), rest)
     finally:
         rp._LIB_OVERRIDE = None
 
