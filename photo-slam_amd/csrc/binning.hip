@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                       float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull,
-                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity)
+                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity, float4* __restrict__ partials, uint32_t fold)
 {
 	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
 	const int w = wave_id(), l = lane_id();
@@ -86,6 +86,14 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		// slot of the Gaussian's first instance = its emission offset (the backward blend writes its per-tile gradient
 		// partials there, preprocess_bwd sums the contiguous run)
 		if (k == 0u) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = slot;
+		// a run of more than LONG_RUN instances is folded into its first LONG_FOLD slots by the backward blend's atomics
+		// (state.h): those accumulators start out zeroed (their reader zeroes them again: partials.h)
+		if (k < fold && wdt * ((r.y >> 16) - miny) > LONG_RUN) {
+			const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+			partials[3 * (size_t)slot] = zero;
+			partials[3 * (size_t)slot + 1] = zero;
+			partials[3 * (size_t)slot + 2] = zero;
+		}
 	}
 }
 
@@ -123,12 +131,13 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          hipStream_t stream, int cull, bool seeded)
+                          float* partials, hipStream_t stream, int cull, bool seeded, uint32_t fold)
 {
 	if (R <= 0) return GSR_OK;
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
 	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
-	           (uint32_t)touched_clear_bytes((size_t)R), cull, seeded ? (const uint32_t*)g.sort_keys_b : (const uint32_t*)nullptr, (uint32_t)P);
+	           (uint32_t)touched_clear_bytes((size_t)R), cull, seeded ? (const uint32_t*)g.sort_keys_b : (const uint32_t*)nullptr, (uint32_t)P,
+	           reinterpret_cast<float4*>(partials), fold);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

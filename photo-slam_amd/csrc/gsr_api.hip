@@ -100,6 +100,13 @@ static bool emit_seeded()
 	static const int env = env_int("GSR_EMIT_SEEDS", 1);
 	return env != 0;
 }
+// GSR_LONG_FOLD (A/B handle): the accumulator slots a run of more than LONG_RUN instances is folded into (state.h); read once,
+// the forward pass (which zeroes them) and the backward pass (which adds into them) of a process agree
+uint32_t long_fold()
+{
+	static const int env = env_int("GSR_LONG_FOLD", (int)LONG_FOLD);
+	return (env >= 1 && env <= (int)LONG_RUN && (env & (env - 1)) == 0) ? (uint32_t)env : LONG_FOLD;
+}
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -325,7 +332,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		// (a sort of zero passes -- a one-tile image -- cannot drop anything: the flag is ignored there)
 		const bool cull = (a->raw_params & GSR_CULL_EMPTY_TILES) != 0 && bits > 0;
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded())) != GSR_OK) return st;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, bs.partials, stream, cull ? 1 : 0, emit_seeded(), long_fold())) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
@@ -493,6 +500,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.touched = bs.touched;
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
+		bp.long_fold = long_fold();
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);
@@ -509,7 +517,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
 	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
-	pb.long_runs = g.long_runs; pb.long_counts = g.long_counts; pb.long_capacity = g.long_capacity;
+	pb.long_fold = long_fold();
 	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
 	pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;

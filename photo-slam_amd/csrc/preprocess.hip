@@ -35,7 +35,6 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 
 #endif
 constexpr int FWD_ROWS = GSR_FWD_STAGE_ROWS;   // SH rows staged per pass and wave
 constexpr int PRE_THREADS = 128;               // 2 waves per workgroup
-static_assert(PRE_THREADS == LONG_LIST_BLOCK, "the long-run sub-lists are sized per preprocess block (state.h)");
 
 __global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
@@ -246,18 +245,6 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 		uint32_t* slot = &g.counters[2 * ((blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS / 2 - 1))];
 		atomicAdd(slot, wsum);
 		atomicAdd(slot + 1, (uint32_t)__popcll(wave_ballot_of_visible));
-	}
-	// Gaussians whose run of instance slots is too long for one lane of the backward preprocess (state.h: LONG_RUN): listed
-	// here, one atomic per wave that has any (a few thousand entries at C3); the list order is irrelevant to the results
-	const unsigned long long lm = wave_ballot(in_range && my_tiles > LONG_RUN);
-	if (lm) {
-		const int leader = __ffsll((long long)lm) - 1;
-		uint32_t base = 0;
-		const uint32_t list = (uint32_t)blockIdx.x % (uint32_t)LONG_LISTS;
-		if (lane_id() == leader) base = atomicAdd(&g.long_counts[list * LONG_COUNT_STRIDE], (uint32_t)__popcll(lm));
-		base = wave_shfl_u32(base, leader);
-		if ((lm >> lane_id()) & 1ull)
-			g.long_runs[(size_t)list * g.long_capacity + base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)idx;
 	}
 }
 

@@ -20,17 +20,20 @@ constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
-// A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length;
-// longer runs (screen-filling splats) are listed by the forward preprocess and summed one WAVE per run by their own kernel
-// (partials.h) -- densification appends the children of split (large) Gaussians consecutively, and 64 of them in one wave
-// turned that wave into the kernel's tail (measured: preprocess_bwd 140 -> 450 us after ten densifications at C3).
+// A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length.
+// A longer run (a screen-filling splat: 3 359 of the 934 k visible Gaussians at C3, the longest 3 192 tiles) is FOLDED: the
+// backward blend adds the sums of instance k to slot first + (k % LONG_FOLD) with float atomics instead of storing them to slot
+// first + k (blend_bwd.hip), so that the owner lane never sums more than LONG_FOLD slots -- densification appends the children of
+// split (large) Gaussians consecutively, and 64 unbounded runs in one wave once turned that wave into the kernel's tail
+// (preprocess_bwd 140 -> 450 us after ten densifications at C3).  Until round 5 those runs were listed by the forward
+// preprocess and summed by a kernel of their own between the two backward kernels (22 us at C3: the longest run's chain of
+// dependent round trips, on an otherwise idle device).  The LONG_FOLD accumulator slots of such a run are zeroed by the
+// instance emission and again by their reader (partials.h); at most cnt / LONG_FOLD atomics meet on one address.
 constexpr uint32_t LONG_RUN = 64;
-constexpr int LONG_LISTS = 64, LONG_COUNT_STRIDE = 32, LONG_LIST_BLOCK = 128;   // LONG_LIST_BLOCK = threads of a preprocess_fwd block
-static inline size_t long_list_capacity(size_t P)
-{
-	const size_t blocks = (P + LONG_LIST_BLOCK - 1) / LONG_LIST_BLOCK;
-	return ((blocks + LONG_LISTS - 1) / LONG_LISTS) * LONG_LIST_BLOCK;
-}   // launch_radix_sort(compact_count != null): "no element" (a culled Gaussian's depth key)
+constexpr uint32_t LONG_FOLD = 8;     // (a power of two <= LONG_RUN; GSR_LONG_FOLD overrides it for A/B runs: long_fold())
+static_assert(LONG_FOLD <= LONG_RUN && (LONG_FOLD & (LONG_FOLD - 1)) == 0, "a folded run uses its own first LONG_FOLD slots");
+uint32_t long_fold();                  // gsr_api.hip
+constexpr uint32_t SLOT_FOLDED = 0x80000000u;   // blend_bwd's slot word: accumulate with atomics (R < 2^31: gsr_forward)
 
 constexpr int SCAN_THREADS = 256;
 
@@ -77,12 +80,6 @@ struct GeometryState {
 	uint2*    rect_sorted;    // [P] the tile rectangles in depth order (entry i belongs to order[i]): gathered once by the offset
 	                          // scan, read linearly by the instance emission
 	uint32_t* visible;        // [32] [0] number of visible Gaussians V, left by the first pass of the depth sort
-	// ids of the Gaussians that touch more than LONG_RUN tiles, in LONG_LISTS sub-lists (preprocess block b appends to
-	// sub-list b % LONG_LISTS, whose capacity long_list_capacity(P) covers all its blocks): one global counter would
-	// serialise a few thousand same-address atomics (~12 ns each) inside preprocess_fwd
-	uint32_t* long_runs;      // [LONG_LISTS * long_list_capacity(P)]
-	uint32_t* long_counts;    // [LONG_LISTS * LONG_COUNT_STRIDE] entries per sub-list, one cache line apart (zeroed per forward)
-	uint32_t  long_capacity;  // long_list_capacity(P)
 
 	static GeometryState carve(char* chunk, size_t P, size_t* bytes = nullptr)
 	{
@@ -104,19 +101,12 @@ struct GeometryState {
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.rect_sorted = c.take<uint2>(P);
 		g.visible = c.take<uint32_t>(32);
-		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
-		// the two arrays the forward pass has to find zeroed sit next to each other: ONE memset (zeroed_bytes())
-		g.counters = c.take<uint32_t>(NUM_COUNTERS);
-		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
-		g.long_capacity = (uint32_t)long_list_capacity(P);
+		g.counters = c.take<uint32_t>(NUM_COUNTERS);   // (the one array the forward pass has to find zeroed: zeroed_bytes())
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
-	// [counters, end of long_counts): zeroed per forward pass
-	size_t zeroed_bytes() const
-	{
-		return (size_t)(reinterpret_cast<const char*>(long_counts + (size_t)LONG_LISTS * LONG_COUNT_STRIDE) - reinterpret_cast<const char*>(counters));
-	}
+	// zeroed per forward pass
+	size_t zeroed_bytes() const { return (size_t)NUM_COUNTERS * sizeof(uint32_t); }
 };
 
 static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }

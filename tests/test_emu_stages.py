@@ -211,11 +211,7 @@ def test_single_huge_splat_and_opaque_wall(emu_lib_path, oracle):
     parity.compare(r, ores, ocolor, oradii, ograds, cam)
 
 
-def test_long_runs_of_instance_slots(emu_lib_path, oracle):
-    """Gaussians that touch more than 64 tiles (state.h LONG_RUN): their per-instance gradient slots are summed by
-    long_run_sums_kernel, one wave per run, from the list the forward preprocess leaves -- here 70 of them CONSECUTIVE in
-    index order at the end of the arrays (what densification produces: the children of split Gaussians), more than one
-    wave of the backward preprocess holds, next to small ones; runs of exactly 64 and 65 tiles sit on the threshold."""
+def _long_run_scene():
     W, H = 176, 160   # 11 x 10 = 110 tiles
     cl = scene.make_cloud(200, W, H, 0.8 * W, 0.8 * W, seed=31, scale_k=0.35)
     cam = cl.cameras[0]
@@ -225,6 +221,25 @@ def test_long_runs_of_instance_slots(emu_lib_path, oracle):
     cl.xyz[big] = cam.campos + (1.5 + rng.random((70, 1)).astype(np.float32)) * fwd + 0.3 * rng.standard_normal((70, 3)).astype(np.float32)
     cl.scaling[big] = np.log(0.25 + 0.6 * rng.random((70, 3))).astype(np.float32)
     cl.opacity[big] = -2.0 + rng.standard_normal((70, 1)).astype(np.float32)   # translucent: every layer contributes
+    return cl, cam, big, rng
+
+
+def test_backward_twice_with_folded_runs(emu_lib_path):
+    """The accumulator slots of the folded runs are zeroed by the instance emission and AGAIN by their reader: a second and a
+    third backward pass on the state of one forward pass give the gradients of a first one."""
+    cl, cam, big, rng = _long_run_scene()
+    parity.check_backward_twice(emu_lib_path, CPU, cl, np.array([0.1, 0.3, 0.2], np.float32))
+
+
+def test_long_runs_of_instance_slots(emu_lib_path, oracle):
+    """Gaussians that touch more than 64 tiles (state.h LONG_RUN): the backward blend folds their per-instance gradient sums
+    into the run's first LONG_FOLD slots with float atomics, and the owner lane of the backward preprocess sums those -- here 70
+    of them CONSECUTIVE in index order at the end of the arrays (what densification produces: the children of split
+    Gaussians), more than one wave of the backward preprocess holds, next to small ones; runs of exactly 64 and 65 tiles sit
+    on the threshold.  A second backward pass on the same forward state must find the accumulators zeroed again
+    (parity.check_backward_twice covers that on a scene with such runs: test_backward_twice_with_folded_runs)."""
+    cl, cam, big, rng = _long_run_scene()
+    W, H = cam.W, cam.H
     bg = np.array([0.1, 0.3, 0.2], np.float32)
     dpix = rng.standard_normal((3, H, W)).astype(np.float32)
     ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)

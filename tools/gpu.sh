@@ -24,6 +24,7 @@
 #   seeds        benchq for scene seeds 0..4 -> seed_spread_C3.json (seeds 1-4 for variance)
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
 #   env:VAR=VAL  export VAR=VAL for the steps behind it (A/B runs; bench outputs get a _VAR_VAL suffix)
+#   ab:<dir>[:n] alternate the quick bench of the tree in <dir> (a built worktree of an older commit) and of this tree, n pairs on one box
 TAG=${1:-r03_x}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT; export TMPDIR=/tmp
@@ -217,6 +218,28 @@ out["iters_per_s_mean"], out["iters_per_s_stdev"], out["iters_per_s_min"], out["
 out["note"] = "bench.py --seed S (scene.make_config seed and the ground-truth noise): one box, one session; seed 0 is the reported number"
 json.dump(out, open(f"{sys.argv[1]}/seed_spread_C3.json", "w"), indent=1)
 print(json.dumps(out)[:900])
+PY
+            ;;
+    ab)     # ab:<dir>[:pairs]: alternate `bench.py` (quick form) of the tree in <dir> (e.g. a git worktree of the commit before a change,
+            # built in this container: it travels with the snapshot) and of this tree on ONE box -> ab_<dir>.json (ms per step, per run)
+            d=${arg%%:*}; n=3; [ "$arg" != "$d" ] && n=${arg##*:}
+            for i in $(seq 1 $n); do
+              (cd $ROOT/$d && timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $ROOT/$OUT/ab_${d}_old_$i.json 2>>$ROOT/$OUT/bench_err.log)
+              timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/ab_${d}_new_$i.json 2>>$OUT/bench_err.log
+            done
+            python - $OUT $d $n <<'PY'
+import json, sys, statistics as st
+out, d, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+res = {}
+for side in ("old", "new"):
+    runs = [json.load(open(f"{out}/ab_{d}_{side}_{i}.json")) for i in range(1, n + 1)]
+    res[side] = {"ms_per_step": [r["ms_per_step"] for r in runs], "median_ms_per_step": [r["protocol"]["median_ms_per_step"] for r in runs],
+                 "stages_ms_mean": {k: round(st.mean(r["roofline"]["stages"][k]["ms"] for r in runs), 4) for k in runs[0]["roofline"]["stages"]}}
+    res[side]["mean_of_medians"] = round(st.mean(res[side]["median_ms_per_step"]), 4)
+res["delta_ms (new - old, mean of medians)"] = round(res["new"]["mean_of_medians"] - res["old"]["mean_of_medians"], 4)
+res["note"] = f"alternating runs (old, new) x {n} on one box; old = the tree in {d}/"
+json.dump(res, open(f"{out}/ab_{d}.json", "w"), indent=1)
+print(json.dumps(res))
 PY
             ;;
     env)    export "$arg"; SUF="${SUF}_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; echo "exported $arg" ;;   # env:VAR=VALUE for the steps behind it (A/B runs)
