@@ -3,9 +3,9 @@
 // backward passes on the caller's HIP stream.
 //
 // Forward launch sequence (reference: Rasterizer::forward, rasterizer_impl.cu:198-336):
-//   memset counters -> preprocess (+ per-wave atomic sum of tiles = num_rendered)
-//   -> async D2H of num_rendered + event            (the reference blocks here, :281)
-//   -> depth sort of the P Gaussians (4 x 8-bit passes) -> exclusive scan in depth order
+//   preprocess (every wave leaves its (tiles, visible) pair with a plain store)
+//   -> depth sort of the P Gaussians (4 x 8-bit passes; its first two launches sum the pairs on the side = num_rendered, into
+//      mapped host memory, event behind them -- the reference blocks on a copy here, :281) -> exclusive scan in depth order
 //   -> host waits for the event only now, sizes the binning buffer
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
 #include <chrono>
@@ -32,6 +32,7 @@ void set_last_hip_error(int err, const char* what)
 // thread, so concurrent callers on different threads do not share state.
 struct HostSync {
 	uint32_t* pinned = nullptr;
+	uint32_t* pinned_dev = nullptr;   // the same words as the device addresses them
 	hipEvent_t ev = nullptr;
 	// second stream for HBM-bound work that runs next to the VALU-bound blend (the culled rows of the fused SH Adam step, gsr_backward), with the
 	// events that fork it from and join it to the caller's stream
@@ -58,7 +59,11 @@ struct HostSync {
 	int init()
 	{
 		if (pinned && ev) return GSR_OK;
-		if (!pinned) GSR_HIP(hipHostMalloc((void**)&pinned, NUM_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
+		if (!pinned) {
+			// mapped: the device stores the forward pass's counts straight into it (sort.hip: RadixHostCount)
+			GSR_HIP(hipHostMalloc((void**)&pinned, 64 * sizeof(uint32_t), hipHostMallocMapped));
+			GSR_HIP(hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0));
+		}
 		if (!ev) GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));   // a failure here is retried by the next call
 		return GSR_OK;
 	}
@@ -262,9 +267,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
-	// (every tiny memset is a ~5 us kernel in the stream: the two zeroed arrays are adjacent, the tile ranges are zeroed by
-	// preprocess_fwd)
-	GSR_HIP(hipMemsetAsync(g.counters, 0, g.zeroed_bytes(), stream));
+	// (nothing to zero: the projection kernel's waves leave their counts with plain stores -- state.h: wave_counts)
 	PROF_FWD(0);
 
 	PreprocessParams pp;
@@ -286,8 +289,10 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if ((st = launch_preprocess_fwd(pp, g, stream)) != GSR_OK) return st;
 
 	PROF_FWD(1);
-	GSR_HIP(hipMemcpyAsync(t_sync.pinned, g.counters, NUM_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-	GSR_HIP(hipEventRecord(t_sync.ev, stream));
+	// num_rendered and the visible count reach the host without a copy in the stream: the depth sort's first two launches add up
+	// the waves' pairs on the side (sort.hip) and store the totals into the mapped pinned words; the event is recorded behind them
+	RadixHostCount hc;
+	hc.pairs = g.wave_counts; hc.n = (int)wave_count_slots((size_t)P); hc.partials = g.count_partials; hc.host_out = t_sync.pinned_dev; hc.ready = t_sync.ev;
 
 	// depth order (stable: equal depths keep ascending Gaussian id).  The first pass reads all P keys and drops the culled
 	// Gaussians (key 0xFFFFFFFF, RADIX_INVALID_KEY), leaving V in g.visible; the other three passes and the scan run over the
@@ -295,7 +300,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
 	uint32_t *kres = nullptr, *vres = nullptr;
 	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
-	                            g.sort_scratch, stream, &kres, &vres, g.visible)) != GSR_OK)
+	                            g.sort_scratch, stream, &kres, &vres, g.visible, &hc)) != GSR_OK)
 		return st;
 	// vres == g.order (4 passes end in the ping buffers)
 	PROF_FWD(2);
@@ -311,11 +316,8 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		t_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
 		t_sync_waits++;
 	}
-	unsigned long long R64 = 0, V64 = 0;
-	for (int i = 0; i < NUM_COUNTERS; i += 2) {   // (even words: tiles; odd words: visible Gaussians -- preprocess_fwd)
-		R64 += t_sync.pinned[i];
-		V64 += t_sync.pinned[i + 1];
-	}
+	const unsigned long long R64 = (unsigned long long)t_sync.pinned[0] | ((unsigned long long)t_sync.pinned[1] << 32);
+	const unsigned long long V64 = t_sync.pinned[2];
 	t_last_visible = (int)V64;
 	if (R64 > 0x7FFFFFFFull) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
 	const int R = (int)R64;

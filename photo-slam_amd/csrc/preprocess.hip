@@ -34,7 +34,7 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 
 #define GSR_FWD_STAGE_ROWS STAGE_ROWS
 #endif
 constexpr int FWD_ROWS = GSR_FWD_STAGE_ROWS;   // SH rows staged per pass and wave
-constexpr int PRE_THREADS = 128;               // 2 waves per workgroup
+// (PRE_THREADS = 128, state.h: 2 waves per workgroup)
 
 __global__ void __launch_bounds__(PRE_THREADS)
 preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
@@ -233,19 +233,14 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 		g.radii[idx] = radius_i;
 		if (p.radii_out) p.radii_out[idx] = radius_i;
 	}
-	// num_rendered = sum of tiles_touched: one atomic per wave, spread over NUM_COUNTERS words that the
-	// host adds up (same-address atomics serialise at ~12 ns each: 31 k waves on ONE word cost 0.37 ms).
-	// Replaces reading back the last element of the scan (rasterizer_impl.cu:281), so the host copy
-	// can overlap the depth sort.
+	// num_rendered = sum of tiles_touched, gsr_last_visible_count() = the number of visible Gaussians: every wave leaves its pair
+	// with ONE plain store (a wave that sees nothing stores zeros: the array is written in full, nothing is zeroed beforehand and
+	// no atomic is issued); the depth sort's first two launches add the pairs up on the side and write the totals into mapped
+	// host memory (sort.hip: RadixHostCount).  Replaces reading back the last element of the scan (rasterizer_impl.cu:281),
+	// so the host's wait can overlap the depth sort.
 	const unsigned long long wave_ballot_of_visible = wave_ballot(my_tiles != 0u);
 	const uint32_t wsum = wave_sum_u32(my_tiles);
-	// even words: tiles touched (their total is num_rendered); odd words: visible Gaussians (gsr_last_visible_count: sizes the
-	// packed exchange of a keyframe batch) -- per-wave sums spread over NUM_COUNTERS / 2 slots (same-address atomics serialise)
-	if (lane_id() == 0 && wsum) {
-		uint32_t* slot = &g.counters[2 * ((blockIdx.x * (PRE_THREADS / 64) + w) & (NUM_COUNTERS / 2 - 1))];
-		atomicAdd(slot, wsum);
-		atomicAdd(slot + 1, (uint32_t)__popcll(wave_ballot_of_visible));
-	}
+	if (lane_id() == 0) g.wave_counts[(size_t)blockIdx.x * (PRE_THREADS / 64) + w] = make_uint2(wsum, (uint32_t)__popcll(wave_ballot_of_visible));
 }
 
 // checkFrustum, cuda_rasterizer/rasterizer_impl.cu:54-66

@@ -152,10 +152,53 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 // the 1024-element sub-range starting at w*1024 and walks it in 16 rounds of 64 lane-
 // consecutive elements, so the original order inside a digit is (wave, round, lane).
 
+// the 64-bit wave sum from 32-bit wave sums of three pieces of every lane's value (64 lanes x 2^16 fits 32 bits; the forward
+// pass's instance total decides "more than 2^31 instances": it must not wrap)
+__device__ __forceinline__ unsigned long long wave_sum_u64_by_parts(unsigned long long t)
+{
+	const uint32_t lo = (uint32_t)(t & 0xFFFFFFFFull), hi = (uint32_t)(t >> 32);
+	return (unsigned long long)wave_sum_u32(lo & 0xFFFFu) + ((unsigned long long)wave_sum_u32(lo >> 16) << 16) +
+	       ((unsigned long long)wave_sum_u32(hi) << 32);
+}
+
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks,
-                  const uint32_t* __restrict__ n_dev, int skip_invalid)
+                  const uint32_t* __restrict__ n_dev, int skip_invalid, const RadixHostCount hc)
 {
+	// The forward pass's count for the host rides in the first two launches of the depth sort (gsr_api.hip): here every workgroup
+	// adds up ITS share of the (tiles touched, visible) pairs the projection kernel's waves left (a few dozen pairs: one
+	// load per thread) and stores the partial sums; an extra workgroup of the row-prefix launch adds those up and stores the
+	// totals into MAPPED HOST memory -- no memset, no atomics, no copy kernel in the stream, no launch of its own.  (One workgroup
+	// summing all 31 k pairs of a 2 M-Gaussian model took 30 us: a chain of dependent round trips.)
+	if (hc.pairs) {
+		__shared__ unsigned long long s_t[SORT_THREADS / 64];
+		__shared__ uint32_t s_v[SORT_THREADS / 64];
+		const int share = (hc.n + nblocks - 1) / nblocks;
+		unsigned long long t = 0ull;
+		uint32_t v = 0u;
+		for (int i = (int)blockIdx.x * share + (int)threadIdx.x; i < min(hc.n, ((int)blockIdx.x + 1) * share); i += SORT_THREADS) {
+			const uint2 c = hc.pairs[i];
+			t += c.x;
+			v += c.y;
+		}
+		const unsigned long long wt = wave_sum_u64_by_parts(t);
+		const uint32_t wv = wave_sum_u32(v);
+		if (lane_id() == 0) {
+			s_t[wave_id()] = wt;
+			s_v[wave_id()] = wv;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long T = 0ull;
+			uint32_t V = 0u;
+			for (int i = 0; i < SORT_THREADS / 64; i++) {
+				T += s_t[i];
+				V += s_v[i];
+			}
+			hc.partials[blockIdx.x] = make_uint4((uint32_t)(T & 0xFFFFFFFFull), (uint32_t)(T >> 32), V, 0u);
+		}
+		__syncthreads();
+	}
 	// n_dev (nullable): the number of elements lives on the device (the compacted depth sort: set by the first pass's
 	// scatter); blocks beyond it still write their (all-zero) histogram columns.  skip_invalid: keys equal to
 	// RADIX_INVALID_KEY are no elements at all (culled Gaussians: never counted, never scattered).
@@ -188,9 +231,40 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 // totals[d].  Together with a 256-entry scan of the totals inside the scatter kernel this replaces the
 // generic three-launch scan of the whole [256][nblocks] table (3 launches per pass instead of 5).
 __global__ void __launch_bounds__(SCAN_THREADS)
-radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks)
+radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblocks, int nrows, const RadixHostCount hc)
 {
 	__shared__ uint32_t s_wave[4];
+	if ((int)blockIdx.x == nrows) {
+		// the extra workgroup of the depth sort's first pass (radix_hist_kernel): the histogram blocks' partial counts -> the totals,
+		// stored into mapped host memory; the event the host waits for is recorded behind this launch
+		__shared__ unsigned long long s_t[SCAN_THREADS / 64];
+		unsigned long long t = 0ull;
+		uint32_t v = 0u;
+		for (int i = (int)threadIdx.x; i < nblocks; i += SCAN_THREADS) {
+			const uint4 c = hc.partials[i];
+			t += (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+			v += c.z;
+		}
+		const unsigned long long wt = wave_sum_u64_by_parts(t);
+		const uint32_t wv = wave_sum_u32(v);
+		if (lane_id() == 0) {
+			s_t[wave_id()] = wt;
+			s_wave[wave_id()] = wv;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long T = 0ull;
+			uint32_t V = 0u;
+			for (int i = 0; i < SCAN_THREADS / 64; i++) {
+				T += s_t[i];
+				V += s_wave[i];
+			}
+			hc.host_out[0] = (uint32_t)(T & 0xFFFFFFFFull);
+			hc.host_out[1] = (uint32_t)(T >> 32);
+			hc.host_out[2] = V;
+		}
+		return;
+	}
 	uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
 	uint32_t carry = 0;
 	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
@@ -304,7 +378,8 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
-                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count)
+                      uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count,
+                      const RadixHostCount* host_count)
 {
 	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
 	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
@@ -335,8 +410,12 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		uint32_t* vout = (p % 2 == 0) ? vals_pong : vals_ping;
 		const uint32_t* n_dev = (compact_count && p > 0) ? compact_count : nullptr;
 		const int skip = (compact_count && p == 0) ? 1 : 0;
-		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip);
-		GSR_LAUNCH(radix_row_prefix_kernel, 1 << nbits, SCAN_THREADS, stream, hist, totals, nb);
+		// (the first pass may carry the forward pass's count for the host: RadixHostCount, state.h)
+		const bool counts_ride = p == 0 && host_count && host_count->pairs;
+		const RadixHostCount hc = counts_ride ? *host_count : RadixHostCount{};
+		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc);
+		GSR_LAUNCH(radix_row_prefix_kernel, (1 << nbits) + (counts_ride ? 1 : 0), SCAN_THREADS, stream, hist, totals, nb, 1 << nbits, hc);
+		if (counts_ride && hc.ready) GSR_HIP(hipEventRecord((hipEvent_t)hc.ready, stream));
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
 		           (const uint32_t*)hist, (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr);
 		kin = kout;

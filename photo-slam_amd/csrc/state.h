@@ -9,7 +9,12 @@ namespace gsr {
 constexpr int TILE = 16;              // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:16-17 (part of the parity contract)
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr uint32_t DEPTH_KEY_CULLED = 0xFFFFFFFFu;
-constexpr int NUM_COUNTERS = 1024;   // same-address atomics serialise (~12 ns each): spread the per-wave sums
+// The forward preprocess runs PRE_THREADS / 64 waves per workgroup; every wave leaves its (tiles touched, visible) pair with a
+// plain store -- no atomics, so no array that would have to be zeroed first (until round 5: atomics spread over 1024 words behind
+// a memset, and a 4 KiB copy to the host: two runtime blit kernels with their bubbles in front of and in the middle of the forward pass)
+constexpr int PRE_THREADS = 128;
+static inline size_t wave_count_slots(size_t P) { return ((P + PRE_THREADS - 1) / PRE_THREADS) * (PRE_THREADS / 64); }
+constexpr int HOST_COUNT_WORDS = 4;   // what the forward pass hands to the host: [0] tiles lo, [1] tiles hi, [2] visible, [3] -
 
 // Radix sort geometry: one workgroup (256 threads = 4 waves) ranks a 2048-element chunk (measured best of 1024/2048/4096 on MI355X);
 // each wave owns 512 consecutive elements so that stability needs no cross-wave ordering.
@@ -62,7 +67,9 @@ static inline size_t sort_scratch_elems(int n)
 constexpr int REC_FLOAT4S = 3;
 
 struct GeometryState {
-	uint32_t* counters;       // [NUM_COUNTERS] partial sums of tiles touched; their total is num_rendered
+	uint2*    wave_counts;    // [wave_count_slots(P)] per wave of preprocess_fwd: (tiles touched, visible Gaussians); the totals are
+	                          // num_rendered and gsr_last_visible_count() (summed inside the depth sort's first two launches)
+	uint4*    count_partials; // [sort_blocks(P)] the first level of that sum
 	uint32_t* depth_key;      // [P]
 	uint32_t* tiles_touched;  // [P]
 	int*      radii;          // [P]
@@ -101,12 +108,11 @@ struct GeometryState {
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.rect_sorted = c.take<uint2>(P);
 		g.visible = c.take<uint32_t>(32);
-		g.counters = c.take<uint32_t>(NUM_COUNTERS);   // (the one array the forward pass has to find zeroed: zeroed_bytes())
+		g.wave_counts = c.take<uint2>(wave_count_slots(P));   // (written in full by every forward pass: nothing has to be zeroed)
+		g.count_partials = c.take<uint4>((size_t)sort_blocks((int)P));
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
-	// zeroed per forward pass
-	size_t zeroed_bytes() const { return (size_t)NUM_COUNTERS * sizeof(uint32_t); }
 };
 
 static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }
@@ -186,6 +192,17 @@ int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* 
                            uint32_t seed_capacity = 0);
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
                     uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
+// A job that rides in the first two launches of a sort: add up n (a, b) pairs -- every histogram workgroup its share into
+// partials[block], an extra workgroup of the row-prefix launch the partials -- and store the totals, sum a as 64 bits in
+// host_out[0..1], sum b in host_out[2], into MAPPED HOST memory; `ready` (a hipEvent_t, nullable) is recorded right behind the
+// second launch.  gsr_forward: the per-wave (tiles touched, visible) pairs of the projection kernel.
+struct RadixHostCount {
+	const uint2* pairs = nullptr;
+	int n = 0;
+	uint4* partials = nullptr;      // [sort_blocks(elements of the sort)]
+	uint32_t* host_out = nullptr;   // device address of mapped host memory (HOST_COUNT_WORDS words)
+	void* ready = nullptr;
+};
 // Stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit), 8 bits per pass.
 // Pass 0 reads (keys_in, vals_in) -- read-only, vals_in == nullptr means value = index -- and writes the
 // pong buffers; later passes alternate ping <- pong <- ping.  *keys_res / *vals_res receive the buffers
@@ -193,7 +210,7 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
-                      uint32_t* compact_count = nullptr);
+                      uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr);
 // compact_count (nullable, a device word): keys equal to RADIX_INVALID_KEY are "no element": the first pass drops them and
 // leaves the number of remaining elements in *compact_count; the later passes read it and touch that many elements only.
 // The result buffers then hold that many sorted pairs followed by undefined content.

@@ -49,7 +49,7 @@ typedef void* hipStream_t;
 typedef void* hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
-enum { hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
+enum { hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipEventDisableTiming = 2 };
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, int, hipStream_t)
@@ -59,6 +59,7 @@ static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s,
 }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
