@@ -25,17 +25,29 @@ namespace gsr {
 // search.  Screen-filling splats near the camera are consecutive in depth order; a per-Gaussian decomposition
 // left a single wave with >100 k instances of them (the kernel's tail was 80 % of its time).
 constexpr int EMIT_SLOTS = (int)EMIT_SEED_STRIDE;
+constexpr int EMIT_WAVES = SORT_CHUNK / EMIT_SLOTS, EMIT_THREADS = 64 * EMIT_WAVES;   // a workgroup emits one chunk of the tile sort
+static_assert(EMIT_WAVES * EMIT_SLOTS == SORT_CHUNK && EMIT_THREADS <= 1024, "one emission workgroup per sort chunk");
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EMIT_THREADS)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                       float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull,
-                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity, float4* __restrict__ partials, uint32_t fold)
+                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity, float4* __restrict__ partials, uint32_t fold,
+                      uint32_t* __restrict__ hist, int hist_bits, int hist_blocks)
 {
-	__shared__ uint32_t s_off[4][EMIT_SLOTS + 4];
+	__shared__ uint32_t s_off[EMIT_WAVES][EMIT_SLOTS + 4];
+	// The tile sort's first histogram (sort.hip: radix_hist_kernel) is counted HERE, where the keys are made: a workgroup emits
+	// exactly one sort chunk (EMIT_WAVES x EMIT_SLOTS == SORT_CHUNK slots), counts its keys' low digits in LDS and stores its
+	// column of the [digit][block] table -- one launch and one pass over the 25 MB of keys less per forward pass.
+	__shared__ uint32_t s_hist[RADIX_BINS];
+	if (hist) {
+		for (int i = (int)threadIdx.x; i < RADIX_BINS; i += EMIT_THREADS) s_hist[i] = 0u;
+		__syncthreads();
+	}
 	const int w = wave_id(), l = lane_id();
-	const uint32_t s0 = ((uint32_t)blockIdx.x * 4u + (uint32_t)w) * (uint32_t)EMIT_SLOTS;
-	if (s0 >= R) return;   // wave-uniform
+	const uint32_t s0 = ((uint32_t)blockIdx.x * (uint32_t)EMIT_WAVES + (uint32_t)w) * (uint32_t)EMIT_SLOTS;
+	const bool idle = s0 >= R;   // wave-uniform (the waves behind the last slot: they still meet the others at the barrier below)
+	if (!idle) {
 	const uint32_t n = (R - s0) < (uint32_t)EMIT_SLOTS ? (R - s0) : (uint32_t)EMIT_SLOTS;
 	// The slot flags of the backward blend (state.h: touched) start out cleared: this wave clears those of its slots (the wave
 	// that holds the last slot: up to the end of the padded array) -- the backward pass then needs no memset of its own in
@@ -94,6 +106,13 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 			partials[3 * (size_t)slot + 1] = zero;
 			partials[3 * (size_t)slot + 2] = zero;
 		}
+		// (one LDS atomic per key, as in radix_hist_kernel; a key the tile sort's first pass drops is not counted)
+		if (hist && key != RADIX_INVALID_KEY) atomicAdd(&s_hist[key & ((1u << hist_bits) - 1u)], 1u);
+	}
+	}   // !idle
+	if (hist) {
+		__syncthreads();
+		for (int d = (int)threadIdx.x; d < (1 << hist_bits); d += EMIT_THREADS) hist[(size_t)d * hist_blocks + blockIdx.x] = s_hist[d];
 	}
 }
 
@@ -131,13 +150,14 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          float* partials, hipStream_t stream, int cull, bool seeded, uint32_t fold)
+                          float* partials, hipStream_t stream, int cull, bool seeded, uint32_t fold, uint32_t* hist, int hist_bits)
 {
 	if (R <= 0) return GSR_OK;
-	GSR_LAUNCH(emit_instances_kernel, div_up(R, 4 * EMIT_SLOTS), 256, stream, P, (uint32_t)R, (const uint32_t*)g.order,
+	// hist (nullable): the [digit][sort_blocks(R)] table of the tile sort's first pass over `hist_bits` low key bits, counted on the way
+	GSR_LAUNCH(emit_instances_kernel, div_up(R, EMIT_WAVES * EMIT_SLOTS), EMIT_THREADS, stream, P, (uint32_t)R, (const uint32_t*)g.order,
 	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
 	           (uint32_t)touched_clear_bytes((size_t)R), cull, seeded ? (const uint32_t*)g.sort_keys_b : (const uint32_t*)nullptr, (uint32_t)P,
-	           reinterpret_cast<float4*>(partials), fold);
+	           reinterpret_cast<float4*>(partials), fold, hist_bits > 0 ? hist : (uint32_t*)nullptr, hist_bits, sort_blocks(R));
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -105,6 +105,11 @@ static bool emit_seeded()
 	static const int env = env_int("GSR_EMIT_SEEDS", 1);
 	return env != 0;
 }
+static bool emit_hist()
+{
+	static const int env = env_int("GSR_EMIT_HIST", 1);
+	return env != 0;
+}
 // GSR_LONG_FOLD (A/B handle): the accumulator slots a run of more than LONG_RUN instances is folded into (state.h); read once,
 // the forward pass (which zeroes them) and the backward pass (which adds into them) of a process agree
 uint32_t long_fold()
@@ -334,11 +339,14 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		// (a sort of zero passes -- a one-tile image -- cannot drop anything: the flag is ignored there)
 		const bool cull = (a->raw_params & GSR_CULL_EMPTY_TILES) != 0 && bits > 0;
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, bs.partials, stream, cull ? 1 : 0, emit_seeded(), long_fold())) != GSR_OK) return st;
+		// (the emission counts the tile sort's first histogram on the way: GSR_EMIT_HIST=0 is the A/B handle for the separate launch)
+		const int hist_bits = emit_hist() ? radix_first_pass_bits(0, bits) : 0;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, bs.partials, stream, cull ? 1 : 0, emit_seeded(), long_fold(),
+		                                bs.sort_scratch, hist_bits)) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
-		                            bs.sort_scratch, stream, &tkeys, &point_list, listed)) != GSR_OK)
+		                            bs.sort_scratch, stream, &tkeys, &point_list, listed, nullptr, hist_bits > 0)) != GSR_OK)
 			return st;
 		PROF_FWD(5);
 		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream, listed)) != GSR_OK) return st;

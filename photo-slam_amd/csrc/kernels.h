@@ -73,7 +73,8 @@ int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t
 // depth rank of the Gaussian that holds its first slot (GeometryState::sort_keys_b, P entries: windows beyond that search)
 constexpr uint32_t EMIT_SEED_STRIDE = 256;
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          float* partials, hipStream_t stream, int cull = 0, bool seeded = false, uint32_t fold = LONG_FOLD);
+                          float* partials, hipStream_t stream, int cull = 0, bool seeded = false, uint32_t fold = LONG_FOLD,
+                          uint32_t* hist = nullptr, int hist_bits = 0);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream, const uint32_t* n_dev = nullptr);
 
 struct BlendFwdParams {

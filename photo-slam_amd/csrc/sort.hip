@@ -379,7 +379,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count,
-                      const RadixHostCount* host_count)
+                      const RadixHostCount* host_count, bool first_hist_ready)
 {
 	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
 	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
@@ -413,7 +413,8 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		// (the first pass may carry the forward pass's count for the host: RadixHostCount, state.h)
 		const bool counts_ride = p == 0 && host_count && host_count->pairs;
 		const RadixHostCount hc = counts_ride ? *host_count : RadixHostCount{};
-		GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc);
+		// (first_hist_ready: the producer of the keys has counted the first pass's digits into `hist` itself -- the instance emission)
+		if (!(p == 0 && first_hist_ready)) GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc);
 		GSR_LAUNCH(radix_row_prefix_kernel, (1 << nbits) + (counts_ride ? 1 : 0), SCAN_THREADS, stream, hist, totals, nb, 1 << nbits, hc);
 		if (counts_ride && hc.ready) GSR_HIP(hipEventRecord((hipEvent_t)hc.ready, stream));
 		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,

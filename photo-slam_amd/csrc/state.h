@@ -210,7 +210,14 @@ struct RadixHostCount {
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
-                      uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr);
+                      uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr, bool first_hist_ready = false);
+// the digit width of the first pass (the key bits are spread evenly over the passes) -- for a producer that counts the first
+// histogram itself (first_hist_ready: the [digit][sort_blocks(n)] table at the head of `scratch`, digits of key bits [begin_bit, +w))
+static inline int radix_first_pass_bits(int begin_bit, int end_bit)
+{
+	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
+	return passes ? div_up(end_bit - begin_bit, passes) : 0;
+}
 // compact_count (nullable, a device word): keys equal to RADIX_INVALID_KEY are "no element": the first pass drops them and
 // leaves the number of remaining elements in *compact_count; the later passes read it and touch that many elements only.
 // The result buffers then hold that many sorted pairs followed by undefined content.

@@ -24,6 +24,7 @@
 #   seeds        benchq for scene seeds 0..4 -> seed_spread_C3.json (seeds 1-4 for variance)
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
 #   env:VAR=VAL  export VAR=VAL for the steps behind it (A/B runs; bench outputs get a _VAR_VAL suffix)
+#   abenv:VAR=A,B[:n] alternate the quick bench with VAR=A and VAR=B (an environment switch of the library), n pairs on one box
 #   ab:<dir>[:n] alternate the quick bench of the tree in <dir> (a built worktree of an older commit) and of this tree, n pairs on one box
 TAG=${1:-r03_x}; shift
 OUT=gpurun_out/$TAG
@@ -239,6 +240,28 @@ for side in ("old", "new"):
 res["delta_ms (new - old, mean of medians)"] = round(res["new"]["mean_of_medians"] - res["old"]["mean_of_medians"], 4)
 res["note"] = f"alternating runs (old, new) x {n} on one box; old = the tree in {d}/"
 json.dump(res, open(f"{out}/ab_{d}.json", "w"), indent=1)
+print(json.dumps(res))
+PY
+            ;;
+    abenv)  # abenv:VAR=A,B[:pairs]: alternate the quick bench with VAR=A and VAR=B (an environment switch of the library) on ONE box -> abenv_VAR.json
+            spec=${arg%%:*}; n=3; [ "$arg" != "$spec" ] && n=${arg##*:}
+            var=${spec%%=*}; vals=${spec#*=}; va=${vals%%,*}; vb=${vals##*,}
+            for i in $(seq 1 $n); do
+              env $var=$va timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_a_$i.json 2>>$OUT/bench_err.log
+              env $var=$vb timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_b_$i.json 2>>$OUT/bench_err.log
+            done
+            python - $OUT $var $va $vb $n <<'PY'
+import json, sys, statistics as st
+out, var, va, vb, n = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+res = {}
+for side, val in (("a", va), ("b", vb)):
+    runs = [json.load(open(f"{out}/abenv_{var}_{side}_{i}.json")) for i in range(1, n + 1)]
+    res[f"{var}={val}"] = {"ms_per_step": [r["ms_per_step"] for r in runs], "median_ms_per_step": [r["protocol"]["median_ms_per_step"] for r in runs],
+                           "stages_ms_mean": {k: round(st.mean(r["roofline"]["stages"][k]["ms"] for r in runs), 4) for k in runs[0]["roofline"]["stages"]},
+                           "mean_of_medians": round(st.mean(r["protocol"]["median_ms_per_step"] for r in runs), 4)}
+res["delta_ms (second - first, mean of medians)"] = round(res[f"{var}={vb}"]["mean_of_medians"] - res[f"{var}={va}"]["mean_of_medians"], 4)
+res["note"] = f"alternating runs x {n} on one box"
+json.dump(res, open(f"{out}/abenv_{var}.json", "w"), indent=1)
 print(json.dumps(res))
 PY
             ;;
