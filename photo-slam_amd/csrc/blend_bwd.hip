@@ -40,7 +40,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 	__shared__ uint32_t s_slot[BWD_SEG];
 	__shared__ uint32_t s_wmax[4];
 
-	const int tile = tile_assignment((int)blockIdx.x, p.tiles);
+	const int tile = tile_assignment((int)blockIdx.x, p.tiles, p.xcd_chunk);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int quad = (int)wave_uniform_u32((uint32_t)wave_id());   // scalar: the LDS record address is SGPR arithmetic
@@ -212,7 +212,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.tiles), 256, stream, p);
+	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.tiles, p.xcd_chunk), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

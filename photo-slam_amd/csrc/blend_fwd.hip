@@ -19,7 +19,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 	__shared__ float4 s_rec[64][3];   // per staged entry: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
 
 	int tile, quad;
-	quad_assignment((int)blockIdx.x, p.tiles, tile, quad);
+	quad_assignment((int)blockIdx.x, p.tiles, p.xcd_chunk, tile, quad);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int l = lane_id();
@@ -148,7 +148,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_fwd_kernel, quad_grid(p.tiles), 64, stream, p);
+	GSR_LAUNCH(blend_fwd_kernel, quad_grid(p.tiles, p.xcd_chunk), 64, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -105,6 +105,19 @@ static bool emit_seeded()
 	static const int env = env_int("GSR_EMIT_SEEDS", 1);
 	return env != 0;
 }
+// tiles per chunk of the blend kernels' workgroup -> XCD deal (blend.h); GSR_XCD_CHUNK overrides (0 = one band per XCD)
+static int xcd_chunk(int tiles)
+{
+	static const int env = env_int("GSR_XCD_CHUNK", -1);
+	if (env >= 0) return env;
+	// Measured at C3 on one box (profiles/r05_h, r05_i: alternating runs): one band per XCD 1.609-1.620 ms per step, chunks of 128
+	// tiles 1.589-1.592, of 32 1.582-1.588, of 8 / 4 / 2 / 1 all 1.566-1.575 (blend_fwd 0.191 -> 0.173 ms, blend_bwd 0.451 -> 0.430):
+	// the balance of the deal decides, the L2 locality of neighbouring tiles does not.  8 keeps what locality is free; small
+	// images get smaller chunks (at least ~16 rounds of the deal, or its last round is the imbalance).
+	int c = 8;
+	while (c > 1 && tiles < 8 * 16 * c) c >>= 1;
+	return c;
+}
 static bool emit_hist()
 {
 	static const int env = env_int("GSR_EMIT_HIST", 1);
@@ -361,6 +374,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.out_color = a->out_color;
 	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
+	bp.xcd_chunk = xcd_chunk(tiles);
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(7);
 	t_prof.fwd_done = t_prof.on == 1;
@@ -511,6 +525,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		bp.long_fold = long_fold();
+		bp.xcd_chunk = xcd_chunk(tiles);
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);

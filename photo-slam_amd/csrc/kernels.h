@@ -88,6 +88,7 @@ struct BlendFwdParams {
 	uint8_t* contrib;       // [4][contrib_stride]: plane of quad q, byte per list entry (state.h)
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
+	int xcd_chunk;          // blend.h: tiles per chunk of the workgroup -> XCD deal (0 = one band per XCD)
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
 
@@ -105,6 +106,7 @@ struct BlendBwdParams {
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
 	uint32_t long_fold;     // state.h: LONG_FOLD
+	int xcd_chunk;          // blend.h: tiles per chunk of the workgroup -> XCD deal (0 = one band per XCD)
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
 
