@@ -56,6 +56,17 @@ __device__ __forceinline__ void quad_assignment(int block, int tiles, int chunk,
 }
 static inline int quad_grid(int tiles, int chunk) { return xcd_tiles_per_xcd(tiles, chunk) * 8 * QUADS_PER_TILE; }
 
+// Work class of a tile for the backward blend's dispatch order (state.h: SCHED_CLASSES): eighth-octaves of the number of list
+// entries its quads blended, 2^5 .. 2^13.
+__device__ __forceinline__ int sched_class(uint32_t work)
+{
+	if (work < 32u) return 0;
+	const int e = 31 - __builtin_clz(work);                     // 5 ..
+	const int frac = (int)((work >> (e - 3)) & 7u);             // the three bits below the leading one
+	const int c = (e - 5) * 8 + frac;
+	return c >= SCHED_CLASSES ? SCHED_CLASSES - 1 : c;
+}
+
 // Conservative per-quad rejection.  A (pixel, Gaussian) pair is skipped by the reference
 // when alpha = min(0.99, o*exp(power)) < 1/255 (forward.cu:343-345, backward.cu:499-501),
 // i.e. when q = -power > ln(255*o).  For a positive-definite conic q is convex, so its

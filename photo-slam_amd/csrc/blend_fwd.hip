@@ -42,6 +42,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 	// pixel state predicates live as 64-bit lane masks in SGPR pairs; their logic is scalar
 	unsigned long long done_m = wave_ballot(!inside);
 
+	uint32_t blended = 0;   // list entries some pixel of the quad blends: what the backward pass will visit (scalar)
 	uint32_t gid_next = (l < n) ? p.point_list[range.x + (uint32_t)l] : 0u;
 	for (int base = 0; base < n; base += 64) {
 		if (~done_m == 0ull) break;
@@ -125,6 +126,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 			// that the register sets alternate -- 22 instead of 15 scalar instructions per visit, 0.212 instead of 0.188 ms.)
 		}
 		const bool wave_done = ~done_m == 0ull;
+		blended += (uint32_t)__popcll(contrib_m);
 		// the backward pass walks the same batches: it visits only the entries flagged here (15 % of the entries that survive the
 		// quad rejection blend into no pixel -- alpha below 1/255 at every pixel centre, or every such pixel saturated)
 		if (have) p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] = (uint8_t)((contrib_m >> l) & 1ull);
@@ -143,6 +145,17 @@ blend_fwd_kernel(const BlendFwdParams p)
 		p.out_color[pix] = Cr + T * p.bg[0];
 		p.out_color[plane + pix] = Cg + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];
+	}
+	// Dispatch order of the backward blend: this quad's count joins the tile's; the tile's last quad files it under its work
+	// class (state.h: ImageState::sched).  One returning atomic per wave carries count and arrival together, so the last quad
+	// sees the other three's counts without a fence.
+	if (p.sched && l == 0) {
+		const uint32_t old = atomicAdd(&p.sched[tile], (blended << 3) | 1u);
+		if ((old & 7u) == (uint32_t)(QUADS_PER_TILE - 1)) {
+			const int c = sched_class((old >> 3) + blended);
+			const uint32_t i = atomicAdd(&p.sched[p.tiles + c], 1u);
+			p.class_list[(size_t)c * p.tiles + i] = (uint32_t)tile;
+		}
 	}
 }
 

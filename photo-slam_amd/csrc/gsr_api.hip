@@ -118,6 +118,12 @@ static int xcd_chunk(int tiles)
 	while (c > 1 && tiles < 8 * 16 * c) c >>= 1;
 	return c;
 }
+// GSR_BWD_HEAVY_FIRST=0 (A/B handle): the backward blend takes its tiles in the forward blend's chunked image order
+static bool heavy_first()
+{
+	static const int env = env_int("GSR_BWD_HEAVY_FIRST", 1);
+	return env != 0;
+}
 static bool emit_hist()
 {
 	static const int env = env_int("GSR_EMIT_HIST", 1);
@@ -299,6 +305,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
 	pp.raw_params = a->raw_params | (cov3D_stored() ? GSR_STORE_COV3D : 0);
 	pp.ranges = im.ranges; pp.tiles = tiles;   // zeroed there: rasterizer_impl.cu:310
+	pp.sched = im.sched;
 	pp.lazy = LazyAdam{};
 	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
 		if (!a->shs) return GSR_ERR_INVALID_ARG;
@@ -375,6 +382,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	bp.xcd_chunk = xcd_chunk(tiles);
+	bp.sched = im.sched; bp.class_list = im.class_list;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(7);
 	t_prof.fwd_done = t_prof.on == 1;
@@ -526,6 +534,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		bp.long_fold = long_fold();
 		bp.xcd_chunk = xcd_chunk(tiles);
+		bp.sched = heavy_first() ? im.sched : nullptr; bp.class_list = im.class_list;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);

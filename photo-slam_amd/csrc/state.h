@@ -147,10 +147,19 @@ struct BinningState {
 	}
 };
 
+// Work classes of the backward blend's tiles (ImageState::sched): eighth-octaves of the number of blended list entries between
+// 2^5 and 2^13 (9 % steps: the tiles of a 1080p view of a 2 M-Gaussian room hold 160 .. 3 100, mean 1 200); class 0 = fewer.
+constexpr int SCHED_CLASSES = 64;
 struct ImageState {
 	float*    final_T;    // [N]
 	uint32_t* n_contrib;  // [N]
 	uint2*    ranges;     // [T]
+	// Dispatch order of the backward blend (blend_bwd.hip): heaviest tiles first.  The forward blend's quad-waves add the number
+	// of list entries they blended to sched[tile] (<< 3, with an arrival count in the low bits); the LAST quad of a tile files the
+	// tile under its work class: sched[T + c] counts class c, class_list[c * T + i] is its i-th tile.  sched is zeroed by the
+	// projection kernel next to the ranges.
+	uint32_t* sched;      // [T + SCHED_CLASSES]
+	uint32_t* class_list; // [SCHED_CLASSES * T]
 
 	static ImageState carve(char* chunk, size_t N, size_t T, size_t* bytes = nullptr)
 	{
@@ -159,6 +168,8 @@ struct ImageState {
 		im.final_T = c.take<float>(N);
 		im.n_contrib = c.take<uint32_t>(N);
 		im.ranges = c.take<uint2>(T);
+		im.sched = c.take<uint32_t>(T + SCHED_CLASSES);
+		im.class_list = c.take<uint32_t>((size_t)SCHED_CLASSES * T);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return im;
 	}
