@@ -221,17 +221,17 @@ json.dump(out, open(f"{sys.argv[1]}/seed_spread_C3.json", "w"), indent=1)
 print(json.dumps(out)[:900])
 PY
             ;;
-    ab)     # ab:<dir>[:pairs]: alternate `bench.py` (quick form) of the tree in <dir> (e.g. a git worktree of the commit before a change,
+    ab)     # ab:<dir>[:pairs[:config]]: alternate `bench.py` (quick form) of the tree in <dir> (e.g. a git worktree of the commit before a change,
             # built in this container: it travels with the snapshot) and of this tree on ONE box -> ab_<dir>.json (ms per step, per run)
-            d=${arg%%:*}; n=3; [ "$arg" != "$d" ] && n=${arg##*:}
+            IFS=: read d n cfg <<< "$arg"; n=${n:-3}; cfg=${cfg:-C3}
             for i in $(seq 1 $n); do
-              (cd $ROOT/$d && timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $ROOT/$OUT/ab_${d}_old_$i.json 2>>$ROOT/$OUT/bench_err.log)
-              timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/ab_${d}_new_$i.json 2>>$OUT/bench_err.log
+              (cd $ROOT/$d && timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $ROOT/$OUT/ab_${d}_old_$i.json 2>>$ROOT/$OUT/bench_err.log)
+              timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/ab_${d}_new_$i.json 2>>$OUT/bench_err.log
             done
-            python - $OUT $d $n <<'PY'
+            python - $OUT $d $n $cfg <<'PY'
 import json, sys, statistics as st
-out, d, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-res = {}
+out, d, n, cfg = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+res = {"config": cfg}
 for side in ("old", "new"):
     runs = [json.load(open(f"{out}/ab_{d}_{side}_{i}.json")) for i in range(1, n + 1)]
     res[side] = {"ms_per_step": [r["ms_per_step"] for r in runs], "median_ms_per_step": [r["protocol"]["median_ms_per_step"] for r in runs],
@@ -239,7 +239,7 @@ for side in ("old", "new"):
     res[side]["mean_of_medians"] = round(st.mean(res[side]["median_ms_per_step"]), 4)
 res["delta_ms (new - old, mean of medians)"] = round(res["new"]["mean_of_medians"] - res["old"]["mean_of_medians"], 4)
 res["note"] = f"alternating runs (old, new) x {n} on one box; old = the tree in {d}/"
-json.dump(res, open(f"{out}/ab_{d}.json", "w"), indent=1)
+json.dump(res, open(f"{out}/ab_{d}_{cfg}.json", "w"), indent=1)
 print(json.dumps(res))
 PY
             ;;
