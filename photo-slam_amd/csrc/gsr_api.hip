@@ -552,6 +552,10 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
 	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
 	pb.long_fold = long_fold();
+	{
+		static const int trip = env_int("GSR_SLOT_TRIP", 2);
+		pb.slot_trip = trip;
+	}
 	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
 	pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;

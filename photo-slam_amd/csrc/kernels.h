@@ -146,6 +146,7 @@ struct PreprocessBwdParams {
 	                          // LONG_RUN slots arrives folded into its first LONG_FOLD slots (state.h)
 	uint8_t* touched;         // [R + 64] 1 where a slot was written
 	uint32_t long_fold;       // state.h: LONG_FOLD
+	int slot_trip;            // partials.h: touched slots per trip (1, 2 or 4; GSR_SLOT_TRIP: the A/B handle)
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0); nullable

@@ -13,8 +13,43 @@
 
 namespace gsr {
 
+// U touched slots of a run in one trip: the loads first, the sums in slot order; a folded run's accumulators are zeroed again
+template <int U>
+__device__ __forceinline__ void sum_slots_trip(float4* src, unsigned long long& live, bool folded, float (&a)[9])
+{
+	int idx[U];
+	float4 x[U], y[U];
+	float z[U];
+#pragma unroll
+	for (int j = 0; j < U; j++) {
+		idx[j] = __ffsll((long long)live) - 1;
+		live &= live - 1ull;
+	}
+#pragma unroll
+	for (int j = 0; j < U; j++) {
+		x[j] = src[3 * (size_t)idx[j]];
+		y[j] = src[3 * (size_t)idx[j] + 1];
+		z[j] = src[3 * (size_t)idx[j] + 2].x;
+	}
+#pragma unroll
+	for (int j = 0; j < U; j++) {
+		a[0] += x[j].x; a[1] += x[j].y; a[2] += x[j].z; a[3] += x[j].w;
+		a[4] += y[j].x; a[5] += y[j].y; a[6] += y[j].z; a[7] += y[j].w;
+		a[8] += z[j];
+	}
+	if (folded) {
+		const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+		for (int j = 0; j < U; j++) {
+			src[3 * (size_t)idx[j]] = zero;
+			src[3 * (size_t)idx[j] + 1] = zero;
+			src[3 * (size_t)idx[j] + 2] = zero;
+		}
+	}
+}
+
 __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t first, float* __restrict__ partials,
-                                                      const uint8_t* __restrict__ touched, uint32_t fold, float (&a)[9])
+                                                      const uint8_t* __restrict__ touched, uint32_t fold, float (&a)[9], int trip = 2)
 {
 	const int l = lane_id();
 	float4* part4 = reinterpret_cast<float4*>(partials);
@@ -38,6 +73,12 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 		}
 		if (n < 64u) live &= (1ull << n) - 1ull;
 		float4* src = part4 + 3 * (size_t)first;
+		// several touched slots per trip: their loads leave together, the sums follow in slot order (a lane's chain of dependent
+		// round trips is what this HBM-latency-bound phase waits for: one slot per trip -> two: the stage 0.463 -> 0.452 ms at C3)
+		if (trip >= 4)
+			while (__popcll(live) >= 4) sum_slots_trip<4>(src, live, folded, a);
+		if (trip >= 2)
+			while (live & (live - 1ull)) sum_slots_trip<2>(src, live, folded, a);
 		while (live) {
 			const int i = __ffsll((long long)live) - 1;
 			live &= live - 1ull;

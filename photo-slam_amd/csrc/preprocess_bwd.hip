@@ -245,7 +245,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	{
 		const uint32_t cnt = (vis && p.partials) ? p.tiles_touched[idx] : 0u;
 		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
-		wave_sum_partial_runs(cnt, first, p.partials, p.touched, p.long_fold, a);   // every lane of the wave takes part
+		wave_sum_partial_runs(cnt, first, p.partials, p.touched, p.long_fold, a, p.slot_trip);   // every lane of the wave takes part
 	}
 	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && !p.adam_exp_avg && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
