@@ -23,41 +23,64 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float4 prescale_q0(const float4 q0) { return make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w); }
 __device__ __forceinline__ float prescale_c(float c) { return -0.5f * LOG2E * c; }
 
-// XCD-aware work assignment: workgroup b is dispatched to XCD b % 8 (observed behaviour, used for speed only).  The tiles are
-// dealt to the XCDs in CHUNKS of `chunk` consecutive tiles of the row-major order, round robin (chunk c -> XCD c % 8); inside an
-// XCD the chunks follow one another, and the four quads of a tile are consecutive workgroups -- a tile's list, its records and
-// those of its neighbours in the chunk are served by one 4 MiB L2.  chunk == 0: ONE chunk per XCD (a contiguous band of the
-// image: the arrangement until round 5).  The dispatcher deals workgroups to the XCDs in order, so the XCDs advance in lockstep
-// through their queues and the kernel ends with the XCD that was dealt the most work: bands are eight different REGIONS of the
-// image (at C3 the heaviest holds 4.6 % more list entries than the mean, at C2 24 %), small chunks eight samples of the whole
-// image (1 %).  Measured (gsr_api.hip: xcd_chunk): bands -> chunks of 8 tiles: blend_fwd 0.191 -> 0.173 ms, blend_bwd 0.451 -> 0.430.
-__device__ __forceinline__ int xcd_tile(int in_xcd, int xcd, int tiles, int chunk)
+// XCD-aware work assignment: workgroup b is dispatched to XCD b % 8 (observed behaviour, used for speed only), every XCD has its
+// own 4 MiB L2, and the dispatcher deals workgroups IN ORDER -- the XCDs advance in lockstep through their shares and the kernel
+// ends with the XCD that holds the most work.  The tiles are dealt to the XCDs in CHUNKS, round robin (chunk c -> XCD c % 8);
+// inside an XCD the chunks follow one another and the four quads of a tile are consecutive workgroups.
+//   mode > 0   chunks of `mode` consecutive tiles of the row-major order: eight samples of the whole image per round of the deal --
+//              the default, 8 tiles
+//   mode < 0   chunks of e x e tiles (e = -mode), SQUARES of the image, whose tiles share most of their Gaussians' records (one L2
+//              serves a chunk); the backward blend then takes the heaviest squares first (A/B handle: equal or slower, gsr_api.hip)
+//   mode == 0  ONE chunk per XCD: a contiguous band of the image -- the arrangement until round 5: eight different REGIONS of the
+//              image (at C3 the heaviest holds 4.6 % more list entries than the mean, at C2 24 %)
+// Measured at C3 (gsr_api.hip: xcd_deal_mode): bands -> row-major chunks of 8: blend_fwd 0.191 -> 0.173 ms, blend_bwd 0.451 -> 0.430.
+// (struct TileDeal, make_tile_deal: state.h)
+// tile t of square chunk c (row-major inside the chunk), or d.tiles beyond the image's edge
+__device__ __forceinline__ int chunk_tile(const TileDeal& d, int c, int t)
 {
-	if (chunk <= 0) {
-		const int per = (tiles + 7) >> 3;
-		return in_xcd >= per ? tiles : xcd * per + in_xcd;
+	const int e = -d.mode;
+	const int tx = (c % d.chunks_x) * e + t % e, ty = (c / d.chunks_x) * e + t / e;
+	return (tx < d.grid_x && ty < d.grid_y) ? ty * d.grid_x + tx : d.tiles;
+}
+// tiles of square chunk c that lie inside the image
+__device__ __forceinline__ int chunk_valid_tiles(const TileDeal& d, int c)
+{
+	const int e = -d.mode;
+	const int w = min(e, d.grid_x - (c % d.chunks_x) * e), h = min(e, d.grid_y - (c / d.chunks_x) * e);
+	return w * h;
+}
+__device__ __forceinline__ int xcd_tile(int in_xcd, int xcd, const TileDeal& d)
+{
+	if (d.mode == 0) {
+		const int per = (d.tiles + 7) >> 3;
+		return in_xcd >= per ? d.tiles : xcd * per + in_xcd;
 	}
-	const int t = ((in_xcd / chunk) * 8 + xcd) * chunk + in_xcd % chunk;
-	return t < tiles ? t : tiles;
+	if (d.mode > 0) {
+		const int t = ((in_xcd / d.mode) * 8 + xcd) * d.mode + in_xcd % d.mode;
+		return t < d.tiles ? t : d.tiles;
+	}
+	const int ct = d.mode * d.mode;
+	const int c = (in_xcd / ct) * 8 + xcd;
+	return c < d.chunks ? chunk_tile(d, c, in_xcd % ct) : d.tiles;
 }
-static inline int xcd_tiles_per_xcd(int tiles, int chunk)
+static inline int xcd_tiles_per_xcd(const TileDeal& d)
 {
-	if (chunk <= 0) return (tiles + 7) >> 3;
-	const int chunks = (tiles + chunk - 1) / chunk;
-	return ((chunks + 7) >> 3) * chunk;
+	if (d.mode == 0) return (d.tiles + 7) >> 3;
+	if (d.mode > 0) return ((((d.tiles + d.mode - 1) / d.mode) + 7) >> 3) * d.mode;
+	return ((d.chunks + 7) >> 3) * d.mode * d.mode;
 }
-__device__ __forceinline__ int tile_assignment(int block, int tiles, int chunk) { return xcd_tile(block >> 3, block & 7, tiles, chunk); }
-static inline int tile_grid(int tiles, int chunk) { return xcd_tiles_per_xcd(tiles, chunk) * 8; }
-__device__ __forceinline__ void quad_assignment(int block, int tiles, int chunk, int& tile, int& quad)
+__device__ __forceinline__ int tile_assignment(int block, const TileDeal& d) { return xcd_tile(block >> 3, block & 7, d); }
+static inline int tile_grid(const TileDeal& d) { return xcd_tiles_per_xcd(d) * 8; }
+__device__ __forceinline__ void quad_assignment(int block, const TileDeal& d, int& tile, int& quad)
 {
 	const int in_xcd = block >> 3;
-	tile = xcd_tile(in_xcd >> 2, block & 7, tiles, chunk);   // tiles: a padding workgroup
+	tile = xcd_tile(in_xcd >> 2, block & 7, d);   // d.tiles: a padding workgroup
 	quad = in_xcd & 3;
 }
-static inline int quad_grid(int tiles, int chunk) { return xcd_tiles_per_xcd(tiles, chunk) * 8 * QUADS_PER_TILE; }
+static inline int quad_grid(const TileDeal& d) { return xcd_tiles_per_xcd(d) * 8 * QUADS_PER_TILE; }
 
-// Work class of a tile for the backward blend's dispatch order (state.h: SCHED_CLASSES): eighth-octaves of the number of list
-// entries its quads blended, 2^5 .. 2^13.
+// Work class of a chunk for the backward blend's dispatch order (state.h: SCHED_CLASSES): eighth-octaves of the number of list
+// entries its quads blended per tile of a full chunk, 2^5 .. 2^13.
 __device__ __forceinline__ int sched_class(uint32_t work)
 {
 	if (work < 32u) return 0;

@@ -40,30 +40,34 @@ blend_bwd_kernel(const BlendBwdParams p)
 	__shared__ uint32_t s_slot[BWD_SEG];
 	__shared__ uint32_t s_wmax[4];
 
-	// Heaviest tiles first: workgroup b takes the b-th tile of the forward blend's work classes, from the top class down
-	// (state.h: ImageState::sched; consecutive workgroups go to consecutive XCDs, so the descending order is dealt round robin).
-	// A tile's backward pass costs what its quads blended; dispatched in image order the kernel ended with whatever heavy tiles
-	// came last (simulated makespan over the ideal: 1.07 in chunked image order, 1.014 sorted).
+	// Heaviest chunks first: the forward blend filed every chunk (a square of tiles, blend.h: TileDeal) under a work class
+	// (state.h: ImageState::sched); the XCDs are dealt the chunks from the top class down, round robin, and the tiles of a chunk
+	// are consecutive workgroups of ONE XCD (their Gaussians' records meet in its L2).  A tile's backward pass costs what its quads
+	// blended and a workgroup runs ~90 us: dispatched in image order the kernel ended with whatever heavy tiles came last
+	// (simulated makespan over the ideal: 1.07 in image order, 1.014 sorted).
 	__shared__ int s_tile;
 	int tile;
-	if (p.sched) {
+	if (p.sched && p.deal.mode < 0) {
 		if (wave_id() == 0) {
 			const int l0 = lane_id();
+			const int ct = p.deal.mode * p.deal.mode, in_xcd = (int)blockIdx.x >> 3;
+			const uint32_t r = (uint32_t)((in_xcd / ct) * 8 + ((int)blockIdx.x & 7));   // rank of this workgroup's chunk, heaviest = 0
 			const uint32_t cnt = p.sched[p.tiles + (SCHED_CLASSES - 1 - l0)];   // (SCHED_CLASSES == 64: one class per lane, descending)
 			const uint32_t incl = wave_incl_scan_u32(cnt);
-			const unsigned long long holds = wave_ballot(incl > (uint32_t)blockIdx.x);
-			int t = p.tiles;   // (beyond the filed tiles: cannot happen after a forward pass of this library; a padding workgroup)
+			const unsigned long long holds = wave_ballot(incl > r);
+			int t = p.tiles;   // (beyond the filed chunks: a padding workgroup of the last round of the deal)
 			if (holds) {
 				const int j = __ffsll((long long)holds) - 1;
 				const uint32_t incl_j = wave_shfl_u32(incl, j), cnt_j = wave_shfl_u32(cnt, j);
-				t = (int)p.class_list[(size_t)(SCHED_CLASSES - 1 - j) * p.tiles + ((uint32_t)blockIdx.x - (incl_j - cnt_j))];
+				const uint32_t chunk = p.class_list[(size_t)(SCHED_CLASSES - 1 - j) * p.deal.chunks + (r - (incl_j - cnt_j))];
+				t = chunk_tile(p.deal, (int)chunk, in_xcd % ct);
 			}
 			if (l0 == 0) s_tile = t;
 		}
 		__syncthreads();
 		tile = s_tile;
 	} else
-		tile = tile_assignment((int)blockIdx.x, p.tiles, p.xcd_chunk);
+		tile = tile_assignment((int)blockIdx.x, p.deal);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int quad = (int)wave_uniform_u32((uint32_t)wave_id());   // scalar: the LDS record address is SGPR arithmetic
@@ -235,7 +239,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_bwd_kernel, p.sched ? p.tiles : tile_grid(p.tiles, p.xcd_chunk), 256, stream, p);
+	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.deal), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -19,7 +19,7 @@ blend_fwd_kernel(const BlendFwdParams p)
 	__shared__ float4 s_rec[64][3];   // per staged entry: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
 
 	int tile, quad;
-	quad_assignment((int)blockIdx.x, p.tiles, p.xcd_chunk, tile, quad);
+	quad_assignment((int)blockIdx.x, p.deal, tile, quad);
 	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int l = lane_id();
@@ -146,22 +146,28 @@ blend_fwd_kernel(const BlendFwdParams p)
 		p.out_color[plane + pix] = Cg + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];
 	}
-	// Dispatch order of the backward blend: this quad's count joins the tile's; the tile's last quad files it under its work
-	// class (state.h: ImageState::sched).  One returning atomic per wave carries count and arrival together, so the last quad
-	// sees the other three's counts without a fence.
-	if (p.sched && l == 0) {
+	// Dispatch order of the backward blend (state.h: ImageState::sched): this quad's count joins the tile's, the tile's last quad
+	// adds the tile's total to its chunk's, the chunk's last tile files the chunk under its work class.  One returning atomic
+	// per level carries count and arrival together, so the last one sees the others' counts without a fence.
+	if (p.sched && p.deal.mode < 0 && l == 0) {
 		const uint32_t old = atomicAdd(&p.sched[tile], (blended << 3) | 1u);
 		if ((old & 7u) == (uint32_t)(QUADS_PER_TILE - 1)) {
-			const int c = sched_class((old >> 3) + blended);
-			const uint32_t i = atomicAdd(&p.sched[p.tiles + c], 1u);
-			p.class_list[(size_t)c * p.tiles + i] = (uint32_t)tile;
+			const int e = -p.deal.mode;
+			const int chunk = (tile_y / e) * p.deal.chunks_x + tile_x / e;
+			const uint32_t work = min((old >> 3) + blended, (1u << 22) - 1u);   // (16 tiles x 2^22 fit the 27-bit field)
+			const uint32_t oldc = atomicAdd(&p.sched[p.tiles + SCHED_CLASSES + chunk], (work << 5) | 1u);
+			if ((int)(oldc & 31u) == chunk_valid_tiles(p.deal, chunk) - 1) {
+				const int c = sched_class(((oldc >> 5) + work) / (uint32_t)(e * e));
+				const uint32_t i = atomicAdd(&p.sched[p.tiles + c], 1u);
+				p.class_list[(size_t)c * p.deal.chunks + i] = (uint32_t)chunk;
+			}
 		}
 	}
 }
 
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_fwd_kernel, quad_grid(p.tiles, p.xcd_chunk), 64, stream, p);
+	GSR_LAUNCH(blend_fwd_kernel, quad_grid(p.deal), 64, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

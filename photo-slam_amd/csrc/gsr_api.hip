@@ -105,20 +105,29 @@ static bool emit_seeded()
 	static const int env = env_int("GSR_EMIT_SEEDS", 1);
 	return env != 0;
 }
-// tiles per chunk of the blend kernels' workgroup -> XCD deal (blend.h); GSR_XCD_CHUNK overrides (0 = one band per XCD)
-static int xcd_chunk(int tiles)
+// The blend kernels' deal of tiles to the XCDs (blend.h: TileDeal::mode); GSR_XCD_CHUNK overrides: 0 = one band per XCD,
+// n > 0 = row-major chunks of n tiles, -e = squares of e x e tiles (and the backward blend takes the heaviest squares first).
+// Measured at C3, alternating runs on one box each (profiles/r05_h, r05_i, r05_t):
+//   one band per XCD            1.609-1.620 ms per step   blend_fwd 0.191  blend_bwd 0.451 ms   TCC traffic of the two 182 / 313 MB
+//   row-major chunks of 128     1.589-1.592
+//   row-major chunks of 32      1.582-1.588                                                                            229 / 380
+//   row-major chunks of 8       1.566-1.575               0.173            0.430                                        261 / 425
+//   chunks of 4 / 2 / 1         as 8
+//   squares of 4 x 4, heaviest first                      0.177            0.430                                        210 / 350
+//   squares of 2 x 2 / single tiles, heaviest first       0.177            0.424                                  280 / 459 (2 x 2), 261 / 695
+// The balance of the deal decides, not the L2 locality.  Heaviest-first gains 6-10 us in the backward blend and costs the forward
+// blend 4-5 us (its waves end with the returning atomics that file the tile) and, tile by tile, 270 MB of record re-reads: the
+// default is the plain row-major chunk of 8.
+static int xcd_deal_mode(int tiles)
 {
-	static const int env = env_int("GSR_XCD_CHUNK", -1);
-	if (env >= 0) return env;
-	// Measured at C3 on one box (profiles/r05_h, r05_i: alternating runs): one band per XCD 1.609-1.620 ms per step, chunks of 128
-	// tiles 1.589-1.592, of 32 1.582-1.588, of 8 / 4 / 2 / 1 all 1.566-1.575 (blend_fwd 0.191 -> 0.173 ms, blend_bwd 0.451 -> 0.430):
-	// the balance of the deal decides, the L2 locality of neighbouring tiles does not.  8 keeps what locality is free; small
-	// images get smaller chunks (at least ~16 rounds of the deal, or its last round is the imbalance).
+	static const int env = env_int("GSR_XCD_CHUNK", -1000);
+	if (env != -1000) return env;
+	// (small images: at least ~16 rounds of the deal, or its last round is the imbalance)
 	int c = 8;
 	while (c > 1 && tiles < 8 * 16 * c) c >>= 1;
 	return c;
 }
-// GSR_BWD_HEAVY_FIRST=0 (A/B handle): the backward blend takes its tiles in the forward blend's chunked image order
+// GSR_BWD_HEAVY_FIRST=0 (A/B handle): the backward blend takes its chunks in the forward blend's image order
 static bool heavy_first()
 {
 	static const int env = env_int("GSR_BWD_HEAVY_FIRST", 1);
@@ -381,7 +390,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.final_T = im.final_T; bp.n_contrib = im.n_contrib; bp.out_color = a->out_color;
 	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
-	bp.xcd_chunk = xcd_chunk(tiles);
+	bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
 	bp.sched = im.sched; bp.class_list = im.class_list;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(7);
@@ -533,7 +542,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		bp.long_fold = long_fold();
-		bp.xcd_chunk = xcd_chunk(tiles);
+		bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
 		bp.sched = heavy_first() ? im.sched : nullptr; bp.class_list = im.class_list;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}

@@ -63,7 +63,7 @@ struct PreprocessParams {
 	int* radii_out;  // caller's radii (nullable)
 	int raw_params;  // GSR_RAW_* mask: activations applied in-kernel
 	uint2* ranges;   // [tiles] per-tile instance ranges: zeroed here (identifyTileRanges fills only the tiles that have instances)
-	uint32_t* sched; // [tiles + SCHED_CLASSES] the backward blend's dispatch bookkeeping (state.h: ImageState): zeroed here
+	uint32_t* sched; // [2 tiles + SCHED_CLASSES] the backward blend's dispatch bookkeeping (state.h: ImageState): zeroed here
 	int tiles;
 	LazyAdam lazy;   // row_step != null: visible rows that lag behind (step - 1) are brought up to date before their SH evaluation
 };
@@ -91,7 +91,7 @@ struct BlendFwdParams {
 	int W, H, grid_x, tiles;
 	uint32_t* sched;        // ImageState::sched / class_list: the tile's blended entries are counted, its last quad files it
 	uint32_t* class_list;
-	int xcd_chunk;          // blend.h: tiles per chunk of the workgroup -> XCD deal (0 = one band per XCD)
+	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
 
@@ -111,7 +111,7 @@ struct BlendBwdParams {
 	uint32_t long_fold;     // state.h: LONG_FOLD
 	const uint32_t* sched;  // ImageState::sched / class_list (null: tiles in the forward blend's chunked order)
 	const uint32_t* class_list;
-	int xcd_chunk;          // blend.h: tiles per chunk of the workgroup -> XCD deal (0 = one band per XCD)
+	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
 

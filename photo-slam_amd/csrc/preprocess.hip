@@ -47,7 +47,7 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	// the per-tile ranges start from zero (rasterizer_impl.cu:310: a memset of its own there; 65 KB at 1080p)
 	for (int t = idx; t < p.tiles; t += (int)(gridDim.x * blockDim.x)) p.ranges[t] = make_uint2(0u, 0u);
 	if (p.sched)
-		for (int t = idx; t < p.tiles + SCHED_CLASSES; t += (int)(gridDim.x * blockDim.x)) p.sched[t] = 0u;
+		for (int t = idx; t < 2 * p.tiles + SCHED_CLASSES; t += (int)(gridDim.x * blockDim.x)) p.sched[t] = 0u;
 	const int w = wave_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
 	const bool in_range = idx < p.P;

@@ -147,18 +147,36 @@ struct BinningState {
 	}
 };
 
-// Work classes of the backward blend's tiles (ImageState::sched): eighth-octaves of the number of blended list entries between
-// 2^5 and 2^13 (9 % steps: the tiles of a 1080p view of a 2 M-Gaussian room hold 160 .. 3 100, mean 1 200); class 0 = fewer.
+// The blend kernels' deal of tiles to the XCDs (blend.h)
+struct TileDeal {
+	int tiles, grid_x, grid_y;
+	int mode;
+	int chunks_x, chunks;   // mode < 0: the image in e x e chunks
+};
+static inline TileDeal make_tile_deal(int tiles, int grid_x, int mode)
+{
+	TileDeal d;
+	d.tiles = tiles; d.grid_x = grid_x; d.grid_y = grid_x > 0 ? tiles / grid_x : 0; d.mode = mode;
+	const int e = mode < 0 ? -mode : 1;
+	d.chunks_x = (grid_x + e - 1) / e;
+	d.chunks = d.chunks_x * ((d.grid_y + e - 1) / e);
+	return d;
+}
+
+// Work classes of the backward blend's chunks (ImageState::sched): eighth-octaves of the number of blended list entries per tile
+// of a full chunk, between 2^5 and 2^13 (9 % steps: the tiles of a 1080p view of a 2 M-Gaussian room hold 160 .. 3 100, mean
+// 1 200); class 0 = fewer.
 constexpr int SCHED_CLASSES = 64;
 struct ImageState {
 	float*    final_T;    // [N]
 	uint32_t* n_contrib;  // [N]
 	uint2*    ranges;     // [T]
-	// Dispatch order of the backward blend (blend_bwd.hip): heaviest tiles first.  The forward blend's quad-waves add the number
-	// of list entries they blended to sched[tile] (<< 3, with an arrival count in the low bits); the LAST quad of a tile files the
-	// tile under its work class: sched[T + c] counts class c, class_list[c * T + i] is its i-th tile.  sched is zeroed by the
-	// projection kernel next to the ranges.
-	uint32_t* sched;      // [T + SCHED_CLASSES]
+	// Dispatch order of the backward blend (blend_bwd.hip): heaviest CHUNKS first (a chunk = a square of tiles, blend.h: TileDeal).
+	// The forward blend's quad-waves add the number of list entries they blended to sched[tile] (<< 3, with an arrival count in
+	// the low bits); the last quad of a tile adds the tile's total to sched[T + SCHED_CLASSES + chunk] (<< 5, with the tiles that
+	// have arrived); the last tile of a chunk files the chunk under its work class: sched[T + c] counts class c,
+	// class_list[c * chunks + i] is its i-th chunk.  sched is zeroed by the projection kernel next to the ranges.
+	uint32_t* sched;      // [T + SCHED_CLASSES + T]   (chunks <= T)
 	uint32_t* class_list; // [SCHED_CLASSES * T]
 
 	static ImageState carve(char* chunk, size_t N, size_t T, size_t* bytes = nullptr)
@@ -168,7 +186,7 @@ struct ImageState {
 		im.final_T = c.take<float>(N);
 		im.n_contrib = c.take<uint32_t>(N);
 		im.ranges = c.take<uint2>(T);
-		im.sched = c.take<uint32_t>(T + SCHED_CLASSES);
+		im.sched = c.take<uint32_t>(2 * T + SCHED_CLASSES);
 		im.class_list = c.take<uint32_t>((size_t)SCHED_CLASSES * T);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return im;
