@@ -102,9 +102,9 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		// (state.h): those accumulators start out zeroed (their reader zeroes them again: partials.h)
 		if (k < fold && wdt * ((r.y >> 16) - miny) > LONG_RUN) {
 			const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-			partials[3 * (size_t)slot] = zero;
-			partials[3 * (size_t)slot + 1] = zero;
-			partials[3 * (size_t)slot + 2] = zero;
+			partials[SLOT_F4 * (size_t)slot] = zero;
+			partials[SLOT_F4 * (size_t)slot + 1] = zero;
+			partials[SLOT_F4 * (size_t)slot + 2] = zero;
 		}
 		// (one LDS atomic per key, as in radix_hist_kernel; a key the tile sort's first pass drops is not counted)
 		if (hist && key != RADIX_INVALID_KEY) atomicAdd(&s_hist[key & ((1u << hist_bits) - 1u)], 1u);

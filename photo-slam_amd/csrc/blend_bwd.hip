@@ -221,12 +221,12 @@ blend_bwd_kernel(const BlendBwdParams p)
 					// instance emission / by their reader) -- nine float atomics for 1.6 % of the slots written at C3
 					const uint32_t acc = slot & ~SLOT_FOLDED;
 					p.touched[acc] = 1;
-					float* dst = p.partials + (size_t)acc * 12;
+					float* dst = p.partials + (size_t)acc * (4 * SLOT_F4);
 #pragma unroll
 					for (int c = 0; c < 9; c++) atomicAdd(dst + c, o[c]);
 				} else {
 					p.touched[slot] = 1;
-					float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * 12);
+					float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * (4 * SLOT_F4));
 					dst[0] = make_float4(o[0], o[1], o[2], o[3]);
 					dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 					reinterpret_cast<float*>(dst + 2)[0] = o[8];

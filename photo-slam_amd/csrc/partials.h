@@ -27,9 +27,9 @@ __device__ __forceinline__ void sum_slots_trip(float4* src, unsigned long long& 
 	}
 #pragma unroll
 	for (int j = 0; j < U; j++) {
-		x[j] = src[3 * (size_t)idx[j]];
-		y[j] = src[3 * (size_t)idx[j] + 1];
-		z[j] = src[3 * (size_t)idx[j] + 2].x;
+		x[j] = src[SLOT_F4 * (size_t)idx[j]];
+		y[j] = src[SLOT_F4 * (size_t)idx[j] + 1];
+		z[j] = src[SLOT_F4 * (size_t)idx[j] + 2].x;
 	}
 #pragma unroll
 	for (int j = 0; j < U; j++) {
@@ -41,9 +41,9 @@ __device__ __forceinline__ void sum_slots_trip(float4* src, unsigned long long& 
 		const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 		for (int j = 0; j < U; j++) {
-			src[3 * (size_t)idx[j]] = zero;
-			src[3 * (size_t)idx[j] + 1] = zero;
-			src[3 * (size_t)idx[j] + 2] = zero;
+			src[SLOT_F4 * (size_t)idx[j]] = zero;
+			src[SLOT_F4 * (size_t)idx[j] + 1] = zero;
+			src[SLOT_F4 * (size_t)idx[j] + 2] = zero;
 		}
 	}
 }
@@ -72,7 +72,7 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 			}
 		}
 		if (n < 64u) live &= (1ull << n) - 1ull;
-		float4* src = part4 + 3 * (size_t)first;
+		float4* src = part4 + SLOT_F4 * (size_t)first;
 		// several touched slots per trip: their loads leave together, the sums follow in slot order (a lane's chain of dependent
 		// round trips is what this HBM-latency-bound phase waits for: one slot per trip -> two: the stage 0.463 -> 0.452 ms at C3)
 		if (trip >= 4)
@@ -82,16 +82,16 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 		while (live) {
 			const int i = __ffsll((long long)live) - 1;
 			live &= live - 1ull;
-			const float4 x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1];
-			const float z = src[3 * (size_t)i + 2].x;
+			const float4 x = src[SLOT_F4 * (size_t)i], y = src[SLOT_F4 * (size_t)i + 1];
+			const float z = src[SLOT_F4 * (size_t)i + 2].x;
 			a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
 			a[4] += y.x; a[5] += y.y; a[6] += y.z; a[7] += y.w;
 			a[8] += z;
 			if (folded) {   // an accumulator of the atomics of blend_bwd: zero again for the next backward pass
 				const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-				src[3 * (size_t)i] = zero;
-				src[3 * (size_t)i + 1] = zero;
-				src[3 * (size_t)i + 2] = zero;
+				src[SLOT_F4 * (size_t)i] = zero;
+				src[SLOT_F4 * (size_t)i + 1] = zero;
+				src[SLOT_F4 * (size_t)i + 2] = zero;
 			}
 		}
 	}

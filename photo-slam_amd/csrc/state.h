@@ -35,6 +35,14 @@ constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
 // dependent round trips, on an otherwise idle device).  The LONG_FOLD accumulator slots of such a run are zeroed by the
 // instance emission and again by their reader (partials.h); at most cnt / LONG_FOLD atomics meet on one address.
 constexpr uint32_t LONG_RUN = 64;
+// float4 per instance gradient slot: nine sums in three float4 (48 bytes).  A 48-byte slot straddles two 64-byte sectors half of
+// the time, and at 22 % density every slot is fetched, and written, on its own; padded to 64 bytes (GSR_EXTRA_FLAGS=-DGSR_SLOT_F4=4)
+// the step was 16 us SLOWER on one box (1.506 -> 1.522 ms median, profiles/r05_v: the per-Gaussian stage +7 us, every stage that
+// touches the 33 % larger binning buffer a little) -- measured in round 5, not kept.
+#ifndef GSR_SLOT_F4
+#define GSR_SLOT_F4 3
+#endif
+constexpr int SLOT_F4 = GSR_SLOT_F4;
 constexpr uint32_t LONG_FOLD = 8;     // (a power of two <= LONG_RUN; GSR_LONG_FOLD overrides it for A/B runs: long_fold())
 static_assert(LONG_FOLD <= LONG_RUN && (LONG_FOLD & (LONG_FOLD - 1)) == 0, "a folded run uses its own first LONG_FOLD slots");
 uint32_t long_fold();                  // gsr_api.hip
@@ -123,7 +131,7 @@ struct BinningState {
 	uint32_t* keys_b;        // [R] (pong)
 	uint32_t* vals_b;        // [R] (pong)
 	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
-	float*    partials;      // [12R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
+	float*    partials;      // [4 SLOT_F4 R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
 	uint8_t*  touched;       // [R] 1 where the backward blend wrote the slot (cleared per backward; the slots themselves are not)
 	uint8_t*  contrib;       // [4][R] per quad of the tile: 1 where the forward blend found a pixel of the quad that blends the
 	                         // list entry (written by blend_fwd for the batches it walks, read by blend_bwd: blend.h)
@@ -137,7 +145,7 @@ struct BinningState {
 		b.keys_b = c.take<uint32_t>(R);
 		b.vals_b = c.take<uint32_t>(R);
 		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
-		b.partials = c.take<float>(12 * R);
+		b.partials = c.take<float>(4 * (size_t)SLOT_F4 * R);
 		// readers fetch flags 16 bytes at a time (+ 64); the clear covers touched_clear_bytes(R): a multiple of 256 bytes, because
 		// the runtime splits a memset of any other size into two kernels (body + tail, 5 us each)
 		b.touched = c.take<uint8_t>(touched_clear_bytes(R));
