@@ -32,8 +32,7 @@ __global__ void __launch_bounds__(EMIT_THREADS)
 emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                       const uint2* __restrict__ rect_sorted, int grid_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                       float4* __restrict__ rec, uint8_t* __restrict__ touched, uint32_t touched_bytes, int cull,
-                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity, float4* __restrict__ partials, uint32_t fold,
-                      uint32_t* __restrict__ hist, int hist_bits, int hist_blocks)
+                      const uint32_t* __restrict__ seeds, uint32_t seed_capacity, uint32_t* __restrict__ hist, int hist_bits, int hist_blocks)
 {
 	__shared__ uint32_t s_off[EMIT_WAVES][EMIT_SLOTS + 4];
 	// The tile sort's first histogram (sort.hip: radix_hist_kernel) is counted HERE, where the keys are made: a workgroup emits
@@ -98,14 +97,6 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 		// slot of the Gaussian's first instance = its emission offset (the backward blend writes its per-tile gradient
 		// partials there, preprocess_bwd sums the contiguous run)
 		if (k == 0u) reinterpret_cast<uint32_t*>(rec + 3 * (size_t)g + 2)[3] = slot;
-		// a run of more than LONG_RUN instances is folded into its first LONG_FOLD slots by the backward blend's atomics
-		// (state.h): those accumulators start out zeroed (their reader zeroes them again: partials.h)
-		if (k < fold && wdt * ((r.y >> 16) - miny) > LONG_RUN) {
-			const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-			partials[SLOT_F4 * (size_t)slot] = zero;
-			partials[SLOT_F4 * (size_t)slot + 1] = zero;
-			partials[SLOT_F4 * (size_t)slot + 2] = zero;
-		}
 		// (one LDS atomic per key, as in radix_hist_kernel; a key the tile sort's first pass drops is not counted)
 		if (hist && key != RADIX_INVALID_KEY) atomicAdd(&s_hist[key & ((1u << hist_bits) - 1u)], 1u);
 	}
@@ -150,14 +141,14 @@ tile_ranges_kernel(int R, const uint32_t* __restrict__ tile_keys, uint2* __restr
 }
 
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          float* partials, hipStream_t stream, int cull, bool seeded, uint32_t fold, uint32_t* hist, int hist_bits)
+                          hipStream_t stream, int cull, bool seeded, uint32_t* hist, int hist_bits)
 {
 	if (R <= 0) return GSR_OK;
 	// hist (nullable): the [digit][sort_blocks(R)] table of the tile sort's first pass over `hist_bits` low key bits, counted on the way
 	GSR_LAUNCH(emit_instances_kernel, div_up(R, EMIT_WAVES * EMIT_SLOTS), EMIT_THREADS, stream, P, (uint32_t)R, (const uint32_t*)g.order,
 	           (const uint32_t*)g.offsets, (const uint2*)g.rect_sorted, grid_x, keys, vals, g.rec, touched,
 	           (uint32_t)touched_clear_bytes((size_t)R), cull, seeded ? (const uint32_t*)g.sort_keys_b : (const uint32_t*)nullptr, (uint32_t)P,
-	           reinterpret_cast<float4*>(partials), fold, hist_bits > 0 ? hist : (uint32_t*)nullptr, hist_bits, sort_blocks(R));
+	           hist_bits > 0 ? hist : (uint32_t*)nullptr, hist_bits, sort_blocks(R));
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -20,8 +20,7 @@
 //     combination (backward.cu:539-546) is linear in them and applied once per Gaussian in
 //     preprocess_bwd (partials.h);
 //   * at the end of a segment of 256 list entries the workgroup writes every touched entry's
-//     nine sums to that instance's private 48-byte slot with plain stores -- except for the runs of more than LONG_RUN
-//     instances (screen-filling splats), which are folded into LONG_FOLD shared slots with float atomics (state.h).
+//     nine sums to that instance's private 48-byte slot with plain stores.
 #include "blend.h"
 #include "kernels.h"
 
@@ -133,12 +132,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 					s_rec[quad][l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
 					s_rec[quad][l][2].x = q2.x;
 					const uint32_t rlo = __float_as_uint(q2.y), rhi = __float_as_uint(q2.z);
-					const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu, maxy = rhi >> 16;
-					const uint32_t wdt = maxx - minx;
-					const uint32_t k = ((uint32_t)tile_y - miny) * wdt + ((uint32_t)tile_x - minx);   // instance of the run
-					// a run of more than LONG_RUN instances is folded into its first LONG_FOLD slots (state.h): marked here, added
-					// with atomics at the segment's end
-					slot = __float_as_uint(q2.w) + (wdt * (maxy - miny) > LONG_RUN ? ((k & (p.long_fold - 1u)) | SLOT_FOLDED) : k);
+					const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu;
+					slot = __float_as_uint(q2.w) + ((uint32_t)tile_y - miny) * (maxx - minx) + ((uint32_t)tile_x - minx);
 					s_slot[base - (int)seg_lo + l] = slot;   // the quads of the tile write the same value
 				}
 				unsigned long long m = wave_ballot(keep);
@@ -214,23 +209,12 @@ blend_bwd_kernel(const BlendBwdParams p)
 #pragma unroll
 			for (int c = 0; c < 9; c++) any += fabsf(s_acc[c][i]);
 			if (slot != 0xFFFFFFFFu && any != 0.f) {   // untouched / all-zero entries stay unflagged: the per-Gaussian sum skips them
+				p.touched[slot] = 1;
+				float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * (4 * SLOT_F4));
 				// slot order (partials.h): colour r g b, w dx, w dy, w dx dx, w dx dy, w dy dy, w
-				const float o[9] = {s_acc[0][i], s_acc[4][i], s_acc[3][i], s_acc[1][i], s_acc[5][i], s_acc[2][i], s_acc[6][i], s_acc[7][i], s_acc[8][i]};
-				if (slot & SLOT_FOLDED) {
-					// one of the few thousand screen-filling splats: its instances share LONG_FOLD accumulator slots (zeroed by the
-					// instance emission / by their reader) -- nine float atomics for 1.6 % of the slots written at C3
-					const uint32_t acc = slot & ~SLOT_FOLDED;
-					p.touched[acc] = 1;
-					float* dst = p.partials + (size_t)acc * (4 * SLOT_F4);
-#pragma unroll
-					for (int c = 0; c < 9; c++) atomicAdd(dst + c, o[c]);
-				} else {
-					p.touched[slot] = 1;
-					float4* dst = reinterpret_cast<float4*>(p.partials + (size_t)slot * (4 * SLOT_F4));
-					dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-					dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-					reinterpret_cast<float*>(dst + 2)[0] = o[8];
-				}
+				dst[0] = make_float4(s_acc[0][i], s_acc[4][i], s_acc[3][i], s_acc[1][i]);
+				dst[1] = make_float4(s_acc[5][i], s_acc[2][i], s_acc[6][i], s_acc[7][i]);
+				reinterpret_cast<float*>(dst + 2)[0] = s_acc[8][i];
 			}
 		}
 		__syncthreads();

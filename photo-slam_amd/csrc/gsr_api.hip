@@ -138,13 +138,6 @@ static bool emit_hist()
 	static const int env = env_int("GSR_EMIT_HIST", 1);
 	return env != 0;
 }
-// GSR_LONG_FOLD (A/B handle): the accumulator slots a run of more than LONG_RUN instances is folded into (state.h); read once,
-// the forward pass (which zeroes them) and the backward pass (which adds into them) of a process agree
-uint32_t long_fold()
-{
-	static const int env = env_int("GSR_LONG_FOLD", (int)LONG_FOLD);
-	return (env >= 1 && env <= (int)LONG_RUN && (env & (env - 1)) == 0) ? (uint32_t)env : LONG_FOLD;
-}
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -340,7 +333,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	PROF_FWD(2);
 	// (g.sort_keys_b, the depth sort's pong buffer, is free again: it receives the emission's seeds -- binning.hip)
 	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
-	                                 g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P)) != GSR_OK)
+	                                 g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P, g.long_runs, g.long_counts, g.long_capacity)) != GSR_OK)
 		return st;
 	PROF_FWD(3);
 
@@ -370,8 +363,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
 		// (the emission counts the tile sort's first histogram on the way: GSR_EMIT_HIST=0 is the A/B handle for the separate launch)
 		const int hist_bits = emit_hist() ? radix_first_pass_bits(0, bits) : 0;
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, bs.partials, stream, cull ? 1 : 0, emit_seeded(), long_fold(),
-		                                bs.sort_scratch, hist_bits)) != GSR_OK) return st;
+		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded(), bs.sort_scratch, hist_bits)) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
@@ -541,7 +533,6 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.touched = bs.touched;
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
-		bp.long_fold = long_fold();
 		bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
 		bp.sched = heavy_first() ? im.sched : nullptr; bp.class_list = im.class_list;
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
@@ -560,10 +551,14 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.focal_x = W / (2.0f * a->tan_fovx);
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
 	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
-	pb.long_fold = long_fold();
+	pb.long_runs = g.long_runs; pb.long_counts = g.long_counts; pb.long_capacity = g.long_capacity;
 	{
 		static const int trip = env_int("GSR_SLOT_TRIP", 2);
 		pb.slot_trip = trip;
+		static const int lrs = env_int("GSR_LRS_MODE", 1);
+		pb.lrs_mode = lrs;
+		static const int lrsb = env_int("GSR_LRS_BLOCKS", 0);
+		pb.lrs_blocks = lrsb;
 	}
 	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
 	pb.rec = g.rec; pb.raw_params = a->raw_params;

@@ -74,8 +74,7 @@ int launch_check_frustum(int P, const float* means3D, const float* view, uint8_t
 // depth rank of the Gaussian that holds its first slot (GeometryState::sort_keys_b, P entries: windows beyond that search)
 constexpr uint32_t EMIT_SEED_STRIDE = 256;
 int launch_emit_instances(int P, int R, const GeometryState& g, int grid_x, uint32_t* keys, uint32_t* vals, uint8_t* touched,
-                          float* partials, hipStream_t stream, int cull = 0, bool seeded = false, uint32_t fold = LONG_FOLD,
-                          uint32_t* hist = nullptr, int hist_bits = 0);
+                          hipStream_t stream, int cull = 0, bool seeded = false, uint32_t* hist = nullptr, int hist_bits = 0);
 int launch_tile_ranges(int R, const uint32_t* tile_keys, uint2* ranges, hipStream_t stream, const uint32_t* n_dev = nullptr);
 
 struct BlendFwdParams {
@@ -108,7 +107,6 @@ struct BlendBwdParams {
 	const uint8_t* contrib; // [4][contrib_stride] the forward blend's per-quad contribution flags
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
-	uint32_t long_fold;     // state.h: LONG_FOLD
 	const uint32_t* sched;  // ImageState::sched / class_list (null: tiles in the forward blend's chunked order)
 	const uint32_t* class_list;
 	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
@@ -142,11 +140,15 @@ struct PreprocessBwdParams {
 	const float* campos;    // [3] device
 	float focal_x, focal_y, tan_fovx, tan_fovy;
 	const uint32_t* tiles_touched;   // [P] length of each Gaussian's run of instance slots (0 = culled)
-	float* partials;          // [R][12] per-instance gradient slots written by the backward blend (blend.h); a run of more than
-	                          // LONG_RUN slots arrives folded into its first LONG_FOLD slots (state.h)
+	float* partials;          // [R][12] per-instance gradient slots written by the backward blend (blend.h); the totals of the
+	                          // long runs are folded into their first slots (long_run_sums_kernel)
 	uint8_t* touched;         // [R + 64] 1 where a slot was written
-	uint32_t long_fold;       // state.h: LONG_FOLD
+	const uint32_t* long_runs;       // ids of the Gaussians with more than LONG_RUN slots, LONG_LISTS sub-lists (the offset scan)
+	const uint32_t* long_counts;     // entries per sub-list (device)
+	uint32_t long_capacity;
 	int slot_trip;            // partials.h: touched slots per trip (1, 2 or 4; GSR_SLOT_TRIP: the A/B handle)
+	int lrs_mode;             // partials.h: wave_sum_long_run's form (GSR_LRS_MODE: the A/B handle)
+	int lrs_blocks;           // workgroups of long_run_sums_kernel (GSR_LRS_BLOCKS; 0 = LRS_BLOCKS)
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0); nullable

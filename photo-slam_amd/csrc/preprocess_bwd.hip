@@ -245,7 +245,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	{
 		const uint32_t cnt = (vis && p.partials) ? p.tiles_touched[idx] : 0u;
 		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
-		wave_sum_partial_runs(cnt, first, p.partials, p.touched, p.long_fold, a, p.slot_trip);   // every lane of the wave takes part
+		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a, p.slot_trip);   // every lane of the wave takes part
 	}
 	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && !p.adam_exp_avg && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
@@ -672,8 +672,27 @@ int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t 
 	return GSR_OK;
 }
 
+// The runs of more than LONG_RUN instance slots (partials.h): one wave per run, a fixed grid that strides over the list the
+// forward pass left (its length lives on the device).
+constexpr int LRS_BLOCKS = 1024;   // (one listed run per wave at C3: 512 -> 1 024 workgroups: 18.6 -> 14.1 us; more: equal)
+__global__ void __launch_bounds__(256)
+long_run_sums_kernel(const PreprocessBwdParams p)
+{
+	// wave -> (sub-list, position): consecutive waves take different sub-lists, waves/LONG_LISTS of them share one
+	const uint32_t wave = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_id(), waves = (uint32_t)gridDim.x * 4u;
+	const uint32_t list = wave % (uint32_t)LONG_LISTS;
+	const uint32_t n = p.long_counts[list * LONG_COUNT_STRIDE];
+	for (uint32_t e = wave / (uint32_t)LONG_LISTS; e < n; e += waves / (uint32_t)LONG_LISTS) {
+		const uint32_t g = p.long_runs[(size_t)list * p.long_capacity + e];
+		const uint32_t cnt = p.tiles_touched[g];
+		const uint32_t first = __float_as_uint(p.rec[3 * (size_t)g + 2].w);
+		wave_sum_long_run(first, cnt, p.partials, p.touched, p.lrs_mode);
+	}
+}
+
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
+	if (p.partials) GSR_LAUNCH(long_run_sums_kernel, p.lrs_blocks > 0 ? p.lrs_blocks : LRS_BLOCKS, 256, stream, p);
 	const bool factored = p.dL_dcolor_view != nullptr;
 	const bool adam = p.adam_exp_avg != nullptr;
 	const bool rows_ok = sh_rows_path(p.shs, p.M, p.D, factored, adam, p.dL_dsh);   // (includes 0 <= D <= 3)

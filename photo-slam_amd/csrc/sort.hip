@@ -62,7 +62,8 @@ scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_reduce_rect_kernel(const uint2* __restrict__ rect, const uint32_t* __restrict__ gather, uint32_t* __restrict__ staged,
                         uint2* __restrict__ rect_sorted, uint32_t* __restrict__ block_sums, int n, int items_per_block,
-                        const uint32_t* __restrict__ n_dev)
+                        const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ long_runs, uint32_t* __restrict__ long_counts,
+                        uint32_t long_capacity)
 {
 	__shared__ uint32_t s_wave[4];
 	const int base = blockIdx.x * items_per_block;
@@ -71,12 +72,32 @@ scan_reduce_rect_kernel(const uint2* __restrict__ rect, const uint32_t* __restri
 	uint32_t acc = 0;
 	if (n_dev)
 		for (int i = max(base, end) + (int)threadIdx.x; i < end_all; i += SCAN_THREADS) staged[i] = 0u;
-	for (int i = base + (int)threadIdx.x; i < end; i += SCAN_THREADS) {
-		const uint2 r = rect[gather[i]];
-		const uint32_t v = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
-		rect_sorted[i] = r;
-		staged[i] = v;
-		acc += v;
+	for (int i0 = base; i0 < end; i0 += SCAN_THREADS) {   // (block-uniform trip count: the ballot below is a wave's)
+		const int i = i0 + (int)threadIdx.x;
+		uint32_t id = 0u, v = 0u;
+		if (i < end) {
+			id = gather[i];
+			const uint2 r = rect[id];
+			v = ((r.y & 0xFFFFu) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.x >> 16));
+			rect_sorted[i] = r;
+			staged[i] = v;
+			acc += v;
+		}
+		// Gaussians whose run of instance slots is too long for one lane of the backward preprocess (state.h: LONG_RUN): listed
+		// here, one atomic per wave that has any (a few thousand entries at C3); the list order is irrelevant to the results
+		const unsigned long long lm = long_runs ? wave_ballot(v > LONG_RUN) : 0ull;
+		if (lm) {
+			const int leader = __ffsll((long long)lm) - 1;
+			uint32_t at = 0;
+			// (the scan runs in DEPTH order and the long runs are the near Gaussians: they sit in its first few blocks -- a sub-list
+			// per block left long_run_sums_kernel with all of them in a handful of sub-lists, 110 us instead of 20.  Every (block,
+			// trip, wave) takes the next sub-list instead.)
+			const uint32_t list = (((uint32_t)blockIdx.x * (uint32_t)(items_per_block / SCAN_THREADS) + (uint32_t)((i0 - base) / SCAN_THREADS)) * (SCAN_THREADS / 64) +
+			                       (uint32_t)wave_id()) % (uint32_t)LONG_LISTS;
+			if (lane_id() == leader) at = atomicAdd(&long_counts[list * LONG_COUNT_STRIDE], (uint32_t)__popcll(lm));
+			at = wave_shfl_u32(at, leader);
+			if ((lm >> lane_id()) & 1ull) long_runs[(size_t)list * long_capacity + at + (uint32_t)__popcll(lm & lanemask_lt())] = id;
+		}
 	}
 	uint32_t tot;
 	block_excl_scan_256(acc, &tot, s_wave);
@@ -117,13 +138,15 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 }
 
 int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
-                           hipStream_t stream, const uint32_t* n_dev, uint32_t* seeds, uint32_t seed_stride, uint32_t seed_capacity)
+                           hipStream_t stream, const uint32_t* n_dev, uint32_t* seeds, uint32_t seed_stride, uint32_t seed_capacity,
+                           uint32_t* long_runs, uint32_t* long_counts, uint32_t long_capacity)
 {
 	if (!rect || !gather || !out || !rect_sorted) return GSR_ERR_INVALID_ARG;
 	if (n <= 0) return GSR_OK;
 	const int ipb = scan_items_per_block(n);
 	const int nb = div_up(n, ipb);
-	GSR_LAUNCH(scan_reduce_rect_kernel, nb, SCAN_THREADS, stream, rect, gather, out, rect_sorted, scratch, n, ipb, n_dev);
+	GSR_LAUNCH(scan_reduce_rect_kernel, nb, SCAN_THREADS, stream, rect, gather, out, rect_sorted, scratch, n, ipb, n_dev, long_runs, long_counts,
+	           long_capacity);
 	GSR_LAUNCH(scan_apply_kernel, nb, SCAN_THREADS, stream, (const uint32_t*)out, (const uint32_t*)nullptr, out,
 	           (const uint32_t*)scratch, n, ipb, 0, seeds, seed_stride, seed_capacity);
 	GSR_CHECK_LAUNCH();

@@ -25,16 +25,21 @@ constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
-// A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length.
-// A longer run (a screen-filling splat: 3 359 of the 934 k visible Gaussians at C3, the longest 3 192 tiles) is FOLDED: the
-// backward blend adds the sums of instance k to slot first + (k % LONG_FOLD) with float atomics instead of storing them to slot
-// first + k (blend_bwd.hip), so that the owner lane never sums more than LONG_FOLD slots -- densification appends the children of
-// split (large) Gaussians consecutively, and 64 unbounded runs in one wave once turned that wave into the kernel's tail
-// (preprocess_bwd 140 -> 450 us after ten densifications at C3).  Until round 5 those runs were listed by the forward
-// preprocess and summed by a kernel of their own between the two backward kernels (22 us at C3: the longest run's chain of
-// dependent round trips, on an otherwise idle device).  The LONG_FOLD accumulator slots of such a run are zeroed by the
-// instance emission and again by their reader (partials.h); at most cnt / LONG_FOLD atomics meet on one address.
+// A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length;
+// longer runs (screen-filling splats: 3 359 of the 934 k visible Gaussians at C3, the longest 3 192 tiles) are LISTED by the
+// forward pass and summed one WAVE per run by a kernel of their own between the two backward kernels (partials.h) --
+// densification appends the children of split (large) Gaussians consecutively, and 64 unbounded runs in one wave of
+// preprocess_bwd once turned that wave into the kernel's tail (140 -> 450 us after ten densifications at C3).
+// (Round 5 also built the alternative without that kernel: the backward blend ADDING such a run's sums into a few shared slots
+// with float atomics.  16 us faster at C3, where 1.6 % of the written slots belong to long runs -- and 83 us SLOWER in the
+// backward blend of the mapper-loop leg, whose inflated scene has them everywhere: nine atomics per touched instance do not
+// scale.  profiles/r05_d, r05_w; reverted.)
 constexpr uint32_t LONG_RUN = 64;
+constexpr int LONG_LISTS = 64, LONG_COUNT_STRIDE = 32;
+// the offset scan's first pass lists them (sort.hip: scan_reduce_rect_kernel; its waves append to the LONG_LISTS sub-lists in
+// turn -- one global counter would serialise a few thousand same-address atomics): the capacity of a sub-list covers its appenders
+static inline size_t long_list_capacity(size_t P);
+
 // float4 per instance gradient slot: nine sums in three float4 (48 bytes).  A 48-byte slot straddles two 64-byte sectors half of
 // the time, and at 22 % density every slot is fetched, and written, on its own; padded to 64 bytes (GSR_EXTRA_FLAGS=-DGSR_SLOT_F4=4)
 // the step was 16 us SLOWER on one box (1.506 -> 1.522 ms median, profiles/r05_v: the per-Gaussian stage +7 us, every stage that
@@ -43,10 +48,6 @@ constexpr uint32_t LONG_RUN = 64;
 #define GSR_SLOT_F4 3
 #endif
 constexpr int SLOT_F4 = GSR_SLOT_F4;
-constexpr uint32_t LONG_FOLD = 8;     // (a power of two <= LONG_RUN; GSR_LONG_FOLD overrides it for A/B runs: long_fold())
-static_assert(LONG_FOLD <= LONG_RUN && (LONG_FOLD & (LONG_FOLD - 1)) == 0, "a folded run uses its own first LONG_FOLD slots");
-uint32_t long_fold();                  // gsr_api.hip
-constexpr uint32_t SLOT_FOLDED = 0x80000000u;   // blend_bwd's slot word: accumulate with atomics (R < 2^31: gsr_forward)
 
 constexpr int SCAN_THREADS = 256;
 
@@ -59,6 +60,13 @@ static inline int scan_items_per_block(int n)
 	return ipb;
 }
 static inline int scan_blocks(int n) { return n > 0 ? div_up(n, scan_items_per_block(n)) : 1; }
+static inline size_t long_list_capacity(size_t P)
+{
+	// every (scan block, trip, wave) appends at most 64 entries to ONE sub-list, and the sub-lists take them in turn
+	const size_t ipb = (size_t)scan_items_per_block((int)P), blocks = (P + ipb - 1) / ipb;
+	const size_t appenders = blocks * (ipb / SCAN_THREADS) * (SCAN_THREADS / 64);
+	return ((appenders + LONG_LISTS - 1) / LONG_LISTS) * 64;
+}
 static inline size_t scan_scratch_elems(int n) { return (size_t)scan_blocks(n) + 64; }
 // histogram [RADIX_BINS][blocks] + its scanned copy + scan spine
 static inline size_t sort_scratch_elems(int n)
@@ -78,6 +86,9 @@ struct GeometryState {
 	uint2*    wave_counts;    // [wave_count_slots(P)] per wave of preprocess_fwd: (tiles touched, visible Gaussians); the totals are
 	                          // num_rendered and gsr_last_visible_count() (summed inside the depth sort's first two launches)
 	uint4*    count_partials; // [sort_blocks(P)] the first level of that sum
+	uint32_t* long_runs;      // [LONG_LISTS * long_list_capacity(P)] ids of the Gaussians that touch more than LONG_RUN tiles
+	uint32_t* long_counts;    // [LONG_LISTS * LONG_COUNT_STRIDE] entries per sub-list, one cache line apart (zeroed by the projection kernel)
+	uint32_t  long_capacity;  // long_list_capacity(P)
 	uint32_t* depth_key;      // [P]
 	uint32_t* tiles_touched;  // [P]
 	int*      radii;          // [P]
@@ -118,6 +129,9 @@ struct GeometryState {
 		g.visible = c.take<uint32_t>(32);
 		g.wave_counts = c.take<uint2>(wave_count_slots(P));   // (written in full by every forward pass: nothing has to be zeroed)
 		g.count_partials = c.take<uint4>((size_t)sort_blocks((int)P));
+		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
+		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
+		g.long_capacity = (uint32_t)long_list_capacity(P);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return g;
 	}
@@ -224,9 +238,11 @@ static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((u
 // exclusive scan of the tile counts of rect[gather[i]] ((maxx - minx) * (maxy - miny), packed as preprocess_fwd writes them) into
 // out, with the gathered rectangles left in rect_sorted; elements from *n_dev on count as zeros
 // seeds (nullable): seeds[k] = the element whose instances hold instance slot k * seed_stride, for k < seed_capacity
+// long_runs / long_counts / long_capacity (nullable): the elements whose count exceeds LONG_RUN are listed (GeometryState)
 int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* out, uint2* rect_sorted, int n, uint32_t* scratch,
                            hipStream_t stream, const uint32_t* n_dev, uint32_t* seeds = nullptr, uint32_t seed_stride = 1,
-                           uint32_t seed_capacity = 0);
+                           uint32_t seed_capacity = 0, uint32_t* long_runs = nullptr, uint32_t* long_counts = nullptr,
+                           uint32_t long_capacity = 0);
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
                     uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
 // A job that rides in the first two launches of a sort: add up n (a, b) pairs -- every histogram workgroup its share into

@@ -211,6 +211,27 @@ def test_single_huge_splat_and_opaque_wall(emu_lib_path, oracle):
     parity.compare(r, ores, ocolor, oradii, ograds, cam)
 
 
+def test_run_of_more_than_4096_instance_slots(emu_lib_path, oracle):
+    """A splat that covers every tile of a 72 x 64-tile image: a run of 4 608 instance slots, i.e. more than 64 slots per lane of
+    the wave that sums it (partials.h: wave_sum_long_run takes a lane's consecutive slots in groups of 64)."""
+    W, H = 72 * 16, 64 * 16
+    cl = scene.make_cloud(60, W, H, 0.9 * W, 0.9 * W, seed=5, scale_k=0.3)
+    cam = cl.cameras[0]
+    fwd = cam.viewmatrix[:3, 2]
+    cl.xyz[0] = cam.campos + 2.0 * fwd
+    cl.scaling[0] = np.log(6.0)
+    cl.opacity[0] = -1.0          # translucent: every pixel of every tile blends it, everything behind it too
+    cl.xyz[1:4] = cam.campos + 2.5 * fwd + 0.3 * np.random.default_rng(2).standard_normal((3, 3)).astype(np.float32)
+    cl.scaling[1:4] = np.log(3.0)
+    cl.opacity[1:4] = -1.5
+    bg = np.array([0.2, 0.1, 0.3], np.float32)
+    dpix = np.random.default_rng(7).standard_normal((3, H, W)).astype(np.float32)
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+    assert ores.tiles_touched[0] == 72 * 64 and (ores.tiles_touched[1:4] > 4096).any()
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix)
+    parity.compare(r, ores, ocolor, oradii, ograds, cam)
+
+
 def _long_run_scene():
     W, H = 176, 160   # 11 x 10 = 110 tiles
     cl = scene.make_cloud(200, W, H, 0.8 * W, 0.8 * W, seed=31, scale_k=0.35)
@@ -224,20 +245,18 @@ def _long_run_scene():
     return cl, cam, big, rng
 
 
-def test_backward_twice_with_folded_runs(emu_lib_path):
-    """The accumulator slots of the folded runs are zeroed by the instance emission and AGAIN by their reader: a second and a
-    third backward pass on the state of one forward pass give the gradients of a first one."""
+def test_backward_twice_with_long_runs(emu_lib_path):
+    """A second and a third backward pass on the state of one forward pass give the gradients of a first one, long runs included
+    (long_run_sums_kernel overwrites a run's first slot with the run's total: the backward blend rewrites every touched slot)."""
     cl, cam, big, rng = _long_run_scene()
     parity.check_backward_twice(emu_lib_path, CPU, cl, np.array([0.1, 0.3, 0.2], np.float32))
 
 
 def test_long_runs_of_instance_slots(emu_lib_path, oracle):
-    """Gaussians that touch more than 64 tiles (state.h LONG_RUN): the backward blend folds their per-instance gradient sums
-    into the run's first LONG_FOLD slots with float atomics, and the owner lane of the backward preprocess sums those -- here 70
-    of them CONSECUTIVE in index order at the end of the arrays (what densification produces: the children of split
-    Gaussians), more than one wave of the backward preprocess holds, next to small ones; runs of exactly 64 and 65 tiles sit
-    on the threshold.  A second backward pass on the same forward state must find the accumulators zeroed again
-    (parity.check_backward_twice covers that on a scene with such runs: test_backward_twice_with_folded_runs)."""
+    """Gaussians that touch more than 64 tiles (state.h LONG_RUN): their per-instance gradient slots are summed by
+    long_run_sums_kernel, one wave per run, from the list the offset scan leaves -- here 70 of them CONSECUTIVE in index order
+    at the end of the arrays (what densification produces: the children of split Gaussians), more than one wave of the
+    backward preprocess holds, next to small ones; runs of exactly 64 and 65 tiles sit on the threshold."""
     cl, cam, big, rng = _long_run_scene()
     W, H = cam.W, cam.H
     bg = np.array([0.1, 0.3, 0.2], np.float32)
