@@ -65,3 +65,46 @@ np.savez(sys.argv[1], point_list=r.point_list, tile_keys=r.tile_keys, ranges=r.r
     assert int(outs[0]["R"]) > 256 * 4      # (several windows)
     for k in ("point_list", "tile_keys", "ranges", "color"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_library_switches_of_round_5_change_no_result(emu_lib_path, tmp_path):
+    """The A/B handles of round 5 select HOW the work is dealt, counted and summed -- never what comes out:
+    the blend kernels' deal of tiles to the XCDs (one band per XCD / row-major chunks / squares with the backward blend taking the
+    heaviest squares first), the tile sort's first histogram counted by the emission or by its own launch, the three forms of the
+    wave that sums a long run, the touched slots per trip.  Image and lists are those of the default setting bit for bit, the
+    gradients to the order of a tile's four LDS adds.  Each switch is read once per process: children."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import conftest, parity
+from photo_slam_amd import scene
+cl = scene.make_cloud(900, 208, 176, 170.0, 170.0, seed=3, scale_k=0.5)      # 13 x 11 tiles: squares of 2 and 4 with ragged edges
+cam = cl.cameras[0]
+dpix = np.random.default_rng(1).standard_normal((3, cam.H, cam.W)).astype(np.float32)
+r = parity.run_backend({emu_lib_path!r}, torch.device('cpu'), cl, cam, np.array([0.2, 0.5, 0.1], np.float32), dL_dpix=dpix)
+np.savez(sys.argv[1], point_list=r.point_list, ranges=r.ranges, color=r.out_color, n_contrib=r.n_contrib, R=r.R,
+         **{{'g_' + k: v for k, v in r.grads.items()}})
+"""
+    # (independent switches share a child: the suite stays short)
+    settings = [{}, {"GSR_XCD_CHUNK": "0", "GSR_LRS_MODE": "2", "GSR_SLOT_TRIP": "4"},
+                {"GSR_XCD_CHUNK": "5", "GSR_EMIT_HIST": "0", "GSR_LRS_MODE": "0", "GSR_SLOT_TRIP": "1"},
+                {"GSR_XCD_CHUNK": "-2"}, {"GSR_XCD_CHUNK": "-4"}, {"GSR_XCD_CHUNK": "-4", "GSR_BWD_HEAVY_FIRST": "0"}]
+    outs = []
+    for i, extra in enumerate(settings):
+        out = str(tmp_path / f"switch_{i}.npz")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, PYTEST_CURRENT_TEST="switches", **extra), timeout=600)
+        outs.append(np.load(out))
+    assert int(outs[0]["R"]) > 2048 and any(k.startswith("g_") for k in outs[0].files)
+    for i, o in enumerate(outs[1:], 1):
+        for k in outs[0].files:
+            if k.startswith("g_"):
+                # (the heaviest-first lookup puts one more barrier in front of the backward blend: the four quad-waves of a tile
+                # then meet the emulator's scheduler in another order, and so do their LDS adds -- the last bits, as on the hardware)
+                d = np.abs(outs[0][k].astype(np.float64) - o[k]).sum() / max(np.abs(outs[0][k]).sum(), 1e-30)
+                assert d < 1e-6, (settings[i], k, d)
+            else:
+                assert np.array_equal(outs[0][k], o[k], equal_nan=True), (settings[i], k)
