@@ -299,3 +299,33 @@ def test_cull_empty_tiles_at_full_size(dev, cfg):
     kept, listed = parity.check_cull_empty_tiles(None, dev, cl, cl.cameras[0], np.array([0.1, 0.2, 0.3], np.float32), exact=False)
     print(f"{cfg}: instances listed {listed} -> {kept} ({kept / listed:.1%})")
     assert kept < 0.8 * listed   # measured: C2 62 %, C5 74 % of the rectangles' instances survive the tile-level bound
+
+
+@pytest.mark.parametrize("switches", [{"GSR_XCD_CHUNK": "0", "GSR_LRS_MODE": "0", "GSR_SLOT_TRIP": "1", "GSR_EMIT_HIST": "0"},
+                                      {"GSR_XCD_CHUNK": "-4", "GSR_LRS_MODE": "2", "GSR_SLOT_TRIP": "4"},
+                                      {"GSR_XCD_CHUNK": "-1"}])
+def test_library_switches_of_round_5_on_gpu(dev, switches, tmp_path):
+    """The A/B handles of round 5 on the hardware: one band of the image per XCD with the rounds-2-to-4
+    forms of the helpers; squares of 4 x 4 tiles / single tiles with the backward blend taking the heaviest first.  Every stage
+    against the oracle at C2, in a child process (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import conftest, parity
+from photo_slam_amd import scene
+from oracle import oracle
+oracle.build()
+cl = scene.make_config("C2", seed=0)
+cam = cl.cameras[0]
+bg = np.zeros(3, np.float32)
+dpix = np.random.default_rng(0).standard_normal((3, cam.H, cam.W)).astype(np.float32)
+ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+r = parity.run_backend(None, torch.device("cuda:0"), cl, cam, bg, dL_dpix=dpix)
+print(parity.compare(r, ores, ocolor, oradii, ograds, cam))
+assert ores.R > 1_000_000
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PYTEST_CURRENT_TEST="switches", **switches), timeout=900)
