@@ -171,8 +171,8 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 
 // ------------------------------------------------------------------ radix sort
 // Pass structure (per 8-bit digit):  histogram -> exclusive scan of the [bin][block] table
-// -> scatter.  Block b always owns elements [b*4096, (b+1)*4096); wave w of the block owns
-// the 1024-element sub-range starting at w*1024 and walks it in 16 rounds of 64 lane-
+// -> scatter.  Block b always owns elements [b*SORT_CHUNK, (b+1)*SORT_CHUNK) (2 048); wave w of the block owns
+// the 512-element sub-range starting at w*512 and walks it in 8 rounds of 64 lane-
 // consecutive elements, so the original order inside a digit is (wave, round, lane).
 
 // the 64-bit wave sum from 32-bit wave sums of three pieces of every lane's value (64 lanes x 2^16 fits 32 bits; the forward
