@@ -122,15 +122,57 @@ scan_apply_kernel(const uint32_t* in, const uint32_t* __restrict__ gather, uint3
 		for (int j = (int)threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) part += block_sums[j];
 		(void)block_excl_scan_256(part, &carry, s_wave);
 	}
+	if (!gather) {
+		// eight consecutive elements per thread and trip (two 16-byte loads, one block scan per 2 048 elements -- it was a block scan
+		// with its two barriers per 256: 8.8 -> about 5 us for the 2 M offsets of C3)
+		constexpr int IPT = 8;
+		const bool aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+		for (int b = base; b < end; b += SCAN_THREADS * IPT) {
+			const int i0 = b + (int)threadIdx.x * IPT;
+			uint32_t v[IPT];
+			const bool vec = i0 + IPT <= end && aligned16;   // (b is a multiple of 2 048 elements: the vectors are as aligned as the arrays)
+			if (vec) {
+				const uint4 lo = *reinterpret_cast<const uint4*>(in + i0), hi = *reinterpret_cast<const uint4*>(in + i0 + 4);
+				v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < IPT; j++) v[j] = i0 + j < end ? in[i0 + j] : 0u;
+			}
+			uint32_t sum = 0;
+#pragma unroll
+			for (int j = 0; j < IPT; j++) sum += v[j];
+			uint32_t tot;
+			uint32_t run = carry + block_excl_scan_256(sum, &tot, s_wave);   // exclusive prefix of this thread's first element
+			uint32_t o[IPT];
+#pragma unroll
+			for (int j = 0; j < IPT; j++) {
+				const uint32_t first = run;
+				run += v[j];
+				o[j] = inclusive ? run : first;
+				if (seeds && i0 + j < end && v[j] != 0u)
+					// (one element in seed_stride / mean count holds a seed position; a screen-filling splat holds a few dozen)
+					for (uint32_t k = (first + seed_stride - 1u) / seed_stride; k < seed_capacity && k * seed_stride < first + v[j]; k++) seeds[k] = (uint32_t)(i0 + j);
+			}
+			if (vec) {
+				*reinterpret_cast<uint4*>(out + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+				*reinterpret_cast<uint4*>(out + i0 + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+			} else {
+#pragma unroll
+				for (int j = 0; j < IPT; j++)
+					if (i0 + j < end) out[i0 + j] = o[j];
+			}
+			carry += tot;
+		}
+		return;
+	}
 	for (int b = base; b < end; b += SCAN_THREADS) {
 		const int i = b + (int)threadIdx.x;
-		const uint32_t v = i < end ? (gather ? in[gather[i]] : in[i]) : 0u;
+		const uint32_t v = i < end ? in[gather[i]] : 0u;
 		uint32_t tot;
 		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
 		if (i < end) out[i] = carry + ex + (inclusive ? v : 0u);
 		if (seeds && i < end && v != 0u) {
 			const uint32_t first = carry + ex;
-			// (one element in seed_stride / mean count holds a seed position; a screen-filling splat holds a few dozen)
 			for (uint32_t k = (first + seed_stride - 1u) / seed_stride; k < seed_capacity && k * seed_stride < first + v; k++) seeds[k] = (uint32_t)i;
 		}
 		carry += tot;
