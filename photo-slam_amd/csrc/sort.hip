@@ -332,12 +332,23 @@ radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tota
 	}
 	uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
 	uint32_t carry = 0;
-	for (int base = 0; base < nblocks; base += SCAN_THREADS) {
-		const int i = base + (int)threadIdx.x;
-		const uint32_t v = i < nblocks ? row[i] : 0u;
+	// (four consecutive entries per thread and trip: one block scan per 1 024 entries -- a row of the depth sort in one trip)
+	constexpr int IPT = 4;
+	for (int base = 0; base < nblocks; base += SCAN_THREADS * IPT) {
+		const int i0 = base + (int)threadIdx.x * IPT;
+		uint32_t v[IPT], sum = 0;
+#pragma unroll
+		for (int j = 0; j < IPT; j++) {
+			v[j] = i0 + j < nblocks ? row[i0 + j] : 0u;
+			sum += v[j];
+		}
 		uint32_t tot;
-		const uint32_t ex = block_excl_scan_256(v, &tot, s_wave);
-		if (i < nblocks) row[i] = carry + ex;
+		uint32_t run = carry + block_excl_scan_256(sum, &tot, s_wave);
+#pragma unroll
+		for (int j = 0; j < IPT; j++) {
+			if (i0 + j < nblocks) row[i0 + j] = run;
+			run += v[j];
+		}
 		carry += tot;
 	}
 	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
