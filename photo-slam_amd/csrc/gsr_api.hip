@@ -307,7 +307,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
 	pp.raw_params = a->raw_params | (cov3D_stored() ? GSR_STORE_COV3D : 0);
 	pp.ranges = im.ranges; pp.tiles = tiles;   // zeroed there: rasterizer_impl.cu:310
-	pp.sched = im.sched;
+	pp.sched = xcd_deal_mode(tiles) < 0 ? im.sched : nullptr;   // (the heaviest-first bookkeeping: only in the deal modes that file chunks)
 	pp.lazy = LazyAdam{};
 	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
 		if (!a->shs) return GSR_ERR_INVALID_ARG;
