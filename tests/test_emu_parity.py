@@ -93,10 +93,13 @@ np.savez(sys.argv[1], point_list=r.point_list, ranges=r.ranges, color=r.out_colo
     settings = [{}, {"GSR_XCD_CHUNK": "0", "GSR_LRS_MODE": "2", "GSR_SLOT_TRIP": "4"},
                 {"GSR_XCD_CHUNK": "5", "GSR_EMIT_HIST": "0", "GSR_LRS_MODE": "0", "GSR_SLOT_TRIP": "1"},
                 {"GSR_XCD_CHUNK": "-2"}, {"GSR_XCD_CHUNK": "-4"}, {"GSR_XCD_CHUNK": "-4", "GSR_BWD_HEAVY_FIRST": "0"}]
-    outs = []
-    for i, extra in enumerate(settings):
+    procs = []
+    for i, extra in enumerate(settings):   # (the children run side by side)
         out = str(tmp_path / f"switch_{i}.npz")
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, PYTEST_CURRENT_TEST="switches", **extra), timeout=600)
+        procs.append((subprocess.Popen([sys.executable, "-c", code, out], env=dict(os.environ, PYTEST_CURRENT_TEST="switches", OMP_NUM_THREADS="2", **extra)), out))
+    outs = []
+    for proc, out in procs:
+        assert proc.wait(timeout=600) == 0
         outs.append(np.load(out))
     assert int(outs[0]["R"]) > 2048 and any(k.startswith("g_") for k in outs[0].files)
     for i, o in enumerate(outs[1:], 1):
