@@ -4,7 +4,7 @@
 //
 // Forward launch sequence (reference: Rasterizer::forward, rasterizer_impl.cu:198-336):
 //   preprocess (every wave leaves its (tiles, visible) pair with a plain store)
-//   -> depth sort of the P Gaussians (4 x 8-bit passes; its first two launches sum the pairs on the side = num_rendered, into
+//   -> depth sort of the P Gaussians (3 x 9-bit passes over key - bits(0.2f); its first two launches sum the pairs on the side = num_rendered, into
 //      mapped host memory, event behind them -- the reference blocks on a copy here, :281) -> exclusive scan in depth order
 //   -> host waits for the event only now, sizes the binning buffer
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
@@ -133,6 +133,18 @@ static bool heavy_first()
 	static const int env = env_int("GSR_BWD_HEAVY_FIRST", 1);
 	return env != 0;
 }
+// The depth sort's significant bits when it runs on key - DEPTH_KEY_BIAS with 9-bit digits (27 = three passes); 0 = the plain
+// sort of 32 bits in four passes.  GSR_DEPTH_SORT_9BIT=0 selects the plain sort (A/B handle); GSR_DEPTH_SORT_BITS=n (tests)
+// narrows the range so that ordinary scenes take the re-sort path.
+static int depth_sort_wide()
+{
+	static const int on = env_int("GSR_DEPTH_SORT_9BIT", 1);
+	static const int bits = env_int("GSR_DEPTH_SORT_BITS", 3 * RADIX_BITS_WIDE);
+	if (!on) return 0;
+	// (an odd number of 9-bit passes: 1 .. 9, 19 .. 27 bits)
+	return (bits >= 1 && bits <= 27 && (div_up(bits, RADIX_BITS_WIDE) & 1)) ? bits : 3 * RADIX_BITS_WIDE;
+}
+static thread_local long long t_depth_resorts = 0;   // forward passes of this thread that took the second path (tests)
 static bool emit_hist()
 {
 	static const int env = env_int("GSR_EMIT_HIST", 1);
@@ -325,16 +337,33 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	// Gaussians (key 0xFFFFFFFF, RADIX_INVALID_KEY), leaving V in g.visible; the other three passes and the scan run over the
 	// V visible ones only (V = 0.47 P at C3).  order[V..P) is undefined, offsets[V..P) = R: the culled Gaussians used to sort
 	// to the end with exactly that offset, so the instance emission sees the same arrays.
+	//
+	// Three passes, not four: a visible Gaussian has z > 0.2 (the frustum test), so its key -- the bits of a positive float --
+	// exceeds DEPTH_KEY_BIAS = bits(0.2f), and key - DEPTH_KEY_BIAS (an order-preserving shift) has its high five bits zero for
+	// every z < 0.2 * 2^16 = 13 107: 27 bits = 3 digits of 9.  The largest key of the view reaches the host with the instance
+	// count; a view that holds a Gaussian beyond that range (or a NaN depth) sorts again with the plain four passes of eight
+	// bits (depth_sort_wide()/GSR_DEPTH_SORT_9BIT=0: the A/B handle; GSR_DEPTH_SORT_BITS: the test handle of the second path).
 	uint32_t *kres = nullptr, *vres = nullptr;
-	if ((st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32,
-	                            g.sort_scratch, stream, &kres, &vres, g.visible, &hc)) != GSR_OK)
-		return st;
-	// vres == g.order (4 passes end in the ping buffers)
+	const int narrow_bits = depth_sort_wide();   // 0 = the plain sort
+	auto plain_depth_sort = [&](const RadixHostCount* ride) {
+		return launch_radix_sort(g.depth_key, nullptr, g.sort_keys_a, g.order, g.sort_keys_b, g.sort_vals_b, P, 0, 32, g.sort_scratch, stream,
+		                         &kres, &vres, g.visible, ride);   // (4 passes end in the ping buffers: vres == g.order)
+	};
+	auto offset_scan = [&]() {
+		// (g.sort_keys_b, the depth sort's spare buffer, is free again: it receives the emission's seeds -- binning.hip)
+		return launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
+		                              g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P, g.long_runs, g.long_counts, g.long_capacity);
+	};
+	if (narrow_bits) {
+		// (ping and pong swapped: an odd number of passes ends in the pong buffers, and the order must end in g.order)
+		st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_b, g.sort_vals_b, g.sort_keys_a, g.order, P, 0, narrow_bits, g.sort_scratch, stream,
+		                       &kres, &vres, g.visible, &hc, false, RADIX_BITS_WIDE, DEPTH_KEY_BIAS);
+		if (st == GSR_OK && vres != g.order) st = GSR_ERR_INVALID_ARG;   // (an even number of wide passes: not a configuration of this library)
+	} else
+		st = plain_depth_sort(&hc);
+	if (st != GSR_OK) return st;
 	PROF_FWD(2);
-	// (g.sort_keys_b, the depth sort's pong buffer, is free again: it receives the emission's seeds -- binning.hip)
-	if ((st = launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
-	                                 g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P, g.long_runs, g.long_counts, g.long_capacity)) != GSR_OK)
-		return st;
+	if ((st = offset_scan()) != GSR_OK) return st;
 	PROF_FWD(3);
 
 	{
@@ -346,6 +375,14 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	const unsigned long long R64 = (unsigned long long)t_sync.pinned[0] | ((unsigned long long)t_sync.pinned[1] << 32);
 	const unsigned long long V64 = t_sync.pinned[2];
 	t_last_visible = (int)V64;
+	if (narrow_bits && V64 != 0 && (t_sync.pinned[3] - DEPTH_KEY_BIAS) >> narrow_bits) {
+		// a depth beyond the three-pass range (z >= 13 107, or not a number): the order just produced is wrong for those keys --
+		// sort again on all 32 bits and redo the offsets (the list of long runs is built by the scan: its counters start over)
+		GSR_HIP(hipMemsetAsync(g.long_counts, 0, (size_t)LONG_LISTS * LONG_COUNT_STRIDE * sizeof(uint32_t), stream));
+		if ((st = plain_depth_sort(nullptr)) != GSR_OK) return st;
+		if ((st = offset_scan()) != GSR_OK) return st;
+		t_depth_resorts++;
+	}
 	if (R64 > 0x7FFFFFFFull) return GSR_ERR_UNSUPPORTED;  // more than 2^31 instances
 	const int R = (int)R64;
 	char* bin_chunk = binningBuffer(binning_ctx, binning_bytes(R));
@@ -698,6 +735,7 @@ int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float*
 }
 
 int gsr_last_visible_count(void) { return t_last_visible; }
+long long gsr_depth_resort_count(void) { return t_depth_resorts; }
 
 int gsr_check_packed_views(int P, int n_views, const uint32_t* messages, long long msg_stride, int capacity_rows, void* stream_)
 {

@@ -244,7 +244,10 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	// so the host's wait can overlap the depth sort.
 	const unsigned long long wave_ballot_of_visible = wave_ballot(my_tiles != 0u);
 	const uint32_t wsum = wave_sum_u32(my_tiles);
-	if (lane_id() == 0) g.wave_counts[(size_t)blockIdx.x * (PRE_THREADS / 64) + w] = make_uint2(wsum, (uint32_t)__popcll(wave_ballot_of_visible));
+	// (the largest depth key of a visible Gaussian rides along: the depth sort runs on 27 bits of key - bits(0.2f) and the host
+	// checks, when it reads the counts, that no key needed more -- gsr_api.hip)
+	const uint32_t wmaxkey = wave_max_u32(my_tiles != 0u ? depth_key : 0u);
+	if (lane_id() == 0) g.wave_counts[(size_t)blockIdx.x * (PRE_THREADS / 64) + w] = make_uint4(wsum, (uint32_t)__popcll(wave_ballot_of_visible), wmaxkey, 0u);
 }
 
 // checkFrustum, cuda_rasterizer/rasterizer_impl.cu:54-66

@@ -226,9 +226,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u64_by_parts(unsigned lon
 	       ((unsigned long long)wave_sum_u32(hi) << 32);
 }
 
+// BINS: 256 (digits of up to 8 bits) or 512 (9 bits: the depth sort's three passes over bias-subtracted keys).  bias is subtracted
+// from every key in front of the digit (0 for everybody else): an order-preserving shift that makes the high bits zero.
+template <int BINS>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits, uint32_t* __restrict__ hist, int nblocks,
-                  const uint32_t* __restrict__ n_dev, int skip_invalid, const RadixHostCount hc)
+                  const uint32_t* __restrict__ n_dev, int skip_invalid, const RadixHostCount hc, uint32_t bias)
 {
 	// The forward pass's count for the host rides in the first two launches of the depth sort (gsr_api.hip): here every workgroup
 	// adds up ITS share of the (tiles touched, visible) pairs the projection kernel's waves left (a few dozen pairs: one
@@ -239,36 +242,41 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 		__shared__ unsigned long long s_t[SORT_THREADS / 64];
 		__shared__ uint32_t s_v[SORT_THREADS / 64];
 		const int share = (hc.n + nblocks - 1) / nblocks;
+		__shared__ uint32_t s_m[SORT_THREADS / 64];
 		unsigned long long t = 0ull;
-		uint32_t v = 0u;
+		uint32_t v = 0u, mx = 0u;
 		for (int i = (int)blockIdx.x * share + (int)threadIdx.x; i < min(hc.n, ((int)blockIdx.x + 1) * share); i += SORT_THREADS) {
-			const uint2 c = hc.pairs[i];
+			const uint4 c = hc.pairs[i];
 			t += c.x;
 			v += c.y;
+			mx = max(mx, c.z);
 		}
 		const unsigned long long wt = wave_sum_u64_by_parts(t);
-		const uint32_t wv = wave_sum_u32(v);
+		const uint32_t wv = wave_sum_u32(v), wm = wave_max_u32(mx);
 		if (lane_id() == 0) {
 			s_t[wave_id()] = wt;
 			s_v[wave_id()] = wv;
+			s_m[wave_id()] = wm;
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			unsigned long long T = 0ull;
-			uint32_t V = 0u;
+			uint32_t V = 0u, M = 0u;
 			for (int i = 0; i < SORT_THREADS / 64; i++) {
 				T += s_t[i];
 				V += s_v[i];
+				M = max(M, s_m[i]);
 			}
-			hc.partials[blockIdx.x] = make_uint4((uint32_t)(T & 0xFFFFFFFFull), (uint32_t)(T >> 32), V, 0u);
+			hc.partials[blockIdx.x] = make_uint4((uint32_t)(T & 0xFFFFFFFFull), (uint32_t)(T >> 32), V, M);
 		}
 		__syncthreads();
 	}
 	// n_dev (nullable): the number of elements lives on the device (the compacted depth sort: set by the first pass's
 	// scatter); blocks beyond it still write their (all-zero) histogram columns.  skip_invalid: keys equal to
 	// RADIX_INVALID_KEY are no elements at all (culled Gaussians: never counted, never scattered).
-	__shared__ uint32_t s_hist[RADIX_BINS];
-	s_hist[threadIdx.x] = 0;
+	__shared__ uint32_t s_hist[BINS];
+#pragma unroll
+	for (int d = (int)threadIdx.x; d < BINS; d += SORT_THREADS) s_hist[d] = 0;
 	if (n_dev) n = min(n, (int)*n_dev);
 	__syncthreads();
 	const uint32_t dmask = (1u << nbits) - 1u;
@@ -285,11 +293,11 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, int n, int shift, int nbits
 		const int i = wbase + r * 64 + lane_id();
 		// one LDS atomic per key: even 64 lanes on one bin (64 serialised adds) cost less than the ~60 VALU of a ballot
 		// match; only the scatter kernel needs the match, for its stable ranks
-		if (i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY)) atomicAdd(&s_hist[(key[r] >> shift) & dmask], 1u);
+		if (i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY)) atomicAdd(&s_hist[((key[r] - bias) >> shift) & dmask], 1u);
 	}
 	__syncthreads();
 	// (rows beyond the pass's digits -- 128 of the 256 in a 7-bit pass of the tile sort -- are never read: not written either)
-	if ((int)threadIdx.x < (1 << nbits)) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
+	for (int d = (int)threadIdx.x; d < (1 << nbits); d += SORT_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = s_hist[d];
 }
 
 // One workgroup per digit: exclusive scan of that digit's row hist[d][0..nblocks) in place, row total to
@@ -303,30 +311,35 @@ radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tota
 		// the extra workgroup of the depth sort's first pass (radix_hist_kernel): the histogram blocks' partial counts -> the totals,
 		// stored into mapped host memory; the event the host waits for is recorded behind this launch
 		__shared__ unsigned long long s_t[SCAN_THREADS / 64];
+		__shared__ uint32_t s_m[SCAN_THREADS / 64];
 		unsigned long long t = 0ull;
-		uint32_t v = 0u;
+		uint32_t v = 0u, mx = 0u;
 		for (int i = (int)threadIdx.x; i < nblocks; i += SCAN_THREADS) {
 			const uint4 c = hc.partials[i];
 			t += (unsigned long long)c.x | ((unsigned long long)c.y << 32);
 			v += c.z;
+			mx = max(mx, c.w);
 		}
 		const unsigned long long wt = wave_sum_u64_by_parts(t);
-		const uint32_t wv = wave_sum_u32(v);
+		const uint32_t wv = wave_sum_u32(v), wm = wave_max_u32(mx);
 		if (lane_id() == 0) {
 			s_t[wave_id()] = wt;
 			s_wave[wave_id()] = wv;
+			s_m[wave_id()] = wm;
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			unsigned long long T = 0ull;
-			uint32_t V = 0u;
+			uint32_t V = 0u, M = 0u;
 			for (int i = 0; i < SCAN_THREADS / 64; i++) {
 				T += s_t[i];
 				V += s_wave[i];
+				M = max(M, s_m[i]);
 			}
 			hc.host_out[0] = (uint32_t)(T & 0xFFFFFFFFull);
 			hc.host_out[1] = (uint32_t)(T >> 32);
 			hc.host_out[2] = V;
+			hc.host_out[3] = M;
 		}
 		return;
 	}
@@ -354,15 +367,17 @@ radix_row_prefix_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ tota
 	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <int BINS>
 __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
                      const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks,
-                     const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out)
+                     const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out, uint32_t bias)
 {
+	constexpr int DPT = BINS / SORT_THREADS;   // digits per thread in phase B: thread t owns digits t DPT .. t DPT + DPT - 1
 	if (n_dev) n = min(n, (int)*n_dev);
-	__shared__ uint32_t s_whist[4][RADIX_BINS];  // per-wave digit counts, then per-wave running write cursors
-	__shared__ uint32_t s_gbase[RADIX_BINS];     // global position of local element i of digit d = s_gbase[d] + i
+	__shared__ uint32_t s_whist[4][BINS];  // per-wave digit counts, then per-wave running write cursors
+	__shared__ uint32_t s_gbase[BINS];     // global position of local element i of digit d = s_gbase[d] + i
 	__shared__ uint32_t s_wave[4];
 	__shared__ uint32_t s_keys[SORT_CHUNK];
 	__shared__ uint32_t s_vals[SORT_CHUNK];
@@ -374,7 +389,9 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 	const int wbase = cbase + w * SORT_ITEMS_PER_WAVE;
 
 #pragma unroll
-	for (int i = 0; i < 4; i++) s_whist[i][tid] = 0;
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int d = tid; d < BINS; d += SORT_THREADS) s_whist[i][d] = 0;
 	__syncthreads();
 
 	uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
@@ -393,7 +410,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 		const int i = wbase + r * 64 + l;
 		const bool valid = i < n && !(skip_invalid && key[r] == RADIX_INVALID_KEY);
 		if (!valid) live &= ~(1u << r);
-		const uint32_t d = (key[r] >> shift) & dmask;
+		const uint32_t d = ((key[r] - bias) >> shift) & dmask;
 		const unsigned long long m = wave_match_digit(d, nbits, valid);
 		const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt()), size = (uint32_t)__popcll(m);
 		place[r] = rank | (size << 8);   // the ballots are not repeated in phase C
@@ -407,17 +424,32 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 	// waves ascending, inside a wave original order.
 	uint32_t block_total;   // elements of this chunk that exist (the same value in every thread)
 	{
-		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
-		const uint32_t tot = c0 + c1 + c2 + c3;
-		const uint32_t lstart = block_excl_scan_256(tot, &block_total, s_wave);
+		uint32_t c[DPT][4], tot[DPT], sum = 0, gsum = 0, gt[DPT];
+#pragma unroll
+		for (int j = 0; j < DPT; j++) {
+			const int d = tid * DPT + j;
+#pragma unroll
+			for (int w4 = 0; w4 < 4; w4++) c[j][w4] = s_whist[w4][d];
+			tot[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
+			sum += tot[j];
+			// (the rows of the digits this pass does not have are neither written nor scanned)
+			gt[j] = d < (1 << nbits) ? totals[d] : 0u;
+			gsum += gt[j];
+		}
+		uint32_t lstart = block_excl_scan_256(sum, &block_total, s_wave);
 		uint32_t all;
-		const bool used = tid < (1 << nbits);   // (the rows of the digits this pass does not have are neither written nor scanned)
-		const uint32_t digit_base = block_excl_scan_256(used ? totals[tid] : 0u, &all, s_wave);   // elements with a smaller digit
-		s_whist[0][tid] = lstart;
-		s_whist[1][tid] = lstart + c0;
-		s_whist[2][tid] = lstart + c0 + c1;
-		s_whist[3][tid] = lstart + c0 + c1 + c2;
-		s_gbase[tid] = digit_base + (used ? hist_rows[(size_t)tid * nblocks + blockIdx.x] : 0u) - lstart;
+		uint32_t digit_base = block_excl_scan_256(gsum, &all, s_wave);   // elements with a smaller digit
+#pragma unroll
+		for (int j = 0; j < DPT; j++) {
+			const int d = tid * DPT + j;
+			s_whist[0][d] = lstart;
+			s_whist[1][d] = lstart + c[j][0];
+			s_whist[2][d] = lstart + c[j][0] + c[j][1];
+			s_whist[3][d] = lstart + c[j][0] + c[j][1] + c[j][2];
+			s_gbase[d] = digit_base + (d < (1 << nbits) ? hist_rows[(size_t)d * nblocks + blockIdx.x] : 0u) - lstart;
+			lstart += tot[j];
+			digit_base += gt[j];
+		}
 		if (count_out && blockIdx.x == 0 && tid == 0) *count_out = all;   // the elements that exist: later passes run over them only
 	}
 	__syncthreads();
@@ -427,7 +459,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 #pragma unroll
 	for (int r = 0; r < SORT_ROUNDS; r++) {
 		const bool valid = (live >> r) & 1u;
-		const uint32_t d = (key[r] >> shift) & dmask;
+		const uint32_t d = ((key[r] - bias) >> shift) & dmask;
 		const uint32_t rank = place[r] & 0xFFu, size = place[r] >> 8;
 		uint32_t cursor = 0;
 		if (valid) cursor = s_whist[w][d];
@@ -445,7 +477,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 	const int count = (int)block_total;
 	for (int i = tid; i < count; i += SORT_THREADS) {
 		const uint32_t k = s_keys[i];
-		const uint32_t d = (k >> shift) & dmask;
+		const uint32_t d = ((k - bias) >> shift) & dmask;
 		const uint32_t pos = s_gbase[d] + (uint32_t)i;
 		keys_out[pos] = k;
 		vals_out[pos] = s_vals[i];
@@ -455,16 +487,20 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count,
-                      const RadixHostCount* host_count, bool first_hist_ready)
+                      const RadixHostCount* host_count, bool first_hist_ready, int digit_bits, uint32_t bias)
 {
 	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
 	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
-	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
+	// digit_bits: 8 (RADIX_BITS) or 9 (RADIX_BITS_WIDE: 512-bin kernels; scratch of sort_scratch_elems_wide(n)); bias: subtracted
+	// from every key in front of the digits (the sort is on key - bias, bits [begin_bit, end_bit): the caller guarantees that the
+	// bits above end_bit of key - bias are zero for every element, or handles the exception itself -- gsr_forward's depth sort).
+	if (digit_bits != RADIX_BITS && digit_bits != RADIX_BITS_WIDE) return GSR_ERR_INVALID_ARG;
+	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, digit_bits) : 0;
 	*keys_res = (passes % 2) ? keys_pong : keys_ping;
 	*vals_res = (passes % 2) ? vals_pong : vals_ping;
 	if (n <= 0) return GSR_OK;
 	const int nb = sort_blocks(n);
-	const int hist_elems = RADIX_BINS * nb;
+	const int hist_elems = (1 << digit_bits) * nb;
 	uint32_t* hist = scratch;
 	uint32_t* totals = scratch + hist_elems;
 	if (passes == 0) {
@@ -479,6 +515,7 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 	// the key bits are spread evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): a pass scatters into 2^nbits streams,
 	// and with fewer streams a workgroup's runs per stream are longer, i.e. its writes better coalesced
 	const int bits_per_pass = div_up(end_bit - begin_bit, passes);
+	const bool wide = bits_per_pass > RADIX_BITS;
 	for (int p = 0; p < passes; p++) {
 		const int shift = begin_bit + p * bits_per_pass;
 		const int nbits = min(bits_per_pass, end_bit - shift);
@@ -490,11 +527,18 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		const bool counts_ride = p == 0 && host_count && host_count->pairs;
 		const RadixHostCount hc = counts_ride ? *host_count : RadixHostCount{};
 		// (first_hist_ready: the producer of the keys has counted the first pass's digits into `hist` itself -- the instance emission)
-		if (!(p == 0 && first_hist_ready)) GSR_LAUNCH(radix_hist_kernel, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc);
+		if (!(p == 0 && first_hist_ready)) {
+			if (wide) GSR_LAUNCH(radix_hist_kernel<512>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
+			else GSR_LAUNCH(radix_hist_kernel<RADIX_BINS>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
+		}
 		GSR_LAUNCH(radix_row_prefix_kernel, (1 << nbits) + (counts_ride ? 1 : 0), SCAN_THREADS, stream, hist, totals, nb, 1 << nbits, hc);
 		if (counts_ride && hc.ready) GSR_HIP(hipEventRecord((hipEvent_t)hc.ready, stream));
-		GSR_LAUNCH(radix_scatter_kernel, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits,
-		           (const uint32_t*)hist, (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr);
+		if (wide)
+			GSR_LAUNCH(radix_scatter_kernel<512>, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits, (const uint32_t*)hist,
+			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias);
+		else
+			GSR_LAUNCH(radix_scatter_kernel<RADIX_BINS>, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits, (const uint32_t*)hist,
+			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias);
 		kin = kout;
 		vin = vout;
 	}

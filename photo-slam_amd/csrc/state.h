@@ -9,12 +9,13 @@ namespace gsr {
 constexpr int TILE = 16;              // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:16-17 (part of the parity contract)
 constexpr int TILE_PIXELS = TILE * TILE;
 constexpr uint32_t DEPTH_KEY_CULLED = 0xFFFFFFFFu;
+constexpr uint32_t DEPTH_KEY_BIAS = 0x3E4CCCCDu;   // bits(0.2f): a visible Gaussian's key is larger (preprocess.hip: vz <= 0.2f is culled)
 // The forward preprocess runs PRE_THREADS / 64 waves per workgroup; every wave leaves its (tiles touched, visible) pair with a
 // plain store -- no atomics, so no array that would have to be zeroed first (until round 5: atomics spread over 1024 words behind
 // a memset, and a 4 KiB copy to the host: two runtime blit kernels with their bubbles in front of and in the middle of the forward pass)
 constexpr int PRE_THREADS = 128;
 static inline size_t wave_count_slots(size_t P) { return ((P + PRE_THREADS - 1) / PRE_THREADS) * (PRE_THREADS / 64); }
-constexpr int HOST_COUNT_WORDS = 4;   // what the forward pass hands to the host: [0] tiles lo, [1] tiles hi, [2] visible, [3] -
+constexpr int HOST_COUNT_WORDS = 4;   // what the forward pass hands to the host: [0] tiles lo, [1] tiles hi, [2] visible, [3] largest depth key
 
 // Radix sort geometry: one workgroup (256 threads = 4 waves) ranks a 2048-element chunk (measured best of 1024/2048/4096 on MI355X);
 // each wave owns 512 consecutive elements so that stability needs no cross-wave ordering.
@@ -23,6 +24,7 @@ constexpr int SORT_ITEMS_PER_WAVE = 512;
 constexpr int SORT_CHUNK = 4 * SORT_ITEMS_PER_WAVE;
 constexpr int SORT_ROUNDS = SORT_ITEMS_PER_WAVE / 64;
 constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BITS_WIDE = 9;   // the depth sort: 27 significant bits of (key - bits(0.2f)) in three passes
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr uint32_t RADIX_INVALID_KEY = 0xFFFFFFFFu;
 // A Gaussian's run of per-instance gradient slots is summed by its owner lane in the backward preprocess up to this length;
@@ -74,6 +76,8 @@ static inline size_t sort_scratch_elems(int n)
 	size_t h = (size_t)RADIX_BINS * sort_blocks(n);
 	return 2 * h + scan_scratch_elems((int)h) + 64;
 }
+// ... of a sort with RADIX_BITS_WIDE-bit digits (the [512][blocks] table + the 512 row totals)
+static inline size_t sort_scratch_elems_wide(int n) { return ((size_t)(1 << RADIX_BITS_WIDE) * sort_blocks(n)) + (1 << RADIX_BITS_WIDE) + 64; }
 
 // The 48-byte per-Gaussian record the blend kernels gather (3 x float4):
 //   q0 = (mean2D.x, mean2D.y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)
@@ -83,7 +87,8 @@ static inline size_t sort_scratch_elems(int n)
 constexpr int REC_FLOAT4S = 3;
 
 struct GeometryState {
-	uint2*    wave_counts;    // [wave_count_slots(P)] per wave of preprocess_fwd: (tiles touched, visible Gaussians); the totals are
+	uint4*    wave_counts;    // [wave_count_slots(P)] per wave of preprocess_fwd: (tiles touched, visible Gaussians, largest depth key of a
+	                          // visible Gaussian, -); the totals are
 	                          // num_rendered and gsr_last_visible_count() (summed inside the depth sort's first two launches)
 	uint4*    count_partials; // [sort_blocks(P)] the first level of that sum
 	uint32_t* long_runs;      // [LONG_LISTS * long_list_capacity(P)] ids of the Gaussians that touch more than LONG_RUN tiles
@@ -101,7 +106,7 @@ struct GeometryState {
 	uint32_t* sort_keys_a;    // [P]
 	uint32_t* sort_keys_b;    // [P]
 	uint32_t* sort_vals_b;    // [P]
-	uint32_t* sort_scratch;   // [sort_scratch_elems(P)]
+	uint32_t* sort_scratch;   // [max(sort_scratch_elems(P), sort_scratch_elems_wide(P))]
 	uint32_t* scan_scratch;   // [scan_scratch_elems(P)]
 	uint2*    rect_sorted;    // [P] the tile rectangles in depth order (entry i belongs to order[i]): gathered once by the offset
 	                          // scan, read linearly by the instance emission
@@ -123,11 +128,11 @@ struct GeometryState {
 		g.sort_keys_a = c.take<uint32_t>(P);
 		g.sort_keys_b = c.take<uint32_t>(P);
 		g.sort_vals_b = c.take<uint32_t>(P);
-		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P));
+		g.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)P) > sort_scratch_elems_wide((int)P) ? sort_scratch_elems((int)P) : sort_scratch_elems_wide((int)P));
 		g.scan_scratch = c.take<uint32_t>(scan_scratch_elems((int)P));
 		g.rect_sorted = c.take<uint2>(P);
 		g.visible = c.take<uint32_t>(32);
-		g.wave_counts = c.take<uint2>(wave_count_slots(P));   // (written in full by every forward pass: nothing has to be zeroed)
+		g.wave_counts = c.take<uint4>(wave_count_slots(P));   // (written in full by every forward pass: nothing has to be zeroed)
 		g.count_partials = c.take<uint4>((size_t)sort_blocks((int)P));
 		g.long_runs = c.take<uint32_t>((size_t)LONG_LISTS * long_list_capacity(P));
 		g.long_counts = c.take<uint32_t>((size_t)LONG_LISTS * LONG_COUNT_STRIDE);
@@ -250,7 +255,7 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 // host_out[0..1], sum b in host_out[2], into MAPPED HOST memory; `ready` (a hipEvent_t, nullable) is recorded right behind the
 // second launch.  gsr_forward: the per-wave (tiles touched, visible) pairs of the projection kernel.
 struct RadixHostCount {
-	const uint2* pairs = nullptr;
+	const uint4* pairs = nullptr;   // (a, b, c, -): sum a (64-bit), sum b, max c
 	int n = 0;
 	uint4* partials = nullptr;      // [sort_blocks(elements of the sort)]
 	uint32_t* host_out = nullptr;   // device address of mapped host memory (HOST_COUNT_WORDS words)
@@ -263,7 +268,8 @@ struct RadixHostCount {
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
-                      uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr, bool first_hist_ready = false);
+                      uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr, bool first_hist_ready = false,
+                      int digit_bits = RADIX_BITS, uint32_t bias = 0);
 // the digit width of the first pass (the key bits are spread evenly over the passes) -- for a producer that counts the first
 // histogram itself (first_hist_ready: the [digit][sort_blocks(n)] table at the head of `scratch`, digits of key bits [begin_bit, +w))
 static inline int radix_first_pass_bits(int begin_bit, int end_bit)

@@ -111,3 +111,52 @@ np.savez(sys.argv[1], point_list=r.point_list, ranges=r.ranges, color=r.out_colo
                 assert d < 1e-6, (settings[i], k, d)
             else:
                 assert np.array_equal(outs[0][k], o[k], equal_nan=True), (settings[i], k)
+
+
+def test_depth_sort_second_path(emu_lib_path, oracle, tmp_path):
+    """The depth sort runs three 9-bit passes over key - bits(0.2f) (27 bits: z < 13 107) and sorts AGAIN with the plain four passes
+    when the host finds a larger key in the view (include/gsr.h: gsr_depth_resort_count).  (a) A Gaussian at z = 20 000 and one
+    whose depth is Inf-like large next to an ordinary scene: the second path runs, every stage equals the oracle.  (b) The range
+    narrowed to 9 bits (GSR_DEPTH_SORT_BITS, read once per process: a child): an ordinary scene takes the second path and gives
+    the lists and the image of the default setting bit for bit; so does the plain sort (GSR_DEPTH_SORT_9BIT=0)."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from photo_slam_amd import capi
+    lib = capi.load(emu_lib_path)
+    lib.gsr_depth_resort_count.restype = C.c_longlong
+    cl = small_scene(800, 96, 64, 4)
+    cam = cl.cameras[0]
+    fwd = cam.viewmatrix[:3, 2]
+    cl.xyz[0] = cam.campos + 20000.0 * fwd          # far beyond the three-pass range, still in front of the camera
+    cl.scaling[0] = np.log(3000.0)                   # (large enough to cover pixels from there)
+    cl.opacity[0] = 2.0
+    bg = np.array([0.2, 0.5, 0.1], np.float32)
+    dpix = np.random.default_rng(0).standard_normal((3, cam.H, cam.W)).astype(np.float32)
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+    assert oradii[0] > 0, "the far Gaussian must be visible for this test to mean anything"
+    before = lib.gsr_depth_resort_count()
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix)
+    assert lib.gsr_depth_resort_count() == before + 1
+    parity.compare(r, ores, ocolor, oradii, ograds, cam)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import conftest, parity
+from photo_slam_amd import scene, capi
+cl = scene.make_cloud(1500, 80, 70, 64.0, 64.0, seed=2, scale_k=0.35)
+r = parity.run_backend({emu_lib_path!r}, torch.device('cpu'), cl, cl.cameras[0], np.array([0.2, 0.5, 0.1], np.float32), do_backward=False)
+lib = capi.load({emu_lib_path!r}); lib.gsr_depth_resort_count.restype = C.c_longlong
+np.savez(sys.argv[1], point_list=r.point_list, tile_keys=r.tile_keys, ranges=r.ranges, color=r.out_color, R=r.R, resorts=lib.gsr_depth_resort_count())
+"""
+    outs = []
+    for extra in ({}, {"GSR_DEPTH_SORT_BITS": "9"}, {"GSR_DEPTH_SORT_9BIT": "0"}):
+        out = str(tmp_path / f"depth_{len(outs)}.npz")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, PYTEST_CURRENT_TEST="depth", **extra), timeout=600)
+        outs.append(np.load(out))
+    assert int(outs[0]["resorts"]) == 0 and int(outs[1]["resorts"]) == 1 and int(outs[2]["resorts"]) == 0
+    for o in outs[1:]:
+        for k in ("point_list", "tile_keys", "ranges", "color"):
+            assert np.array_equal(outs[0][k], o[k]), k
