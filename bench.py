@@ -83,7 +83,7 @@ def stage_bounds(stages, top=6):
 
 
 def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=4, sorted_gaussians=None, fused_sh_adam=False,
-                      touched_slots=None, lazy_window=0, fused_geom_adam=False):
+                      touched_slots=None, lazy_window=0, fused_geom_adam=False, tile_first=False):
     """Compulsory HBM bytes per stage (each array read/written once per stage that needs it), restated for
     this implementation's stage split.  fused_sh_adam: the backward preprocess also carries the Adam step of the SH tensor
     (no gradient rows written; both moments read, parameter + moments written for every Gaussian, the parameter row read for
@@ -103,11 +103,13 @@ def algorithmic_bytes(P, V, R, Npix, T, K=16, M=16, tile_passes=2, depth_passes=
     slots = 0 if touched_slots is None else 48 * touched_slots + R
     return {
         "preprocess_fwd": 52 * P + (12 * K + 67) * V,
-        "depth_sort": depth_passes * 16 * S,         # passes x (8 B read + 8 B write) over the sorted pairs
-        "offset_scan": 12 * S,
+        # (tile-first binning: this stage is the compaction -- tile counts read, id / offset / rectangle of the visible ones written)
+        "depth_sort": 4 * P + 24 * V if tile_first else depth_passes * 16 * S,   # passes x (8 B read + 8 B write) over the sorted pairs
+        "offset_scan": 0 if tile_first else 12 * S,
         "emit_instances": 20 * S + 8 * R,
         "tile_sort": tile_passes * 16 * R,
         "tile_ranges": 4 * R + 8 * T,
+        "tile_depth_sort": 12 * R if tile_first else 0,   # tile-first binning: list entry read, depth key gathered, entry written
         "blend_fwd": 40 * R + 20 * Npix,
         "grad_memset": R,                            # one flag byte per instance slot
         "blend_bwd": 40 * R + 20 * Npix + 88 * V,
@@ -960,8 +962,10 @@ def main():
     tile_bits = int(np.ceil(np.log2(max(T, 2))))
     fused_sh_adam = not dp and not args.raster_only   # both hosts fuse the SH Adam step into backward at one rank
     lazy_window = args.sh_adam_window if fused_sh_adam and args.sh_adam_window >= 2 else 0
+    from photo_slam_amd import capi as _capi
+    tile_first = bool(_capi.load().gsr_binning_tile_first(0, P, W, H))   # the binning arrangement gsr_forward takes at this size
     ab = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=fused_sh_adam, lazy_window=lazy_window,
-                           fused_geom_adam=fused_sh_adam and not args.no_fused_geom_adam)
+                           fused_geom_adam=fused_sh_adam and not args.no_fused_geom_adam, tile_first=tile_first)
     stages = {}
     for k, ms in stage_ms.items():
         ms = [m for m in ms if m >= 0]
@@ -1006,6 +1010,7 @@ def main():
                        "raster_only": bool(args.raster_only), "densify_interval": args.densify_interval,
                        "learning_rates": lr_note,
                        "cull_empty_tiles": os.environ.get("GSR_CULL_EMPTY_TILES", "0") == "1",   # (include/gsr.h: same image and gradients)
+                       "binning": "tile-first" if tile_first else "depth-first",   # (include/gsr.h: GSR_BINNING_*; the same lists either way)
                        "sh_adam_fused_into_backward": fused_sh_adam,
                        "sh_adam_lazy_window": lazy_window, "scene_index_order": args.scene_order,
                        "geometry_adam_fused_into_backward": bool(fused_sh_adam and not args.no_fused_geom_adam),
@@ -1016,7 +1021,7 @@ def main():
         }
         if unfused_ms:
             # rasterizer stages without optimizer work (SH Adam as a separate pass): medians of 12 further steps
-            ab_u = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=False)
+            ab_u = algorithmic_bytes(P, V, R, W * H, T, tile_passes=(tile_bits + 7) // 8, fused_sh_adam=False, tile_first=tile_first)
             u = {k: float(np.median([m for m in ms if m >= 0])) for k, ms in unfused_ms.items() if any(m >= 0 for m in ms)}
             ums = sum(u.values())
             out["rasterizer_only"] = {"fwd_bwd_ms": round(ums, 4), "mpix_per_s": round(world * W * H / (ums * 1e-3) / 1e6, 1),

@@ -153,6 +153,14 @@ typedef struct gsr_forward_args {
  * gsr_backward recomputes them from scales / rotations, the same arithmetic and the same bits -- so by default they are not
  * written; the test-suite's view into the buffer (tests/dev) asks for them. */
 #define GSR_STORE_COV3D 16
+/* ... and two that choose how the per-tile lists are built (ignored by gsr_backward; neither = the library decides by the size
+ * of the view; the lists, the image and the gradients are the same either way, bit for bit).  DEPTH_FIRST: the Gaussians are
+ * sorted by depth once (nine launches whatever the size), their instances emitted in that order, and the stable tile sort carries
+ * the order into the tiles -- the least work per instance, the arrangement for large views.  TILE_FIRST: the visible Gaussians are
+ * only compacted (ascending id) and every tile's list is sorted by depth on its own behind the tile sort, one workgroup per tile
+ * in LDS -- eight launches fewer, the arrangement for the small and mid-size views a SLAM session starts with. */
+#define GSR_BINNING_DEPTH_FIRST 32
+#define GSR_BINNING_TILE_FIRST 64
 
 /* Rasterizer::forward, cuda_rasterizer/rasterizer_impl.cu:198-336.
  * Fills out_color and radii, returns the number of (tile, Gaussian) instances in
@@ -331,6 +339,9 @@ int gsr_last_visible_count(void);
  * instance count; a view with a Gaussian at z >= 13 107 (or a depth that is not a number) is sorted again on all 32 bits.  The
  * results are the same either way; the second path costs about 0.15 ms at 2 M Gaussians. */
 long long gsr_depth_resort_count(void);
+/* Introspection: the binning arrangement gsr_forward takes for a view of this size with these raw_params bits (1 = tile-first,
+ * 0 = depth-first; GSR_BINNING_* above, the GSR_BINNING environment override included). */
+int gsr_binning_tile_first(int raw_params, int P, int width, int height);
 /* The loud form of the decoders' silent guards (they decode nothing from a message whose P differs and read no row beyond the
  * rows a message holds): copies the n_views headers to the host, WAITS for `stream`, and returns GSR_ERR_INVALID_ARG unless
  * every message says P rows total, K <= min(its own capacity, `capacity_rows` = the rows that travelled) and "nothing dropped".  A synchronisation: for

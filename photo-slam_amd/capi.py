@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
     "gsr_neighborhood_depth_pinhole", "gsr_packed_view_words", "gsr_pack_scratch_bytes", "gsr_pack_color_view", "gsr_pack_view_plan",
     "gsr_sh_grad_from_packed_views", "gsr_sh_adam_from_packed_views", "gsr_last_visible_count", "gsr_check_packed_views", "gsr_depth_resort_count",
-    "gsr_host_wait_stats",
+    "gsr_host_wait_stats", "gsr_binning_tile_first",
 ]
 
 _libs = {}

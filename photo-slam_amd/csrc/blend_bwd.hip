@@ -7,8 +7,9 @@
 //
 // The reference issues nine global float atomics per contributing (pixel, Gaussian) pair
 // (backward.cu:523-554).  Here there are none (see blend.h):
-//   * entries behind the deepest last-contributor of the quad are never loaded, and the
-//     per-quad rejection mask removes whole-wave work exactly as in the forward pass;
+//   * entries behind the deepest last-contributor of the tile are never loaded; a segment of 256 list entries is staged once
+//     per tile by all 256 threads, and only the entries the forward blend flagged as blended by some quad of the tile
+//     (state.h: contrib); every quad-wave then walks the entries flagged for ITS quad;
 //   * the per-pair arithmetic is branch-free; 1/(1-alpha) is one v_rcp_f32 shared by the two
 //     divisions of the reference;
 //   * the nine terms are summed across the 64 pixels of a quad with a butterfly packed from the
@@ -26,17 +27,16 @@
 
 namespace gsr {
 
-#ifndef GSR_BWD_SEG
-#define GSR_BWD_SEG 256
-#endif
-constexpr int BWD_SEG = GSR_BWD_SEG;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB)
+constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB); thread i stages entry i of the segment
 
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
 {
-	__shared__ float4 s_rec[4][64][3];   // per wave and entry: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
+	static_assert(BWD_SEG == 256, "one thread per entry of a segment");
+	__shared__ float4 s_rec[BWD_SEG][3];   // per entry of the segment: (x, y, A', B') (C', opacity, r, g) (b, -, -, -)
 	__shared__ float s_acc[9][BWD_SEG];
 	__shared__ uint32_t s_slot[BWD_SEG];
+	__shared__ uint8_t s_flag[BWD_SEG];    // bit q: quad q of the tile blends the entry (a byte each: 7 workgroups per CU fit the 160 KiB of LDS)
 	__shared__ uint32_t s_wmax[4];
 
 	// Heaviest chunks first: the forward blend filed every chunk (a square of tiles, blend.h: TileDeal) under a work class
@@ -105,39 +105,63 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const uint32_t bmax = wave_uniform_u32(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
 	const int nseg = (int)((bmax + BWD_SEG - 1) / BWD_SEG);
 
+	// The segment's records are staged ONCE per tile, by all 256 threads (thread i: list entry seg_lo + i), and only for the entries
+	// some quad of the tile blended (the forward blend's flags: a quarter of the entries of a 1080p view, a tenth at 640 x 480 with
+	// 2 M Gaussians).  Until round 5 every quad-wave gathered every record of its part of the list itself, 64 at a time: four
+	// dependent round trips per segment and wave, and four times the gathers -- in a view of a few thousand entries per tile the
+	// waves waited for records instead of blending (VALU utilisation 56 % at 640 x 480, profiles/r06_a_sq_counters_full_C4.json).
+	// The list entries and flags of the NEXT segment are asked for while this one is walked.
+	auto seg_flags = [&](int seg_) -> uint32_t {
+		const uint32_t e = (uint32_t)seg_ * BWD_SEG + (uint32_t)tid;
+		uint32_t f = 0u;
+		if (e < bmax) {
+#pragma unroll
+			for (int q = 0; q < QUADS_PER_TILE; q++)
+				// (behind a quad's deepest last contributor the forward blend may not have walked: no flags were written there)
+				if (e < s_wmax[q] && p.contrib[(size_t)q * p.contrib_stride + range.x + e] != 0) f |= 1u << q;
+		}
+		return f;
+	};
+	auto seg_gid = [&](int seg_) -> uint32_t {
+		const uint32_t e = (uint32_t)seg_ * BWD_SEG + (uint32_t)tid;
+		return e < bmax ? p.point_list[range.x + e] : 0u;
+	};
+	uint32_t flags_next = nseg > 0 ? seg_flags(nseg - 1) : 0u, gid_next = nseg > 0 ? seg_gid(nseg - 1) : 0u;
 	for (int seg = nseg - 1; seg >= 0; seg--) {
 		const uint32_t seg_lo = (uint32_t)seg * BWD_SEG;
 		const uint32_t seg_hi = min(bmax, seg_lo + BWD_SEG);
 		for (int i = tid; i < 9 * BWD_SEG; i += 256) (&s_acc[0][0])[i] = 0.f;
-		for (int i = tid; i < BWD_SEG; i += 256) s_slot[i] = 0xFFFFFFFFu;
+		{
+			const uint32_t f = flags_next, gid = gid_next;
+			uint32_t slot = 0xFFFFFFFFu;
+			float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+			if (f) {
+				q0 = p.rec[3 * (size_t)gid + 0];
+				q1 = p.rec[3 * (size_t)gid + 1];
+				q2 = p.rec[3 * (size_t)gid + 2];
+			}
+			if (seg > 0) {   // (asked for in front of the wait for the records)
+				flags_next = seg_flags(seg - 1);
+				gid_next = seg_gid(seg - 1);
+			}
+			if (f) {
+				s_rec[tid][0] = prescale_q0(q0);
+				s_rec[tid][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
+				s_rec[tid][2].x = q2.x;
+				const uint32_t rlo = __float_as_uint(q2.y), rhi = __float_as_uint(q2.z);
+				const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu;
+				slot = __float_as_uint(q2.w) + ((uint32_t)tile_y - miny) * (maxx - minx) + ((uint32_t)tile_x - minx);
+			}
+			s_slot[tid] = slot;
+			s_flag[tid] = (uint8_t)f;
+		}
 		__syncthreads();
 
-		const uint32_t w_hi = min(wmax, seg_hi);   // this quad needs [seg_lo, w_hi) of the segment
-		if (w_hi > seg_lo) {
-			int base = (int)((w_hi - 1u) & ~63u);
-			uint32_t gid_next = ((uint32_t)(base + l) < w_hi) ? p.point_list[range.x + (uint32_t)(base + l)] : 0u;
-			for (; base >= (int)seg_lo; base -= 64) {
-				const bool have = (uint32_t)(base + l) < w_hi;
-				const uint32_t gid = gid_next;
-				if (base >= (int)seg_lo + 64) gid_next = p.point_list[range.x + (uint32_t)(base - 64 + l)];
-				bool keep = false;
-				uint32_t slot = 0xFFFFFFFFu;
-				if (have) {
-					const float4 q0 = p.rec[3 * (size_t)gid + 0];
-					const float4 q1 = p.rec[3 * (size_t)gid + 1];
-					const float4 q2 = p.rec[3 * (size_t)gid + 2];
-					// the forward blend's verdict for (quad, entry): a subset of the quad rejection test's survivors
-					keep = p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] != 0;
-					s_rec[quad][l][0] = prescale_q0(q0);
-					s_rec[quad][l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
-					s_rec[quad][l][2].x = q2.x;
-					const uint32_t rlo = __float_as_uint(q2.y), rhi = __float_as_uint(q2.z);
-					const uint32_t minx = rlo & 0xFFFFu, miny = rlo >> 16, maxx = rhi & 0xFFFFu;
-					slot = __float_as_uint(q2.w) + ((uint32_t)tile_y - miny) * (maxx - minx) + ((uint32_t)tile_x - minx);
-					s_slot[base - (int)seg_lo + l] = slot;   // the quads of the tile write the same value
-				}
-				unsigned long long m = wave_ballot(keep);
-				wave_fence();
+		for (int b = (int)((seg_hi - seg_lo - 1u) >> 6); b >= 0; b--) {
+			{
+				unsigned long long m = wave_ballot((((uint32_t)s_flag[b * 64 + l] >> quad) & 1u) != 0u);
+				const int base = (int)seg_lo + b * 64;
+				const float4(*rec_b)[3] = &s_rec[b * 64];
 				while (m) {
 					const int bit = 63 - __clzll((long long)m);
 #ifdef GSR_EMU
@@ -146,9 +170,9 @@ blend_bwd_kernel(const BlendBwdParams p)
 					asm volatile("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));   // (one scalar instruction instead of shift + andn2)
 #endif
 					const uint32_t pos = (uint32_t)(base + bit);
-					const float4 g0 = s_rec[quad][bit][0];
-					const float4 g1 = s_rec[quad][bit][1];
-					const float gb = s_rec[quad][bit][2].x;
+					const float4 g0 = rec_b[bit][0];
+					const float4 g1 = rec_b[bit][1];
+					const float gb = rec_b[bit][2].x;
 					const v2f dxy = (v2f){g0.x, g0.y} - pxy;
 					const float dx = dxy[0], dy = dxy[1];
 					const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
@@ -197,7 +221,6 @@ blend_bwd_kernel(const BlendBwdParams p)
 					GSR_OPAQUE_F32(ninth_row);   // sinks them into the 12-lane branch as mov_dpp + add)
 					if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
 				}
-				wave_fence();  // all lanes have read this batch before the next one overwrites the slice
 			}
 		}
 		__syncthreads();

@@ -8,6 +8,9 @@
 //      mapped host memory, event behind them -- the reference blocks on a copy here, :281) -> exclusive scan in depth order
 //   -> host waits for the event only now, sizes the binning buffer
 //   -> emit instances -> tile-id sort over R (ceil(msb(T)/8) passes) -> tile ranges -> blend.
+// Tile-first binning (binning_tile_first below; small and mid-size views): no depth sort of the Gaussians -- the visible ones are
+// compacted in id order (the count for the host by a one-workgroup launch in front of the compaction), and behind the tile sort
+// every tile's list is sorted by depth on its own (tile_depth_sort.hip): 12 launches instead of 20, the same lists bit for bit.
 #include <chrono>
 #include <cmath>
 #include <vector>
@@ -150,6 +153,18 @@ static bool emit_hist()
 	static const int env = env_int("GSR_EMIT_HIST", 1);
 	return env != 0;
 }
+// Which binning: depth-first (sort the Gaussians by depth, emit in that order: nine launches for the sort whatever the size) or
+// tile-first (compact in id order, sort every tile's list by depth behind the tile sort).  gsr_forward_args.raw_params may force
+// either (GSR_BINNING_DEPTH_FIRST / GSR_BINNING_TILE_FIRST); GSR_BINNING=0/1 overrides (the A/B handle); otherwise by size.
+static bool binning_tile_first(int raw_params, int P, int tiles)
+{
+	static const int env = env_int("GSR_BINNING", -1);
+	if (env >= 0) return env != 0;
+	if (raw_params & GSR_BINNING_TILE_FIRST) return true;
+	if (raw_params & GSR_BINNING_DEPTH_FIRST) return false;
+	(void)P; (void)tiles;
+	return false;
+}
 static int side_blocks(const gsr_sh_adam* o)
 {
 	static const int env = env_int("GSR_SH_ADAM_SIDE_BLOCKS", -1);
@@ -159,15 +174,18 @@ static int side_blocks(const gsr_sh_adam* o)
 // Optional per-stage HIP-event timing (gsr_profile_*): events are recorded on the caller's
 // stream between the stages of gsr_forward / gsr_backward, so bench.py can price each kernel
 // group against its algorithmic bytes without a profiler attached.
-enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_OFFSET_SCAN, ST_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_BLEND_FWD,
+// (depth_sort: the depth sort of the Gaussians, or -- tile-first binning -- the count + compaction launches, with offset_scan empty;
+// tile_depth_sort: tile-first binning only)
+enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_OFFSET_SCAN, ST_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_TILE_DEPTH_SORT, ST_BLEND_FWD,
        ST_GRAD_MEMSET, ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+constexpr int ST_FWD_COUNT = ST_BLEND_FWD + 1;
 static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sort", "offset_scan", "emit_instances",
-                                                    "tile_sort", "tile_ranges", "blend_fwd", "grad_memset",
+                                                    "tile_sort", "tile_ranges", "tile_depth_sort", "blend_fwd", "grad_memset",
                                                     "blend_bwd", "preprocess_bwd"};
 struct Profiler {
 	int on = 0;               // 0 off, 1 every stage, 2 only the backward blend (its two events: an event record costs a
 	                          // ~5 us pipeline bubble, eleven of them 2 % of a C3 train step)
-	hipEvent_t fwd[8] = {};   // boundaries of the 7 forward stages
+	hipEvent_t fwd[ST_FWD_COUNT + 1] = {};   // boundaries of the forward stages
 	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
 	bool created = false, fwd_done = false, bwd_done = false;
 	int create()
@@ -354,16 +372,27 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		return launch_scan_rect_tiles(reinterpret_cast<const uint2*>(g.rect), g.order, g.offsets, g.rect_sorted, P, g.scan_scratch, stream,
 		                              g.visible, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P, g.long_runs, g.long_counts, g.long_capacity);
 	};
-	if (narrow_bits) {
-		// (ping and pong swapped: an odd number of passes ends in the pong buffers, and the order must end in g.order)
-		st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_b, g.sort_vals_b, g.sort_keys_a, g.order, P, 0, narrow_bits, g.sort_scratch, stream,
-		                       &kres, &vres, g.visible, &hc, false, RADIX_BITS_WIDE, DEPTH_KEY_BIAS);
-		if (st == GSR_OK && vres != g.order) st = GSR_ERR_INVALID_ARG;   // (an even number of wide passes: not a configuration of this library)
-	} else
-		st = plain_depth_sort(&hc);
-	if (st != GSR_OK) return st;
-	PROF_FWD(2);
-	if ((st = offset_scan()) != GSR_OK) return st;
+	const bool tile_first = binning_tile_first(a->raw_params, P, tiles);
+	if (tile_first) {
+		// no order among the Gaussians: the visible ones compacted by ascending id (g.order), their offsets, rectangles, the emission's
+		// seeds and the list of long runs in ONE pass; the counts reach the host from a one-workgroup launch in front of it
+		st = launch_compact_visible(g.tiles_touched, reinterpret_cast<const uint2*>(g.rect), g.wave_counts, hc.n, g.count_partials, g.order, g.offsets,
+		                            g.rect_sorted, P, t_sync.pinned_dev, t_sync.ev, stream, g.sort_keys_b, EMIT_SEED_STRIDE, (uint32_t)P, g.long_runs,
+		                            g.long_counts, g.long_capacity, g.visible);
+		if (st != GSR_OK) return st;
+		PROF_FWD(2);
+	} else {
+		if (narrow_bits) {
+			// (ping and pong swapped: an odd number of passes ends in the pong buffers, and the order must end in g.order)
+			st = launch_radix_sort(g.depth_key, nullptr, g.sort_keys_b, g.sort_vals_b, g.sort_keys_a, g.order, P, 0, narrow_bits, g.sort_scratch, stream,
+			                       &kres, &vres, g.visible, &hc, false, RADIX_BITS_WIDE, DEPTH_KEY_BIAS);
+			if (st == GSR_OK && vres != g.order) st = GSR_ERR_INVALID_ARG;   // (an even number of wide passes: not a configuration of this library)
+		} else
+			st = plain_depth_sort(&hc);
+		if (st != GSR_OK) return st;
+		PROF_FWD(2);
+		if ((st = offset_scan()) != GSR_OK) return st;
+	}
 	PROF_FWD(3);
 
 	{
@@ -375,7 +404,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	const unsigned long long R64 = (unsigned long long)t_sync.pinned[0] | ((unsigned long long)t_sync.pinned[1] << 32);
 	const unsigned long long V64 = t_sync.pinned[2];
 	t_last_visible = (int)V64;
-	if (narrow_bits && V64 != 0 && (t_sync.pinned[3] - DEPTH_KEY_BIAS) >> narrow_bits) {
+	if (!tile_first && narrow_bits && V64 != 0 && (t_sync.pinned[3] - DEPTH_KEY_BIAS) >> narrow_bits) {
 		// a depth beyond the three-pass range (z >= 13 107, or not a number): the order just produced is wrong for those keys --
 		// sort again on all 32 bits and redo the offsets (the list of long runs is built by the scan: its counters start over)
 		GSR_HIP(hipMemsetAsync(g.long_counts, 0, (size_t)LONG_LISTS * LONG_COUNT_STRIDE * sizeof(uint32_t), stream));
@@ -400,7 +429,8 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
 		// (the emission counts the tile sort's first histogram on the way: GSR_EMIT_HIST=0 is the A/B handle for the separate launch)
 		const int hist_bits = emit_hist() ? radix_first_pass_bits(0, bits) : 0;
-		if ((st = launch_emit_instances(P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded(), bs.sort_scratch, hist_bits)) != GSR_OK) return st;
+		// (tile-first: the compacted arrays hold V entries and nothing behind them -- the emission is told so)
+		if ((st = launch_emit_instances(tile_first ? (int)V64 : P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded(), bs.sort_scratch, hist_bits)) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
@@ -408,11 +438,21 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 			return st;
 		PROF_FWD(5);
 		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream, listed)) != GSR_OK) return st;
+		PROF_FWD(6);
+		if (tile_first) {
+			// the instances reached their tiles in id order: every tile's list by depth now (equal depths keep ascending id).  Scratch:
+			// the tile sort's spare pair and the forward blend's flag planes (4 R bytes, written only by the blend behind this)
+			const bool in_a = point_list == bs.vals_a;
+			if ((st = launch_tile_depth_sort(im.ranges, tiles, g.depth_key, point_list, in_a ? bs.keys_b : bs.keys_a, in_a ? bs.vals_b : bs.vals_a,
+			                                 reinterpret_cast<uint32_t*>(bs.contrib), stream)) != GSR_OK)
+				return st;
+		}
 	} else {
 		PROF_FWD(4);
 		PROF_FWD(5);
+		PROF_FWD(6);
 	}
-	PROF_FWD(6);
+	PROF_FWD(7);
 
 	BlendFwdParams bp;
 	bp.ranges = im.ranges; bp.point_list = point_list; bp.rec = g.rec; bp.bg = a->background;
@@ -421,8 +461,12 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
 	bp.sched = im.sched; bp.class_list = im.class_list;
+	{
+		static const int pf = env_int("GSR_FWD_PREFETCH", 1);
+		bp.prefetch = pf;
+	}
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
-	PROF_FWD(7);
+	PROF_FWD(8);
 	t_prof.fwd_done = t_prof.on == 1;
 	*num_rendered = R;
 	return GSR_OK;
@@ -736,6 +780,11 @@ int gsr_sh_adam_from_packed_views(int P, int D, int M, int n_views, const float*
 
 int gsr_last_visible_count(void) { return t_last_visible; }
 long long gsr_depth_resort_count(void) { return t_depth_resorts; }
+int gsr_binning_tile_first(int raw_params, int P, int width, int height)
+{
+	if (P <= 0 || width <= 0 || height <= 0) return 0;
+	return binning_tile_first(raw_params, P, div_up(width, TILE) * div_up(height, TILE)) ? 1 : 0;
+}
 
 int gsr_check_packed_views(int P, int n_views, const uint32_t* messages, long long msg_stride, int capacity_rows, void* stream_)
 {
@@ -795,15 +844,15 @@ int gsr_profile_read(float* ms, int count)
 	if (!ms || count < ST_COUNT) return GSR_ERR_INVALID_ARG;
 	for (int i = 0; i < ST_COUNT; i++) ms[i] = -1.f;
 	if (t_prof.fwd_done) {
-		GSR_HIP(hipEventSynchronize(t_prof.fwd[7]));
-		for (int i = 0; i < 7; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
+		GSR_HIP(hipEventSynchronize(t_prof.fwd[ST_FWD_COUNT]));
+		for (int i = 0; i < ST_FWD_COUNT; i++) GSR_HIP(hipEventElapsedTime(&ms[i], t_prof.fwd[i], t_prof.fwd[i + 1]));
 	}
 	if (t_prof.bwd_done && t_prof.on == 2) {
 		GSR_HIP(hipEventSynchronize(t_prof.bwd[2]));
 		GSR_HIP(hipEventElapsedTime(&ms[ST_BLEND_BWD], t_prof.bwd[1], t_prof.bwd[2]));
 	} else if (t_prof.bwd_done) {
 		GSR_HIP(hipEventSynchronize(t_prof.bwd[3]));
-		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[7 + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
+		for (int i = 0; i < 3; i++) GSR_HIP(hipEventElapsedTime(&ms[ST_FWD_COUNT + i], t_prof.bwd[i], t_prof.bwd[i + 1]));
 	}
 	return GSR_OK;
 }

@@ -91,6 +91,7 @@ struct BlendFwdParams {
 	uint32_t* sched;        // ImageState::sched / class_list: the tile's blended entries are counted, its last quad files it
 	uint32_t* class_list;
 	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
+	int prefetch;           // the next batch's records in flight while this one is walked
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
 

@@ -12,26 +12,7 @@
 namespace gsr {
 
 // ------------------------------------------------------------------ scan
-// Block-wide exclusive scan of one value per thread (256 threads = 4 waves).
-// Returns the exclusive prefix; *total receives the block sum (valid in all threads).
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* s_wave /*[4]*/)
-{
-	const uint32_t incl = wave_incl_scan_u32(v);
-	const int w = wave_id(), l = lane_id();
-	__syncthreads();  // s_wave reuse across calls
-	if (l == 63) s_wave[w] = incl;
-	__syncthreads();
-	uint32_t base = 0, tot = 0;
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		const uint32_t sw = s_wave[i];
-		if (i < w) base += sw;
-		tot += sw;
-	}
-	*total = tot;
-	return base + incl - v;
-}
-
+// (block_excl_scan_256: wave64.h)
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather, uint32_t* __restrict__ staged,
                    uint32_t* __restrict__ block_sums, int n, int items_per_block, const uint32_t* __restrict__ n_dev)
@@ -211,12 +192,6 @@ int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, i
 	return GSR_OK;
 }
 
-// ------------------------------------------------------------------ radix sort
-// Pass structure (per 8-bit digit):  histogram -> exclusive scan of the [bin][block] table
-// -> scatter.  Block b always owns elements [b*SORT_CHUNK, (b+1)*SORT_CHUNK) (2 048); wave w of the block owns
-// the 512-element sub-range starting at w*512 and walks it in 8 rounds of 64 lane-
-// consecutive elements, so the original order inside a digit is (wave, round, lane).
-
 // the 64-bit wave sum from 32-bit wave sums of three pieces of every lane's value (64 lanes x 2^16 fits 32 bits; the forward
 // pass's instance total decides "more than 2^31 instances": it must not wrap)
 __device__ __forceinline__ unsigned long long wave_sum_u64_by_parts(unsigned long long t)
@@ -225,6 +200,181 @@ __device__ __forceinline__ unsigned long long wave_sum_u64_by_parts(unsigned lon
 	return (unsigned long long)wave_sum_u32(lo & 0xFFFFu) + ((unsigned long long)wave_sum_u32(lo >> 16) << 16) +
 	       ((unsigned long long)wave_sum_u32(hi) << 32);
 }
+
+// ------------------------------------------------------------------ tile-first binning: the visible Gaussians compacted in id order
+// (gsr_api.hip: binning_tile_first).  The depth-first arrangement sorts the Gaussians by depth before their instances are emitted --
+// nine launches whatever the size, 56 us for the 17 k visible Gaussians of a 50 k-Gaussian map.  Here the visible Gaussians are only
+// COMPACTED (ascending id) and scanned; the instances then reach their tiles in id order (the tile sort is stable) and every tile's
+// list is sorted by depth on its own (tile_depth_sort.hip) -- same final order: (tile, depth bits, id).
+
+// the block sum of the projection kernel's per-wave counts: (tiles touched as 64 bits, visible, largest depth key)
+__device__ __forceinline__ void block_sum_counts(unsigned long long t, uint32_t v, uint32_t mx, unsigned long long& T, uint32_t& V, uint32_t& M)
+{
+	__shared__ unsigned long long s_t[SCAN_THREADS / 64];
+	__shared__ uint32_t s_v[SCAN_THREADS / 64], s_m[SCAN_THREADS / 64];
+	const unsigned long long wt = wave_sum_u64_by_parts(t);
+	const uint32_t wv = wave_sum_u32(v), wm = wave_max_u32(mx);
+	__syncthreads();   // (reuse across calls)
+	if (lane_id() == 0) {
+		s_t[wave_id()] = wt;
+		s_v[wave_id()] = wv;
+		s_m[wave_id()] = wm;
+	}
+	__syncthreads();
+	T = 0ull; V = 0u; M = 0u;
+	for (int i = 0; i < SCAN_THREADS / 64; i++) {
+		T += s_t[i];
+		V += s_v[i];
+		M = max(M, s_m[i]);
+	}
+}
+// entry i of a count table: level 0 = the projection kernel's per-wave pairs (tiles, visible, largest key, -), level 1 = block
+// sums of those (tiles lo, tiles hi, visible, largest key)
+__device__ __forceinline__ void add_count_entry(const uint4 c, int level, unsigned long long& t, uint32_t& v, uint32_t& mx)
+{
+	if (level == 0) {
+		t += c.x; v += c.y; mx = max(mx, c.z);
+	} else {
+		t += (unsigned long long)c.x | ((unsigned long long)c.y << 32); v += c.z; mx = max(mx, c.w);
+	}
+}
+
+// block b: the sum of ITS `pairs_per_block` per-wave pairs -> partials[b] (models of more than 128 k Gaussians: two levels)
+__global__ void __launch_bounds__(SCAN_THREADS)
+count_partials_kernel(const uint4* __restrict__ pairs, int n_pairs, int pairs_per_block, uint4* __restrict__ partials)
+{
+	const int lo = (int)blockIdx.x * pairs_per_block, hi = min(n_pairs, lo + pairs_per_block);
+	unsigned long long t = 0ull;
+	uint32_t v = 0u, mx = 0u;
+	for (int i = lo + (int)threadIdx.x; i < hi; i += SCAN_THREADS) add_count_entry(pairs[i], 0, t, v, mx);
+	unsigned long long T;
+	uint32_t V, M;
+	block_sum_counts(t, v, mx, T, V, M);
+	if (threadIdx.x == 0) partials[blockIdx.x] = make_uint4((uint32_t)(T & 0xFFFFFFFFull), (uint32_t)(T >> 32), V, M);
+}
+
+// ONE workgroup: the totals of a count table -> mapped host memory (state.h: HOST_COUNT_WORDS); the event the host waits for is
+// recorded behind this launch, and the compaction that follows needs nothing from the host: it covers the host's reaction time
+__global__ void __launch_bounds__(SCAN_THREADS)
+host_count_kernel(const uint4* __restrict__ entries, int n, int level, uint32_t* __restrict__ host_out)
+{
+	unsigned long long t = 0ull;
+	uint32_t v = 0u, mx = 0u;
+	for (int i = (int)threadIdx.x; i < n; i += SCAN_THREADS) add_count_entry(entries[i], level, t, v, mx);
+	unsigned long long T;
+	uint32_t V, M;
+	block_sum_counts(t, v, mx, T, V, M);
+	if (threadIdx.x == 0) {
+		host_out[0] = (uint32_t)(T & 0xFFFFFFFFull);
+		host_out[1] = (uint32_t)(T >> 32);
+		host_out[2] = V;
+		host_out[3] = M;
+	}
+}
+
+// Compaction + offsets in ONE pass over the ids: block b owns ids [b ipb, (b + 1) ipb); its carry -- visible Gaussians and tiles
+// in front of it -- is the sum of the count-table entries in front of it (`sums`: `epb` entries per block at `level`), so no
+// pass over tiles_touched precedes this one.  For the r-th visible Gaussian (ascending id): order[r] = id, offsets[r] = the
+// exclusive sum of the tile counts, rect_sorted[r] = its rectangle; seeds / long runs as scan_apply_kernel / scan_reduce_rect_kernel.
+__global__ void __launch_bounds__(SCAN_THREADS)
+compact_scan_kernel(const uint32_t* __restrict__ tiles_touched, const uint2* __restrict__ rect, const uint4* __restrict__ sums, int level, int epb,
+                    uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted, int n, int items_per_block,
+                    uint32_t* __restrict__ seeds, uint32_t seed_stride, uint32_t seed_capacity, uint32_t* __restrict__ long_runs,
+                    uint32_t* __restrict__ long_counts, uint32_t long_capacity, uint32_t* __restrict__ visible_out)
+{
+	__shared__ uint32_t s_wave[4];
+	constexpr int IPT = 8, TRIP = SCAN_THREADS * IPT;
+	const int base = (int)blockIdx.x * items_per_block;
+	const int end = min(n, base + items_per_block);
+	uint32_t carry_t, carry_v;
+	{
+		unsigned long long t = 0ull;
+		uint32_t v = 0u, mx = 0u;
+		for (int i = (int)threadIdx.x; i < (int)blockIdx.x * epb; i += SCAN_THREADS) add_count_entry(sums[i], level, t, v, mx);
+		unsigned long long T;
+		uint32_t M;
+		block_sum_counts(t, v, mx, T, carry_v, M);
+		carry_t = (uint32_t)T;   // (offsets are 32-bit: a view of more than 2^31 instances is refused by the host, which sees the 64-bit total)
+	}
+	const bool aligned16 = (reinterpret_cast<uintptr_t>(tiles_touched) & 15) == 0;
+	for (int b = base; b < end; b += TRIP) {   // (block-uniform trip count: the ballots below are a wave's)
+		const int i0 = b + (int)threadIdx.x * IPT;
+		uint32_t v[IPT];
+		if (i0 + IPT <= end && aligned16) {
+			const uint4 lo = *reinterpret_cast<const uint4*>(tiles_touched + i0), hi = *reinterpret_cast<const uint4*>(tiles_touched + i0 + 4);
+			v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+		} else {
+#pragma unroll
+			for (int j = 0; j < IPT; j++) v[j] = i0 + j < end ? tiles_touched[i0 + j] : 0u;
+		}
+		uint32_t sum = 0, cnt = 0;
+#pragma unroll
+		for (int j = 0; j < IPT; j++) {
+			sum += v[j];
+			cnt += v[j] != 0u ? 1u : 0u;
+		}
+		uint32_t tot_t, tot_v;
+		uint32_t run = carry_t + block_excl_scan_256(sum, &tot_t, s_wave);
+		uint32_t r = carry_v + block_excl_scan_256(cnt, &tot_v, s_wave);
+#pragma unroll
+		for (int j = 0; j < IPT; j++) {
+			const uint32_t id = (uint32_t)(i0 + j);
+			// Gaussians whose run of instance slots is too long for one lane of the backward preprocess (state.h: LONG_RUN): one atomic
+			// per wave that has any; every (block, trip, wave, j) appends to the next sub-list (as scan_reduce_rect_kernel)
+			const unsigned long long lm = long_runs ? wave_ballot(v[j] > LONG_RUN) : 0ull;
+			if (lm) {
+				const int leader = __ffsll((long long)lm) - 1;
+				uint32_t at = 0;
+				const uint32_t list = ((((uint32_t)b / (uint32_t)TRIP) * (SCAN_THREADS / 64) + (uint32_t)wave_id()) * (uint32_t)IPT + (uint32_t)j) % (uint32_t)LONG_LISTS;
+				if (lane_id() == leader) at = atomicAdd(&long_counts[list * LONG_COUNT_STRIDE], (uint32_t)__popcll(lm));
+				at = wave_shfl_u32(at, leader);
+				if ((lm >> lane_id()) & 1ull) long_runs[(size_t)list * long_capacity + at + (uint32_t)__popcll(lm & lanemask_lt())] = id;
+			}
+			if (v[j] != 0u) {
+				order[r] = id;
+				offsets[r] = run;
+				rect_sorted[r] = rect[id];
+				if (seeds)
+					for (uint32_t k = (run + seed_stride - 1u) / seed_stride; k < seed_capacity && k * seed_stride < run + v[j]; k++) seeds[k] = r;
+				r++;
+				run += v[j];
+			}
+		}
+		carry_t += tot_t;
+		carry_v += tot_v;
+	}
+	if (visible_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *visible_out = carry_v;
+}
+
+int launch_compact_visible(const uint32_t* tiles_touched, const uint2* rect, const uint4* wave_counts, int n_pairs, uint4* partials,
+                           uint32_t* order, uint32_t* offsets, uint2* rect_sorted, int n, uint32_t* host_out, void* ready, hipStream_t stream,
+                           uint32_t* seeds, uint32_t seed_stride, uint32_t seed_capacity, uint32_t* long_runs, uint32_t* long_counts,
+                           uint32_t long_capacity, uint32_t* visible_out)
+{
+	if (!tiles_touched || !rect || !wave_counts || !partials || !order || !offsets || !rect_sorted || !host_out) return GSR_ERR_INVALID_ARG;
+	if (n <= 0) return GSR_OK;
+	const int ipb = scan_items_per_block(n);   // (a multiple of 2 048 = 32 waves of the projection kernel; at most 1 024 blocks)
+	const int nb = div_up(n, ipb);
+	const int ppb = ipb / 64;
+	const bool two_levels = n_pairs > COMPACT_ONE_LEVEL_PAIRS;
+	if (two_levels) {
+		GSR_LAUNCH(count_partials_kernel, nb, SCAN_THREADS, stream, wave_counts, n_pairs, ppb, partials);
+		GSR_LAUNCH(host_count_kernel, 1, SCAN_THREADS, stream, (const uint4*)partials, nb, 1, host_out);
+	} else
+		GSR_LAUNCH(host_count_kernel, 1, SCAN_THREADS, stream, wave_counts, n_pairs, 0, host_out);
+	if (ready) GSR_HIP(hipEventRecord((hipEvent_t)ready, stream));
+	GSR_LAUNCH(compact_scan_kernel, nb, SCAN_THREADS, stream, tiles_touched, rect, two_levels ? (const uint4*)partials : wave_counts,
+	           two_levels ? 1 : 0, two_levels ? 1 : ppb, order, offsets, rect_sorted, n, ipb, seeds, seed_stride, seed_capacity, long_runs,
+	           long_counts, long_capacity, visible_out);
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
+// ------------------------------------------------------------------ radix sort
+// Pass structure (per 8-bit digit):  histogram -> exclusive scan of the [bin][block] table
+// -> scatter.  Block b always owns elements [b*SORT_CHUNK, (b+1)*SORT_CHUNK) (2 048); wave w of the block owns
+// the 512-element sub-range starting at w*512 and walks it in 8 rounds of 64 lane-
+// consecutive elements, so the original order inside a digit is (wave, round, lane).
 
 // BINS: 256 (digits of up to 8 bits) or 512 (9 bits: the depth sort's three passes over bias-subtracted keys).  bias is subtracted
 // from every key in front of the digit (0 for everybody else): an order-preserving shift that makes the high bits zero.

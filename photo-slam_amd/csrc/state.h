@@ -250,6 +250,21 @@ int launch_scan_rect_tiles(const uint2* rect, const uint32_t* gather, uint32_t* 
                            uint32_t long_capacity = 0);
 int launch_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int n, bool inclusive,
                     uint32_t* scratch, hipStream_t stream, const uint32_t* n_dev = nullptr);
+// Tile-first binning (sort.hip: compact_scan_kernel; tile_depth_sort.hip): the visible Gaussians compacted in id order -- for the
+// r-th of them order[r] = its id, offsets[r] = the exclusive sum of the tile counts, rect_sorted[r] = its rectangle (+ the emission's
+// seeds and the list of long runs, as launch_scan_rect_tiles) -- from tiles_touched / rect and the projection kernel's per-wave
+// counts (wave_counts, n_pairs = wave_count_slots(n); partials: [scan_blocks(n)] scratch).  The totals (HOST_COUNT_WORDS) are stored
+// into the mapped host words host_out by a one-workgroup launch IN FRONT of the compaction; `ready` (a hipEvent_t, nullable) is
+// recorded right behind it.  visible_out (nullable, a device word): the number of visible Gaussians.
+constexpr int COMPACT_ONE_LEVEL_PAIRS = 2048;   // up to this many per-wave pairs (128 k Gaussians) every block sums the pairs in front of it itself
+int launch_compact_visible(const uint32_t* tiles_touched, const uint2* rect, const uint4* wave_counts, int n_pairs, uint4* partials,
+                           uint32_t* order, uint32_t* offsets, uint2* rect_sorted, int n, uint32_t* host_out, void* ready, hipStream_t stream,
+                           uint32_t* seeds = nullptr, uint32_t seed_stride = 1, uint32_t seed_capacity = 0, uint32_t* long_runs = nullptr,
+                           uint32_t* long_counts = nullptr, uint32_t long_capacity = 0, uint32_t* visible_out = nullptr);
+// every tile's list [ranges[t].x, ranges[t].y) of point_list (ascending id on entry) sorted by depth_key[id], stable: one workgroup
+// per tile.  spare_keys / spare_vals / spare_words: three arrays as long as point_list; tile t uses its own segment of each.
+int launch_tile_depth_sort(const uint2* ranges, int tiles, const uint32_t* depth_key, uint32_t* point_list, uint32_t* spare_keys,
+                           uint32_t* spare_vals, uint32_t* spare_words, hipStream_t stream);
 // A job that rides in the first two launches of a sort: add up n (a, b) pairs -- every histogram workgroup its share into
 // partials[block], an extra workgroup of the row-prefix launch the partials -- and store the totals, sum a as 64 bits in
 // host_out[0..1], sum b in host_out[2], into MAPPED HOST memory; `ready` (a hipEvent_t, nullable) is recorded right behind the

@@ -270,6 +270,26 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 	return (1ull << (threadIdx.x & 63u)) - 1ull;
 }
 
+// Block-wide exclusive scan of one value per thread (256 threads = 4 waves).
+// Returns the exclusive prefix; *total receives the block sum (valid in all threads).
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* s_wave /*[4]*/)
+{
+	const uint32_t incl = wave_incl_scan_u32(v);
+	const int w = wave_id(), l = lane_id();
+	__syncthreads();  // s_wave reuse across calls
+	if (l == 63) s_wave[w] = incl;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const uint32_t sw = s_wave[i];
+		if (i < w) base += sw;
+		tot += sw;
+	}
+	*total = tot;
+	return base + incl - v;
+}
+
 // For every lane, the set of lanes (among `valid` ones) holding the same `nbits`-bit digit.
 __device__ __forceinline__ unsigned long long wave_match_digit(uint32_t digit, int nbits, bool valid)
 {

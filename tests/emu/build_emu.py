@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "photo-slam_amd", "csrc")
 OUT = os.path.join(HERE, "libgsr_emu.so")
-SOURCES = ["gsr_api.hip", "preprocess.hip", "sort.hip", "binning.hip", "blend_fwd.hip", "blend_bwd.hip",
+SOURCES = ["gsr_api.hip", "preprocess.hip", "sort.hip", "binning.hip", "tile_depth_sort.hip", "blend_fwd.hip", "blend_bwd.hip",
            "preprocess_bwd.hip", "knn.hip", "train_ops.hip", "points.hip", "densify.hip"]
 
 

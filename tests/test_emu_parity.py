@@ -29,6 +29,42 @@ def test_forward_backward_matches_oracle(emu_lib_path, oracle, P, W, H, seed):
     print(rep)
 
 
+@pytest.mark.parametrize("P,W,H,seed,scale_k,flags", [
+    (600, 64, 48, 1, 0.35, 64), (1500, 80, 70, 2, 0.35, 64),
+    (300, 96, 64, 5, 1.5, 64),       # large splats: long runs of instance slots
+    (40, 16, 16, 7, 0.35, 64),       # a one-tile image: a tile sort of zero passes
+    (6000, 64, 64, 3, 0.5, 64),      # lists of ~1 000 entries: several passes in LDS
+    (30000, 32, 32, 4, 0.3, 64),     # lists of more than 2 048 entries: the chunked passes through the tile's own segments
+    (150000, 96, 64, 6, 0.5, 64),    # more than 128 k Gaussians: the counts in two levels
+    (1500, 80, 70, 2, 0.35, 64 | 8),  # with GSR_CULL_EMPTY_TILES: compared with the culled depth-first run below
+])
+def test_tile_first_binning_matches_oracle(emu_lib_path, oracle, P, W, H, seed, scale_k, flags):
+    """GSR_BINNING_TILE_FIRST (include/gsr.h): no depth sort of the Gaussians -- the visible ones compacted in id order, every tile's
+    list sorted by depth on its own behind the tile sort (tile_depth_sort.hip).  Every stage equals the oracle exactly as with the
+    depth-first arrangement: the final (tile, depth bits, id) order is the reference's."""
+    cl = small_scene(P, W, H, seed, scale_k=scale_k)
+    cam = cl.cameras[0]
+    bg = np.array([0.2, 0.5, 0.1], np.float32)
+    dpix = np.random.default_rng(seed).standard_normal((3, H, W)).astype(np.float32)
+    if flags & 8:
+        a = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix, flags=32 | 8)
+        b = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix, flags=flags)
+        kept = int(a.ranges[:, 1].max())   # (behind the instances the tile sort kept the list's content is undefined)
+        assert 0 < kept < a.R and np.array_equal(a.point_list[:kept], b.point_list[:kept])
+        for k in ("ranges", "out_color", "n_contrib"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), k
+        for k, g in a.grads.items():
+            assert np.array_equal(g, b.grads[k]), k
+        return
+    ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix)
+    r = parity.run_backend(emu_lib_path, CPU, cl, cam, bg, dL_dpix=dpix, flags=flags)
+    parity.compare(r, ores, ocolor, oradii, ograds, cam)
+    lens = ores.ranges[:, 1] - ores.ranges[:, 0]
+    print("R", r.R, "longest list", int(lens.max()))
+    if P == 30000:
+        assert lens.max() > 4096     # (at least three chunks per pass)
+
+
 @pytest.mark.parametrize("P,W,H,seed,scale_k", [(600, 64, 48, 1, 0.35), (1500, 80, 70, 2, 0.35), (300, 96, 64, 5, 1.5), (40, 16, 16, 7, 0.35)])
 def test_cull_empty_tiles_keeps_image_and_gradients(emu_lib_path, P, W, H, seed, scale_k):
     """GSR_CULL_EMPTY_TILES: shorter instance lists, the same image and the same gradients bit for bit (the last case is a

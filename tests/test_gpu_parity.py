@@ -19,15 +19,21 @@ def dev():
     return torch.device("cuda:0")
 
 
+BINNINGS = (("depth-first", 32), ("tile-first", 64))   # GSR_BINNING_DEPTH_FIRST / GSR_BINNING_TILE_FIRST (include/gsr.h)
+
+
 def _check(oracle, dev, cl, cam, bg, seed=0, **kw):
+    """Every stage of the HIP path against the oracle -- once per binning arrangement (the Gaussians sorted by depth in front of
+    the emission / every tile's list sorted by depth behind the tile sort): both must give the reference's lists bit for bit."""
     rng = np.random.default_rng(seed)
     dpix = rng.standard_normal((3, cam.H, cam.W)).astype(np.float32)
     ores, ocolor, oradii, ograds = parity.run_oracle(oracle, cl, cam, bg, dL_dpix=dpix, **kw)
-    r = parity.run_backend(None, dev, cl, cam, bg, dL_dpix=dpix, **kw)
-    rep = parity.compare(r, ores, ocolor, oradii, ograds, cam,
-                         use_colors_precomp=kw.get("use_colors_precomp", False),
-                         use_cov3D_precomp=kw.get("use_cov3D_precomp", False))
-    print(dict(P=ores.P, V=int((oradii > 0).sum()), R=ores.R), rep)
+    for name, flag in BINNINGS:
+        r = parity.run_backend(None, dev, cl, cam, bg, dL_dpix=dpix, flags=flag, **kw)
+        rep = parity.compare(r, ores, ocolor, oradii, ograds, cam,
+                             use_colors_precomp=kw.get("use_colors_precomp", False),
+                             use_cov3D_precomp=kw.get("use_cov3D_precomp", False))
+        print(name, dict(P=ores.P, V=int((oradii > 0).sum()), R=ores.R), rep)
     return r, ores
 
 

@@ -10,10 +10,10 @@
 #   bench        `bench.py --no-cpu-baseline` (100 steps + median of 100)      bench:C2 | bench:C4 | bench:C5  other configs
 #   big:<points> the C3 view with <points> Gaussians (default 16 M): the path at 8x the stated model size
 #   raster       `bench.py --raster-only --no-cpu-baseline`
-#   kstats       rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline) -> kernel_stats_bench_full_C3.csv
+#   kstats       rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline) -> kernel_stats_bench_full_C3.csv   kstats:C2  another config
 #   knnstats     rocprofv3 --kernel-trace --stats of distCUDA2 at 100 k and 1 M points -> knn_kernel_stats_<points>.csv
-#   pmc          TCC traffic per launch, rasterizer only (two --pmc passes)      pmc:full  the fused train step
-#   sq           SQ counters (VALU / SALU / LDS issue, busy cycles), fused step  sq:raster  rasterizer only
+#   pmc          TCC traffic per launch, rasterizer only (two --pmc passes)      pmc:full  the fused train step   pmc:full:C2  another config
+#   sq           SQ counters (VALU / SALU / LDS issue, busy cycles), fused step  sq:raster  rasterizer only   sq:full:C2  another config
 #   dp           the data-parallel program at ONE rank over RCCL (GSR_BENCH_FORCE_DP=1): C3 and a C4 view, view-factored
 #   dp:allreduce the same with the plain all-reduce      dp:py  view-factored with the collectives issued from Python
 #   dpstats      rocprofv3 --kernel-trace --stats of the data-parallel program at one rank -> kernel_stats_dp_path_1rank_C3.csv
@@ -24,7 +24,7 @@
 #   seeds        benchq for scene seeds 0..4 -> seed_spread_C3.json (seeds 1-4 for variance)
 #   py:<file>    python tools/<file> (an experiment script), output -> <file>.log
 #   env:VAR=VAL  export VAR=VAL for the steps behind it (A/B runs; bench outputs get a _VAR_VAL suffix)
-#   abenv:VAR=A,B[:n] alternate the quick bench with VAR=A and VAR=B (an environment switch of the library), n pairs on one box
+#   abenv:VAR=A,B[:n[:config]] alternate the quick bench with VAR=A and VAR=B (an environment switch of the library), n pairs on one box
 #   ab:<dir>[:n] alternate the quick bench of the tree in <dir> (a built worktree of an older commit) and of this tree, n pairs on one box
 TAG=${1:-r03_x}; shift
 OUT=gpurun_out/$TAG
@@ -83,14 +83,14 @@ if steps:
 PY
 }
 
-pmc_pass() {  # $1 = mode (raster|full) -> $OUT/pmc_traffic_<mode>.json
-  local mode=$1
+pmc_pass() {  # $1 = mode (raster|full), $2 = config (default C3) -> $OUT/pmc_traffic_<mode>[_<config>].json
+  local mode=$1 cfg=${2:-C3}
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
-    (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
+    (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $ROOT/bench.py --config $cfg --steps 3 --warmup 1 \
         $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 > /tmp/pmc_$c.log 2>&1)
   done
-  python - "$OUT/pmc_traffic_$mode.json" <<'PY'
+  python - "$OUT/pmc_traffic_$mode$( [ $cfg = C3 ] || echo _$cfg ).json" <<'PY'
 import csv, glob, collections, json, sys
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -112,20 +112,20 @@ for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
 PY
 }
 
-sq_pass() {  # $1 = mode (raster|full) -> $OUT/sq_counters_<mode>.json
-  local mode=$1
+sq_pass() {  # $1 = mode (raster|full), $2 = config (default C3) -> $OUT/sq_counters_<mode>[_<config>].json
+  local mode=$1 cfg=${2:-C3}
   local sets=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE")
   local i=0
   for set in "${sets[@]}"; do
     rm -rf /tmp/sq_$i
-    (cd /tmp && timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$i -o p -- python $ROOT/bench.py --steps 3 --warmup 1 \
+    (cd /tmp && timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$i -o p -- python $ROOT/bench.py --config $cfg --steps 3 --warmup 1 \
         $( [ "$mode" = full ] || echo --raster-only ) --no-cpu-baseline --median-steps 0 --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 > /tmp/sq_$i.log 2>&1)
     i=$((i+1))
   done
-  python - "$OUT/sq_counters_$mode.json" <<'PY'
+  python - "$OUT/sq_counters_$mode$( [ $cfg = C3 ] || echo _$cfg ).json" <<'PY'
 import csv, glob, collections, json, sys
 out = {}
-for d in glob.glob("/tmp/sq_*"):
+for d in glob.glob("/tmp/sq_[0-9]"):
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         with open(fn) as f:
@@ -175,10 +175,10 @@ import json; d=json.load(open('$OUT/benchq_$cfg$SUF.json')); print('$cfg$SUF', d
             python -c "
 import json; d=json.load(open('$OUT/bench_C3_${n}_points.json')); print('C3 view,', d['config']['gaussians'], 'Gaussians:', d['ms_per_step'], 'ms', d['value'], 'it/s', 'visible', d['config']['visible'], 'instances', d['config']['instances'], {k: v['ms'] for k, v in d['roofline']['stages'].items()})" || tail -5 $OUT/big_err.log ;;
     raster) timeout 400 python bench.py --raster-only --no-cpu-baseline --no-knn-leg > $OUT/bench_raster_only_C3.json 2>>$OUT/bench_err.log; cut -c1-200 $OUT/bench_raster_only_C3.json ;;
-    kstats) kernel_stats $OUT/kernel_stats_bench_full_C3.csv python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 ;;
+    kstats) cfg=${arg:-C3}; kernel_stats $OUT/kernel_stats_bench_full_$cfg.csv python $ROOT/bench.py --config $cfg --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --densify-leg-steps 0 --no-knn-leg --dropin-steps 0 ;;
     knnstats) for n in 100000 1000000; do kernel_stats $OUT/knn_kernel_stats_$n.csv python $ROOT/tools/knn_probe.py $n; done ;;
-    pmc)    pmc_pass ${arg:-raster} ;;
-    sq)     sq_pass ${arg:-full} ;;
+    pmc)    IFS=: read m c <<< "$arg"; pmc_pass ${m:-raster} ${c:-C3} ;;   # pmc | pmc:full | pmc:full:C2
+    sq)     IFS=: read m c <<< "$arg"; sq_pass ${m:-full} ${c:-C3} ;;       # sq | sq:raster | sq:full:C2
     dp)     # dp | dp:allreduce | dp:py (view-factored, collectives issued from Python as in round 2) | dp:late (GSR_EARLY_GATHER=0)
             ex=factored; pyx=0; form=auto; [ "$arg" = allreduce ] && ex=allreduce; [ "$arg" = py ] && pyx=1
             [ "$arg" = packed ] && form=packed; [ "$arg" = dense ] && form=dense   # dp:packed | dp:dense: the form of the view-factored exchange (default: the guarded trial)
@@ -244,16 +244,16 @@ print(json.dumps(res))
 PY
             ;;
     abenv)  # abenv:VAR=A,B[:pairs]: alternate the quick bench with VAR=A and VAR=B (an environment switch of the library) on ONE box -> abenv_VAR.json
-            spec=${arg%%:*}; n=3; [ "$arg" != "$spec" ] && n=${arg##*:}
+            IFS=: read spec n cfg <<< "$arg"; n=${n:-3}; cfg=${cfg:-C3}   # abenv:VAR=A,B[:pairs[:config]]
             var=${spec%%=*}; vals=${spec#*=}; va=${vals%%,*}; vb=${vals##*,}
             for i in $(seq 1 $n); do
-              env $var=$va timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_a_$i.json 2>>$OUT/bench_err.log
-              env $var=$vb timeout 300 python bench.py --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_b_$i.json 2>>$OUT/bench_err.log
+              env $var=$va timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_a_$i.json 2>>$OUT/bench_err.log
+              env $var=$vb timeout 300 python bench.py --config $cfg --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/abenv_${var}_b_$i.json 2>>$OUT/bench_err.log
             done
-            python - $OUT $var $va $vb $n <<'PY'
+            python - $OUT $var $va $vb $n $cfg <<'PY'
 import json, sys, statistics as st
-out, var, va, vb, n = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
-res = {}
+out, var, va, vb, n, cfg = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
+res = {"config": cfg}
 for side, val in (("a", va), ("b", vb)):
     runs = [json.load(open(f"{out}/abenv_{var}_{side}_{i}.json")) for i in range(1, n + 1)]
     res[f"{var}={val}"] = {"ms_per_step": [r["ms_per_step"] for r in runs], "median_ms_per_step": [r["protocol"]["median_ms_per_step"] for r in runs],
@@ -261,7 +261,7 @@ for side, val in (("a", va), ("b", vb)):
                            "mean_of_medians": round(st.mean(r["protocol"]["median_ms_per_step"] for r in runs), 4)}
 res["delta_ms (second - first, mean of medians)"] = round(res[f"{var}={vb}"]["mean_of_medians"] - res[f"{var}={va}"]["mean_of_medians"], 4)
 res["note"] = f"alternating runs x {n} on one box"
-json.dump(res, open(f"{out}/abenv_{var}.json", "w"), indent=1)
+json.dump(res, open(f"{out}/abenv_{var}_{va}_{vb}_{cfg}.json".replace("-", "m"), "w"), indent=1)
 print(json.dumps(res))
 PY
             ;;
