@@ -49,7 +49,68 @@ ISSUE_COST_FILES = sorted((os.path.relpath(f, ROOT) for f in glob.glob(os.path.j
                           reverse=True)
 
 
-def stage_bounds(stages, top=6):
+def sq_probe(config, seed=0):
+    """VALU issue of the two blend kernels MEASURED on this box: one `rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE` pass (counters
+    only, next to --kernel-trace, as the pool's rules ask) over a short run of this program at `config` -> per kernel the mean
+    counter values per launch, or (None, reason) when the profiler is not on the box / the pass fails."""
+    import collections
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 is not on PATH"
+    d = tempfile.mkdtemp(prefix="gsr_sq_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+           sys.executable, os.path.abspath(__file__), "--config", config, "--seed", str(seed), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--median-steps", "0", "--densify-leg-steps", "0", "--no-knn-leg", "--dropin-steps", "0", "--no-config-legs", "--no-sq-probe"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=True)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, "the counter pass left no counter_collection.csv"
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                if "gsr::blend_" in r["Kernel_Name"]:
+                    acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+        for k in out:
+            out[k]["launches"] = len(next(iter(acc[k].values())))
+        return (out, None) if out else (None, "no blend kernel in the counter file")
+    except Exception as e:   # (a box without counter access, a timeout: the committed profile is used and the record says so)
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def config_leg(config, seed, steps=40, warmup=10):
+    """One more single-GPU BASELINE config in THIS record: the same program at `config` in a child process (quick form: no CPU /
+    kNN / densify / drop-in legs), reduced to its step time, the rasterizer alone, its own roofline entry and the blend kernels'
+    VALU issue utilisation measured there."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--seed", str(seed), "--steps", str(steps), "--warmup", str(warmup),
+           "--median-steps", str(steps), "--no-cpu-baseline", "--no-knn-leg", "--densify-leg-steps", "0", "--dropin-steps", "0", "--no-config-legs"]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"metric"')), None)
+        if r.returncode != 0 or line is None:
+            return {"config": config, "error": (r.stderr or "no JSON line")[-300:]}
+        d = json.loads(line)
+    except Exception as e:
+        return {"config": config, "error": f"{type(e).__name__}: {e}"[:300]}
+    rf = d.get("roofline", {})
+    return {"workload": d["config"]["workload"], "gaussians": d["config"]["gaussians"], "width": d["config"]["width"], "height": d["config"]["height"],
+            "visible": d["config"]["visible"], "instances": d["config"]["instances"], "binning": d["config"].get("binning"),
+            "iters_per_s": d["value"], "ms_per_step": d["ms_per_step"], "median_ms_per_step": d.get("protocol", {}).get("median_ms_per_step"),
+            "steps": d["steps"], "warmup": d["warmup"], "rasterizer_only": d.get("rasterizer_only"),
+            "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "valu_issue_utilisation", "traffic",
+                                                "raster_fwd_bwd_frac", "bounds")},
+            "stages_ms": {k: v["ms"] for k, v in rf.get("stages", {}).items()}, "leg_wall_s": round(time.time() - t0, 1)}
+
+
+def stage_bounds(stages, top=6, sq_live=None, sq_live_note=None):
     """What bounds each of the `top` largest stages, so that the claim rides in this record and not only in DESIGN.md:
       * the two blend kernels: "valu-issue" -- SIMD cycles available per wave-VALU instruction issued (SQ counters of the newest
         committed profile of this program: GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / SQ_INSTS_VALU) against the mean issue cost of
@@ -58,6 +119,9 @@ def stage_bounds(stages, top=6):
       * the streaming stages: "hbm" with achieved = algorithmic bytes / stage time of THIS run against the 8 TB/s peak;
       * the sorts and scans: "launch-latency" (6-12 launches of 5-20 us each) with the same achieved figure for reference."""
     sq = json.load(open(os.path.join(ROOT, SQ_FILES[0]))) if SQ_FILES else {}
+    sq_src = SQ_FILES[0] + " (committed profile of this program: NOT measured in this run" + (f" -- {sq_live_note})" if sq_live_note else ")") if SQ_FILES else None
+    if sq_live:   # (sq_probe: measured on this box, in this run)
+        sq, sq_src = sq_live, "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE over 3 steps of this program on this box"
     cost = json.load(open(os.path.join(ROOT, ISSUE_COST_FILES[0]))) if ISSUE_COST_FILES else {}
     out = {}
     for k in sorted(stages, key=lambda k: -stages[k]["ms"])[:top]:
@@ -69,7 +133,7 @@ def stage_bounds(stages, top=6):
             if c and c.get("SQ_INSTS_VALU"):
                 avail = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / c["SQ_INSTS_VALU"]
                 e["simd_cycles_per_valu_instruction"] = round(avail, 3)
-                e["sq_counters_source"] = SQ_FILES[0]
+                e["sq_counters_source"] = sq_src
                 if k in cost:
                     e["issue_cost_of_the_instruction_mix"] = cost[k]["mean_cycles_per_valu"]
                     e["valu_issue_utilisation"] = round(cost[k]["mean_cycles_per_valu"] / avail, 3)
@@ -422,6 +486,10 @@ def main():
                          "measures faster on this node (auto)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
+    ap.add_argument("--no-config-legs", dest="config_legs", action="store_false",
+                    help="skip the `configs` block (the other single-GPU BASELINE configs -- C2, a C4 view, a C5 view -- each in a child process)")
+    ap.add_argument("--no-sq-probe", dest="sq_probe", action="store_false",
+                    help="do not measure the blend kernels' VALU issue with a rocprofv3 counter pass (the committed profile is cited instead)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         import __graft_entry__ as entry
@@ -1103,19 +1171,38 @@ def main():
                                          "combined_GBps_if_fully_overlapped": round((ab[dom] + side_bytes) / (stages[dom]["ms"] * 1e-3) / 1e9, 1)}
         if dom:
             a = stages[dom]["GBps"]
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # what the dominant kernel is ACTUALLY bound by: the blend kernels issue VALU instructions at the machine's rate while
+            # HBM idles (achieved / peak / frac stay the HBM figures the contract asks for, so that the distance is on record);
+            # the utilisation is measured here when the profiler is on the box (one rocprofv3 --pmc pass in a child), else cited
+            sq_live = sq_note = None
+            if args.sq_probe and world == 1 and not dp and args.points is None:
+                sq_live, sq_note = sq_probe(args.config, args.seed)
+            bounds = stage_bounds(stages, sq_live=sq_live, sq_live_note=sq_note)
+            dom_b = bounds.get(dom, {})
+            out["roofline"] = {"kernel": dom, "bound": dom_b.get("bound", "hbm"), "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(a / HBM_PEAK_GBS, 4),
+                               "valu_issue_utilisation": dom_b.get("valu_issue_utilisation"),
+                               "valu_issue_source": dom_b.get("sq_counters_source"),
+                               "traffic": traffic,
                                "traffic_source": traffic_src and f"{traffic_src} (rocprofv3 --pmc of the same build; not measured in this run)",
                                # the rasterizer alone (SH Adam as a separate pass: rasterizer bytes / rasterizer time); the fused
                                # program's figure -- whose backward also carries the optimizer's bytes -- under its own key
                                "raster_fwd_bwd_frac": out.get("rasterizer_only", {}).get("hbm_frac"),
                                "fused_step_stage_bytes_frac": round(sum(ab.values()) / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "bounds": stage_bounds(stages),
+                               "bounds": bounds,
                                "stage_table_source": "median of 20 further steps of the SAME program with HIP events between all "
                                                      "stages (preprocess_bwd carries the fused Adam step of the SH tensor when "
                                                      "config.sh_adam_fused_into_backward); the dominant kernel's entry is its mean "
                                                      "duration inside the timed region",
                                "stages": stages}
+        if world == 1 and not dp and args.config_legs and args.config == "C3" and args.points is None and not args.raster_only:
+            # the other single-GPU configs of BASELINE.json in the SAME record (C2 = Replica's native resolution; one keyframe of
+            # the C4 and C5 batches = the per-rank work of the 8-GPU runs), each with its own roofline entry.  This process's
+            # model is released first: a C5 view wants 4 M Gaussians of its own.
+            torch.cuda.synchronize()
+            out["configs"] = {}
+            for c in ("C2", "C4", "C5"):
+                out["configs"][c] = config_leg(c, args.seed)
         if world == 1 and not args.no_cpu_baseline:
             base, kept = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline, want_inputs=True)
             main = base.get(args.config, base["C1"])

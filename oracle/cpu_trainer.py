@@ -228,28 +228,41 @@ def reference_reset_opacity(model, kind="cpu"):
 
 def train_sequence(cloud, cams, gt_images, iterations, densification_interval=0, densify_from_iter=0, opacity_reset_interval=0,
                    densify_until_iter=15000, densify_grad_threshold=0.0002, min_opacity=0.005, lambda_dssim=0.2, seed=0,
-                   kind="cpu", threads=None, on_iteration=None, keyframe_order=None, step_on_last_iteration=True):
+                   kind="cpu", threads=None, on_iteration=None, keyframe_order=None, step_on_last_iteration=True, plan=None):
     """trainingOnce's loop (src/gaussian_trainer.cpp:45-133) over the keyframes cams[(it - 1) % len(cams)], it = 1..iterations,
     with the reference's own densifyAndPrune / resetOpacity on the schedule of :108-127.  Returns dict(losses, points per
     iteration, densified_at, reset_at, model).  The split samples come from the default generator of `kind`'s device,
     seeded once with `seed` (the hosts under test seed a generator of their own identically).
     keyframe_order: the keyframe index of every iteration instead of the cycle (trainingOnce draws it with std::rand, :59);
-    step_on_last_iteration=False: trainingOnce's `if (iteration < opt.iterations_)` around the optimizer step (:129)."""
+    step_on_last_iteration=False: trainingOnce's `if (iteration < opt.iterations_)` around the optimizer step (:129).
+    plan (instead of cams / gt_images): per iteration a dict(cam, gt [3,H,W], mask [3,H,W] or None, lr_step or None) -- the SLAM
+    flavour of the step, GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:631-699): the keyframe rendered at the size of
+    its current Gaussian-pyramid level (cam.H, cam.W) against that level's image, `rendered * mask` (:692), and the position
+    learning rate at the keyframe's use count (:663-671) instead of the iteration."""
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
     oracle.build()
     l1_loss, ssim, loss_kind = _loss_ops()
     model = CpuModel(cloud, cloud.extent)
     model.exist_since_iter = torch.zeros(model.xyz.shape[0], dtype=torch.int32)
-    gts = [torch.from_numpy(np.ascontiguousarray(g, np.float32)) for g in gt_images]
+    gts = [torch.from_numpy(np.ascontiguousarray(g, np.float32)) for g in gt_images] if plan is None else None
     bg = np.zeros(3, np.float32)
     (torch.cuda.manual_seed if kind == "cuda" else torch.manual_seed)(seed)
     losses, points, densified_at, reset_at = [], [], [], []
     for it in range(1, iterations + 1):
-        model.update_learning_rate(it)
-        k = keyframe_order[it - 1] if keyframe_order is not None else (it - 1) % len(cams)
-        image, viewspace, visibility, radii = render(model, cams[k], bg)
-        loss = (1.0 - lambda_dssim) * l1_loss(image, gts[k]) + lambda_dssim * (1.0 - ssim(image, gts[k]))
+        if plan is not None:
+            step = plan[it - 1]
+            model.update_learning_rate(it if step.get("lr_step") is None else min(int(step["lr_step"]), model.max_steps))
+            image, viewspace, visibility, radii = render(model, step["cam"], bg)
+            if step.get("mask") is not None:
+                image = image * torch.from_numpy(np.ascontiguousarray(step["mask"], np.float32))       # :692
+            gt = torch.from_numpy(np.ascontiguousarray(step["gt"], np.float32))
+        else:
+            model.update_learning_rate(it)
+            k = keyframe_order[it - 1] if keyframe_order is not None else (it - 1) % len(cams)
+            image, viewspace, visibility, radii = render(model, cams[k], bg)
+            gt = gts[k]
+        loss = (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
         loss.backward()
         with torch.no_grad():
             losses.append(float(loss))

@@ -11,6 +11,7 @@
 // Tile-first binning (binning_tile_first below; small and mid-size views): no depth sort of the Gaussians -- the visible ones are
 // compacted in id order (the count for the host by a one-workgroup launch in front of the compaction), and behind the tile sort
 // every tile's list is sorted by depth on its own (tile_depth_sort.hip): 12 launches instead of 20, the same lists bit for bit.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <vector>
@@ -31,8 +32,10 @@ void set_last_hip_error(int err, const char* what)
 	snprintf(t_last_what, sizeof(t_last_what), "%s: %s", what ? what : "?", hipGetErrorString((hipError_t)err));
 }
 
-// Pinned word + event used for the single device->host read of num_rendered; one per host
-// thread, so concurrent callers on different threads do not share state.
+// Pinned words + event for the single device->host read of num_rendered, and the second stream with its events: one set per host
+// thread AND device (a thread that renders on a second device -- a viewer on another GPU, a test harness -- must not wait on the
+// first device's event or launch on its stream), created on first use on the device that is current then, released when the
+// thread exits.
 struct HostSync {
 	uint32_t* pinned = nullptr;
 	uint32_t* pinned_dev = nullptr;   // the same words as the device addresses them
@@ -61,17 +64,49 @@ struct HostSync {
 	}
 	int init()
 	{
-		if (pinned && ev) return GSR_OK;
+		if (pinned && pinned_dev && ev) return GSR_OK;
 		if (!pinned) {
 			// mapped: the device stores the forward pass's counts straight into it (sort.hip: RadixHostCount)
 			GSR_HIP(hipHostMalloc((void**)&pinned, 64 * sizeof(uint32_t), hipHostMallocMapped));
-			GSR_HIP(hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0));
 		}
-		if (!ev) GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));   // a failure here is retried by the next call
+		// (a failure of any step is retried by the next call: a half-initialised set is never used)
+		if (!pinned_dev) GSR_HIP(hipHostGetDevicePointer((void**)&pinned_dev, pinned, 0));
+		if (!ev) GSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		return GSR_OK;
 	}
+	void release()
+	{
+		if (ev) (void)hipEventDestroy(ev);
+		if (fork) (void)hipEventDestroy(fork);
+		if (join) (void)hipEventDestroy(join);
+		if (notify) (void)hipEventDestroy(notify);
+		if (side) (void)hipStreamDestroy(side);
+		if (pinned) (void)hipHostFree(pinned);
+		*this = HostSync();
+	}
 };
-static thread_local HostSync t_sync;
+constexpr int MAX_DEVICES = 16;
+struct ThreadState {
+	HostSync dev[MAX_DEVICES];
+	~ThreadState()
+	{
+		int cur = 0;
+		if (hipGetDevice(&cur) != hipSuccess) return;   // (no runtime left to talk to)
+		for (int d = 0; d < MAX_DEVICES; d++)
+			if (dev[d].pinned || dev[d].ev || dev[d].side) {
+				if (hipSetDevice(d) == hipSuccess) dev[d].release();
+			}
+		(void)hipSetDevice(cur);
+	}
+};
+static thread_local ThreadState t_state;
+// the calling thread's set for the CURRENT device (the device the caller's stream belongs to: PyTorch and the reference keep it current)
+static HostSync* host_sync()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return nullptr;
+	return &t_state.dev[d];
+}
 static thread_local int t_last_visible = -1;   // gsr_last_visible_count()
 // gsr_host_wait_stats(): how long the calling thread was blocked in gsr_forward's ONE host synchronisation (the instance count)
 static thread_local double t_sync_wait_us = 0.0;
@@ -82,7 +117,10 @@ static thread_local long long t_sync_waits = 0;
 static int env_int(const char* name, int unset)
 {
 	const char* e = getenv(name);
-	return (e && *e) ? atoi(e) : unset;
+	if (!(e && *e)) return unset;
+	// (every caller keeps the value in a function-local static: this line appears once per switch and process)
+	fprintf(stderr, "[gsr] environment override %s=%s (wins over the API field / the library's default)\n", name, e);
+	return atoi(e);
 }
 static bool side_stream_enabled(const gsr_sh_adam* o)
 {
@@ -183,11 +221,13 @@ static const char* const k_stage_names[ST_COUNT] = {"preprocess_fwd", "depth_sor
                                                     "tile_sort", "tile_ranges", "tile_depth_sort", "blend_fwd", "grad_memset",
                                                     "blend_bwd", "preprocess_bwd"};
 struct Profiler {
-	int on = 0;               // 0 off, 1 every stage, 2 only the backward blend (its two events: an event record costs a
+	std::atomic<int> on{0};   // 0 off, 1 every stage, 2 only the backward blend (its two events: an event record costs a
 	                          // ~5 us pipeline bubble, eleven of them 2 % of a C3 train step)
 	hipEvent_t fwd[ST_FWD_COUNT + 1] = {};   // boundaries of the forward stages
 	hipEvent_t bwd[4] = {};   // boundaries of the 3 backward stages
-	bool created = false, fwd_done = false, bwd_done = false;
+	// (written by the thread that runs the pass -- PyTorch's autograd worker for the backward pass -- and read by the thread that
+	// asks for the timings: atomics; the event handles are created once, before `on` is set)
+	std::atomic<bool> created{false}, fwd_done{false}, bwd_done{false};
 	int create()
 	{
 		if (created) return GSR_OK;
@@ -321,6 +361,9 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if (!img_chunk) return GSR_ERR_ALLOC;
 	ImageState im = ImageState::carve(img_chunk, (size_t)W * H, (size_t)tiles);
 
+	HostSync* const sync_ = host_sync();
+	if (!sync_) return GSR_ERR_UNSUPPORTED;   // (a device ordinal beyond MAX_DEVICES)
+	HostSync& t_sync = *sync_;
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
 	// (nothing to zero: the projection kernel's waves leave their counts with plain stores -- state.h: wave_counts)
@@ -507,6 +550,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	const int passes = tile_sort_passes(tiles);
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
+	HostSync* const sync_ = host_sync();
+	if (!sync_) return GSR_ERR_UNSUPPORTED;
+	HostSync& t_sync = *sync_;
 	t_prof.bwd_done = false;
 	// ---- the rest of the validation, BEFORE anything is enqueued: a call that is going to be refused must not have applied a
 	// part of an optimizer step already (the culled rows' update below is forked onto a second stream first thing)

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(PKG)
 # the link-level boundary of the reference (its `cuda_rasterizer` + `simple_knn` libraries) and what this repository adds on top
 BOUNDARY_SRCS = ["rasterize_points.cpp", "operate_points.cpp", "spatial.cpp", "loss_utils.cpp"]
 HOST_SRCS = ["gaussian_rasterizer.cpp", "train_step.cpp", "gaussian_model_densify.cpp", "ply_io.cpp", "keyframe_batch_exchange.cpp",
-             "ops_register.cpp"]
+             "keyframe_scheduler.cpp", "ops_register.cpp"]
 HIP_OUT = {"cuda_rasterizer": os.path.join(PKG, "lib", "libcuda_rasterizer.so"), "simple_knn": os.path.join(PKG, "lib", "libsimple_knn.so"),
            "photoslam_host": os.path.join(HERE, "libphotoslam_host.so")}
 EMU_OUT = {"cuda_rasterizer": os.path.join(ROOT, "tests", "emu", "libcuda_rasterizer_emu.so"),

@@ -234,6 +234,10 @@ public:
 	// finishBegin(); an iteration that rebuilt the tensors skips its optimizer step exactly as the reference does (the
 	// fresh leaves have no gradient).
 	bool densify_ = false;
+	// The step of the position learning-rate schedule for the NEXT iteration(s): -1 = the iteration count (the COLMAP flavour,
+	// src/gaussian_mapper.cpp:672-674); a SLAM session sets the keyframe's use count before every iteration (:663-671:
+	// kfs_used_times_[fid], capped at position_lr_max_steps_)
+	int position_lr_step_ = -1;
 	float cameras_extent_ = 1.0f, densify_min_opacity_ = 0.005f;
 	int prune_big_point_after_iter_ = 30000;   // Optimization.prune_big_point_after_iter of the shipped Replica / EuRoC configs (no in-code default in the reference)
 	c10::optional<at::Generator> generator_;

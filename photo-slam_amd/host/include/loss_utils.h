@@ -4,9 +4,10 @@
 // gradient in two launches instead of 5 + 10 grouped 11x11 convolutions and ~20 elementwise ATen kernels per call: 10 of the
 // 15.4 ms a step of the reference's unchanged host code takes at 2 M Gaussians @ 1080p on MI355X are MIOpen convolutions).
 // Same results to 1e-6 (tests/test_train_ops.py against the reference's own header compiled, tests/test_reference_pinning.py).
-// Everything else in the header -- psnr, psnr_gaussian_splatting, gaussian, create_window, _ssim -- is the reference's ATen
-// composition, restated, and ssim() falls back to it for the calls the kernels do not cover (another window, no size average, a
-// batch, a target that requires a gradient, host tensors).
+// Everything else in the header -- psnr, psnr_gaussian_splatting, gaussian, create_window, _ssim -- keeps the reference's names,
+// signatures and values (tests/test_cpp_host.py pins them to the reference's header compiled) and is computed this library's way
+// in ATen: separable windows, the five local statistics of an image pair in one grouped convolution pair.  ssim() falls back to
+// it for the calls the kernels do not cover (another window, no size average, a batch, a target that requires a gradient, host tensors).
 // The definitions live in lib cuda_rasterizer (host/src/loss_utils.cpp); the reference's header is all-inline.
 #pragma once
 #include <vector>

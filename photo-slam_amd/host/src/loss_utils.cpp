@@ -86,54 +86,78 @@ torch::Tensor l1_loss(torch::Tensor &network_output, torch::Tensor &gt)
 	return torch::abs(network_output - gt).mean();
 }
 
+// ---- the calls the kernels do not cover (another window, no size average, a batch, a target with a gradient, host tensors).
+// Same names, signatures and values as the reference's header (the drop-in contract: include/loss_utils.h:33-108), computed this
+// library's way: the SSIM window is the outer product of one normalised 1-D Gaussian, so every local statistic is TWO 1-D
+// convolutions (11 + 11 taps per pixel instead of 121), and the five statistics of a pair of images -- means, second moments, the
+// mixed moment -- ride in ONE grouped convolution pair over a 5C-channel stack.
+
 torch::Tensor psnr(torch::Tensor &img1, torch::Tensor &img2)
 {
-	auto mse = torch::pow(img1 - img2, 2).mean();
-	return 10.0f * torch::log10(1.0f / mse);
+	// 10 log10(1 / mse), mse over the whole tensor
+	return -10.0f * torch::log10(torch::mse_loss(img1, img2));
 }
 
 torch::Tensor psnr_gaussian_splatting(torch::Tensor &img1, torch::Tensor &img2)
 {
-	auto mse = torch::pow(img1 - img2, 2).view({img1.size(0) , -1}).mean(1, /*keepdim=*/true);
-	return 20.0f * torch::log10(1.0f / torch::sqrt(mse)).mean();
+	// the Inria evaluation's form: per image of the batch 20 log10(1 / rmse), then the mean over the batch
+	const auto per_image = (img1 - img2).square().flatten(1).mean(1, /*keepdim=*/true);
+	return (-10.0f * torch::log10(per_image)).mean();
 }
 
 torch::Tensor gaussian(int window_size, float sigma, torch::DeviceType device_type)
 {
-	std::vector<float> gauss_values(window_size);
-	for (int x = 0; x < window_size; ++x) {
-		int temp = x - window_size / 2;
-		gauss_values[x] = std::exp(-temp * temp / (2.0f * sigma * sigma));
-	}
-	torch::Tensor gauss = torch::tensor(gauss_values, torch::TensorOptions().device(device_type));
-	return gauss / gauss.sum();
+	// taps exp(-(x - window_size / 2)^2 / (2 sigma^2)), x = 0 .. window_size - 1 (integer centre), normalised to sum 1
+	const auto x = torch::arange(window_size, torch::TensorOptions().dtype(torch::kFloat32).device(device_type)) - static_cast<float>(window_size / 2);
+	const auto w = torch::exp(x.square() * (-1.0f / (2.0f * sigma * sigma)));
+	return w / w.sum();
 }
 
 torch::autograd::Variable create_window(int window_size, int64_t channel, torch::DeviceType device_type)
 {
-	auto _1D_window = gaussian(window_size, 1.5f, device_type).unsqueeze(1);
-	auto _2D_window = _1D_window.mm(_1D_window.t()).to(torch::kFloat).unsqueeze(0).unsqueeze(0);
-	return torch::autograd::Variable(_2D_window.expand({channel, 1, window_size, window_size}).contiguous());
+	// [channel, 1, k, k]: the same 2-D window for every channel (a grouped convolution's weight)
+	const auto taps = gaussian(window_size, 1.5f, device_type);
+	return torch::outer(taps, taps).to(torch::kFloat).expand({channel, 1, window_size, window_size}).contiguous();
 }
+
+namespace {
+// local window sums of every channel of x [N, C, H, W] (zero padding, as conv2d with padding k / 2): separable when the window is
+// the outer product of its marginals (any window create_window makes), the plain grouped 2-D convolution otherwise
+torch::Tensor window_filter(const torch::Tensor& x, const torch::Tensor& window2d, int window_size)
+{
+	namespace F = torch::nn::functional;
+	const int64_t C = x.size(1);
+	const int pad = window_size / 2;
+	const auto k2 = window2d.select(0, 0).select(0, 0);                     // [k, k] (the same for every channel)
+	const auto col = k2.sum(1), row = k2.sum(0);                            // marginals: vertical and horizontal taps
+	const auto total = k2.sum();
+	const bool separable = torch::allclose(torch::outer(col, row), k2 * total, 1e-6, 1e-9);
+	if (!separable)
+		return F::conv2d(x, k2.reshape({1, 1, window_size, window_size}).expand({C, 1, window_size, window_size}), F::Conv2dFuncOptions().padding(pad).groups(C));
+	const auto horizontal = (row / total).reshape({1, 1, 1, window_size}).expand({C, 1, 1, window_size});
+	const auto vertical = col.reshape({1, 1, window_size, 1}).expand({C, 1, window_size, 1});
+	const auto h = F::conv2d(x, horizontal, F::Conv2dFuncOptions().padding({0, pad}).groups(C));
+	return F::conv2d(h, vertical, F::Conv2dFuncOptions().padding({pad, 0}).groups(C));
+}
+}  // namespace
 
 torch::Tensor _ssim(torch::Tensor &img1, torch::Tensor &img2, torch::autograd::Variable &window, int window_size, int64_t channel,
                     bool size_average)
 {
-	namespace F = torch::nn::functional;
-	const auto opts = F::Conv2dFuncOptions().padding(window_size / 2).groups(channel);
-	auto mu1 = F::conv2d(img1, window, opts);
-	auto mu2 = F::conv2d(img2, window, opts);
-	auto mu1_sq = mu1.pow(2);
-	auto mu2_sq = mu2.pow(2);
-	auto mu1_mu2 = mu1 * mu2;
-	auto sigma1_sq = F::conv2d(img1 * img1, window, opts) - mu1_sq;
-	auto sigma2_sq = F::conv2d(img2 * img2, window, opts) - mu2_sq;
-	auto sigma12 = F::conv2d(img1 * img2, window, opts) - mu1_mu2;
-	auto C1 = 0.01 * 0.01;
-	auto C2 = 0.03 * 0.03;
-	auto ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2));
-	if (size_average) return ssim_map.mean();
-	return ssim_map.mean(1).mean(1).mean(1);
+	const bool batched = img1.dim() == 4;
+	const auto a = batched ? img1 : img1.unsqueeze(0), b = batched ? img2 : img2.unsqueeze(0);
+	// one filter pass over [a | b | a a | b b | a b]
+	const auto stats = window_filter(torch::cat({a, b, a * a, b * b, a * b}, 1), window, window_size).split(channel, 1);
+	const auto& mean_a = stats[0];
+	const auto& mean_b = stats[1];
+	const auto cross = mean_a * mean_b, energy = mean_a.square() + mean_b.square();
+	const auto spread = stats[2] + stats[3] - energy;      // var(a) + var(b)
+	const auto covariance = stats[4] - cross;
+	const double c1 = 1e-4, c2 = 9e-4;                      // (0.01 L)^2, (0.03 L)^2 with a dynamic range L of 1
+	auto map = ((2 * cross + c1) * (2 * covariance + c2)) / ((energy + c1) * (spread + c2));
+	if (!batched) map = map.squeeze(0);
+	if (size_average) return map.mean();
+	return map.mean(1).mean(1).mean(1);   // (the reference's reduction order: dims 1, 1, 1 of what is left)
 }
 
 torch::Tensor ssim(torch::Tensor &img1, torch::Tensor &img2, torch::DeviceType device_type, int window_size, bool size_average)
@@ -141,10 +165,9 @@ torch::Tensor ssim(torch::Tensor &img1, torch::Tensor &img2, torch::DeviceType d
 	// the train step's call (11 x 11 window, sigma 1.5, mean over the map): 1 - [(1 - lambda) L1 + lambda (1 - SSIM)] at lambda = 1
 	if (window_size == 11 && size_average && fused_applies(img1, img2))
 		return 1.0 - FusedL1SSIMFunction::apply(img1, img2, torch::empty({0}, img2.options()), 1.0, false);
-	auto channel = img1.size(-3);
-	auto window = create_window(window_size, channel, img1.device().type());
-	window = window.type_as(img1);
-	return _ssim(img1, img2, window, window_size, channel, size_average);
+	const int64_t channels = img1.size(-3);
+	torch::autograd::Variable window = create_window(window_size, channels, img1.device().type()).to(img1.scalar_type());
+	return _ssim(img1, img2, window, window_size, channels, size_average);
 }
 
 }

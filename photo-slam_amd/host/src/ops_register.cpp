@@ -1,6 +1,7 @@
 // ops_register.cpp -- exposes the C++ host layer to Python (torch.ops.photoslam_amd.*) so that the
 // test-suite and bench.py can drive the very code a C++ caller (gaussian_mapper) would link against.
 #include <torch/library.h>
+#include "loss_utils.h"
 #include <torch/torch.h>
 
 #include <map>
@@ -8,6 +9,7 @@
 
 #include "gaussian_model_lite.h"
 #include "gaussian_renderer.h"
+#include "keyframe_scheduler.h"
 #include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
 #include "operate_points.h"
 #include "spatial.h"
@@ -177,6 +179,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "convert_SHs") t->pipe_.convert_SHs_ = v != 0.0;
 		else if (k == "compute_cov3D") t->pipe_.compute_cov3D_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
+		else if (k == "position_lr_step") t->position_lr_step_ = (int)v;
 		else if (k == "lr_scale") t->gaussians_->lr_scale_ = v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
 		else if (k == "prune_big_point_after_iter") t->prune_big_point_after_iter_ = (int)v;
@@ -327,6 +330,49 @@ std::vector<torch::Tensor> trainer_stats(int64_t h)
 	auto g = get(h)->gaussians_;
 	return {g->xyz_gradient_accum_, g->denom_, g->max_radii2D_};
 }
+// KeyframeScheduler (host/include/keyframe_scheduler.h) behind handles, for the tests and for a Python driver of a keyframe batch
+std::map<int64_t, std::shared_ptr<KeyframeScheduler>> g_schedulers;
+int64_t g_next_scheduler = 1;
+std::shared_ptr<KeyframeScheduler> scheduler(int64_t h)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	auto it = g_schedulers.find(h);
+	TORCH_CHECK(it != g_schedulers.end(), "unknown keyframe scheduler handle ", h);
+	return it->second;
+}
+int64_t keyframe_scheduler_create(int64_t seed)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_schedulers[g_next_scheduler] = std::make_shared<KeyframeScheduler>((uint64_t)seed);
+	return g_next_scheduler++;
+}
+void keyframe_scheduler_destroy(int64_t h)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	g_schedulers.erase(h);
+}
+int64_t keyframe_scheduler_add(int64_t h, int64_t times_of_use) { return scheduler(h)->addKeyframe((int)times_of_use); }
+void keyframe_scheduler_increase(int64_t h, int64_t keyframe, int64_t times) { scheduler(h)->increaseTimesOfUse((int)keyframe, (int)times); }
+int64_t keyframe_scheduler_use_one(int64_t h) { return scheduler(h)->useOne(); }
+std::vector<int64_t> keyframe_scheduler_use_batch(int64_t h, int64_t B)
+{
+	const auto b = scheduler(h)->useBatch((int)B);
+	return std::vector<int64_t>(b.begin(), b.end());
+}
+std::vector<int64_t> keyframe_scheduler_use_batch_on_ranks(int64_t h, std::string group_name)
+{
+	const auto b = scheduler(h)->useBatchOnRanks(c10d::resolve_process_group(group_name));
+	return std::vector<int64_t>(b.begin(), b.end());
+}
+// [used times, remaining times of use] of every keyframe
+std::vector<int64_t> keyframe_scheduler_state(int64_t h)
+{
+	auto s = scheduler(h);
+	std::vector<int64_t> out;
+	for (int k = 0; k < s->size(); k++) out.push_back(s->usedTimes(k));
+	for (int k = 0; k < s->size(); k++) out.push_back(s->remainingTimesOfUse(k));
+	return out;
+}
 void trainer_destroy(int64_t h)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -341,6 +387,20 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("mark_visible", &mark_visible);
 	m.def("dist_cuda2", &dist_cuda2);
 	m.def("l1_ssim_loss", &l1_ssim_loss);
+	// host/include/loss_utils.h, the functions behind the reference's names (tests pin them to the reference's header compiled)
+	m.def("loss_ssim", +[](torch::Tensor a, torch::Tensor b, int64_t window_size, bool size_average) {
+		return loss_utils::ssim(a, b, a.device().type(), (int)window_size, size_average);
+	});
+	m.def("loss_ssim_with_window", +[](torch::Tensor a, torch::Tensor b, torch::Tensor window, int64_t window_size, bool size_average) {
+		torch::autograd::Variable w = window;
+		return loss_utils::_ssim(a, b, w, (int)window_size, a.size(-3), size_average);
+	});
+	m.def("loss_psnr", +[](torch::Tensor a, torch::Tensor b) { return loss_utils::psnr(a, b); });
+	m.def("loss_psnr_gaussian_splatting", +[](torch::Tensor a, torch::Tensor b) { return loss_utils::psnr_gaussian_splatting(a, b); });
+	m.def("loss_create_window", +[](int64_t window_size, int64_t channel, torch::Tensor like) {
+		return loss_utils::create_window((int)window_size, channel, like.device().type());
+	});
+	m.def("loss_l1", +[](torch::Tensor a, torch::Tensor b) { return loss_utils::l1_loss(a, b); });
 	m.def("transform_points", &transform_points);
 	m.def("scale_transform_mark_visible", &scale_transform_mark_visible);
 	m.def("reproject_depth_pinhole", &reproject_depth_pinhole);
@@ -388,4 +448,12 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_geom_adam", &trainer_geom_adam);
 	m.def("sh_grad_from_views", &sh_grad_from_views);
 	m.def("trainer_destroy", &trainer_destroy);
+	m.def("keyframe_scheduler_create", &keyframe_scheduler_create);
+	m.def("keyframe_scheduler_destroy", &keyframe_scheduler_destroy);
+	m.def("keyframe_scheduler_add", &keyframe_scheduler_add);
+	m.def("keyframe_scheduler_increase", &keyframe_scheduler_increase);
+	m.def("keyframe_scheduler_use_one", &keyframe_scheduler_use_one);
+	m.def("keyframe_scheduler_use_batch", &keyframe_scheduler_use_batch);
+	m.def("keyframe_scheduler_use_batch_on_ranks", &keyframe_scheduler_use_batch_on_ranks);
+	m.def("keyframe_scheduler_state", &keyframe_scheduler_state);
 }

@@ -185,7 +185,9 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 {
 	auto& g = gaussians_;
 	iteration_++;
-	g->updateLearningRate(iteration_);
+	// the position learning rate follows the iteration (src/gaussian_mapper.cpp:672-674) or -- a SLAM session -- the number of
+	// times THIS keyframe has been used (:663-671): the caller says which through position_lr_step_
+	g->updateLearningRate(position_lr_step_ >= 0 ? std::min(position_lr_step_, g->opt_.position_lr_max_steps_) : iteration_);
 	GaussianPipelineParams& pipe = pipe_;
 	torch::Tensor override_color;
 	if (factored_exchange_) {

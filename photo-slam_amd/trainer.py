@@ -249,11 +249,13 @@ class TrainStep:
                 entry = cache[id(mask)] = (weakref.ref(mask), mask._version, bool((mask == 1).all().item()))
         return None if entry[2] else mask
 
-    def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True):
+    def trainForOneIteration(self, viewpoint_cam, gt_image, mask, sync_loss=True, position_lr_step=None):
+        """position_lr_step: the step of the position learning-rate schedule -- None = the iteration (src/gaussian_mapper.cpp:672-674,
+        the COLMAP flavour); a SLAM session passes the keyframe's use count (:663-671, capped at position_lr_max_steps_)."""
         g, opt = self.gaussians_, self.opt_
         self.iteration_ += 1
         it = self.iteration_
-        g.updateLearningRate(it)                                         # :661-674 (COLMAP flavour)
+        g.updateLearningRate(it if position_lr_step is None else min(int(position_lr_step), opt.position_lr_max_steps_))   # :661-674
         sh_send = sh_view = sh_adam = geom_adam = sh_adam_views = None
         if self.world_size_ > 1 and self.factored_exchange_:
             sh_send, sh_view = ViewFactoredExchange.send_buffer(g.xyz_.size(0), g.xyz_.device)

@@ -25,6 +25,19 @@ import devapi  # noqa: E402  (tests/dev: the TEST-ONLY introspection of the scra
 RGB_L1_TOL = 1e-4
 GRAD_REL_L1_TOL = 1e-4      # north_star: "within 1e-4 L1 on rendered RGB / gradients" (measured: 3e-7 ... 6e-7)
 FRAGILE_PX_MAX_FRAC = 0.01   # the oracle-flagged pixels excluded from the exact n_contrib check must stay a sliver
+# Per-Gaussian bounds next to the aggregate L1 (an aggregate over 2 M x 48 floats would hide a defect confined to a few thousand
+# rows): e_i = |g_i - ref_i|_1 / (|ref_i|_1 + ROW_EPS * mean row norm) over the visible rows of every gradient tensor -- the
+# 99.99th percentile and the maximum are asserted, and the maxima of two subsets are reported (and held to the same bar): the
+# Gaussians with more than 64 tiles (their slots are summed by long_run_sums_kernel) and the Gaussians listed in the heaviest 1 %
+# of the tiles.  Bars: 10x what one run per BASELINE shape measured on the MI355X (profiles/r06_*_test_gpu.log; the outliers are
+# rows with a handful of contributing pixels one of which is "fragile" -- a skip / terminate decision inside exp() rounding noise).
+ROW_EPS = 1e-3
+ROW_P9999_TOL = 5e-3          # measured at C2 / C3 / a C4 view / a C5 view on the MI355X: <= 6.4e-4 (profiles/r06_c_test_gpu.log)
+ROW_OUTLIER = 1e-2            # rows beyond this are counted: at most ROW_OUTLIER_FRAC of the visible rows (measured: a handful per view --
+ROW_OUTLIER_FRAC = 1e-4       # Gaussians with two or three contributing pixels one of which is fragile; the worst row seen: 0.27)
+ROW_MAX_TOL = 1.0             # ... and none of them may be off by its whole norm
+ROW_LONG_RUN_MAX_TOL = 2e-2   # the Gaussians with > 64 tiles (long_run_sums_kernel): measured <= 2.2e-3
+ROW_HEAVY_TILE_MAX_TOL = 1e-2 # the Gaussians of the heaviest 1 % of the tiles: measured <= 7.1e-4
 
 
 def _t(a, dev):
@@ -207,7 +220,35 @@ def compare(r, ores, ocolor, oradii, ograds, cam, use_colors_precomp=False, use_
             assert rep["grad_" + name] <= GRAD_REL_L1_TOL, (name, rep["grad_" + name])
             # culled Gaussians: exact zeros
             assert not np.any(g.reshape(g.shape[0], -1)[~vis]), f"{name} non-zero on culled Gaussians"
+        # ---- per-Gaussian bounds (see ROW_EPS above)
+        long_runs = ores.tiles_touched > 64
+        lens = (ores.ranges[:, 1].astype(np.int64) - ores.ranges[:, 0].astype(np.int64))
+        heavy = np.zeros(oradii.shape[0], bool)
+        if lens.size and lens.max() > 0:
+            for t in np.argsort(-lens)[:max(1, lens.size // 100)]:
+                heavy[ores.point_list[ores.ranges[t, 0]:ores.ranges[t, 1]]] = True
+        rep["rows"] = {"visible": int(vis.sum()), "long_runs": int((long_runs & vis).sum()), "heaviest_tiles": int((heavy & vis).sum())}
+        for name, g in r.grads.items():
+            if g.size == 0 or name not in ograds or not vis.any():
+                continue
+            e = row_errors(g, ograds[name])
+            ev = e[vis]
+            row = {"p9999": float(np.quantile(ev, 0.9999)), "max": float(ev.max()), "rows_beyond_1e-2": int((ev > ROW_OUTLIER).sum()),
+                   "max_long_runs": float(e[long_runs & vis].max(initial=0.0)), "max_heaviest_tiles": float(e[heavy & vis].max(initial=0.0))}
+            rep["rows_" + name] = row
+            assert row["p9999"] <= ROW_P9999_TOL and row["max"] <= ROW_MAX_TOL, (name, row)
+            assert row["rows_beyond_1e-2"] <= max(3, ROW_OUTLIER_FRAC * ev.size), (name, row)
+            assert row["max_long_runs"] <= ROW_LONG_RUN_MAX_TOL and row["max_heaviest_tiles"] <= ROW_HEAVY_TILE_MAX_TOL, (name, row)
     return rep
+
+
+def row_errors(g, ref):
+    """per-row relative L1 error |g_i - ref_i|_1 / (|ref_i|_1 + ROW_EPS * mean non-zero row norm)"""
+    n = g.shape[0]
+    a, b = g.reshape(n, -1).astype(np.float64), ref.reshape(n, -1).astype(np.float64)
+    den = np.abs(b).sum(1)
+    scale = float(den[den > 0].mean()) if (den > 0).any() else 1.0
+    return np.abs(a - b).sum(1) / (den + ROW_EPS * scale)
 
 
 def check_view_factored(lib_path, dev, cl, bg, sh_degree=3, sh_coeffs=None, seed=0):

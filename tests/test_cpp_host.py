@@ -523,3 +523,73 @@ def test_cpp_point_operators_match_python_mirror(emu_lib_path, oracle):
     mk = torch.from_numpy(rng.random(40 * 30) < 0.5)
     assert torch.equal(ops.reproject_depth_pinhole(d, mk, [50.0, 52.0, 19.5, 14.5], 40),
                        torch.from_numpy(oracle.reproject_depth_pinhole(d.numpy(), mk.numpy(), [50.0, 52.0, 19.5, 14.5], 40)))
+
+
+def _reference_loss_ops():
+    from oracle import build_ref
+    path = build_ref.build_loss()
+    if not path or not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_loss.so was never built (no reference tree, no prebuilt library)")
+    torch.ops.load_library(path)
+    ops = torch.ops.photoslam_reference
+    if not hasattr(ops, "ssim_ex"):
+        pytest.skip("a libref_loss.so from before round 6 (no reference tree here to rebuild it)")
+    return ops
+
+
+def _check_loss_header_functions(ops, ref, dev):
+    """host/include/loss_utils.h keeps the reference's names and signatures (include/loss_utils.h:24-126) and computes the functions
+    the fused kernels do not cover its own way (separable windows, one grouped convolution pair for the five statistics): the VALUES
+    are the reference's -- its own header compiled (oracle/ref_loss.cpp) -- for every call shape the fallback takes."""
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *shape: torch.rand(*shape, generator=g).to(dev)
+    cpu = lambda t: t.detach().cpu()
+    for shape, ws, avg in (((1, 3, 40, 56), 11, False),      # no size average: per-image values
+                           ((2, 3, 33, 47), 11, True),       # a batch
+                           ((2, 3, 33, 47), 11, False),
+                           ((1, 3, 40, 56), 7, True),        # another window
+                           ((1, 1, 24, 31), 5, True),        # one channel
+                           ((3, 40, 56), 9, True)):          # unbatched [3,H,W]
+        a, b = rnd(*shape), rnd(*shape)
+        got, want = cpu(ops.loss_ssim(a, b, ws, avg)), ref.ssim_ex(cpu(a), cpu(b), ws, avg)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=1e-6), (shape, ws, avg, float((got - want).abs().max()))
+    a, b = rnd(1, 3, 40, 56), rnd(1, 3, 40, 56)
+    # a target that requires a gradient: the fallback, differentiable in both arguments
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ops.loss_ssim(a1, b1, 11, True).backward()
+    a2, b2 = cpu(a).clone().requires_grad_(True), cpu(b).clone().requires_grad_(True)
+    ref.ssim_ex(a2, b2, 11, True).backward()
+    # (gradients of ~1e-4 per pixel through two summation orders: 1e-4 relative + a few float ulps of the largest absolute)
+    assert torch.allclose(cpu(a1.grad), a2.grad, rtol=1e-4, atol=2e-9) and torch.allclose(cpu(b1.grad), b2.grad, rtol=1e-4, atol=2e-9), \
+        (float((cpu(a1.grad) - a2.grad).abs().max()), float((cpu(b1.grad) - b2.grad).abs().max()), float(a2.grad.abs().max()))
+    # the window itself, and _ssim with a caller's window: a separable one and one that is not (the plain 2-D path)
+    for ws, ch in ((11, 3), (7, 1)):
+        assert torch.allclose(cpu(ops.loss_create_window(ws, ch, a)), ref.create_window(ws, ch, cpu(a)), rtol=0, atol=1e-7)
+    w = ref.create_window(11, 3, cpu(a)).to(dev)
+    assert torch.allclose(cpu(ops.loss_ssim_with_window(a, b, w, 11, True)), ref.ssim_ex(cpu(a), cpu(b), 11, True), rtol=0, atol=1e-6)
+    lumpy = torch.rand(11, 11, generator=g)
+    lumpy = (lumpy / lumpy.sum()).expand(3, 1, 11, 11).contiguous()
+    import torch.nn.functional as F
+    from photo_slam_amd import loss_utils as mirror
+    want = mirror._ssim(cpu(a), cpu(b), lumpy, 11, 3, True)
+    assert torch.allclose(cpu(ops.loss_ssim_with_window(a, b, lumpy.to(dev), 11, True)), want, rtol=0, atol=1e-6)
+    assert torch.allclose(cpu(ops.loss_psnr(a, b)), ref.psnr(cpu(a), cpu(b)), rtol=1e-6, atol=1e-5)
+    x, y = rnd(4, 3, 20, 30), rnd(4, 3, 20, 30)
+    assert torch.allclose(cpu(ops.loss_psnr_gaussian_splatting(x, y)), ref.psnr_gaussian_splatting(cpu(x), cpu(y)), rtol=1e-6, atol=1e-5)
+    # host tensors of another dtype / layout take the fallback too (the fused kernels are float32 [3,H,W] only)
+    ad, bd = cpu(a).double(), cpu(b).double()
+    if dev.type == "cpu":
+        # (the window is float32 on both sides; the reference multiplies its 2-D product, this library its two 1-D factors)
+        assert torch.allclose(ops.loss_ssim(ad, bd, 11, True), ref.ssim_ex(ad, bd, 11, True), rtol=0, atol=1e-7)
+        assert torch.equal(ops.loss_l1(ad, bd), ref.l1_loss(ad, bd))
+
+
+def test_loss_header_functions_equal_the_reference_header_emu():
+    _check_loss_header_functions(load_host("emu"), _reference_loss_ops(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_loss_header_functions_equal_the_reference_header_on_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    _check_loss_header_functions(load_host("hip"), _reference_loss_ops(), torch.device("cuda:0"))
