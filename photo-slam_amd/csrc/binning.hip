@@ -38,9 +38,9 @@ emit_instances_kernel(int P, uint32_t R, const uint32_t* __restrict__ order, con
 	// The tile sort's first histogram (sort.hip: radix_hist_kernel) is counted HERE, where the keys are made: a workgroup emits
 	// exactly one sort chunk (EMIT_WAVES x EMIT_SLOTS == SORT_CHUNK slots), counts its keys' low digits in LDS and stores its
 	// column of the [digit][block] table -- one launch and one pass over the 25 MB of keys less per forward pass.
-	__shared__ uint32_t s_hist[RADIX_BINS];
+	__shared__ uint32_t s_hist[1 << RADIX_BITS_ONE_PASS];   // (up to 11 bits: the one-pass tile sort of a small view, state.h)
 	if (hist) {
-		for (int i = (int)threadIdx.x; i < RADIX_BINS; i += EMIT_THREADS) s_hist[i] = 0u;
+		for (int i = (int)threadIdx.x; i < (1 << hist_bits); i += EMIT_THREADS) s_hist[i] = 0u;
 		__syncthreads();
 	}
 	const int w = wave_id(), l = lane_id();

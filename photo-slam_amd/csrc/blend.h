@@ -29,45 +29,26 @@ __device__ __forceinline__ float prescale_c(float c) { return -0.5f * LOG2E * c;
 // inside an XCD the chunks follow one another and the four quads of a tile are consecutive workgroups.
 //   mode > 0   chunks of `mode` consecutive tiles of the row-major order: eight samples of the whole image per round of the deal --
 //              the default, 8 tiles
-//   mode < 0   chunks of e x e tiles (e = -mode), SQUARES of the image, whose tiles share most of their Gaussians' records (one L2
-//              serves a chunk); the backward blend then takes the heaviest squares first (A/B handle: equal or slower, gsr_api.hip)
 //   mode == 0  ONE chunk per XCD: a contiguous band of the image -- the arrangement until round 5: eight different REGIONS of the
 //              image (at C3 the heaviest holds 4.6 % more list entries than the mean, at C2 24 %)
 // Measured at C3 (gsr_api.hip: xcd_deal_mode): bands -> row-major chunks of 8: blend_fwd 0.191 -> 0.173 ms, blend_bwd 0.451 -> 0.430.
+// (Squares of e x e tiles with the backward blend taking the heaviest squares first -- filed under work classes by the forward
+// blend -- were built in round 5 and measured again in round 6 at C2 / C4 / C5: -3 ... -7 % of blend_bwd, +3 % of blend_fwd, twice
+// the record re-reads; removed: EXPERIMENTS.md.)
 // (struct TileDeal, make_tile_deal: state.h)
-// tile t of square chunk c (row-major inside the chunk), or d.tiles beyond the image's edge
-__device__ __forceinline__ int chunk_tile(const TileDeal& d, int c, int t)
-{
-	const int e = -d.mode;
-	const int tx = (c % d.chunks_x) * e + t % e, ty = (c / d.chunks_x) * e + t / e;
-	return (tx < d.grid_x && ty < d.grid_y) ? ty * d.grid_x + tx : d.tiles;
-}
-// tiles of square chunk c that lie inside the image
-__device__ __forceinline__ int chunk_valid_tiles(const TileDeal& d, int c)
-{
-	const int e = -d.mode;
-	const int w = min(e, d.grid_x - (c % d.chunks_x) * e), h = min(e, d.grid_y - (c / d.chunks_x) * e);
-	return w * h;
-}
 __device__ __forceinline__ int xcd_tile(int in_xcd, int xcd, const TileDeal& d)
 {
 	if (d.mode == 0) {
 		const int per = (d.tiles + 7) >> 3;
 		return in_xcd >= per ? d.tiles : xcd * per + in_xcd;
 	}
-	if (d.mode > 0) {
-		const int t = ((in_xcd / d.mode) * 8 + xcd) * d.mode + in_xcd % d.mode;
-		return t < d.tiles ? t : d.tiles;
-	}
-	const int ct = d.mode * d.mode;
-	const int c = (in_xcd / ct) * 8 + xcd;
-	return c < d.chunks ? chunk_tile(d, c, in_xcd % ct) : d.tiles;
+	const int t = ((in_xcd / d.mode) * 8 + xcd) * d.mode + in_xcd % d.mode;
+	return t < d.tiles ? t : d.tiles;
 }
 static inline int xcd_tiles_per_xcd(const TileDeal& d)
 {
 	if (d.mode == 0) return (d.tiles + 7) >> 3;
-	if (d.mode > 0) return ((((d.tiles + d.mode - 1) / d.mode) + 7) >> 3) * d.mode;
-	return ((d.chunks + 7) >> 3) * d.mode * d.mode;
+	return ((((d.tiles + d.mode - 1) / d.mode) + 7) >> 3) * d.mode;
 }
 __device__ __forceinline__ int tile_assignment(int block, const TileDeal& d) { return xcd_tile(block >> 3, block & 7, d); }
 static inline int tile_grid(const TileDeal& d) { return xcd_tiles_per_xcd(d) * 8; }
@@ -78,17 +59,6 @@ __device__ __forceinline__ void quad_assignment(int block, const TileDeal& d, in
 	quad = in_xcd & 3;
 }
 static inline int quad_grid(const TileDeal& d) { return xcd_tiles_per_xcd(d) * 8 * QUADS_PER_TILE; }
-
-// Work class of a chunk for the backward blend's dispatch order (state.h: SCHED_CLASSES): eighth-octaves of the number of list
-// entries its quads blended per tile of a full chunk, 2^5 .. 2^13.
-__device__ __forceinline__ int sched_class(uint32_t work)
-{
-	if (work < 32u) return 0;
-	const int e = 31 - __builtin_clz(work);                     // 5 ..
-	const int frac = (int)((work >> (e - 3)) & 7u);             // the three bits below the leading one
-	const int c = (e - 5) * 8 + frac;
-	return c >= SCHED_CLASSES ? SCHED_CLASSES - 1 : c;
-}
 
 // Conservative per-quad rejection.  A (pixel, Gaussian) pair is skipped by the reference
 // when alpha = min(0.99, o*exp(power)) < 1/255 (forward.cu:343-345, backward.cu:499-501),

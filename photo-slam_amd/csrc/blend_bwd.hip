@@ -1,5 +1,6 @@
 // blend_bwd.hip -- backward of the alpha blend: per-pixel loss gradients -> per-instance
-// gradients of colour, 2D mean, conic and opacity.  One workgroup per tile, one wave per 8x8 quad.
+// gradients of colour, 2D mean, conic and opacity.  One wave per 8x8 quad, four quads = one 256-thread workgroup per tile
+// (or per SEGMENT of 256 list entries of a tile, below).
 //
 // Per-pixel semantics are renderCUDA's backward (cuda_rasterizer/backward.cu:399-557): walk
 // the tile list back to front starting at each pixel's last contributor, recompute alpha,
@@ -12,6 +13,8 @@
 //     (state.h: contrib); every quad-wave then walks the entries flagged for ITS quad;
 //   * the per-pair arithmetic is branch-free; 1/(1-alpha) is one v_rcp_f32 shared by the two
 //     divisions of the reference;
+//   * "everything behind entry j, dotted with the pixel's loss gradient" is ONE running scalar per pixel (below) instead of
+//     the reference's three-channel accum_rec;
 //   * the nine terms are summed across the 64 pixels of a quad with a butterfly packed from the
 //     top through v_permlane32_swap / v_permlane16_swap (wave64.h, 19 VALU) that leaves eight
 //     totals in one register (one per 8-lane group) and the ninth as four row sums; ONE ds_add_f32
@@ -22,13 +25,30 @@
 //     preprocess_bwd (partials.h);
 //   * at the end of a segment of 256 list entries the workgroup writes every touched entry's
 //     nine sums to that instance's private 48-byte slot with plain stores.
+//
+// The running scalar.  The reference keeps accum_rec = the colour blended BEHIND entry j, normalised by the transmittance
+// there (A_{j+1}), and forms dL/dalpha_j = T_j (c_j - A_{j+1}) . dpix - T_final / (1 - alpha_j) (bg . dpix)
+// (backward.cu:505-534).  With the un-normalised suffix S_{j+1} = sum_{k > j} c_k alpha_k T_k = T_{j+1} A_{j+1} and
+// T_{j+1} = T_j (1 - alpha_j) this is   dL/dalpha_j = T_j (c_j . dpix) - B_{j+1} / (1 - alpha_j),
+//   B_{j+1} = S_{j+1} . dpix + T_final (bg . dpix),     B_j = B_{j+1} + (c_j . dpix) alpha_j T_j,
+// one scalar recurrence instead of three (six VALU per visit instead of eleven), no division by a small transmittance -- and a
+// state that can be re-created at ANY list position from what the forward pass knows: T before the position and the colour
+// blended behind it.
+//
+// Segments.  A tile's backward pass is a serial chain per pixel, and a view of a few thousand entries per tile on a grid of
+// 1 200 tiles (640 x 480, 2 M Gaussians) has all its workgroups resident at once: the kernel lasts as long as its heaviest tile
+// while most of the machine idles (VALU utilisation 56 %, profiles/r06_a_sq_counters_full_C4.json).  The forward blend therefore
+// leaves, per pixel and 256-entry boundary it passes, the transmittance in front of the boundary and the colour blended behind it
+// (state.h: BinningState::seg_state, 16 bytes); blend_bwd_kernel<true> then runs ONE workgroup per (tile, segment): short, uniform
+// jobs the dispatcher balances, each starting from the boundary state behind its segment (or from the pixel's final state).
 #include "blend.h"
 #include "kernels.h"
 
 namespace gsr {
 
-constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB); thread i stages entry i of the segment
+constexpr int BWD_SEG = SEG_ENTRIES;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB); thread i stages entry i of the segment
 
+template <bool SEGMENTS>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
 {
@@ -39,35 +59,28 @@ blend_bwd_kernel(const BlendBwdParams p)
 	__shared__ uint8_t s_flag[BWD_SEG];    // bit q: quad q of the tile blends the entry (a byte each: 7 workgroups per CU fit the 160 KiB of LDS)
 	__shared__ uint32_t s_wmax[4];
 
-	// Heaviest chunks first: the forward blend filed every chunk (a square of tiles, blend.h: TileDeal) under a work class
-	// (state.h: ImageState::sched); the XCDs are dealt the chunks from the top class down, round robin, and the tiles of a chunk
-	// are consecutive workgroups of ONE XCD (their Gaussians' records meet in its L2).  A tile's backward pass costs what its quads
-	// blended and a workgroup runs ~90 us: dispatched in image order the kernel ended with whatever heavy tiles came last
-	// (simulated makespan over the ideal: 1.07 in image order, 1.014 sorted).
-	__shared__ int s_tile;
-	int tile;
-	if (p.sched && p.deal.mode < 0) {
-		if (wave_id() == 0) {
-			const int l0 = lane_id();
-			const int ct = p.deal.mode * p.deal.mode, in_xcd = (int)blockIdx.x >> 3;
-			const uint32_t r = (uint32_t)((in_xcd / ct) * 8 + ((int)blockIdx.x & 7));   // rank of this workgroup's chunk, heaviest = 0
-			const uint32_t cnt = p.sched[p.tiles + (SCHED_CLASSES - 1 - l0)];   // (SCHED_CLASSES == 64: one class per lane, descending)
-			const uint32_t incl = wave_incl_scan_u32(cnt);
-			const unsigned long long holds = wave_ballot(incl > r);
-			int t = p.tiles;   // (beyond the filed chunks: a padding workgroup of the last round of the deal)
-			if (holds) {
-				const int j = __ffsll((long long)holds) - 1;
-				const uint32_t incl_j = wave_shfl_u32(incl, j), cnt_j = wave_shfl_u32(cnt, j);
-				const uint32_t chunk = p.class_list[(size_t)(SCHED_CLASSES - 1 - j) * p.deal.chunks + (r - (incl_j - cnt_j))];
-				t = chunk_tile(p.deal, (int)chunk, in_xcd % ct);
-			}
-			if (l0 == 0) s_tile = t;
+	int tile, first_seg = -1;   // first_seg >= 0: this workgroup walks exactly that GROUP of segments (GROUP_ENTRIES list entries)
+	if (SEGMENTS) {
+		// workgroups [0, tiles): segment 0 of every tile; behind them one workgroup per boundary slot: segment s >= 1 of tile t sits
+		// at slot (range.x >> 8) + s (unique over all tiles: boundaries of different tiles are more than 256 entries apart), and the
+		// forward blend left the tile's id there.  A slot no tile owns in THIS view holds anything: the owner is checked.
+		const int g = (int)blockIdx.x;
+		if (g < p.tiles) {
+			tile = g;
+			first_seg = 0;
+		} else {
+			const uint32_t slot = (uint32_t)(g - p.tiles);
+			tile = (int)p.seg_tile[slot];
+			if (tile < 0 || tile >= p.tiles) return;
+			const uint2 r = p.ranges[tile];
+			const int s = (int)slot - (int)(r.x >> GROUP_SHIFT);
+			if (s < 1 || (uint32_t)s * GROUP_ENTRIES >= r.y - r.x) return;
+			first_seg = s;
 		}
-		__syncthreads();
-		tile = s_tile;
-	} else
+	} else {
 		tile = tile_assignment((int)blockIdx.x, p.deal);
-	if (tile >= p.tiles) return;
+		if (tile >= p.tiles) return;
+	}
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int quad = (int)wave_uniform_u32((uint32_t)wave_id());   // scalar: the LDS record address is SGPR arithmetic
 	const int l = lane_id(), tid = (int)threadIdx.x;
@@ -80,14 +93,36 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const size_t pix = (size_t)py * p.W + px;
 	const size_t plane = (size_t)p.H * p.W;
 
+	uint32_t last_contributor = inside ? p.n_contrib[pix] : 0u;
+	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
+	const uint32_t wmax = wave_uniform_u32(wave_max_u32(last_contributor));
+	if (l == 0) s_wmax[quad] = wmax;
+	__syncthreads();
+	const uint32_t bmax = wave_uniform_u32(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
+	if (SEGMENTS && (uint32_t)first_seg * GROUP_ENTRIES >= bmax) return;   // (nothing of this group reached a pixel: block-uniform)
+
 	const float T_final = inside ? p.final_T[pix] : 0.f;
-	float T = T_final;
-	const uint32_t last_contributor = inside ? p.n_contrib[pix] : 0u;
 	float dpr = 0.f, dpg = 0.f, dpb = 0.f;
 	if (inside) {
 		dpr = p.dL_dpix[pix];
 		dpg = p.dL_dpix[plane + pix];
 		dpb = p.dL_dpix[2 * plane + pix];
+	}
+	// the pixel's state at the END of what this workgroup walks: T = the transmittance in front of that position, B = (everything
+	// blended behind it, background included) . dpix
+	float T = T_final;
+	float B = T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
+	if (SEGMENTS) {
+		const uint32_t end = ((uint32_t)first_seg + 1u) * GROUP_ENTRIES;
+		if (last_contributor > end) {
+			// the pixel blends entries behind this group: start from the state the forward blend left at the boundary
+			const float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)first_seg + 1u) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
+			T = st[l];
+			B += st[64 + l] * dpr + st[128 + l] * dpg + st[192 + l] * dpb;   // (the colour blended behind the boundary)
+			last_contributor = end;   // (entries at or behind `end` are another workgroup's)
+		} else if (last_contributor <= (uint32_t)first_seg * GROUP_ENTRIES) {
+			last_contributor = 0u;    // (nothing of this segment reaches the pixel)
+		}
 	}
 	// lanes 0, 8, .., 56 deliver the eight packed totals, lanes 1, 17, 33, 49 the four row sums of the ninth
 	// (wave_reduce9_swap_f32): one ds_add_f32 with twelve active lanes
@@ -95,26 +130,18 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const bool red_lane = ((l & 7) == 0) || red_ninth;
 	const int red_off = (red_ninth ? 8 : wave_swap9_component(l)) * BWD_SEG;
 	const v2f dprg = {dpr, dpg};
-	const float neg_Tfinal_bg = -T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
-	float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
 
-	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
-	const uint32_t wmax = wave_uniform_u32(wave_max_u32(last_contributor));
-	if (l == 0) s_wmax[quad] = wmax;
-	__syncthreads();
-	const uint32_t bmax = wave_uniform_u32(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
-	const int nseg = (int)((bmax + BWD_SEG - 1) / BWD_SEG);
-
+	constexpr int SPG = GROUP_ENTRIES / BWD_SEG;   // segments per group
+	const int seg_top = (int)((bmax + BWD_SEG - 1) / BWD_SEG) - 1;   // the last segment any pixel of the tile reaches
+	const int seg_first = SEGMENTS ? min(seg_top, (first_seg + 1) * SPG - 1) : seg_top;
+	const int seg_last = SEGMENTS ? first_seg * SPG : 0;
 	// The segment's records are staged ONCE per tile, by all 256 threads (thread i: list entry seg_lo + i), and only for the entries
 	// some quad of the tile blended (the forward blend's flags: a quarter of the entries of a 1080p view, a tenth at 640 x 480 with
-	// 2 M Gaussians).  Until round 5 every quad-wave gathered every record of its part of the list itself, 64 at a time: four
-	// dependent round trips per segment and wave, and four times the gathers -- in a view of a few thousand entries per tile the
-	// waves waited for records instead of blending (VALU utilisation 56 % at 640 x 480, profiles/r06_a_sq_counters_full_C4.json).
-	// The list entries and flags of the NEXT segment are asked for while this one is walked.
+	// 2 M Gaussians).  The list entries and flags of the NEXT segment are asked for while this one is walked.
 	auto seg_flags = [&](int seg_) -> uint32_t {
 		const uint32_t e = (uint32_t)seg_ * BWD_SEG + (uint32_t)tid;
 		uint32_t f = 0u;
-		if (e < bmax) {
+		if (e < bmax) {   // (a group's last segment ends at the group's end: seg_first / seg_last keep the walk inside the group)
 #pragma unroll
 			for (int q = 0; q < QUADS_PER_TILE; q++)
 				// (behind a quad's deepest last contributor the forward blend may not have walked: no flags were written there)
@@ -126,8 +153,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 		const uint32_t e = (uint32_t)seg_ * BWD_SEG + (uint32_t)tid;
 		return e < bmax ? p.point_list[range.x + e] : 0u;
 	};
-	uint32_t flags_next = nseg > 0 ? seg_flags(nseg - 1) : 0u, gid_next = nseg > 0 ? seg_gid(nseg - 1) : 0u;
-	for (int seg = nseg - 1; seg >= 0; seg--) {
+	uint32_t flags_next = seg_first >= 0 ? seg_flags(seg_first) : 0u, gid_next = seg_first >= 0 ? seg_gid(seg_first) : 0u;
+	for (int seg = seg_first; seg >= seg_last; seg--) {
 		const uint32_t seg_lo = (uint32_t)seg * BWD_SEG;
 		const uint32_t seg_hi = min(bmax, seg_lo + BWD_SEG);
 		for (int i = tid; i < 9 * BWD_SEG; i += 256) (&s_acc[0][0])[i] = 0.f;
@@ -140,7 +167,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 				q1 = p.rec[3 * (size_t)gid + 1];
 				q2 = p.rec[3 * (size_t)gid + 2];
 			}
-			if (seg > 0) {   // (asked for in front of the wait for the records)
+			if (seg > seg_last) {   // (asked for in front of the wait for the records)
 				flags_next = seg_flags(seg - 1);
 				gid_next = seg_gid(seg - 1);
 			}
@@ -158,69 +185,63 @@ blend_bwd_kernel(const BlendBwdParams p)
 		__syncthreads();
 
 		for (int b = (int)((seg_hi - seg_lo - 1u) >> 6); b >= 0; b--) {
-			{
-				unsigned long long m = wave_ballot((((uint32_t)s_flag[b * 64 + l] >> quad) & 1u) != 0u);
-				const int base = (int)seg_lo + b * 64;
-				const float4(*rec_b)[3] = &s_rec[b * 64];
-				while (m) {
-					const int bit = 63 - __clzll((long long)m);
+			unsigned long long m = wave_ballot((((uint32_t)s_flag[b * 64 + l] >> quad) & 1u) != 0u);
+			const int base = (int)seg_lo + b * 64;
+			const float4(*rec_b)[3] = &s_rec[b * 64];
+			while (m) {
+				const int bit = 63 - __clzll((long long)m);
 #ifdef GSR_EMU
-					m &= ~(1ull << bit);
+				m &= ~(1ull << bit);
 #else
-					asm volatile("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));   // (one scalar instruction instead of shift + andn2)
+				asm volatile("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));   // (one scalar instruction instead of shift + andn2)
 #endif
-					const uint32_t pos = (uint32_t)(base + bit);
-					const float4 g0 = rec_b[bit][0];
-					const float4 g1 = rec_b[bit][1];
-					const float gb = rec_b[bit][2].x;
-					const v2f dxy = (v2f){g0.x, g0.y} - pxy;
-					const float dx = dxy[0], dy = dxy[1];
-					const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
-					const float G = __builtin_amdgcn_exp2f(pw);
-					const float alpha = fminf(0.99f, g1.y * G);
-					const bool ok = (pos < last_contributor) && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
-					if (wave_ballot(ok) == 0ull) continue;  // wave-uniform
-					const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
-					const float Tn = T * rinv;
-					// accum_rec of the reference (backward.cu:509-511), advanced eagerly: acc <- acc + alpha (c - acc)
-					// (the reference delays the same update by one entry through last_alpha / last_color)
-					const float dcr = g1.z - acr, dcg = g1.w - acg, dcb = gb - acb;
-					float dL_dalpha = dcr * dpr + dcg * dpg + dcb * dpb;
-					dL_dalpha = dL_dalpha * Tn + neg_Tfinal_bg * rinv;
-					// lanes that do not blend this entry contribute exact zeros and keep their state
-					const float am = ok ? alpha : 0.f;
-					const float dLm = ok ? dL_dalpha : 0.f;
-					const float dcol = am * Tn;
-					// the per-Gaussian constants (opacity, -1/2, W/2, H/2, the conic in the mean2D terms) are applied
-					// after the reduction (preprocess_bwd, partials.h); pairs of products ride in v_pk_mul_f32
-					const float wG = dLm * G;
-					const v2f c01 = dprg * (v2f){dcol, dcol};
-					const v2f t = dxy * (v2f){wG, wG};          // sum w dx, sum w dy
-					const v2f m56 = dxy * (v2f){t[0], t[0]};    // sum w dx dx, sum w dx dy
-					// order of the nine sums in the LDS accumulators: 0 colour r, 1 w dx, 2 w dx dx, 3 colour b, 4 colour g, 5 w dy,
-					// 6 w dx dy, 7 w dy dy, 8 w -- chosen so that the halves of each packed product sit four apart: the
-					// butterfly's first level then adds (v0, v4) + (v1, v5) and (v2, v6) + (v3, v7) as register pairs
-					// without a move (wave_reduce9_swap_f32); the segment write-out below restores the slot order
-					float v[9];
-					v[0] = c01[0];
-					v[4] = c01[1];
-					v[1] = t[0];
-					v[5] = t[1];
-					v[2] = m56[0];
-					v[6] = m56[1];
-					v[3] = dcol * dpb;
-					v[7] = t[1] * dy;
-					v[8] = wG;
-					T = ok ? Tn : T;
-					acr += am * dcr;
-					acg += am * dcg;
-					acb += am * dcb;
-					float packed, ninth_row;
-					wave_reduce9_swap_f32(v, packed, ninth_row);
-					GSR_OPAQUE_F32(packed);      // keep the last butterfly adds fused with their DPP moves (the compiler otherwise
-					GSR_OPAQUE_F32(ninth_row);   // sinks them into the 12-lane branch as mov_dpp + add)
-					if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
-				}
+				const uint32_t pos = (uint32_t)(base + bit);
+				const float4 g0 = rec_b[bit][0];
+				const float4 g1 = rec_b[bit][1];
+				const float gb = rec_b[bit][2].x;
+				const v2f dxy = (v2f){g0.x, g0.y} - pxy;
+				const float dx = dxy[0], dy = dxy[1];
+				const float pw = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;
+				const float G = __builtin_amdgcn_exp2f(pw);
+				const float alpha = fminf(0.99f, g1.y * G);
+				const bool ok = (pos < last_contributor) && !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
+				if (wave_ballot(ok) == 0ull) continue;  // wave-uniform
+				const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+				const float Tn = T * rinv;   // the transmittance in FRONT of this entry
+				// dL/dalpha = T_j (c_j . dpix) - B_{j+1} / (1 - alpha_j)   (the running scalar: file header)
+				const float cdp = g1.z * dpr + g1.w * dpg + gb * dpb;
+				const float dL_dalpha = cdp * Tn - B * rinv;
+				// lanes that do not blend this entry contribute exact zeros and keep their state
+				const float am = ok ? alpha : 0.f;
+				const float dLm = ok ? dL_dalpha : 0.f;
+				const float dcol = am * Tn;
+				// the per-Gaussian constants (opacity, -1/2, W/2, H/2, the conic in the mean2D terms) are applied
+				// after the reduction (preprocess_bwd, partials.h); pairs of products ride in v_pk_mul_f32
+				const float wG = dLm * G;
+				const v2f c01 = dprg * (v2f){dcol, dcol};
+				const v2f t = dxy * (v2f){wG, wG};          // sum w dx, sum w dy
+				const v2f m56 = dxy * (v2f){t[0], t[0]};    // sum w dx dx, sum w dx dy
+				// order of the nine sums in the LDS accumulators: 0 colour r, 1 w dx, 2 w dx dx, 3 colour b, 4 colour g, 5 w dy,
+				// 6 w dx dy, 7 w dy dy, 8 w -- chosen so that the halves of each packed product sit four apart: the
+				// butterfly's first level then adds (v0, v4) + (v1, v5) and (v2, v6) + (v3, v7) as register pairs
+				// without a move (wave_reduce9_swap_f32); the segment write-out below restores the slot order
+				float v[9];
+				v[0] = c01[0];
+				v[4] = c01[1];
+				v[1] = t[0];
+				v[5] = t[1];
+				v[2] = m56[0];
+				v[6] = m56[1];
+				v[3] = dcol * dpb;
+				v[7] = t[1] * dy;
+				v[8] = wG;
+				T = ok ? Tn : T;
+				B += dcol * cdp;   // (dcol is zero where the entry is not blended)
+				float packed, ninth_row;
+				wave_reduce9_swap_f32(v, packed, ninth_row);
+				GSR_OPAQUE_F32(packed);      // keep the last butterfly adds fused with their DPP moves (the compiler otherwise
+				GSR_OPAQUE_F32(ninth_row);   // sinks them into the 12-lane branch as mov_dpp + add)
+				if (red_lane) atomicAdd(&(&s_acc[0][0])[red_off + ((int)pos - (int)seg_lo)], red_ninth ? ninth_row : packed);
 			}
 		}
 		__syncthreads();
@@ -240,13 +261,14 @@ blend_bwd_kernel(const BlendBwdParams p)
 				reinterpret_cast<float*>(dst + 2)[0] = s_acc[8][i];
 			}
 		}
-		__syncthreads();
+		if (seg > seg_last) __syncthreads();
 	}
 }
 
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream)
 {
-	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.deal), 256, stream, p);
+	if (p.seg_state) GSR_LAUNCH(blend_bwd_kernel<true>, p.tiles + (int)p.seg_slots, 256, stream, p);
+	else GSR_LAUNCH(blend_bwd_kernel<false>, tile_grid(p.deal), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -13,7 +13,6 @@
 
 namespace gsr {
 
-template <bool PF>
 __global__ void __launch_bounds__(64)
 blend_fwd_kernel(const BlendFwdParams p)
 {
@@ -43,37 +42,22 @@ blend_fwd_kernel(const BlendFwdParams p)
 	// pixel state predicates live as 64-bit lane masks in SGPR pairs; their logic is scalar
 	unsigned long long done_m = wave_ballot(!inside);
 
-	uint32_t blended = 0;   // list entries some pixel of the quad blends: what the backward pass will visit (scalar)
-	// Two batches in flight: the RECORDS of the next batch are asked for before this batch is walked, the list entries of the one
-	// behind it with them -- a quad-wave of a small view (a few thousand list entries, most of them rejected for the quad) spends
-	// its time waiting for one gather per batch, not blending (640 x 480 with 2 M Gaussians: 39 % VALU utilisation before).
-	uint32_t gid_next = (64 + l < n) ? p.point_list[range.x + (uint32_t)(64 + l)] : 0u;
-	float4 q0n = make_float4(0.f, 0.f, 0.f, 0.f), q1n = q0n;
-	float cbn = 0.f;
-	if (l < n) {
-		const uint32_t g0 = p.point_list[range.x + (uint32_t)l];
-		q0n = p.rec[3 * (size_t)g0 + 0];
-		q1n = p.rec[3 * (size_t)g0 + 1];
-		cbn = p.rec[3 * (size_t)g0 + 2].x;
-	}
+	// Segment-parallel backward blend (blend_bwd.hip): the tile's id at the slot of every 256-entry boundary of its list ...
+	if (p.seg_tile && quad == 0)
+		for (int s = 1 + l; s * GROUP_ENTRIES < n; s += 64) p.seg_tile[(range.x >> GROUP_SHIFT) + (uint32_t)s] = (uint32_t)tile;
+	int seg_passed = 0;   // boundaries this wave has walked past (scalar)
+	uint32_t gid_next = (l < n) ? p.point_list[range.x + (uint32_t)l] : 0u;
 	for (int base = 0; base < n; base += 64) {
 		if (~done_m == 0ull) break;
 		const bool have = base + l < n;
-		const float4 q0 = q0n, q1 = q1n;
-		const float cb = cbn;
-		auto fetch_next = [&]() {
-			const uint32_t gid = gid_next;   // entry base + 64 + l
-			const int e_next = base + 128 + l;
-			gid_next = (e_next < n) ? p.point_list[range.x + (uint32_t)e_next] : 0u;
-			if (base + 64 + l < n) {
-				q0n = p.rec[3 * (size_t)gid + 0];
-				q1n = p.rec[3 * (size_t)gid + 1];
-				cbn = p.rec[3 * (size_t)gid + 2].x;
-			}
-		};
-		if (PF) fetch_next();
+		const uint32_t gid = gid_next;
+		const int e_next = base + 64 + l;
+		gid_next = (e_next < n) ? p.point_list[range.x + (uint32_t)e_next] : 0u;
 		bool keep = false;
 		if (have) {
+			const float4 q0 = p.rec[3 * (size_t)gid + 0];
+			const float4 q1 = p.rec[3 * (size_t)gid + 1];
+			const float cb = p.rec[3 * (size_t)gid + 2].x;
 			keep = quad_keep(q0, q1, (float)qx0, (float)qy0);
 			s_rec[l][0] = prescale_q0(q0);
 			s_rec[l][1] = make_float4(prescale_c(q1.x), q1.y, q1.z, q1.w);
@@ -145,13 +129,50 @@ blend_fwd_kernel(const BlendFwdParams p)
 			// that the register sets alternate -- 22 instead of 15 scalar instructions per visit, 0.212 instead of 0.188 ms.)
 		}
 		const bool wave_done = ~done_m == 0ull;
-		blended += (uint32_t)__popcll(contrib_m);
 		// the backward pass walks the same batches: it visits only the entries flagged here (15 % of the entries that survive the
 		// quad rejection blend into no pixel -- alpha below 1/255 at every pixel centre, or every such pixel saturated)
 		if (have) p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] = (uint8_t)((contrib_m >> l) & 1ull);
 		if (wave_done) break;
-		if (!PF) fetch_next();   // (A/B handle GSR_FWD_PREFETCH=0: the next batch's records asked for only now, as until round 5)
+		// ... and, at every boundary the wave walks past, its pixels' state there: the transmittance in front of the boundary and the
+		// colour accumulated so far (16 bytes per pixel; a quad that saturates earlier leaves nothing: none of its pixels has a
+		// contributor behind the boundary, and the backward pass asks for the state of such pixels only)
+		if (p.seg_state && ((base + 64) & (GROUP_ENTRIES - 1)) == 0 && base + 64 < n) {
+			// T in front of the boundary, and the colour accumulated SINCE THE LAST boundary -- the accumulators start over, so that
+			// every stored partial keeps the relative precision of its own magnitude (the sums behind a boundary are formed from the
+			// back at the end of the walk: a difference C_total - C_prefix would carry the absolute rounding error of the whole colour
+			// into the faint tail of a long list)
+			seg_passed = (base + 64) / GROUP_ENTRIES;
+			float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)seg_passed) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
+			st[l] = T;
+#ifdef GSR_EMU
+			st[64 + l] = Crg[0];
+			st[128 + l] = Crg[1];
+			Crg = (v2f){0.f, 0.f};
+#else
+			st[64 + l] = Cr;
+			st[128 + l] = Cg;
+			Cr = 0.f;
+			Cg = 0.f;
+#endif
+			st[192 + l] = Cb;
+			Cb = 0.f;
+		}
 		wave_fence();  // all lanes have read this batch before the next one overwrites the slice
+	}
+#ifdef GSR_EMU
+	float Cr = Crg[0], Cg = Crg[1];
+#endif
+	// the boundaries' partial colours -> the colour blended BEHIND each boundary (what the backward blend starts a segment from), summed
+	// from the back; what is left at the front is the pixel's colour
+	for (int b = seg_passed; b >= 1; b--) {
+		float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)b) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
+		const float dr = st[64 + l], dg = st[128 + l], db = st[192 + l];
+		st[64 + l] = Cr;
+		st[128 + l] = Cg;
+		st[192 + l] = Cb;
+		Cr += dr;
+		Cg += dg;
+		Cb += db;
 	}
 
 	if (inside) {
@@ -159,36 +180,15 @@ blend_fwd_kernel(const BlendFwdParams p)
 		const size_t plane = (size_t)p.H * p.W;
 		p.final_T[pix] = T;
 		p.n_contrib[pix] = last_contributor;
-#ifdef GSR_EMU
-		const float Cr = Crg[0], Cg = Crg[1];
-#endif
 		p.out_color[pix] = Cr + T * p.bg[0];
 		p.out_color[plane + pix] = Cg + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];
-	}
-	// Dispatch order of the backward blend (state.h: ImageState::sched): this quad's count joins the tile's, the tile's last quad
-	// adds the tile's total to its chunk's, the chunk's last tile files the chunk under its work class.  One returning atomic
-	// per level carries count and arrival together, so the last one sees the others' counts without a fence.
-	if (p.sched && p.deal.mode < 0 && l == 0) {
-		const uint32_t old = atomicAdd(&p.sched[tile], (blended << 3) | 1u);
-		if ((old & 7u) == (uint32_t)(QUADS_PER_TILE - 1)) {
-			const int e = -p.deal.mode;
-			const int chunk = (tile_y / e) * p.deal.chunks_x + tile_x / e;
-			const uint32_t work = min((old >> 3) + blended, (1u << 22) - 1u);   // (16 tiles x 2^22 fit the 27-bit field)
-			const uint32_t oldc = atomicAdd(&p.sched[p.tiles + SCHED_CLASSES + chunk], (work << 5) | 1u);
-			if ((int)(oldc & 31u) == chunk_valid_tiles(p.deal, chunk) - 1) {
-				const int c = sched_class(((oldc >> 5) + work) / (uint32_t)(e * e));
-				const uint32_t i = atomicAdd(&p.sched[p.tiles + c], 1u);
-				p.class_list[(size_t)c * p.deal.chunks + i] = (uint32_t)chunk;
-			}
-		}
 	}
 }
 
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream)
 {
-	if (p.prefetch) GSR_LAUNCH(blend_fwd_kernel<true>, quad_grid(p.deal), 64, stream, p);
-	else GSR_LAUNCH(blend_fwd_kernel<false>, quad_grid(p.deal), 64, stream, p);
+	GSR_LAUNCH(blend_fwd_kernel, quad_grid(p.deal), 64, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

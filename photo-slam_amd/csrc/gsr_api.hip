@@ -147,32 +147,31 @@ static bool emit_seeded()
 	return env != 0;
 }
 // The blend kernels' deal of tiles to the XCDs (blend.h: TileDeal::mode); GSR_XCD_CHUNK overrides: 0 = one band per XCD,
-// n > 0 = row-major chunks of n tiles, -e = squares of e x e tiles (and the backward blend takes the heaviest squares first).
-// Measured at C3, alternating runs on one box each (profiles/r05_h, r05_i, r05_t):
+// n > 0 = row-major chunks of n tiles.  Measured at C3, alternating runs on one box each (profiles/r05_h, r05_i):
 //   one band per XCD            1.609-1.620 ms per step   blend_fwd 0.191  blend_bwd 0.451 ms   TCC traffic of the two 182 / 313 MB
 //   row-major chunks of 128     1.589-1.592
 //   row-major chunks of 32      1.582-1.588                                                                            229 / 380
 //   row-major chunks of 8       1.566-1.575               0.173            0.430                                        261 / 425
 //   chunks of 4 / 2 / 1         as 8
-//   squares of 4 x 4, heaviest first                      0.177            0.430                                        210 / 350
-//   squares of 2 x 2 / single tiles, heaviest first       0.177            0.424                                  280 / 459 (2 x 2), 261 / 695
-// The balance of the deal decides, not the L2 locality.  Heaviest-first gains 6-10 us in the backward blend and costs the forward
-// blend 4-5 us (its waves end with the returning atomics that file the tile) and, tile by tile, 270 MB of record re-reads: the
-// default is the plain row-major chunk of 8.
+// The balance of the deal decides, not the L2 locality.
 static int xcd_deal_mode(int tiles)
 {
-	static const int env = env_int("GSR_XCD_CHUNK", -1000);
-	if (env != -1000) return env;
+	static const int env = env_int("GSR_XCD_CHUNK", -1);
+	if (env >= 0) return env;
 	// (small images: at least ~16 rounds of the deal, or its last round is the imbalance)
 	int c = 8;
 	while (c > 1 && tiles < 8 * 16 * c) c >>= 1;
 	return c;
 }
-// GSR_BWD_HEAVY_FIRST=0 (A/B handle): the backward blend takes its chunks in the forward blend's image order
-static bool heavy_first()
+// The backward blend one workgroup per (tile, 256-entry segment) instead of one per tile (blend_bwd.hip): the forward blend then
+// leaves the pixels' state at the segment boundaries.  GSR_BWD_SEGMENTS=0/1 overrides (the A/B handle); otherwise by the size of
+// the tile grid -- a pure function of the view, so that gsr_forward and gsr_backward agree.
+static bool bwd_segments(int tiles)
 {
-	static const int env = env_int("GSR_BWD_HEAVY_FIRST", 1);
-	return env != 0;
+	static const int env = env_int("GSR_BWD_SEGMENTS", -1);
+	if (env >= 0) return env != 0;
+	(void)tiles;
+	return false;
 }
 // The depth sort's significant bits when it runs on key - DEPTH_KEY_BIAS with 9-bit digits (27 = three passes); 0 = the plain
 // sort of 32 bits in four passes.  GSR_DEPTH_SORT_9BIT=0 selects the plain sort (A/B handle); GSR_DEPTH_SORT_BITS=n (tests)
@@ -194,14 +193,19 @@ static bool emit_hist()
 // Which binning: depth-first (sort the Gaussians by depth, emit in that order: nine launches for the sort whatever the size) or
 // tile-first (compact in id order, sort every tile's list by depth behind the tile sort).  gsr_forward_args.raw_params may force
 // either (GSR_BINNING_DEPTH_FIRST / GSR_BINNING_TILE_FIRST); GSR_BINNING=0/1 overrides (the A/B handle); otherwise by size.
+constexpr int TILE_FIRST_MAX_GAUSSIANS = 256 * 1024;
 static bool binning_tile_first(int raw_params, int P, int tiles)
 {
 	static const int env = env_int("GSR_BINNING", -1);
 	if (env >= 0) return env != 0;
 	if (raw_params & GSR_BINNING_TILE_FIRST) return true;
 	if (raw_params & GSR_BINNING_DEPTH_FIRST) return false;
-	(void)P; (void)tiles;
-	return false;
+	// Measured (profiles/r06_c, r06_d; same box, alternating): the depth sort of the Gaussians is launch-bound up to ~0.5 M visible
+	// ones (60 us at 17 k keys, 62 us at 262 k), the per-tile sorts cost ~17-40 ns per thousand instances.  50 k Gaussians @ 640 x 480:
+	// the step 0.292 -> 0.259 ms tile-first; 500 k @ 1200 x 680: 0.696 -> 0.686; 2 M @ 1080p: 1.567 -> 1.569; 4 M @ 752 x 480: equal.
+	// The instance count is not known when the choice is made: the model's size stands in for it.
+	(void)tiles;
+	return P <= TILE_FIRST_MAX_GAUSSIANS;
 }
 static int side_blocks(const gsr_sh_adam* o)
 {
@@ -380,7 +384,6 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	pp.grid_x = grid_x; pp.grid_y = grid_y; pp.radii_out = a->radii;
 	pp.raw_params = a->raw_params | (cov3D_stored() ? GSR_STORE_COV3D : 0);
 	pp.ranges = im.ranges; pp.tiles = tiles;   // zeroed there: rasterizer_impl.cu:310
-	pp.sched = xcd_deal_mode(tiles) < 0 ? im.sched : nullptr;   // (the heaviest-first bookkeeping: only in the deal modes that file chunks)
 	pp.lazy = LazyAdam{};
 	if (a->sh_adam && a->sh_adam->lazy) {   // lazy SH Adam: visible rows that lag behind take their missed steps first
 		if (!a->shs) return GSR_ERR_INVALID_ARG;
@@ -471,16 +474,20 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 		const bool cull = (a->raw_params & GSR_CULL_EMPTY_TILES) != 0 && bits > 0;
 		uint32_t* const listed = cull ? g.visible + 16 : nullptr;
 		// (the emission counts the tile sort's first histogram on the way: GSR_EMIT_HIST=0 is the A/B handle for the separate launch)
-		const int hist_bits = emit_hist() ? radix_first_pass_bits(0, bits) : 0;
+		// (a small list on a grid of up to 2 048 tiles: all tile bits in one pass, the ranges from that pass -- state.h: tile_sort_digit_bits)
+		const int digit_bits = tile_sort_digit_bits(tiles, R);
+		const bool one_pass = digit_bits == RADIX_BITS_ONE_PASS;
+		const int hist_bits = emit_hist() ? radix_first_pass_bits(0, bits, digit_bits) : 0;
 		// (tile-first: the compacted arrays hold V entries and nothing behind them -- the emission is told so)
 		if ((st = launch_emit_instances(tile_first ? (int)V64 : P, R, g, grid_x, bs.keys_a, bs.vals_a, bs.touched, stream, cull ? 1 : 0, emit_seeded(), bs.sort_scratch, hist_bits)) != GSR_OK) return st;
 		PROF_FWD(4);
 		uint32_t* tkeys = nullptr;
 		if ((st = launch_radix_sort(bs.keys_a, bs.vals_a, bs.keys_a, bs.vals_a, bs.keys_b, bs.vals_b, R, 0, bits,
-		                            bs.sort_scratch, stream, &tkeys, &point_list, listed, nullptr, hist_bits > 0)) != GSR_OK)
+		                            bs.sort_scratch, stream, &tkeys, &point_list, listed, nullptr, hist_bits > 0, digit_bits, 0u,
+		                            one_pass ? im.ranges : (uint2*)nullptr)) != GSR_OK)
 			return st;
 		PROF_FWD(5);
-		if ((st = launch_tile_ranges(R, tkeys, im.ranges, stream, listed)) != GSR_OK) return st;
+		if (!one_pass && (st = launch_tile_ranges(R, tkeys, im.ranges, stream, listed)) != GSR_OK) return st;
 		PROF_FWD(6);
 		if (tile_first) {
 			// the instances reached their tiles in id order: every tile's list by depth now (equal depths keep ascending id).  Scratch:
@@ -503,11 +510,8 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
-	bp.sched = im.sched; bp.class_list = im.class_list;
-	{
-		static const int pf = env_int("GSR_FWD_PREFETCH", 1);
-		bp.prefetch = pf;
-	}
+	const bool segs = bwd_segments(tiles) && R > 0;
+	bp.seg_state = segs ? bs.seg_state : nullptr; bp.seg_tile = segs ? bs.seg_tile : nullptr;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(8);
 	t_prof.fwd_done = t_prof.on == 1;
@@ -547,7 +551,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	GeometryState g = GeometryState::carve(a->geom_buffer, (size_t)P);
 	ImageState im = ImageState::carve(a->image_buffer, (size_t)W * H, (size_t)tiles);
 	BinningState bs = BinningState::carve(a->binning_buffer, (size_t)R);
-	const int passes = tile_sort_passes(tiles);
+	const int passes = tile_sort_passes(tiles, R);
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
 	HostSync* const sync_ = host_sync();
@@ -661,7 +665,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
-		bp.sched = heavy_first() ? im.sched : nullptr; bp.class_list = im.class_list;
+		const bool segs = bwd_segments(tiles);
+		bp.seg_state = segs ? bs.seg_state : nullptr; bp.seg_tile = segs ? bs.seg_tile : nullptr;
+		bp.seg_slots = (uint32_t)seg_slots((size_t)R);
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);
@@ -679,14 +685,6 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	pb.tan_fovx = a->tan_fovx; pb.tan_fovy = a->tan_fovy;
 	pb.tiles_touched = g.tiles_touched; pb.partials = R > 0 ? bs.partials : nullptr; pb.touched = R > 0 ? bs.touched : nullptr;
 	pb.long_runs = g.long_runs; pb.long_counts = g.long_counts; pb.long_capacity = g.long_capacity;
-	{
-		static const int trip = env_int("GSR_SLOT_TRIP", 2);
-		pb.slot_trip = trip;
-		static const int lrs = env_int("GSR_LRS_MODE", 1);
-		pb.lrs_mode = lrs;
-		static const int lrsb = env_int("GSR_LRS_BLOCKS", 0);
-		pb.lrs_blocks = lrsb;
-	}
 	pb.half_w = 0.5f * (float)W; pb.half_h = 0.5f * (float)H;
 	pb.rec = g.rec; pb.raw_params = a->raw_params;
 	pb.dL_dmean2D = a->dL_dmean2D; pb.dL_dconic = a->dL_dconic; pb.dL_dopacity = a->dL_dopacity; pb.dL_dcolor = a->dL_dcolor;

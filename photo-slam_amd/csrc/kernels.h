@@ -63,7 +63,6 @@ struct PreprocessParams {
 	int* radii_out;  // caller's radii (nullable)
 	int raw_params;  // GSR_RAW_* mask: activations applied in-kernel
 	uint2* ranges;   // [tiles] per-tile instance ranges: zeroed here (identifyTileRanges fills only the tiles that have instances)
-	uint32_t* sched; // [2 tiles + SCHED_CLASSES] the backward blend's dispatch bookkeeping (state.h: ImageState): zeroed here
 	int tiles;
 	LazyAdam lazy;   // row_step != null: visible rows that lag behind (step - 1) are brought up to date before their SH evaluation
 };
@@ -88,10 +87,11 @@ struct BlendFwdParams {
 	uint8_t* contrib;       // [4][contrib_stride]: plane of quad q, byte per list entry (state.h)
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
-	uint32_t* sched;        // ImageState::sched / class_list: the tile's blended entries are counted, its last quad files it
-	uint32_t* class_list;
 	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
-	int prefetch;           // the next batch's records in flight while this one is walked
+	// segment-parallel backward blend (blend_bwd.hip; both null = off): per pixel and 256-entry boundary of a tile's list the
+	// transmittance in front of it and the colour blended behind it, and the owner of every boundary slot
+	float* seg_state;       // BinningState::seg_state
+	uint32_t* seg_tile;     // BinningState::seg_tile
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
 
@@ -108,9 +108,11 @@ struct BlendBwdParams {
 	const uint8_t* contrib; // [4][contrib_stride] the forward blend's per-quad contribution flags
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
-	const uint32_t* sched;  // ImageState::sched / class_list (null: tiles in the forward blend's chunked order)
-	const uint32_t* class_list;
-	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
+	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles (one workgroup per tile)
+	// one workgroup per (tile, 256-entry segment) instead (null seg_state = one per tile): what the forward blend left
+	const float* seg_state;
+	const uint32_t* seg_tile;
+	uint32_t seg_slots;     // boundary slots: state.h: seg_slots(R)
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
 
@@ -147,9 +149,6 @@ struct PreprocessBwdParams {
 	const uint32_t* long_runs;       // ids of the Gaussians with more than LONG_RUN slots, LONG_LISTS sub-lists (the offset scan)
 	const uint32_t* long_counts;     // entries per sub-list (device)
 	uint32_t long_capacity;
-	int slot_trip;            // partials.h: touched slots per trip (1, 2 or 4; GSR_SLOT_TRIP: the A/B handle)
-	int lrs_mode;             // partials.h: wave_sum_long_run's form (GSR_LRS_MODE: the A/B handle)
-	int lrs_blocks;           // workgroups of long_run_sums_kernel (GSR_LRS_BLOCKS; 0 = LRS_BLOCKS)
 	float half_w, half_h;     // W/2, H/2: the ndc -> pixel factors of dL_dmean2D (backward.cu:460-461)
 	const float4* rec;        // [3P] blend records (activated opacity for the raw-parameter chain rule)
 	float* dL_dmean2D;        // [P,3]  unpacked here (x, y, 0); nullable

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t squeeze_flags16(const uint8_t* p)
 }
 
 __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t first, const float* __restrict__ partials,
-                                                      const uint8_t* __restrict__ touched, float (&a)[9], int trip = 2)
+                                                      const uint8_t* __restrict__ touched, float (&a)[9])
 {
 	const float4* part4 = reinterpret_cast<const float4*>(partials);
 #pragma unroll
@@ -63,12 +63,9 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 			if (16u * c < cnt) live |= (unsigned long long)squeeze_flags16(touched + first + 16 * c) << (16 * c);
 		if (cnt < 64u) live &= (1ull << cnt) - 1ull;
 		const float4* src = part4 + SLOT_F4 * (size_t)first;
-		// several touched slots per trip: their loads leave together, the sums follow in slot order (a lane's chain of dependent
-		// round trips is what this HBM-latency-bound phase waits for: one slot per trip -> two: the stage 0.463 -> 0.452 ms at C3)
-		if (trip >= 4)
-			while (__popcll(live) >= 4) sum_slots_trip<4>(src, live, a);
-		if (trip >= 2)
-			while (live & (live - 1ull)) sum_slots_trip<2>(src, live, a);
+		// two touched slots per trip: their loads leave together, the sums follow in slot order (a lane's chain of dependent round
+		// trips is what this HBM-latency-bound phase waits for: one slot per trip -> two: the stage 0.463 -> 0.452 ms at C3; four: equal)
+		while (live & (live - 1ull)) sum_slots_trip<2>(src, live, a);
 		while (live) sum_slots_trip<1>(src, live, a);
 	}
 	// a longer run was summed by long_run_sums_kernel (one wave per run), which left the total in the run's FIRST slot
@@ -81,12 +78,10 @@ __device__ __forceinline__ void wave_sum_partial_runs(uint32_t cnt, uint32_t fir
 	}
 }
 
-// One wave per listed run: sum its touched slots in a fixed order, store the total in the run's first slot and flag it.
-// mode 0 (rounds 2-4): lane-strided slots, four flags then the touched among those four slots per trip.
-// mode 1: lane l owns the k = ceil(cnt / 64) CONSECUTIVE slots [l k, (l + 1) k): 16-byte flag loads, then only the touched slots.
-// mode 2: lane-strided slots (a wave's loads stay contiguous), ALL of the lane's flags first, then only the touched slots, four
-//         per trip.
-__device__ __forceinline__ void wave_sum_long_run(uint32_t first, uint32_t cnt, float* __restrict__ partials, uint8_t* __restrict__ touched, int mode)
+// One wave per listed run: sum its touched slots in a fixed order, store the total in the run's first slot and flag it.  Lane l owns
+// the k = ceil(cnt / 64) CONSECUTIVE slots [l k, (l + 1) k): 16-byte flag loads, then only the touched slots, four per trip.
+// (Rounds 2-5 also carried two lane-strided forms behind GSR_LRS_MODE; this one measured fastest -- 20 -> 14 us at C3 -- and stayed.)
+__device__ __forceinline__ void wave_sum_long_run(uint32_t first, uint32_t cnt, float* __restrict__ partials, uint8_t* __restrict__ touched)
 {
 	const int l = lane_id();
 	float4* part4 = reinterpret_cast<float4*>(partials);
@@ -94,92 +89,20 @@ __device__ __forceinline__ void wave_sum_long_run(uint32_t first, uint32_t cnt, 
 #pragma unroll
 	for (int c = 0; c < 9; c++) v[c] = 0.f;
 	bool any = false;
-	if (mode == 1) {
-		const uint32_t k = (cnt + 63u) >> 6;
-		const uint32_t lo = (uint32_t)l * k, hi = min(cnt, lo + k);
-		for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {   // (one pass for runs of up to 4 096 slots)
-			const uint32_t n = min(64u, hi - g0);
-			unsigned long long live = 0ull;
+	const uint32_t k = (cnt + 63u) >> 6;
+	const uint32_t lo = (uint32_t)l * k, hi = min(cnt, lo + k);
+	for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {   // (one pass for runs of up to 4 096 slots)
+		const uint32_t n = min(64u, hi - g0);
+		unsigned long long live = 0ull;
 #pragma unroll
-			for (int c = 0; c < 4; c++)
-				if (16u * c < n) live |= (unsigned long long)squeeze_flags16(touched + first + g0 + 16 * c) << (16 * c);   // (the array is padded by 64 bytes)
-			if (n < 64u) live &= (1ull << n) - 1ull;
-			any = any || live != 0ull;
-			const float4* src = part4 + SLOT_F4 * (size_t)(first + g0);
-			while (__popcll(live) >= 4) sum_slots_trip<4>(src, live, v);
-			while (live & (live - 1ull)) sum_slots_trip<2>(src, live, v);
-			while (live) sum_slots_trip<1>(src, live, v);
-		}
-	} else if (mode == 2) {
-		// the lane's slots are l, l + 64, ...: bit j of `live` = slot l + 64 j (64 of them per pass: runs of up to 4 096 slots in one)
-		for (uint32_t p0 = 0; p0 < cnt; p0 += 64u * 64u) {
-			unsigned long long live = 0ull;
-			const uint32_t rows = min(64u, (cnt - p0 + 63u) >> 6);
-			for (uint32_t j = 0; j < rows; j++) {
-				const uint32_t i = p0 + 64u * j + (uint32_t)l;
-				if (i < cnt && touched[first + i] != 0) live |= 1ull << j;
-			}
-			any = any || live != 0ull;
-			// (slot of bit j: base + 64 j -- sum_slots_trip indexes src by SLOT_F4 * idx: a stride of 64 slots per bit)
-			const float4* src = part4 + SLOT_F4 * (size_t)(first + p0 + (uint32_t)l);
-			while (live) {
-				int idx[4];
-				float4 x[4], y[4];
-				float z[4];
-				bool ok[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					ok[u] = live != 0ull;
-					idx[u] = ok[u] ? __ffsll((long long)live) - 1 : 0;
-					if (ok[u]) live &= live - 1ull;
-				}
-#pragma unroll
-				for (int u = 0; u < 4; u++)
-					if (ok[u]) {
-						x[u] = src[SLOT_F4 * 64 * (size_t)idx[u]];
-						y[u] = src[SLOT_F4 * 64 * (size_t)idx[u] + 1];
-						z[u] = src[SLOT_F4 * 64 * (size_t)idx[u] + 2].x;
-					}
-#pragma unroll
-				for (int u = 0; u < 4; u++)
-					if (ok[u]) {
-						v[0] += x[u].x; v[1] += x[u].y; v[2] += x[u].z; v[3] += x[u].w;
-						v[4] += y[u].x; v[5] += y[u].y; v[6] += y[u].z; v[7] += y[u].w;
-						v[8] += z[u];
-					}
-			}
-		}
-	} else {
-		const float4* src = part4 + SLOT_F4 * (size_t)first;
-		constexpr int U = 4;
-		for (uint32_t i0 = (uint32_t)l; i0 < cnt; i0 += 64u * U) {
-			bool t[U];
-			float4 x[U], y[U];
-			float z[U];
-#pragma unroll
-			for (int j = 0; j < U; j++) {
-				const uint32_t i = i0 + 64u * (uint32_t)j;
-				t[j] = i < cnt && touched[first + i] != 0;
-			}
-#pragma unroll
-			for (int j = 0; j < U; j++) {
-				const size_t i = (size_t)i0 + 64u * (size_t)j;
-				if (t[j]) {
-					x[j] = src[SLOT_F4 * i];
-					y[j] = src[SLOT_F4 * i + 1];
-					z[j] = src[SLOT_F4 * i + 2].x;
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < U; j++) {
-				if (t[j]) {
-					any = true;
-					v[0] += x[j].x; v[1] += x[j].y; v[2] += x[j].z; v[3] += x[j].w;
-					v[4] += y[j].x; v[5] += y[j].y; v[6] += y[j].z; v[7] += y[j].w;
-					v[8] += z[j];
-				}
-			}
-		}
+		for (int c = 0; c < 4; c++)
+			if (16u * c < n) live |= (unsigned long long)squeeze_flags16(touched + first + g0 + 16 * c) << (16 * c);   // (the array is padded by 64 bytes)
+		if (n < 64u) live &= (1ull << n) - 1ull;
+		any = any || live != 0ull;
+		const float4* src = part4 + SLOT_F4 * (size_t)(first + g0);
+		while (__popcll(live) >= 4) sum_slots_trip<4>(src, live, v);
+		while (live & (live - 1ull)) sum_slots_trip<2>(src, live, v);
+		while (live) sum_slots_trip<1>(src, live, v);
 	}
 	const bool some = wave_ballot(any) != 0ull;
 	wave_reduce9_f32(v);  // totals in lane 63; every lane has read its slots by now (the reduction is a rendezvous)

@@ -48,8 +48,6 @@ preprocess_fwd_kernel(const PreprocessParams p, GeometryState g)
 	for (int t = idx; t < p.tiles; t += (int)(gridDim.x * blockDim.x)) p.ranges[t] = make_uint2(0u, 0u);
 	// (the offset scan lists the Gaussians with more than LONG_RUN tiles behind this kernel: its counters start from zero)
 	for (int t = idx; t < LONG_LISTS * LONG_COUNT_STRIDE; t += (int)(gridDim.x * blockDim.x)) g.long_counts[t] = 0u;
-	if (p.sched)
-		for (int t = idx; t < 2 * p.tiles + SCHED_CLASSES; t += (int)(gridDim.x * blockDim.x)) p.sched[t] = 0u;
 	const int w = wave_id();
 	const size_t wave_first = (size_t)(blockIdx.x * blockDim.x) + (size_t)w * 64;
 	const bool in_range = idx < p.P;

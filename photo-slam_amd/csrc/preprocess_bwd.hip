@@ -245,7 +245,7 @@ preprocess_bwd_kernel(const PreprocessBwdParams p)
 	{
 		const uint32_t cnt = (vis && p.partials) ? p.tiles_touched[idx] : 0u;
 		const uint32_t first = cnt ? __float_as_uint(p.rec[3 * (size_t)idx + 2].w) : 0u;
-		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a, p.slot_trip);   // every lane of the wave takes part
+		wave_sum_partial_runs(cnt, first, p.partials, p.touched, a);   // every lane of the wave takes part
 	}
 	float* out_sh = (p.dL_dsh && !p.dL_dcolor_view && !p.adam_exp_avg && in_range) ? p.dL_dsh + (size_t)idx * M3 : nullptr;
 
@@ -686,13 +686,13 @@ long_run_sums_kernel(const PreprocessBwdParams p)
 		const uint32_t g = p.long_runs[(size_t)list * p.long_capacity + e];
 		const uint32_t cnt = p.tiles_touched[g];
 		const uint32_t first = __float_as_uint(p.rec[3 * (size_t)g + 2].w);
-		wave_sum_long_run(first, cnt, p.partials, p.touched, p.lrs_mode);
+		wave_sum_long_run(first, cnt, p.partials, p.touched);
 	}
 }
 
 int launch_preprocess_bwd(const PreprocessBwdParams& p, hipStream_t stream)
 {
-	if (p.partials) GSR_LAUNCH(long_run_sums_kernel, p.lrs_blocks > 0 ? p.lrs_blocks : LRS_BLOCKS, 256, stream, p);
+	if (p.partials) GSR_LAUNCH(long_run_sums_kernel, LRS_BLOCKS, 256, stream, p);
 	const bool factored = p.dL_dcolor_view != nullptr;
 	const bool adam = p.adam_exp_avg != nullptr;
 	const bool rows_ok = sh_rows_path(p.shs, p.M, p.D, factored, adam, p.dL_dsh);   // (includes 0 <= D <= 3)
@@ -789,7 +789,12 @@ sh_grad_from_views_kernel(int P, int n_views, const float* __restrict__ means3D,
 			// (wave-uniform header words.  A message written for another P is not decoded at all, and no row beyond the rows the
 			// message HOLDS is read -- a sender whose capacity was too small has set msg[3] and dropped them; gsr_check_packed_views
 			// is the loud form of the same test)
-			const uint32_t held = msg[1] == (uint32_t)P ? (msg[0] < msg[2] ? msg[0] : msg[2]) : 0u;
+			// (msg[2] is the capacity of the SENDER's buffer -- gsr_backward writes its message with room for every row -- which may
+			// exceed the rows that travelled: the stride between two gathered messages says how many rows one of them has room for)
+			const long long room = (pk.stride - (long long)(PACK_HEADER + pk_prefix_words + pk_mask_words + 4)) / 3;
+			const uint32_t travelled = room > 0 ? (uint32_t)(room < 0x7FFFFFFFll ? room : 0x7FFFFFFFll) : 0u;
+			uint32_t held = msg[1] == (uint32_t)P ? (msg[0] < msg[2] ? msg[0] : msg[2]) : 0u;
+			held = held < travelled ? held : travelled;
 			if (in_range) {
 				const uint32_t* prefix = msg + PACK_HEADER;
 				const unsigned long long mw = reinterpret_cast<const unsigned long long*>(prefix + pk_prefix_words)[idx >> 6];

@@ -522,7 +522,8 @@ __global__ void __launch_bounds__(SORT_THREADS)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift, int nbits,
                      const uint32_t* __restrict__ hist_rows, const uint32_t* __restrict__ totals, int nblocks,
-                     const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out, uint32_t bias)
+                     const uint32_t* __restrict__ n_dev, int skip_invalid, uint32_t* __restrict__ count_out, uint32_t bias,
+                     uint2* __restrict__ ranges_out)
 {
 	constexpr int DPT = BINS / SORT_THREADS;   // digits per thread in phase B: thread t owns digits t DPT .. t DPT + DPT - 1
 	if (n_dev) n = min(n, (int)*n_dev);
@@ -597,6 +598,8 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 			s_whist[2][d] = lstart + c[j][0] + c[j][1];
 			s_whist[3][d] = lstart + c[j][0] + c[j][1] + c[j][2];
 			s_gbase[d] = digit_base + (d < (1 << nbits) ? hist_rows[(size_t)d * nblocks + blockIdx.x] : 0u) - lstart;
+			// (a one-pass sort on the whole key: the run of key d in the output is [digit_base, digit_base + its total))
+			if (ranges_out && blockIdx.x == 0 && gt[j] != 0u) ranges_out[d] = make_uint2(digit_base, digit_base + gt[j]);
 			lstart += tot[j];
 			digit_base += gt[j];
 		}
@@ -637,15 +640,16 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_ping, uint32_t* vals_ping,
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res, uint32_t* compact_count,
-                      const RadixHostCount* host_count, bool first_hist_ready, int digit_bits, uint32_t bias)
+                      const RadixHostCount* host_count, bool first_hist_ready, int digit_bits, uint32_t bias, uint2* ranges_out)
 {
 	// compact_count (nullable, device word): keys equal to RADIX_INVALID_KEY are dropped by the first pass, which leaves the
 	// number of remaining elements there; the later passes (and the caller's consumers) run over that many elements only.
 	// digit_bits: 8 (RADIX_BITS) or 9 (RADIX_BITS_WIDE: 512-bin kernels; scratch of sort_scratch_elems_wide(n)); bias: subtracted
 	// from every key in front of the digits (the sort is on key - bias, bits [begin_bit, end_bit): the caller guarantees that the
 	// bits above end_bit of key - bias are zero for every element, or handles the exception itself -- gsr_forward's depth sort).
-	if (digit_bits != RADIX_BITS && digit_bits != RADIX_BITS_WIDE) return GSR_ERR_INVALID_ARG;
+	if (digit_bits != RADIX_BITS && digit_bits != RADIX_BITS_WIDE && digit_bits != RADIX_BITS_ONE_PASS) return GSR_ERR_INVALID_ARG;
 	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, digit_bits) : 0;
+	if (ranges_out && (passes != 1 || begin_bit != 0)) return GSR_ERR_INVALID_ARG;
 	*keys_res = (passes % 2) ? keys_pong : keys_ping;
 	*vals_res = (passes % 2) ? vals_pong : vals_ping;
 	if (n <= 0) return GSR_OK;
@@ -665,7 +669,7 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 	// the key bits are spread evenly over the passes (13 tile bits: 7 + 6, not 8 + 5): a pass scatters into 2^nbits streams,
 	// and with fewer streams a workgroup's runs per stream are longer, i.e. its writes better coalesced
 	const int bits_per_pass = div_up(end_bit - begin_bit, passes);
-	const bool wide = bits_per_pass > RADIX_BITS;
+	const int bins = bits_per_pass <= RADIX_BITS ? RADIX_BINS : (bits_per_pass <= RADIX_BITS_WIDE ? 512 : 2048);
 	for (int p = 0; p < passes; p++) {
 		const int shift = begin_bit + p * bits_per_pass;
 		const int nbits = min(bits_per_pass, end_bit - shift);
@@ -678,17 +682,21 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 		const RadixHostCount hc = counts_ride ? *host_count : RadixHostCount{};
 		// (first_hist_ready: the producer of the keys has counted the first pass's digits into `hist` itself -- the instance emission)
 		if (!(p == 0 && first_hist_ready)) {
-			if (wide) GSR_LAUNCH(radix_hist_kernel<512>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
+			if (bins == 2048) GSR_LAUNCH(radix_hist_kernel<2048>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
+			else if (bins == 512) GSR_LAUNCH(radix_hist_kernel<512>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
 			else GSR_LAUNCH(radix_hist_kernel<RADIX_BINS>, nb, SORT_THREADS, stream, kin, n, shift, nbits, hist, nb, n_dev, skip, hc, bias);
 		}
 		GSR_LAUNCH(radix_row_prefix_kernel, (1 << nbits) + (counts_ride ? 1 : 0), SCAN_THREADS, stream, hist, totals, nb, 1 << nbits, hc);
 		if (counts_ride && hc.ready) GSR_HIP(hipEventRecord((hipEvent_t)hc.ready, stream));
-		if (wide)
+		if (bins == 2048)
+			GSR_LAUNCH(radix_scatter_kernel<2048>, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits, (const uint32_t*)hist,
+			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias, ranges_out);
+		else if (bins == 512)
 			GSR_LAUNCH(radix_scatter_kernel<512>, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits, (const uint32_t*)hist,
-			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias);
+			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias, ranges_out);
 		else
 			GSR_LAUNCH(radix_scatter_kernel<RADIX_BINS>, nb, SORT_THREADS, stream, kin, vin, kout, vout, n, shift, nbits, (const uint32_t*)hist,
-			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias);
+			           (const uint32_t*)totals, nb, n_dev, skip, skip ? compact_count : (uint32_t*)nullptr, bias, ranges_out);
 		kin = kout;
 		vin = vout;
 	}

@@ -78,6 +78,14 @@ static inline size_t sort_scratch_elems(int n)
 }
 // ... of a sort with RADIX_BITS_WIDE-bit digits (the [512][blocks] table + the 512 row totals)
 static inline size_t sort_scratch_elems_wide(int n) { return ((size_t)(1 << RADIX_BITS_WIDE) * sort_blocks(n)) + (1 << RADIX_BITS_WIDE) + 64; }
+// ... of the tile sort of n instances: the 8-bit passes' tables, or -- a list short enough for the one-pass form on some tile grid
+// -- the [2048][blocks] table + 2 048 row totals
+static inline size_t tile_sort_scratch_elems(int n)
+{
+	const size_t a = sort_scratch_elems(n);
+	const size_t b = n <= 512 * 1024 ? ((size_t)(1 << 11) * sort_blocks(n)) + (1 << 11) + 64 : 0;
+	return a > b ? a : b;
+}
 
 // The 48-byte per-Gaussian record the blend kernels gather (3 x float4):
 //   q0 = (mean2D.x, mean2D.y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)
@@ -143,17 +151,30 @@ struct GeometryState {
 };
 
 static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }
+constexpr int SEG_ENTRIES = 256;   // list entries per segment of the backward blend (what it accumulates in LDS at a time)
+#ifndef GSR_GROUP_ENTRIES
+#define GSR_GROUP_ENTRIES 1024
+#endif
+constexpr int GROUP_ENTRIES = GSR_GROUP_ENTRIES;   // list entries per WORKGROUP of the group-parallel backward blend: a multiple of SEG_ENTRIES
+constexpr int GROUP_SHIFT = GROUP_ENTRIES == 256 ? 8 : (GROUP_ENTRIES == 512 ? 9 : (GROUP_ENTRIES == 1024 ? 10 : 11));
+static_assert((1 << GROUP_SHIFT) == GROUP_ENTRIES && GROUP_ENTRIES % SEG_ENTRIES == 0, "groups of whole segments");
+static inline size_t seg_slots(size_t R) { return (R >> GROUP_SHIFT) + 1; }
 
 struct BinningState {
 	uint32_t* keys_a;        // [R] tile id per instance (ping)
 	uint32_t* vals_a;        // [R] Gaussian id per instance (ping)
 	uint32_t* keys_b;        // [R] (pong)
 	uint32_t* vals_b;        // [R] (pong)
-	uint32_t* sort_scratch;  // [sort_scratch_elems(R)]
+	uint32_t* sort_scratch;  // [tile_sort_scratch_elems(R)]
 	float*    partials;      // [4 SLOT_F4 R] per-instance gradient slots of the backward blend (blend.h), indexed by emission order
 	uint8_t*  touched;       // [R] 1 where the backward blend wrote the slot (cleared per backward; the slots themselves are not)
 	uint8_t*  contrib;       // [4][R] per quad of the tile: 1 where the forward blend found a pixel of the quad that blends the
 	                         // list entry (written by blend_fwd for the batches it walks, read by blend_bwd: blend.h)
+	// Group-parallel backward blend (blend_bwd.hip): boundary s >= 1 of a tile's list -- entry s * GROUP_ENTRIES -- owns slot
+	// (range.x >> GROUP_SHIFT) + s (unique over all tiles: boundaries of two tiles are more than GROUP_ENTRIES entries apart); the forward blend
+	// leaves there, per quad and pixel, the transmittance in front of the boundary and the colour blended behind it, and the tile's id
+	float*    seg_state;     // [seg_slots(R)][4 quads][T, r, g, b][64 lanes]
+	uint32_t* seg_tile;      // [seg_slots(R)]
 
 	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
 	{
@@ -163,12 +184,14 @@ struct BinningState {
 		b.vals_a = c.take<uint32_t>(R);
 		b.keys_b = c.take<uint32_t>(R);
 		b.vals_b = c.take<uint32_t>(R);
-		b.sort_scratch = c.take<uint32_t>(sort_scratch_elems((int)R));
+		b.sort_scratch = c.take<uint32_t>(tile_sort_scratch_elems((int)R));
 		b.partials = c.take<float>(4 * (size_t)SLOT_F4 * R);
 		// readers fetch flags 16 bytes at a time (+ 64); the clear covers touched_clear_bytes(R): a multiple of 256 bytes, because
 		// the runtime splits a memset of any other size into two kernels (body + tail, 5 us each)
 		b.touched = c.take<uint8_t>(touched_clear_bytes(R));
 		b.contrib = c.take<uint8_t>(4 * R + 64);
+		b.seg_state = c.take<float>(seg_slots(R) * (size_t)(4 * 4 * 64));
+		b.seg_tile = c.take<uint32_t>(seg_slots(R));
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}
@@ -176,35 +199,20 @@ struct BinningState {
 
 // The blend kernels' deal of tiles to the XCDs (blend.h)
 struct TileDeal {
-	int tiles, grid_x, grid_y;
-	int mode;
-	int chunks_x, chunks;   // mode < 0: the image in e x e chunks
+	int tiles, grid_x;
+	int mode;   // > 0: row-major chunks of `mode` tiles, round robin over the XCDs; 0: one band per XCD
 };
 static inline TileDeal make_tile_deal(int tiles, int grid_x, int mode)
 {
 	TileDeal d;
-	d.tiles = tiles; d.grid_x = grid_x; d.grid_y = grid_x > 0 ? tiles / grid_x : 0; d.mode = mode;
-	const int e = mode < 0 ? -mode : 1;
-	d.chunks_x = (grid_x + e - 1) / e;
-	d.chunks = d.chunks_x * ((d.grid_y + e - 1) / e);
+	d.tiles = tiles; d.grid_x = grid_x; d.mode = mode < 0 ? 8 : mode;
 	return d;
 }
 
-// Work classes of the backward blend's chunks (ImageState::sched): eighth-octaves of the number of blended list entries per tile
-// of a full chunk, between 2^5 and 2^13 (9 % steps: the tiles of a 1080p view of a 2 M-Gaussian room hold 160 .. 3 100, mean
-// 1 200); class 0 = fewer.
-constexpr int SCHED_CLASSES = 64;
 struct ImageState {
 	float*    final_T;    // [N]
 	uint32_t* n_contrib;  // [N]
 	uint2*    ranges;     // [T]
-	// Dispatch order of the backward blend (blend_bwd.hip): heaviest CHUNKS first (a chunk = a square of tiles, blend.h: TileDeal).
-	// The forward blend's quad-waves add the number of list entries they blended to sched[tile] (<< 3, with an arrival count in
-	// the low bits); the last quad of a tile adds the tile's total to sched[T + SCHED_CLASSES + chunk] (<< 5, with the tiles that
-	// have arrived); the last tile of a chunk files the chunk under its work class: sched[T + c] counts class c,
-	// class_list[c * chunks + i] is its i-th chunk.  sched is zeroed by the projection kernel next to the ranges.
-	uint32_t* sched;      // [T + SCHED_CLASSES + T]   (chunks <= T)
-	uint32_t* class_list; // [SCHED_CLASSES * T]
 
 	static ImageState carve(char* chunk, size_t N, size_t T, size_t* bytes = nullptr)
 	{
@@ -213,8 +221,6 @@ struct ImageState {
 		im.final_T = c.take<float>(N);
 		im.n_contrib = c.take<uint32_t>(N);
 		im.ranges = c.take<uint2>(T);
-		im.sched = c.take<uint32_t>(2 * T + SCHED_CLASSES);
-		im.class_list = c.take<uint32_t>((size_t)SCHED_CLASSES * T);
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return im;
 	}
@@ -236,7 +242,21 @@ static inline uint32_t higher_msb(uint32_t n)
 
 // After `passes` ping-pong radix passes starting in buffer A, where does the result live?
 static inline bool result_in_a(int passes) { return (passes % 2) == 0; }
-static inline int tile_sort_passes(int tiles) { return div_up((int)higher_msb((uint32_t)tiles), RADIX_BITS); }
+// The tile sort's digit width: 8 bits per pass -- or, for a SMALL list (up to TILE_SORT_ONE_PASS_MAX instances) on a tile grid of
+// up to 2 048 tiles, ALL tile bits in ONE pass of up to 11 bits (RADIX_BITS_ONE_PASS): the [digit][block] table, whose column-wise
+// accesses sink wide digits on large lists (2 048 scattered lines per workgroup: depth_sort 0.101 -> 0.187 ms at C3, round 3), has
+// at most 256 columns there, a pass with its two launches goes, and so does identifyTileRanges -- with the whole tile id as the
+// digit the ranges ARE the digit totals' prefix sums (the scatter pass writes them).  A view of 50 k Gaussians at 640 x 480 is
+// launch-bound: every launch is ~5 us of a 250 us step.  A pure function of (tiles, R): gsr_forward, gsr_backward and the
+// test-suite's view of the buffer agree on where the sorted list lives.
+constexpr int RADIX_BITS_ONE_PASS = 11;
+constexpr int TILE_SORT_ONE_PASS_MAX = 512 * 1024;
+static inline int tile_sort_digit_bits(int tiles, int R)
+{
+	const int bits = (int)higher_msb((uint32_t)tiles);
+	return (bits > RADIX_BITS && bits <= RADIX_BITS_ONE_PASS && R <= TILE_SORT_ONE_PASS_MAX) ? RADIX_BITS_ONE_PASS : RADIX_BITS;
+}
+static inline int tile_sort_passes(int tiles, int R) { return div_up((int)higher_msb((uint32_t)tiles), tile_sort_digit_bits(tiles, R)); }
 
 // ---- device launchers (one per translation unit) ------------------------------------
 // n_dev (nullable, with gather only): a device word; elements from *n_dev on count as zeros (their gather indices are undefined)
@@ -284,12 +304,14 @@ int launch_radix_sort(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
                       uint32_t* keys_pong, uint32_t* vals_pong, int n, int begin_bit, int end_bit,
                       uint32_t* scratch, hipStream_t stream, uint32_t** keys_res, uint32_t** vals_res,
                       uint32_t* compact_count = nullptr, const RadixHostCount* host_count = nullptr, bool first_hist_ready = false,
-                      int digit_bits = RADIX_BITS, uint32_t bias = 0);
+                      int digit_bits = RADIX_BITS, uint32_t bias = 0, uint2* ranges_out = nullptr);
+// ranges_out (nullable; a ONE-pass sort whose digit is the whole key): ranges_out[k] = [first, end) of key k's run in the output
+// for every key that occurs (the others are left alone: the caller zeroed them) -- identifyTileRanges without its launch
 // the digit width of the first pass (the key bits are spread evenly over the passes) -- for a producer that counts the first
 // histogram itself (first_hist_ready: the [digit][sort_blocks(n)] table at the head of `scratch`, digits of key bits [begin_bit, +w))
-static inline int radix_first_pass_bits(int begin_bit, int end_bit)
+static inline int radix_first_pass_bits(int begin_bit, int end_bit, int digit_bits = RADIX_BITS)
 {
-	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, RADIX_BITS) : 0;
+	const int passes = end_bit > begin_bit ? div_up(end_bit - begin_bit, digit_bits) : 0;
 	return passes ? div_up(end_bit - begin_bit, passes) : 0;
 }
 // compact_count (nullable, a device word): keys equal to RADIX_INVALID_KEY are "no element": the first pass drops them and

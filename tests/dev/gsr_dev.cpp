@@ -29,7 +29,7 @@ int gsr_view_binning(char* binning_buffer, int R, int width, int height, gsr_bin
 {
 	if (!binning_buffer || R < 0 || !out || width <= 0 || height <= 0) return GSR_ERR_INVALID_ARG;
 	BinningState b = BinningState::carve(binning_buffer, (size_t)R);
-	const int passes = tile_sort_passes(div_up(width, TILE) * div_up(height, TILE));
+	const int passes = tile_sort_passes(div_up(width, TILE) * div_up(height, TILE), R);
 	out->point_list = (passes % 2) ? b.vals_b : b.vals_a;
 	out->tile_keys = (passes % 2) ? b.keys_b : b.keys_a;
 	return GSR_OK;

@@ -74,10 +74,16 @@ def make_case(name, P, W, H, f):
 
 
 def check_case(lib_path, dev, oracle, name, P, W, H, f):
+    """both binning arrangements (include/gsr.h: GSR_BINNING_DEPTH_FIRST with its second depth-sort path for out-of-range and NaN
+    depths, GSR_BINNING_TILE_FIRST with the per-tile sorts on the raw key bits); returns the worst gradient deviation"""
+    return max(_check_case(lib_path, dev, oracle, name, P, W, H, f, flags) for flags in (32, 64))
+
+
+def _check_case(lib_path, dev, oracle, name, P, W, H, f, flags):
     a, cam = make_case(name, P, W, H, f)
     bg = np.array([0.2, 0.1, 0.4], np.float32)
     dpix = np.random.default_rng(9).standard_normal((3, H, W)).astype(np.float32)
-    r = parity.run_backend(lib_path, dev, a, cam, bg, sh_degree=3, dL_dpix=dpix)
+    r = parity.run_backend(lib_path, dev, a, cam, bg, sh_degree=3, dL_dpix=dpix, flags=flags)
     ores, ocolor, oradii, ograds = parity.run_oracle(oracle, a, cam, bg, sh_degree=3, dL_dpix=dpix)
     vis = oradii > 0
     # ---- decisions: exact

@@ -307,13 +307,13 @@ def test_cull_empty_tiles_at_full_size(dev, cfg):
     assert kept < 0.8 * listed   # measured: C2 62 %, C5 74 % of the rectangles' instances survive the tile-level bound
 
 
-@pytest.mark.parametrize("switches", [{"GSR_XCD_CHUNK": "0", "GSR_LRS_MODE": "0", "GSR_SLOT_TRIP": "1", "GSR_EMIT_HIST": "0"},
-                                      {"GSR_XCD_CHUNK": "-4", "GSR_LRS_MODE": "2", "GSR_SLOT_TRIP": "4"},
-                                      {"GSR_XCD_CHUNK": "-1"}])
-def test_library_switches_of_round_5_on_gpu(dev, switches, tmp_path):
-    """The A/B handles of round 5 on the hardware: one band of the image per XCD with the rounds-2-to-4
-    forms of the helpers; squares of 4 x 4 tiles / single tiles with the backward blend taking the heaviest first.  Every stage
-    against the oracle at C2, in a child process (the switches are read once per process)."""
+@pytest.mark.parametrize("switches", [{"GSR_XCD_CHUNK": "0", "GSR_EMIT_HIST": "0", "GSR_BWD_SEGMENTS": "0", "GSR_BINNING": "0"},
+                                      {"GSR_XCD_CHUNK": "1", "GSR_BWD_SEGMENTS": "1", "GSR_BINNING": "1"},
+                                      {"GSR_BWD_SEGMENTS": "1", "GSR_BINNING": "0"}])
+def test_library_switches_on_gpu(dev, switches, tmp_path):
+    """The A/B handles on the hardware: one band of the image per XCD / single tiles; the backward blend one workgroup per tile or
+    per (tile, segment); depth-first or tile-first binning.  Every stage against the oracle at C2, in a child process (the
+    switches are read once per process)."""
     import os
     import subprocess
     import sys
@@ -335,3 +335,47 @@ print(parity.compare(r, ores, ocolor, oradii, ograds, cam))
 assert ores.R > 1_000_000
 """
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PYTEST_CURRENT_TEST="switches", **switches), timeout=900)
+
+
+def test_forward_from_two_host_threads_and_devices(oracle, dev):
+    """The library's per-call state (the mapped count words, the event, the second stream) belongs to the calling THREAD and the
+    CURRENT DEVICE (csrc/gsr_api.hip: host_sync): two host threads render different views at the same time, each on a stream of its
+    own, ten times over -- every result equals the single-threaded one bit for bit (forward) / to the order of the LDS adds
+    (backward); where the box has a second device, one thread then renders on both in turn."""
+    import threading
+    cl = scene.make_cloud(60000, 400, 300, 350.0, 350.0, seed=21, scale_k=0.2, n_views=2)
+    bg = np.array([0.1, 0.3, 0.2], np.float32)
+    dpix = np.random.default_rng(4).standard_normal((3, 300, 400)).astype(np.float32)
+    want = [parity.run_backend(None, dev, cl, cl.cameras[v], bg, dL_dpix=dpix) for v in range(2)]
+    errors, got = [], {0: [], 1: []}
+
+    def work(v):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                for _ in range(10):
+                    got[v].append(parity.run_backend(None, dev, cl, cl.cameras[v], bg, dL_dpix=dpix))
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception as e:   # (an assertion in a thread would otherwise vanish)
+            errors.append((v, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(v,)) for v in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for v in range(2):
+        assert len(got[v]) == 10
+        for r in got[v]:
+            assert r.R == want[v].R and np.array_equal(r.point_list, want[v].point_list) and np.array_equal(r.ranges, want[v].ranges)
+            assert np.array_equal(r.out_color, want[v].out_color) and np.array_equal(r.n_contrib, want[v].n_contrib)
+            for k, g in r.grads.items():
+                assert parity.rel_l1(g, want[v].grads[k]) <= 1e-5, (v, k)
+    if torch.cuda.device_count() > 1:
+        other = torch.device("cuda", 1)
+        for d in (other, dev, other):
+            with torch.cuda.device(d):   # (the caller keeps the device of its stream current, as the reference's single-device code does)
+                r = parity.run_backend(None, d, cl, cl.cameras[0], bg, dL_dpix=dpix)
+            assert r.R == want[0].R and np.array_equal(r.out_color, want[0].out_color)
+    else:
+        print("one device on this box: the two-device half of the test did not run")
