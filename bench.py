@@ -333,7 +333,7 @@ def replica_checksum(torch, dist, tensors, dev, backend):
     return bool(torch.equal(lo, hi)), [int(x) for x in h.cpu()]
 
 
-def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
+def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window, morton_reindex=False):
     """BASELINE config C5's SHAPE on one GPU (`--mapper-loop`, opt-in): 4 M Gaussians @ 752x480, the fused train step cycling
     through EIGHT keyframes, and the map maintenance of GaussianMapper::trainForOneIteration / run (src/gaussian_mapper.cpp:614-774,
     371-542) on its schedule: increasePcd of 5 k new map points every 10 iterations (a new keyframe's points, :854,955),
@@ -350,7 +350,7 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window):
     h = ops.trainer_create(t(cl.xyz), t(feats), t(cl.opacity), t(cl.scaling), t(cl.rotation), 3, float(cl.extent), bg)
     ops.trainer_set_options(h, {"lazy_sh_adam_window": float(sh_adam_window), "densify": 1.0, "cameras_extent": float(cl.extent),
                                 "seed": float(seed), "densify_from_iter": 0.0, "densification_interval": 100.0,
-                                "opacity_reset_interval": 150.0, "active_sh_degree": 2.0})
+                                "opacity_reset_interval": 150.0, "active_sh_degree": 2.0, "morton_reindex": 1.0 if morton_reindex else 0.0})
     kfs, gts = [], []
     gen = torch.Generator(device="cpu").manual_seed(4321 + seed)
     for c in cams:
@@ -486,6 +486,9 @@ def main():
                          "measures faster on this node (auto)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
+    ap.add_argument("--morton-reindex", action="store_true",
+                    help="densify_run / mapper-loop legs: densifyAndPrune lays the new set out along a Z-order curve (GaussianModel::morton_reindex_; "
+                         "include/gsr.h: gsr_densify_gather_args.morton_scratch) -- the same Gaussians in another row order")
     ap.add_argument("--no-config-legs", dest="config_legs", action="store_false",
                     help="skip the `configs` block (the other single-GPU BASELINE configs -- C2, a C4 view, a C5 view -- each in a child process)")
     ap.add_argument("--no-sq-probe", dest="sq_probe", action="store_false",
@@ -539,7 +542,7 @@ def main():
         import build_host
         torch.ops.load_library(build_host.build("hip"))
         print(json.dumps({"mapper_loop": mapper_loop_leg(torch, dev, torch.ops.photoslam_amd, scene, args.mapper_loop_steps, args.seed,
-                                                         args.sh_adam_window)}), flush=True)
+                                                         args.sh_adam_window, args.morton_reindex)}), flush=True)
         return
 
     cfg = scene.CONFIGS[args.config]
@@ -932,7 +935,7 @@ def main():
         ops.trainer_set_options(h2, {"lazy_sh_adam_window": float(args.sh_adam_window), "densify": 1.0,
                                      "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0,
                                      "cameras_extent": float(cl.extent), "seed": 0.0, "densify_from_iter": 0.0,
-                                     "densification_interval": float(interval)})
+                                     "densification_interval": float(interval), "morton_reindex": 1.0 if args.morton_reindex else 0.0})
         n_d = args.densify_leg_steps
         P_before = int(ops.trainer_params(h2)[0].shape[0])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_d + 1)]
@@ -964,7 +967,7 @@ def main():
                        "ms_per_densifying_step": [round(float(per[i]), 3) for i in calls],
                        "ms_median_other_steps": round(float(np.median(plain)), 3),
                        "ms_per_densify_call_over_a_plain_step": [round(float(per[i] - np.median(plain)), 3) for i in calls],
-                       "gaussians_before": P_before, "gaussians_after": P_after,
+                       "gaussians_before": P_before, "gaussians_after": P_after, "morton_reindex": bool(args.morton_reindex),
                        "last_call": dict(zip(("cloned", "split", "pruned", "points"), last)),
                        "note": "BASELINE config C3 as stated: densifyAndPrune (src/gaussian_model.cpp:716-815) every 100 steps inside the "
                                "timed loop, training learning rates; a densifying step skips its optimizer update as the reference's does; "

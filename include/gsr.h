@@ -468,7 +468,17 @@ typedef struct gsr_densify_gather_args {
 	 * value -- prunePoints (:636), clones (:782) and split children (:744) alike */
 	const int* exist_since_iter_in;
 	int* exist_since_iter_out;
+	/* Extension (NULL = the reference's row order: kept originals, clones, first children, second children, each in source order):
+	 * gsr_densify_morton_scratch_bytes(n_new) device bytes -- the rows of the new set are then laid out along a Z-order curve of
+	 * their (parents') positions.  The SAME Gaussians with the same values, moments, statistics and exist_since_iter, in another
+	 * order (a view's depth ties then resolve by the new ids).  Why: every per-Gaussian kernel of a step fetches the rows of the
+	 * Gaussians a view sees, a spatially compact subset; when neighbours in space are neighbours in memory those rows share 128-byte
+	 * lines instead of being a random half of every line (measured on the synthetic cloud, whose ids carry no locality at all:
+	 * -5 % of the train step; a SLAM map that grows keyframe by keyframe has some of it by construction).  The gather rewrites every
+	 * tensor anyway: the order is free. */
+	char* morton_scratch;
 } gsr_densify_gather_args;
+size_t gsr_densify_morton_scratch_bytes(int n_new);
 int gsr_densify_gather(const gsr_densify_gather_args* args, const char* scratch, void* stream);
 
 /* ---- Photo-SLAM's point-cloud kernels ----

@@ -123,7 +123,7 @@ class DensifyGatherArgs(C.Structure):
                 ("param_in", C.c_void_p * 5), ("exp_avg_in", C.c_void_p * 5), ("exp_avg_sq_in", C.c_void_p * 5),
                 ("param_out", C.c_void_p * 5), ("exp_avg_out", C.c_void_p * 5), ("exp_avg_sq_out", C.c_void_p * 5),
                 ("samples", C.c_void_p), ("stats_out", C.c_void_p * 3), ("exist_since_iter_in", C.c_void_p),
-                ("exist_since_iter_out", C.c_void_p)]
+                ("exist_since_iter_out", C.c_void_p), ("morton_scratch", C.c_void_p)]
 
 
 RAW_OPACITY, RAW_SCALING, RAW_ROTATION = 1, 2, 4   # GSR_RAW_* of include/gsr.h
@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "gsr_densify_select", "gsr_densify_gather", "gsr_transform_points", "gsr_scale_transform_points", "gsr_reproject_depth_pinhole",
     "gsr_neighborhood_depth_pinhole", "gsr_packed_view_words", "gsr_pack_scratch_bytes", "gsr_pack_color_view", "gsr_pack_view_plan",
     "gsr_sh_grad_from_packed_views", "gsr_sh_adam_from_packed_views", "gsr_last_visible_count", "gsr_check_packed_views", "gsr_depth_resort_count",
-    "gsr_host_wait_stats", "gsr_binning_tile_first",
+    "gsr_host_wait_stats", "gsr_binning_tile_first", "gsr_densify_morton_scratch_bytes",
 ]
 
 _libs = {}
@@ -203,6 +203,8 @@ def load(path=None):
     L.gsr_densify_scratch_bytes.argtypes = [i32]
     L.gsr_densify_select.restype = i32
     L.gsr_densify_select.argtypes = [C.POINTER(DensifySelectArgs), vp, vp, vp]
+    L.gsr_densify_morton_scratch_bytes.restype = sz
+    L.gsr_densify_morton_scratch_bytes.argtypes = [i32]
     L.gsr_densify_gather.restype = i32
     L.gsr_densify_gather.argtypes = [C.POINTER(DensifyGatherArgs), vp, vp]
     L.gsr_transform_points.restype = i32

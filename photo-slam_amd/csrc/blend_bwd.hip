@@ -1,6 +1,5 @@
 // blend_bwd.hip -- backward of the alpha blend: per-pixel loss gradients -> per-instance
-// gradients of colour, 2D mean, conic and opacity.  One wave per 8x8 quad, four quads = one 256-thread workgroup per tile
-// (or per SEGMENT of 256 list entries of a tile, below).
+// gradients of colour, 2D mean, conic and opacity.  One wave per 8x8 quad, four quads = one 256-thread workgroup per tile.
 //
 // Per-pixel semantics are renderCUDA's backward (cuda_rasterizer/backward.cu:399-557): walk
 // the tile list back to front starting at each pixel's last contributor, recompute alpha,
@@ -32,23 +31,18 @@
 // T_{j+1} = T_j (1 - alpha_j) this is   dL/dalpha_j = T_j (c_j . dpix) - B_{j+1} / (1 - alpha_j),
 //   B_{j+1} = S_{j+1} . dpix + T_final (bg . dpix),     B_j = B_{j+1} + (c_j . dpix) alpha_j T_j,
 // one scalar recurrence instead of three (six VALU per visit instead of eleven), no division by a small transmittance -- and a
-// state that can be re-created at ANY list position from what the forward pass knows: T before the position and the colour
-// blended behind it.
+// state that could be re-created at any list position from T before the position and the colour blended behind it.  (Round 6
+// built that: the forward blend left both per pixel at every 256- / 1 024-entry boundary and the backward blend ran one workgroup
+// per (tile, group of segments) -- parity green, -7 % of this kernel at 500 k @ 1200 x 680 and 2 M @ 640 x 480, nothing elsewhere,
+// +4 us in the forward blend and 16 bytes per instance: removed, commit 2e10ed9, EXPERIMENTS.md R6.)
 //
-// Segments.  A tile's backward pass is a serial chain per pixel, and a view of a few thousand entries per tile on a grid of
-// 1 200 tiles (640 x 480, 2 M Gaussians) has all its workgroups resident at once: the kernel lasts as long as its heaviest tile
-// while most of the machine idles (VALU utilisation 56 %, profiles/r06_a_sq_counters_full_C4.json).  The forward blend therefore
-// leaves, per pixel and 256-entry boundary it passes, the transmittance in front of the boundary and the colour blended behind it
-// (state.h: BinningState::seg_state, 16 bytes); blend_bwd_kernel<true> then runs ONE workgroup per (tile, segment): short, uniform
-// jobs the dispatcher balances, each starting from the boundary state behind its segment (or from the pixel's final state).
 #include "blend.h"
 #include "kernels.h"
 
 namespace gsr {
 
-constexpr int BWD_SEG = SEG_ENTRIES;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB); thread i stages entry i of the segment
+constexpr int BWD_SEG = 256;  // list entries accumulated in LDS per segment (9 x 256 floats = 9 KiB); thread i stages entry i of the segment
 
-template <bool SEGMENTS>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdParams p)
 {
@@ -59,28 +53,8 @@ blend_bwd_kernel(const BlendBwdParams p)
 	__shared__ uint8_t s_flag[BWD_SEG];    // bit q: quad q of the tile blends the entry (a byte each: 7 workgroups per CU fit the 160 KiB of LDS)
 	__shared__ uint32_t s_wmax[4];
 
-	int tile, first_seg = -1;   // first_seg >= 0: this workgroup walks exactly that GROUP of segments (GROUP_ENTRIES list entries)
-	if (SEGMENTS) {
-		// workgroups [0, tiles): segment 0 of every tile; behind them one workgroup per boundary slot: segment s >= 1 of tile t sits
-		// at slot (range.x >> 8) + s (unique over all tiles: boundaries of different tiles are more than 256 entries apart), and the
-		// forward blend left the tile's id there.  A slot no tile owns in THIS view holds anything: the owner is checked.
-		const int g = (int)blockIdx.x;
-		if (g < p.tiles) {
-			tile = g;
-			first_seg = 0;
-		} else {
-			const uint32_t slot = (uint32_t)(g - p.tiles);
-			tile = (int)p.seg_tile[slot];
-			if (tile < 0 || tile >= p.tiles) return;
-			const uint2 r = p.ranges[tile];
-			const int s = (int)slot - (int)(r.x >> GROUP_SHIFT);
-			if (s < 1 || (uint32_t)s * GROUP_ENTRIES >= r.y - r.x) return;
-			first_seg = s;
-		}
-	} else {
-		tile = tile_assignment((int)blockIdx.x, p.deal);
-		if (tile >= p.tiles) return;
-	}
+	const int tile = tile_assignment((int)blockIdx.x, p.deal);
+	if (tile >= p.tiles) return;
 	const int tile_x = tile % p.grid_x, tile_y = tile / p.grid_x;
 	const int quad = (int)wave_uniform_u32((uint32_t)wave_id());   // scalar: the LDS record address is SGPR arithmetic
 	const int l = lane_id(), tid = (int)threadIdx.x;
@@ -93,13 +67,12 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const size_t pix = (size_t)py * p.W + px;
 	const size_t plane = (size_t)p.H * p.W;
 
-	uint32_t last_contributor = inside ? p.n_contrib[pix] : 0u;
+	const uint32_t last_contributor = inside ? p.n_contrib[pix] : 0u;
 	// entries at or behind wmax touch no pixel of the quad; bmax: none of the tile
 	const uint32_t wmax = wave_uniform_u32(wave_max_u32(last_contributor));
 	if (l == 0) s_wmax[quad] = wmax;
 	__syncthreads();
 	const uint32_t bmax = wave_uniform_u32(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
-	if (SEGMENTS && (uint32_t)first_seg * GROUP_ENTRIES >= bmax) return;   // (nothing of this group reached a pixel: block-uniform)
 
 	const float T_final = inside ? p.final_T[pix] : 0.f;
 	float dpr = 0.f, dpg = 0.f, dpb = 0.f;
@@ -108,22 +81,10 @@ blend_bwd_kernel(const BlendBwdParams p)
 		dpg = p.dL_dpix[plane + pix];
 		dpb = p.dL_dpix[2 * plane + pix];
 	}
-	// the pixel's state at the END of what this workgroup walks: T = the transmittance in front of that position, B = (everything
-	// blended behind it, background included) . dpix
+	// the pixel's state behind its last contributor: T = the final transmittance, B = (everything blended behind, i.e. the
+	// background) . dpix
 	float T = T_final;
 	float B = T_final * (p.bg[0] * dpr + p.bg[1] * dpg + p.bg[2] * dpb);
-	if (SEGMENTS) {
-		const uint32_t end = ((uint32_t)first_seg + 1u) * GROUP_ENTRIES;
-		if (last_contributor > end) {
-			// the pixel blends entries behind this group: start from the state the forward blend left at the boundary
-			const float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)first_seg + 1u) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
-			T = st[l];
-			B += st[64 + l] * dpr + st[128 + l] * dpg + st[192 + l] * dpb;   // (the colour blended behind the boundary)
-			last_contributor = end;   // (entries at or behind `end` are another workgroup's)
-		} else if (last_contributor <= (uint32_t)first_seg * GROUP_ENTRIES) {
-			last_contributor = 0u;    // (nothing of this segment reaches the pixel)
-		}
-	}
 	// lanes 0, 8, .., 56 deliver the eight packed totals, lanes 1, 17, 33, 49 the four row sums of the ninth
 	// (wave_reduce9_swap_f32): one ds_add_f32 with twelve active lanes
 	const bool red_ninth = (l & 15) == 1;
@@ -131,17 +92,14 @@ blend_bwd_kernel(const BlendBwdParams p)
 	const int red_off = (red_ninth ? 8 : wave_swap9_component(l)) * BWD_SEG;
 	const v2f dprg = {dpr, dpg};
 
-	constexpr int SPG = GROUP_ENTRIES / BWD_SEG;   // segments per group
-	const int seg_top = (int)((bmax + BWD_SEG - 1) / BWD_SEG) - 1;   // the last segment any pixel of the tile reaches
-	const int seg_first = SEGMENTS ? min(seg_top, (first_seg + 1) * SPG - 1) : seg_top;
-	const int seg_last = SEGMENTS ? first_seg * SPG : 0;
+	const int seg_first = (int)((bmax + BWD_SEG - 1) / BWD_SEG) - 1, seg_last = 0;
 	// The segment's records are staged ONCE per tile, by all 256 threads (thread i: list entry seg_lo + i), and only for the entries
 	// some quad of the tile blended (the forward blend's flags: a quarter of the entries of a 1080p view, a tenth at 640 x 480 with
 	// 2 M Gaussians).  The list entries and flags of the NEXT segment are asked for while this one is walked.
 	auto seg_flags = [&](int seg_) -> uint32_t {
 		const uint32_t e = (uint32_t)seg_ * BWD_SEG + (uint32_t)tid;
 		uint32_t f = 0u;
-		if (e < bmax) {   // (a group's last segment ends at the group's end: seg_first / seg_last keep the walk inside the group)
+		if (e < bmax) {
 #pragma unroll
 			for (int q = 0; q < QUADS_PER_TILE; q++)
 				// (behind a quad's deepest last contributor the forward blend may not have walked: no flags were written there)
@@ -267,8 +225,7 @@ blend_bwd_kernel(const BlendBwdParams p)
 
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream)
 {
-	if (p.seg_state) GSR_LAUNCH(blend_bwd_kernel<true>, p.tiles + (int)p.seg_slots, 256, stream, p);
-	else GSR_LAUNCH(blend_bwd_kernel<false>, tile_grid(p.deal), 256, stream, p);
+	GSR_LAUNCH(blend_bwd_kernel, tile_grid(p.deal), 256, stream, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;
 }

@@ -42,10 +42,6 @@ blend_fwd_kernel(const BlendFwdParams p)
 	// pixel state predicates live as 64-bit lane masks in SGPR pairs; their logic is scalar
 	unsigned long long done_m = wave_ballot(!inside);
 
-	// Segment-parallel backward blend (blend_bwd.hip): the tile's id at the slot of every 256-entry boundary of its list ...
-	if (p.seg_tile && quad == 0)
-		for (int s = 1 + l; s * GROUP_ENTRIES < n; s += 64) p.seg_tile[(range.x >> GROUP_SHIFT) + (uint32_t)s] = (uint32_t)tile;
-	int seg_passed = 0;   // boundaries this wave has walked past (scalar)
 	uint32_t gid_next = (l < n) ? p.point_list[range.x + (uint32_t)l] : 0u;
 	for (int base = 0; base < n; base += 64) {
 		if (~done_m == 0ull) break;
@@ -133,53 +129,16 @@ blend_fwd_kernel(const BlendFwdParams p)
 		// quad rejection blend into no pixel -- alpha below 1/255 at every pixel centre, or every such pixel saturated)
 		if (have) p.contrib[(size_t)quad * p.contrib_stride + range.x + (uint32_t)(base + l)] = (uint8_t)((contrib_m >> l) & 1ull);
 		if (wave_done) break;
-		// ... and, at every boundary the wave walks past, its pixels' state there: the transmittance in front of the boundary and the
-		// colour accumulated so far (16 bytes per pixel; a quad that saturates earlier leaves nothing: none of its pixels has a
-		// contributor behind the boundary, and the backward pass asks for the state of such pixels only)
-		if (p.seg_state && ((base + 64) & (GROUP_ENTRIES - 1)) == 0 && base + 64 < n) {
-			// T in front of the boundary, and the colour accumulated SINCE THE LAST boundary -- the accumulators start over, so that
-			// every stored partial keeps the relative precision of its own magnitude (the sums behind a boundary are formed from the
-			// back at the end of the walk: a difference C_total - C_prefix would carry the absolute rounding error of the whole colour
-			// into the faint tail of a long list)
-			seg_passed = (base + 64) / GROUP_ENTRIES;
-			float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)seg_passed) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
-			st[l] = T;
-#ifdef GSR_EMU
-			st[64 + l] = Crg[0];
-			st[128 + l] = Crg[1];
-			Crg = (v2f){0.f, 0.f};
-#else
-			st[64 + l] = Cr;
-			st[128 + l] = Cg;
-			Cr = 0.f;
-			Cg = 0.f;
-#endif
-			st[192 + l] = Cb;
-			Cb = 0.f;
-		}
 		wave_fence();  // all lanes have read this batch before the next one overwrites the slice
 	}
-#ifdef GSR_EMU
-	float Cr = Crg[0], Cg = Crg[1];
-#endif
-	// the boundaries' partial colours -> the colour blended BEHIND each boundary (what the backward blend starts a segment from), summed
-	// from the back; what is left at the front is the pixel's colour
-	for (int b = seg_passed; b >= 1; b--) {
-		float* st = p.seg_state + ((size_t)((range.x >> GROUP_SHIFT) + (uint32_t)b) * QUADS_PER_TILE + (size_t)quad) * (4 * 64);
-		const float dr = st[64 + l], dg = st[128 + l], db = st[192 + l];
-		st[64 + l] = Cr;
-		st[128 + l] = Cg;
-		st[192 + l] = Cb;
-		Cr += dr;
-		Cg += dg;
-		Cb += db;
-	}
-
 	if (inside) {
 		const size_t pix = (size_t)py * p.W + px;
 		const size_t plane = (size_t)p.H * p.W;
 		p.final_T[pix] = T;
 		p.n_contrib[pix] = last_contributor;
+#ifdef GSR_EMU
+		const float Cr = Crg[0], Cg = Crg[1];
+#endif
 		p.out_color[pix] = Cr + T * p.bg[0];
 		p.out_color[plane + pix] = Cg + T * p.bg[1];
 		p.out_color[2 * plane + pix] = Cb + T * p.bg[2];

@@ -193,6 +193,7 @@ struct DensifyGather {
 	int n_new, n_first_child;     // rows; first row of the children block = n_keep + n_clone_kept
 	const uint32_t* src_of;
 	const uint32_t* child_sample;
+	const uint32_t* row_perm;     // null, or: row r of the new set is row row_perm[r] of the plan (gsr_densify_gather_args.morton_scratch)
 	const float* samples;         // [2k,3] standard normal draws (at::normal's randn before the scale), null if no children
 	GatherTensor t[5];            // xyz, features, opacity, scaling, rotation
 	float* stats[3];              // xyz_gradient_accum, denom, max_radii2D of the new set: zero-filled (may be null)
@@ -224,7 +225,7 @@ densify_gather_kernel(const DensifyGather p)
 		const int a = (int)(e / p.n_new);
 		const long long row = e - (long long)a * p.n_new;
 		if (a == 3) {
-			if (p.exist_out) p.exist_out[row] = p.exist_in[p.src_of[row] & 0x3FFFFFFFu];
+			if (p.exist_out) p.exist_out[row] = p.exist_in[p.src_of[p.row_perm ? p.row_perm[row] : (uint32_t)row] & 0x3FFFFFFFu];
 		} else if (p.stats[a]) {
 			p.stats[a][row] = 0.f;
 		}
@@ -238,7 +239,8 @@ densify_gather_kernel(const DensifyGather p)
 	const bool vec = (t.row_floats & 3) == 0;            // rows of whole float4s: features (12), rotation (1)
 	const int units = vec ? t.row_floats / 4 : t.row_floats;
 	const int row = (int)(local / units), u = (int)(local - (long long)row * units);
-	const uint32_t code = p.src_of[row];
+	const int prow = p.row_perm ? (int)p.row_perm[row] : row;   // the plan's row (its position decides a child's sample)
+	const uint32_t code = p.src_of[prow];
 	const uint32_t src = code & 0x3FFFFFFFu, kind = code >> 30;
 	if (vec) {
 		const size_t so = ((size_t)src * units + u), dn = ((size_t)row * units + u);
@@ -256,7 +258,7 @@ densify_gather_kernel(const DensifyGather p)
 		if (ti == 3) {
 			v = logf(child_scale(expf(v)));
 		} else {
-			const float* z = p.samples + 3 * (size_t)p.child_sample[row - p.n_first_child];
+			const float* z = p.samples + 3 * (size_t)p.child_sample[prow - p.n_first_child];
 			// at::normal(mean 0, std): randn * std (+ 0)
 			const float sx = z[0] * expf(ps[0]), sy = z[1] * expf(ps[1]), sz = z[2] * expf(ps[2]);
 			float o[3];
@@ -269,6 +271,18 @@ densify_gather_kernel(const DensifyGather p)
 	if (t.dst[2]) t.dst[2][dn] = kind ? 0.f : t.src[2][so];
 }
 
+// the position every row of the plan is ordered by: its source's (a child: its parent's)
+__global__ void __launch_bounds__(256)
+densify_plan_positions_kernel(int n_new, const uint32_t* __restrict__ src_of, const float* __restrict__ xyz, float* __restrict__ pos)
+{
+	const int r = (int)blockIdx.x * 256 + (int)threadIdx.x;
+	if (r >= n_new) return;
+	const size_t s = (size_t)(src_of[r] & 0x3FFFFFFFu);
+	pos[3 * (size_t)r] = xyz[3 * s];
+	pos[3 * (size_t)r + 1] = xyz[3 * s + 1];
+	pos[3 * (size_t)r + 2] = xyz[3 * s + 2];
+}
+
 static inline int densify_blocks(int P) { return div_up(P, DS_BLOCK); }
 
 }  // namespace gsr
@@ -276,6 +290,8 @@ static inline int densify_blocks(int P) { return div_up(P, DS_BLOCK); }
 using namespace gsr;
 
 extern "C" {
+
+size_t gsr_densify_morton_scratch_bytes(int n_new) { return knn_scratch_bytes(n_new < 0 ? 0 : n_new); }
 
 size_t gsr_densify_scratch_bytes(int P)
 {
@@ -357,6 +373,18 @@ int gsr_densify_gather(const gsr_densify_gather_args* a, const char* scratch, vo
 	p.items_before[6] = items;
 	const long long blocks = (items + 255) / 256;
 	if (blocks > 0x7FFFFFFFll) return GSR_ERR_UNSUPPORTED;
+	p.row_perm = nullptr;
+	if (a->morton_scratch) {
+		// the plan's rows along the Z-order curve of their sources' positions (the simple-knn front half: bounding box, Morton codes,
+		// radix sort); the gather below then reads the plan through the permutation
+		float* pos = morton_points_buffer(a->n_new, a->morton_scratch);
+		GSR_LAUNCH(densify_plan_positions_kernel, div_up(a->n_new, 256), 256, (hipStream_t)stream_, a->n_new, p.src_of, a->param_in[0], pos);
+		uint32_t* perm = nullptr;
+		const int st = launch_morton_order(a->n_new, pos, &perm, a->morton_scratch, (hipStream_t)stream_);
+		if (st != GSR_OK) return st;
+		p.row_perm = perm;
+	}
+
 	GSR_LAUNCH(densify_gather_kernel, (int)blocks, 256, (hipStream_t)stream_, p);
 	GSR_CHECK_LAUNCH();
 	return GSR_OK;

@@ -101,11 +101,13 @@ struct ThreadState {
 };
 static thread_local ThreadState t_state;
 // the calling thread's set for the CURRENT device (the device the caller's stream belongs to: PyTorch and the reference keep it current)
-static HostSync* host_sync()
+static gsr_status host_sync(HostSync** out)
 {
 	int d = 0;
-	if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return nullptr;
-	return &t_state.dev[d];
+	GSR_HIP(hipGetDevice(&d));   // (no ROCm device at all: the library's own HIP error, as every later call would give)
+	if (d < 0 || d >= MAX_DEVICES) return GSR_ERR_UNSUPPORTED;
+	*out = &t_state.dev[d];
+	return GSR_OK;
 }
 static thread_local int t_last_visible = -1;   // gsr_last_visible_count()
 // gsr_host_wait_stats(): how long the calling thread was blocked in gsr_forward's ONE host synchronisation (the instance count)
@@ -162,16 +164,6 @@ static int xcd_deal_mode(int tiles)
 	int c = 8;
 	while (c > 1 && tiles < 8 * 16 * c) c >>= 1;
 	return c;
-}
-// The backward blend one workgroup per (tile, 256-entry segment) instead of one per tile (blend_bwd.hip): the forward blend then
-// leaves the pixels' state at the segment boundaries.  GSR_BWD_SEGMENTS=0/1 overrides (the A/B handle); otherwise by the size of
-// the tile grid -- a pure function of the view, so that gsr_forward and gsr_backward agree.
-static bool bwd_segments(int tiles)
-{
-	static const int env = env_int("GSR_BWD_SEGMENTS", -1);
-	if (env >= 0) return env != 0;
-	(void)tiles;
-	return false;
 }
 // The depth sort's significant bits when it runs on key - DEPTH_KEY_BIAS with 9-bit digits (27 = three passes); 0 = the plain
 // sort of 32 bits in four passes.  GSR_DEPTH_SORT_9BIT=0 selects the plain sort (A/B handle); GSR_DEPTH_SORT_BITS=n (tests)
@@ -365,8 +357,8 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	if (!img_chunk) return GSR_ERR_ALLOC;
 	ImageState im = ImageState::carve(img_chunk, (size_t)W * H, (size_t)tiles);
 
-	HostSync* const sync_ = host_sync();
-	if (!sync_) return GSR_ERR_UNSUPPORTED;   // (a device ordinal beyond MAX_DEVICES)
+	HostSync* sync_ = nullptr;
+	if ((st = host_sync(&sync_)) != GSR_OK) return st;   // (GSR_ERR_UNSUPPORTED: a device ordinal beyond MAX_DEVICES)
 	HostSync& t_sync = *sync_;
 	if ((st = t_sync.init()) != GSR_OK) return st;
 	t_prof.fwd_done = false;
@@ -510,8 +502,6 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geometryBuffer, void* ge
 	bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 	bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 	bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
-	const bool segs = bwd_segments(tiles) && R > 0;
-	bp.seg_state = segs ? bs.seg_state : nullptr; bp.seg_tile = segs ? bs.seg_tile : nullptr;
 	if ((st = launch_blend_fwd(bp, stream)) != GSR_OK) return st;
 	PROF_FWD(8);
 	t_prof.fwd_done = t_prof.on == 1;
@@ -554,8 +544,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 	const int passes = tile_sort_passes(tiles, R);
 	const uint32_t* point_list = (passes % 2) ? bs.vals_b : bs.vals_a;
 
-	HostSync* const sync_ = host_sync();
-	if (!sync_) return GSR_ERR_UNSUPPORTED;
+	HostSync* sync_ = nullptr;
+	if (gsr_status hs = host_sync(&sync_); hs != GSR_OK) return hs;
 	HostSync& t_sync = *sync_;
 	t_prof.bwd_done = false;
 	// ---- the rest of the validation, BEFORE anything is enqueued: a call that is going to be refused must not have applied a
@@ -665,9 +655,6 @@ int gsr_backward(const gsr_backward_args* a, void* stream_)
 		bp.contrib = bs.contrib; bp.contrib_stride = (size_t)R;
 		bp.W = W; bp.H = H; bp.grid_x = grid_x; bp.tiles = tiles;
 		bp.deal = make_tile_deal(tiles, grid_x, xcd_deal_mode(tiles));
-		const bool segs = bwd_segments(tiles);
-		bp.seg_state = segs ? bs.seg_state : nullptr; bp.seg_tile = segs ? bs.seg_tile : nullptr;
-		bp.seg_slots = (uint32_t)seg_slots((size_t)R);
 		if ((st = launch_blend_bwd(bp, stream)) != GSR_OK) return fail(st);
 	}
 	PROF_BWD(2);

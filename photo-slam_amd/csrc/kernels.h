@@ -88,10 +88,6 @@ struct BlendFwdParams {
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
 	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
-	// segment-parallel backward blend (blend_bwd.hip; both null = off): per pixel and 256-entry boundary of a tile's list the
-	// transmittance in front of it and the colour blended behind it, and the owner of every boundary slot
-	float* seg_state;       // BinningState::seg_state
-	uint32_t* seg_tile;     // BinningState::seg_tile
 };
 int launch_blend_fwd(const BlendFwdParams& p, hipStream_t stream);
 
@@ -108,11 +104,7 @@ struct BlendBwdParams {
 	const uint8_t* contrib; // [4][contrib_stride] the forward blend's per-quad contribution flags
 	size_t contrib_stride;
 	int W, H, grid_x, tiles;
-	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles (one workgroup per tile)
-	// one workgroup per (tile, 256-entry segment) instead (null seg_state = one per tile): what the forward blend left
-	const float* seg_state;
-	const uint32_t* seg_tile;
-	uint32_t seg_slots;     // boundary slots: state.h: seg_slots(R)
+	TileDeal deal;          // blend.h: the workgroup -> XCD deal of the tiles
 };
 int launch_blend_bwd(const BlendBwdParams& p, hipStream_t stream);
 
@@ -229,6 +221,10 @@ int launch_sh_adam_lazy(int P, const int* radii, const LazyAdam& a, hipStream_t 
 // simple-knn
 size_t knn_scratch_bytes(int P);
 int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipStream_t stream);
+// the first half of it on its own: the points' order along the Z-order curve of their bounding box (*order_out: n ids inside
+// `scratch`, knn_scratch_bytes(n) bytes; *points_buf: 3 n floats inside scratch the caller may fill and pass as `points`)
+int launch_morton_order(int n, const float* points, uint32_t** order_out, char* scratch, hipStream_t stream);
+float* morton_points_buffer(int n, char* scratch);
 
 // computeCov3D, forward.cu:118-152 (M = S*R with S diagonal: M[c][r] = s_r * R[c][r]; Sigma = transpose(M) * M), with the
 // activations of raw_params applied first (getScalingActivation / getRotationActivation, gaussian_model.cpp:48-56).

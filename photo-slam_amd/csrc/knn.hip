@@ -321,6 +321,22 @@ knn_mean_dist_kernel(int P, const float* __restrict__ spts, const uint32_t* __re
 	dists[indices[idx]] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
+float* morton_points_buffer(int n, char* scratch) { return KnnState::carve(scratch, (size_t)n).sorted_pts; }
+
+int launch_morton_order(int n, const float* points, uint32_t** order_out, char* scratch, hipStream_t stream)
+{
+	KnnState k = KnnState::carve(scratch, (size_t)n);
+	const int nblk = div_up(n, 1024);
+	GSR_LAUNCH(knn_aabb_partial_kernel, nblk, KNN_THREADS, stream, n, points, k.partial);
+	GSR_LAUNCH(knn_aabb_final_kernel, 1, KNN_THREADS, stream, nblk, (const float*)k.partial, k.aabb);
+	GSR_LAUNCH(knn_morton_kernel, div_up(n, KNN_THREADS), KNN_THREADS, stream, n, points, (const float*)k.aabb, k.codes);
+	uint32_t* kres = nullptr;
+	const int st = launch_radix_sort(k.codes, nullptr, k.keys_a, k.vals_a, k.keys_b, k.vals_b, n, 0, 32, k.sort_scratch, stream, &kres, order_out);
+	if (st != GSR_OK) return st;
+	GSR_CHECK_LAUNCH();
+	return GSR_OK;
+}
+
 int launch_knn(int P, const float* points, float* meanDists, char* scratch, hipStream_t stream)
 {
 	KnnState k = KnnState::carve(scratch, (size_t)P);

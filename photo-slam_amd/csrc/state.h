@@ -151,15 +151,6 @@ struct GeometryState {
 };
 
 static inline size_t touched_clear_bytes(size_t R) { return (R + 64 + 255) & ~(size_t)255; }
-constexpr int SEG_ENTRIES = 256;   // list entries per segment of the backward blend (what it accumulates in LDS at a time)
-#ifndef GSR_GROUP_ENTRIES
-#define GSR_GROUP_ENTRIES 1024
-#endif
-constexpr int GROUP_ENTRIES = GSR_GROUP_ENTRIES;   // list entries per WORKGROUP of the group-parallel backward blend: a multiple of SEG_ENTRIES
-constexpr int GROUP_SHIFT = GROUP_ENTRIES == 256 ? 8 : (GROUP_ENTRIES == 512 ? 9 : (GROUP_ENTRIES == 1024 ? 10 : 11));
-static_assert((1 << GROUP_SHIFT) == GROUP_ENTRIES && GROUP_ENTRIES % SEG_ENTRIES == 0, "groups of whole segments");
-static inline size_t seg_slots(size_t R) { return (R >> GROUP_SHIFT) + 1; }
-
 struct BinningState {
 	uint32_t* keys_a;        // [R] tile id per instance (ping)
 	uint32_t* vals_a;        // [R] Gaussian id per instance (ping)
@@ -170,11 +161,6 @@ struct BinningState {
 	uint8_t*  touched;       // [R] 1 where the backward blend wrote the slot (cleared per backward; the slots themselves are not)
 	uint8_t*  contrib;       // [4][R] per quad of the tile: 1 where the forward blend found a pixel of the quad that blends the
 	                         // list entry (written by blend_fwd for the batches it walks, read by blend_bwd: blend.h)
-	// Group-parallel backward blend (blend_bwd.hip): boundary s >= 1 of a tile's list -- entry s * GROUP_ENTRIES -- owns slot
-	// (range.x >> GROUP_SHIFT) + s (unique over all tiles: boundaries of two tiles are more than GROUP_ENTRIES entries apart); the forward blend
-	// leaves there, per quad and pixel, the transmittance in front of the boundary and the colour blended behind it, and the tile's id
-	float*    seg_state;     // [seg_slots(R)][4 quads][T, r, g, b][64 lanes]
-	uint32_t* seg_tile;      // [seg_slots(R)]
 
 	static BinningState carve(char* chunk, size_t R, size_t* bytes = nullptr)
 	{
@@ -190,8 +176,6 @@ struct BinningState {
 		// the runtime splits a memset of any other size into two kernels (body + tail, 5 us each)
 		b.touched = c.take<uint8_t>(touched_clear_bytes(R));
 		b.contrib = c.take<uint8_t>(4 * R + 64);
-		b.seg_state = c.take<float>(seg_slots(R) * (size_t)(4 * 4 * 64));
-		b.seg_tile = c.take<uint32_t>(seg_slots(R));
 		if (bytes) *bytes = c.used(chunk) + 128;
 		return b;
 	}

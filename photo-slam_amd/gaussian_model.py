@@ -512,7 +512,7 @@ class GaussianModel:
         self._arena = None
         self._densify_scratch = None
 
-    def _compact(self, select, generator=None):
+    def _compact(self, select, generator=None, morton_reindex=False):
         """select: fills a capi.DensifySelectArgs.  Returns the counts [kept, clones, child parents, split, clone-selected,
         rows of the new set]."""
         lib = rp._lib()
@@ -565,6 +565,10 @@ class GaussianModel:
             if exist_old is not None:   # every new row inherits its source's value (:636, :744, :782)
                 assert exist_old.is_contiguous() and exist_old.dtype == torch.int32 and exist_old.numel() == P
                 g.exist_since_iter_in, g.exist_since_iter_out = exist_old.data_ptr(), exist_new.data_ptr()
+            morton = None
+            if morton_reindex and n_new:   # (densifyAndPrune only: prunePoints copies its statistics by the mask's order)
+                morton = torch.empty(int(lib.gsr_densify_morton_scratch_bytes(n_new)) + 256, dtype=torch.uint8, device=dev)
+                g.morton_scratch = morton.data_ptr()
             if n_new:
                 capi.check(lib, lib.gsr_densify_gather(C.byref(g), scratch.data_ptr(), stream), "gsr_densify_gather")
         for name, (old, _, m, _), outs in zip(self._PARAM_NAMES, olds, news):
@@ -607,7 +611,10 @@ class GaussianModel:
             a.percent_dense, a.max_grad, a.min_opacity, a.extent = self.percent_dense_, max_grad, min_opacity, extent
             a.max_screen_size = int(max_screen_size)
             return tensors
-        n_keep, n_clone, n_child, n_split, n_clone_sel, n_new = self._compact(select, generator)
+        # morton_reindex_ (off by default; GaussianModel::morton_reindex_ of the C++ host): the new set laid out along a Z-order curve
+        # of the Gaussians' positions (include/gsr.h: gsr_densify_gather_args.morton_scratch) -- the same Gaussians in another order
+        n_keep, n_clone, n_child, n_split, n_clone_sel, n_new = self._compact(select, generator,
+                                                                              morton_reindex=getattr(self, "morton_reindex_", False))
         pruned = (P - n_split - n_keep) + (n_clone_sel - n_clone) + 2 * (n_split - n_child)
         return dict(cloned=n_clone_sel, split=n_split, pruned=pruned, points=n_new, children_kept=2 * n_child)
 

@@ -153,13 +153,19 @@ public:
 	void loadPly(const std::string& ply_path);
 	torch::Device device_ = torch::kCPU;   // where loadPly() / createFromPcd() put a model that has no tensors yet
 
+	// densifyAndPrune lays the new set out along a Z-order curve of the Gaussians' positions (include/gsr.h:
+	// gsr_densify_gather_args.morton_scratch): the same Gaussians, values, moments and statistics in another row order -- the
+	// per-Gaussian kernels of the following steps then find a view's Gaussians in shared 128-byte lines.  Off by default (the
+	// reference's order: kept originals, clones, children).
+	bool morton_reindex_ = false;
+
 private:
 	torch::Tensor& paramByIndex(int i);
 	void replaceParam(int group, torch::Tensor fresh, torch::Tensor exp_avg, torch::Tensor exp_avg_sq, bool rows_kept = false);
 	void preloadMaintenanceKernels();   // first-use code-object loads of the ATen kernels behind resetOpacity / loop closure, paid in trainingSetup
 	void replaceParamValues(int group, torch::Tensor fresh);   // same shape, zero moments: in place while the leaf lives in the arena
 	// gsr_densify_select + one host read + gsr_densify_gather; returns kept, clones, child parents, split, clone-selected, rows
-	std::array<int64_t, 6> compact(struct gsr_densify_select_args& sel, c10::optional<at::Generator> generator);
+	std::array<int64_t, 6> compact(struct gsr_densify_select_args& sel, c10::optional<at::Generator> generator, bool morton_reindex = false);
 	static void* hostStream(const torch::Tensor& t);   // the current HIP stream of the tensor's device (null on the host)
 	struct Arena {
 		int64_t capacity = 0;

@@ -321,7 +321,7 @@ void* GaussianModel::hostStream(const torch::Tensor& t)
 	return nullptr;
 }
 
-std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10::optional<at::Generator> generator)
+std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10::optional<at::Generator> generator, bool morton_reindex)
 {
 	torch::NoGradGuard ng;
 	syncFeatures();   // the gather copies rows of features_ and of its moments: none may be behind (lazy SH Adam)
@@ -378,6 +378,11 @@ std::array<int64_t, 6> GaussianModel::compact(gsr_densify_select_args& sel, c10:
 		g.exist_since_iter_in = exist_old.data_ptr<int>();
 		g.exist_since_iter_out = exist_new.data_ptr<int>();
 	}
+	torch::Tensor morton;
+	if (morton_reindex && n_new) {   // (densifyAndPrune only: prunePoints copies its statistics by the mask's order)
+		morton = torch::empty({static_cast<int64_t>(gsr_densify_morton_scratch_bytes((int)n_new)) + 256}, xyz_.options().dtype(torch::kUInt8).requires_grad(false));
+		g.morton_scratch = reinterpret_cast<char*>(morton.data_ptr<uint8_t>());
+	}
 	if (n_new) check_gsr(gsr_densify_gather(&g, reinterpret_cast<const char*>(densify_scratch_.data_ptr<uint8_t>()), stream), "gsr_densify_gather");
 	if (exist_new.defined()) exist_since_iter_ = exist_new;
 	for (int i = 0; i < 5; i++) {
@@ -424,7 +429,7 @@ GaussianModel::DensifyResult GaussianModel::densifyAndPrune(float max_grad, floa
 	sel.min_opacity = min_opacity;
 	sel.extent = extent;
 	sel.max_screen_size = max_screen_size;
-	const auto c = compact(sel, generator);
+	const auto c = compact(sel, generator, morton_reindex_);
 	DensifyResult res;
 	res.cloned = c[4];
 	res.split = c[3];

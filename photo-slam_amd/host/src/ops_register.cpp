@@ -180,6 +180,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "compute_cov3D") t->pipe_.compute_cov3D_ = v != 0.0;
 		else if (k == "cameras_extent") t->cameras_extent_ = (float)v;
 		else if (k == "position_lr_step") t->position_lr_step_ = (int)v;
+		else if (k == "morton_reindex") t->gaussians_->morton_reindex_ = v != 0.0;
 		else if (k == "lr_scale") t->gaussians_->lr_scale_ = v;
 		else if (k == "densify_min_opacity") t->densify_min_opacity_ = (float)v;
 		else if (k == "prune_big_point_after_iter") t->prune_big_point_after_iter_ = (int)v;

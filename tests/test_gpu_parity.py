@@ -307,12 +307,12 @@ def test_cull_empty_tiles_at_full_size(dev, cfg):
     assert kept < 0.8 * listed   # measured: C2 62 %, C5 74 % of the rectangles' instances survive the tile-level bound
 
 
-@pytest.mark.parametrize("switches", [{"GSR_XCD_CHUNK": "0", "GSR_EMIT_HIST": "0", "GSR_BWD_SEGMENTS": "0", "GSR_BINNING": "0"},
-                                      {"GSR_XCD_CHUNK": "1", "GSR_BWD_SEGMENTS": "1", "GSR_BINNING": "1"},
-                                      {"GSR_BWD_SEGMENTS": "1", "GSR_BINNING": "0"}])
+@pytest.mark.parametrize("switches", [{"GSR_XCD_CHUNK": "0", "GSR_EMIT_HIST": "0", "GSR_BINNING": "0"},
+                                      {"GSR_XCD_CHUNK": "1", "GSR_BINNING": "1"},
+                                      {"GSR_EMIT_SEEDS": "0", "GSR_DEPTH_SORT_9BIT": "0"}])
 def test_library_switches_on_gpu(dev, switches, tmp_path):
-    """The A/B handles on the hardware: one band of the image per XCD / single tiles; the backward blend one workgroup per tile or
-    per (tile, segment); depth-first or tile-first binning.  Every stage against the oracle at C2, in a child process (the
+    """The A/B handles on the hardware: one band of the image per XCD / single tiles; depth-first or tile-first binning; the
+    emission without seeds, the plain four-pass depth sort.  Every stage against the oracle at C2, in a child process (the
     switches are read once per process)."""
     import os
     import subprocess

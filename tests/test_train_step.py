@@ -494,3 +494,69 @@ def test_fused_activations_match_the_reference_data_flow(emu):
     for a, b in zip(g0 + [v0], g1 + [v1]):
         rel = (a - b).abs().sum() / (a.abs().sum() + 1e-30)
         assert rel < 1e-4, rel
+
+
+def test_morton_reindex_is_a_permutation_of_the_reference_order(emu):
+    """GaussianModel::morton_reindex_ (include/gsr.h: gsr_densify_gather_args.morton_scratch): densifyAndPrune lays the new set out
+    along a Z-order curve of the Gaussians' positions.  The SAME rows -- parameters, the split children's sampled positions, both Adam
+    moments, exist_since_iter -- as the reference's order gives, permuted; neighbouring rows are neighbours in space; training
+    continues.  Python host and C++ host."""
+    import math
+    cl, _, kfs = _setup(P=2500)
+
+    def rows(params, moments, exist):
+        n = params[0].shape[0]
+        cols = [p.detach().reshape(n, -1) for p in params] + [m.reshape(n, -1) for m in moments] + [exist.reshape(n, 1).float()]
+        a = torch.cat(cols, 1).numpy()
+        return a[np.lexsort(a.T[::-1])]
+
+    def py_run(morton):
+        g = GaussianModel.from_cloud(cl, device="cpu")
+        g.trainingSetup(GaussianOptimizationParams())
+        ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+        torch.manual_seed(0)
+        gt = torch.rand(3, 32, 48)
+        for _ in range(2):
+            ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+        g.exist_since_iter_ = torch.arange(g.xyz_.shape[0], dtype=torch.int32)
+        grads = (g.xyz_gradient_accum_ / g.denom_).nan_to_num(0.0)
+        thr = float(grads[grads > 0].median())
+        g.morton_reindex_ = morton
+        dense = float(torch.exp(g.scaling_.detach()).max(1).values.median())   # half clone, half split
+        info = g.densifyAndPrune(thr, 0.005, dense / g.percent_dense_, 0, generator=torch.Generator().manual_seed(5))
+        moments = [t for p in g.params() for t in g.optimizer_.moments(p)]
+        out = rows(g.params(), moments, g.exist_since_iter_), g.xyz_.detach().clone(), info
+        assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
+        return out
+    (r0, x0, i0), (r1, x1, i1) = py_run(False), py_run(True)
+    assert i0 == i1 and i0["split"] > 0 and i0["cloned"] > 0
+    assert np.array_equal(r0, r1) and not torch.equal(x0, x1)
+    step = lambda x: float((x[1:] - x[:-1]).norm(dim=1).mean())
+    assert step(x1) < 0.4 * step(x0), (step(x0), step(x1))
+    # the C++ host: the same option through trainer_set_options
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_cpp_host import load_host
+    ops = load_host("emu")
+    outs = []
+    for morton in (0.0, 1.0):
+        g0 = GaussianModel.from_cloud(cl, device="cpu")
+        h = ops.trainer_create(g0.xyz_.detach(), g0.features_.detach(), g0.opacity_.detach(), g0.scaling_.detach(), g0.rotation_.detach(), 3,
+                               float(cl.extent), torch.zeros(3))
+        ops.trainer_set_options(h, {"morton_reindex": morton})
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        cam = cl.cameras[0]
+        torch.manual_seed(0)
+        gt = torch.rand(3, 32, 48)
+        for _ in range(2):
+            ops.trainer_render_and_backward(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), 2 * math.atan(cam.tanfovx),
+                                            2 * math.atan(cam.tanfovy), cam.H, cam.W, gt, torch.ones(3, 32, 48))
+            ops.trainer_finish(h)
+        acc, den, _ = ops.trainer_stats(h)
+        grads = (acc / den).nan_to_num(0.0)
+        thr = float(grads[grads > 0].median())
+        ops.trainer_set_exist_since_iter(h, torch.arange(acc.shape[0], dtype=torch.int32))
+        dense = float(torch.exp(ops.trainer_params(h)[3].detach()).max(1).values.median())
+        info = [int(x) for x in ops.trainer_densify_and_prune(h, thr, 0.005, dense / 0.01, 0, 5)]
+        outs.append((rows(ops.trainer_params(h), ops.trainer_moments(h), ops.trainer_exist_since_iter(h)), ops.trainer_params(h)[0].detach().clone(), info))
+        ops.trainer_destroy(h)
+    assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][0], outs[1][0]) and step(outs[1][1]) < 0.4 * step(outs[0][1])
