@@ -84,13 +84,14 @@ def sq_probe(config, seed=0):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def config_leg(config, seed, steps=40, warmup=10):
+def config_leg(config, seed, steps=40, warmup=10, extra=()):
     """One more single-GPU BASELINE config in THIS record: the same program at `config` in a child process (quick form: no CPU /
     kNN / densify / drop-in legs), reduced to its step time, the rasterizer alone, its own roofline entry and the blend kernels'
     VALU issue utilisation measured there."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--seed", str(seed), "--steps", str(steps), "--warmup", str(warmup),
            "--median-steps", str(steps), "--no-cpu-baseline", "--no-knn-leg", "--densify-leg-steps", "0", "--dropin-steps", "0", "--no-config-legs"]
+    cmd += list(extra)
     t0 = time.time()
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -925,8 +926,13 @@ def main():
     # ---- BASELINE config C3 as stated ("with densify/prune + simple-knn"): the same program with the training learning rates and
     # densifyAndPrune every 100 steps (the reference's densification_interval_), on a fresh model; every step timed by its own
     # HIP event so that the densifying steps can be read separately.  `value` stays the stationary leg above.
-    densify_run = None
+    densify_run = densify_run_morton = None
+    densify_legs = []
     if stationary and not args.raster_only and not dp and ops is not None and not args.densify_interval and args.densify_leg_steps > 0:
+        # (twice: the reference's row order, then GaussianModel::morton_reindex_ -- the same Gaussians laid out along a Z-order curve by
+        # every densifyAndPrune, include/gsr.h: gsr_densify_gather_args.morton_scratch; --morton-reindex runs only the second)
+        densify_legs = [True] if args.morton_reindex else [False, True]
+    for leg_morton in densify_legs:
         g2 = GaussianModel.from_cloud(cl, device=dev)
         h2 = ops.trainer_create(g2.xyz_.detach(), g2.features_.detach(), g2.opacity_.detach(), g2.scaling_.detach(),
                                 g2.rotation_.detach(), 3, float(cl.extent), bg)
@@ -935,7 +941,7 @@ def main():
         ops.trainer_set_options(h2, {"lazy_sh_adam_window": float(args.sh_adam_window), "densify": 1.0,
                                      "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0,
                                      "cameras_extent": float(cl.extent), "seed": 0.0, "densify_from_iter": 0.0,
-                                     "densification_interval": float(interval), "morton_reindex": 1.0 if args.morton_reindex else 0.0})
+                                     "densification_interval": float(interval), "morton_reindex": 1.0 if leg_morton else 0.0})
         n_d = args.densify_leg_steps
         P_before = int(ops.trainer_params(h2)[0].shape[0])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_d + 1)]
@@ -967,7 +973,7 @@ def main():
                        "ms_per_densifying_step": [round(float(per[i]), 3) for i in calls],
                        "ms_median_other_steps": round(float(np.median(plain)), 3),
                        "ms_per_densify_call_over_a_plain_step": [round(float(per[i] - np.median(plain)), 3) for i in calls],
-                       "gaussians_before": P_before, "gaussians_after": P_after, "morton_reindex": bool(args.morton_reindex),
+                       "gaussians_before": P_before, "gaussians_after": P_after, "morton_reindex": bool(leg_morton),
                        "last_call": dict(zip(("cloned", "split", "pruned", "points"), last)),
                        "note": "BASELINE config C3 as stated: densifyAndPrune (src/gaussian_model.cpp:716-815) every 100 steps inside the "
                                "timed loop, training learning rates; a densifying step skips its optimizer update as the reference's does; "
@@ -992,6 +998,11 @@ def main():
                                                "points + append with zero moments; the first call may grow the arena"}
         ops.trainer_destroy(h2)
         torch.cuda.empty_cache()
+        if leg_morton:
+            densify_run_morton = densify_run
+            densify_run = None if args.morton_reindex else first_densify_run
+        else:
+            first_densify_run = densify_run
 
     # ---- simple-knn (distCUDA2, third_party/simple-knn/simple_knn.cu:185-221): the other half of "with densify/prune + simple-knn"
     knn_run = None
@@ -1122,6 +1133,8 @@ def main():
             out["training_lr_run_100"] = train_run_100
         if densify_run:
             out["densify_run"] = densify_run
+        if densify_run_morton:
+            out["densify_run_morton_reindex"] = densify_run_morton
         if dropin_run:
             out["dropin_unfused"] = dropin_run
         if dropin_fl_run:
@@ -1131,6 +1144,8 @@ def main():
         out["stated_config"] = {
             "value_is": "stationary leg (learning rates x 0, one fixed view)",
             "densify_every_100_training_lr_iters_per_s": densify_run["iters_per_s"] if densify_run else None,
+            "densify_every_100_training_lr_morton_reindex_iters_per_s (opt-in: GaussianModel::morton_reindex_)":
+                densify_run_morton["iters_per_s"] if densify_run_morton else None,
             "training_lr_100_steps_iters_per_s": train_run_100["iters_per_s"] if train_run_100 else None,
             "changing_views_iters_per_s": views_run["iters_per_s"] if views_run else None,
             "reference_host_code_on_these_kernels_iters_per_s": dropin_run.get("iters_per_s") if dropin_run else None,
@@ -1206,6 +1221,11 @@ def main():
             out["configs"] = {}
             for c in ("C2", "C4", "C5"):
                 out["configs"][c] = config_leg(c, args.seed)
+            # the C3 workload itself with the model's rows along a Z-order curve (the order GaussianModel::morton_reindex_ leaves behind
+            # every densifyAndPrune): the synthetic cloud's i.i.d. order is the worst case for the per-Gaussian kernels' cache lines
+            out["configs"]["C3_rows_in_z_order"] = config_leg("C3", args.seed, extra=("--scene-order", "morton", "--no-sq-probe"))
+            out["configs"]["C3_rows_in_z_order"]["note"] = ("same cloud, same view, same instances; rows sorted along a Z-order curve "
+                                                            "(--scene-order morton).  Not `value`: that keeps the cloud as generated")
         if world == 1 and not args.no_cpu_baseline:
             base, kept = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline, want_inputs=True)
             main = base.get(args.config, base["C1"])

@@ -203,10 +203,12 @@ import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d
             python -c "
 import json; d=json.load(open('$f')); print('C2 $n ranks one GPU gloo', d['n_gpus'], d['ms_per_step'], d['rccl'], 'replicas_identical', d.get('replicas_identical'), d.get('exposed_communication'), 'per_rank', len(d.get('per_rank') or []))" || tail -20 $OUT/share_err.log ;;
     mapper) timeout 900 python bench.py --mapper-loop $( [ "$arg" = morton ] && echo --morton-reindex ) > $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json 2>$OUT/mapper_err.log; cut -c1-700 $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json; tail -3 $OUT/mapper_err.log ;;   # mapper | mapper:morton
-    densify) # densify | densify:morton -- the stated-config leg alone (250 steps, densify every 100, training learning rates)
-            timeout 600 python bench.py --steps 5 --warmup 2 --median-steps 0 --no-cpu-baseline --no-knn-leg --dropin-steps 0 --no-config-legs --no-sq-probe $( [ "$arg" = morton ] && echo --morton-reindex ) > $OUT/densify_run_C3$( [ -n "$arg" ] && echo _$arg ).json 2>>$OUT/bench_err.log
+    densify) # the stated-config leg alone (250 steps, densify every 100, training learning rates): the reference's row order, then morton_reindex
+            timeout 600 python bench.py --steps 5 --warmup 2 --median-steps 0 --no-cpu-baseline --no-knn-leg --dropin-steps 0 --no-config-legs --no-sq-probe > $OUT/densify_run_C3.json 2>>$OUT/bench_err.log
             python -c "
-import json; d=json.load(open('$OUT/densify_run_C3$( [ -n "$arg" ] && echo _$arg ).json'))['densify_run']; print('densify_run ${arg}', d['iters_per_s'], {k: d[k] for k in d if k in ('ms_per_step', 'ms_median_other_steps', 'ms_per_densifying_step', 'gaussians_after')})" ;;
+import json; j=json.load(open('$OUT/densify_run_C3.json'))
+for k in ('densify_run', 'densify_run_morton_reindex'):
+    d=j[k]; print(k, d['iters_per_s'], {q: d[q] for q in d if q in ('ms_per_step', 'ms_median_other_steps', 'ms_per_densifying_step', 'gaussians_after')})" ;;
     dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
     dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
     seeds)  for sd in 0 1 2 3 4; do timeout 300 python bench.py --seed $sd --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_C3_seed$sd.json 2>>$OUT/bench_err.log; done
