@@ -125,6 +125,23 @@ def compare(ref, got, n_children, what):
         assert a.shape == b.shape and torch.equal(a, b), (what, "statistics")
 
 
+def same_rows_in_z_order(got, got_z, what):
+    """morton_reindex_: the state `got_z` holds the rows of `got` (all five parameters, both moments, the statistics, exist_since_iter_
+    -- row for row the same values) in another order, and that order follows a space-filling curve of the positions."""
+    def table(st):
+        params, m, v, steps, stats, exist = st
+        n = params[0].shape[0]
+        cols = [t.detach().reshape(n, -1).double() for t in list(params) + list(m) + list(v) + list(stats)] + [exist.reshape(n, 1).double()]
+        a = torch.cat(cols, 1).cpu().numpy()
+        return a, a[np.lexsort(a.T[::-1])]
+    a, sa = table(got)
+    z, sz = table(got_z)
+    assert a.shape == z.shape and np.array_equal(sa, sz, equal_nan=True), (what, "not the same multiset of rows")
+    assert list(got[3]) == list(got_z[3]), (what, "steps")
+    step = lambda t: float(np.linalg.norm(np.diff(t[:, :3], axis=0), axis=1).mean())
+    assert step(z) < 0.5 * step(a), (what, "rows are not neighbours in space", step(z), step(a))
+
+
 # (max_grad, min_opacity, extent, max_screen_size, scale spread): the selection cases VERDICT r01 asks for
 CASES = {
     "clone_only": dict(max_grad=2e-4, min_opacity=0.0, extent=1e3, mss=0, spread=0.5),     # nothing is "big": clones only
@@ -167,6 +184,18 @@ def run_case(kind, dev, host_ops, lib_path, name, P=700, seed=0):
         got = list(host_ops.trainer_densify_and_prune(h, c["max_grad"], c["min_opacity"], extent, c["mss"], seed_rng))
         assert got == [info["cloned"], info["split"], info["pruned"], info["points"]], (name, got, info)
         compare(ref, cpp_state(host_ops, h), info["children_kept"], name + "/c++")
+        if name in ("mixed", "clone_only", "split_only"):
+            # the opt-in Z-order layout (GaussianModel::morton_reindex_): the same rows as the order just checked, permuted
+            gz = python_host(st, dev)
+            gz.morton_reindex_ = True
+            info_z = gz.densifyAndPrune(c["max_grad"], c["min_opacity"], extent, c["mss"], generator=torch.Generator(device=dev).manual_seed(seed_rng))
+            assert info_z == info
+            same_rows_in_z_order(python_state(g), python_state(gz), name + "/python/morton")
+            hz = cpp_host(host_ops, st, dev)
+            host_ops.trainer_set_options(hz, {"morton_reindex": 1.0})
+            assert list(host_ops.trainer_densify_and_prune(hz, c["max_grad"], c["min_opacity"], extent, c["mss"], seed_rng)) == got
+            same_rows_in_z_order(cpp_state(host_ops, h), cpp_state(host_ops, hz), name + "/c++/morton")
+            host_ops.trainer_destroy(hz)
         host_ops.trainer_destroy(h)
     finally:
         rp._LIB_OVERRIDE = None
