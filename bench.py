@@ -718,6 +718,9 @@ def main():
     def timed(steps, read_dominant=False):
         """EXACTLY `steps` steps between barrier + synchronize; max over ranks.  Returns (seconds, dominant-kernel ms list)."""
         dom = []
+        import gc
+        gc.collect()
+        gc.disable()     # (a generation-2 collection of the interpreter inside a 20-step window is a 2 ms step: 7 % of the window)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -728,6 +731,7 @@ def main():
                     dom.append(v)
         barrier()
         el = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

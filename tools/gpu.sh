@@ -209,6 +209,12 @@ import json; d=json.load(open('$f')); print('C2 $n ranks one GPU gloo', d['n_gpu
 import json; j=json.load(open('$OUT/densify_run_C3.json'))
 for k in ('densify_run', 'densify_run_morton_reindex'):
     d=j[k]; print(k, d['iters_per_s'], {q: d[q] for q in d if q in ('ms_per_step', 'ms_median_other_steps', 'ms_per_densifying_step', 'gaussians_after')})" ;;
+    drv20)  # drv20[:n]: the driver's protocol (20 timed steps behind 5 warm-up steps) n times in a row on one box: the spread of `value`
+            for i in $(seq 1 ${arg:-5}); do
+              timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 --no-config-legs --no-sq-probe > $OUT/drv20_$i.json 2>>$OUT/bench_err.log
+              python -c "
+import json; d=json.load(open('$OUT/drv20_$i.json')); print('run $i: timed', d['ms_per_step'], 'ms  value', d['value'], ' median of 100 further steps', d['protocol']['median_ms_per_step'], 'p90', d['protocol']['p90_ms'])"
+            done ;;
     dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
     dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
     seeds)  for sd in 0 1 2 3 4; do timeout 300 python bench.py --seed $sd --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_C3_seed$sd.json 2>>$OUT/bench_err.log; done
