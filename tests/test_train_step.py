@@ -353,8 +353,9 @@ def test_packed_exchange_equals_the_dense_one_bit_for_bit_gloo(emu, tmp_path):
     """The packed form of the view-factored exchange (only the rows a view sees travel; include/gsr.h: gsr_pack_color_view)
     against the dense one, C++-driven: the same parameters and statistics BIT FOR BIT after the same iterations -- at 2 ranks,
     at the EIGHT ranks of BASELINE config C4's batch, and with a densification in the sequence."""
+    dense_at = {}
     for n, port in ((2, 29541), (8, 29545)):
-        dense = [{k: r[k].copy() for k in r.files} for r in _launch_cpp(tmp_path, emu, n, port, "factored")]
+        dense = dense_at[n] = [{k: r[k].copy() for k in r.files} for r in _launch_cpp(tmp_path, emu, n, port, "factored")]
         packed = _launch_cpp(tmp_path, emu, n, port + 2, "packed")
         for r in range(n):
             for k in ("xyz", "features", "opacity", "scaling", "rotation", "accum", "denom", "maxr"):
@@ -362,7 +363,7 @@ def test_packed_exchange_equals_the_dense_one_bit_for_bit_gloo(emu, tmp_path):
         for k in ("xyz", "features", "opacity", "scaling", "rotation"):
             assert np.array_equal(packed[0][k], packed[n - 1][k]), f"replicas diverged on {k}"
     late = _launch_cpp(tmp_path, emu, 2, 29553, "packed_late")          # the message packed behind the backward pass (gsr_pack_color_view)
-    dense2 = _launch_cpp(tmp_path, emu, 2, 29555, "factored")
+    dense2 = dense_at[2]
     for r in range(2):
         for k in ("xyz", "features", "opacity", "scaling", "rotation", "accum", "denom", "maxr"):
             assert np.array_equal(late[r][k], dense2[r][k]), (r, k)
