@@ -1227,9 +1227,11 @@ def main():
                 out["configs"][c] = config_leg(c, args.seed)
             # the C3 workload itself with the model's rows along a Z-order curve (the order GaussianModel::morton_reindex_ leaves behind
             # every densifyAndPrune): the synthetic cloud's i.i.d. order is the worst case for the per-Gaussian kernels' cache lines
-            out["configs"]["C3_rows_in_z_order"] = config_leg("C3", args.seed, extra=("--scene-order", "morton", "--no-sq-probe"))
+            out["configs"]["C3_rows_in_z_order"] = config_leg("C3", args.seed, steps=args.steps, warmup=args.warmup,
+                                                              extra=("--scene-order", "morton", "--no-sq-probe", "--median-steps", "100"))
             out["configs"]["C3_rows_in_z_order"]["note"] = ("same cloud, same view, same instances; rows sorted along a Z-order curve "
-                                                            "(--scene-order morton).  Not `value`: that keeps the cloud as generated")
+                                                            "(--scene-order morton), the main leg's protocol (same steps / warm-up, median of 100 further steps).  Not `value`: that "
+                                                            "keeps the cloud as generated")
         if world == 1 and not args.no_cpu_baseline:
             base, kept = cpu_train_step_baseline(scene, args, W, H, quick=args.quick_cpu_baseline, want_inputs=True)
             main = base.get(args.config, base["C1"])

@@ -215,6 +215,12 @@ for k in ('densify_run', 'densify_run_morton_reindex'):
               python -c "
 import json; d=json.load(open('$OUT/drv20_$i.json')); print('run $i: timed', d['ms_per_step'], 'ms  value', d['value'], ' median of 100 further steps', d['protocol']['median_ms_per_step'], 'p90', d['protocol']['p90_ms'])"
             done ;;
+    zorder) # zorder[:n]: the driver's protocol at C3 with the cloud as generated and with its rows along a Z-order curve (--scene-order morton), alternating
+            for i in $(seq 1 ${arg:-3}); do for o in random morton; do
+              timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --scene-order $o --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 --no-config-legs --no-sq-probe > $OUT/zorder_${o}_$i.json 2>>$OUT/bench_err.log
+              python -c "
+import json; d=json.load(open('$OUT/zorder_${o}_$i.json')); print('run $i $o: timed', d['ms_per_step'], 'ms  value', d['value'], ' median of 100 further steps', d['protocol']['median_ms_per_step'], {k: v['ms'] for k, v in d['roofline']['stages'].items() if k in ('preprocess_fwd', 'blend_fwd', 'blend_bwd', 'preprocess_bwd')})"
+            done; done ;;
     dropin) timeout 600 python bench.py --dropin-only > $OUT/dropin_unfused_C3$SUF.json 2>$OUT/dropin_err.log; cut -c1-700 $OUT/dropin_unfused_C3$SUF.json; tail -3 $OUT/dropin_err.log ;;
     dropinstats) kernel_stats $OUT/kernel_stats_dropin_unfused_C3.csv python $ROOT/bench.py --dropin-only --dropin-steps 10 ;;
     seeds)  for sd in 0 1 2 3 4; do timeout 300 python bench.py --seed $sd --no-cpu-baseline --no-knn-leg --densify-leg-steps 0 --dropin-steps 0 > $OUT/benchq_C3_seed$sd.json 2>>$OUT/bench_err.log; done
