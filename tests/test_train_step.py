@@ -304,8 +304,9 @@ bg = torch.zeros(3)
 h = ops.trainer_create(g0.xyz_.detach(), g0.features_.detach(), g0.opacity_.detach(), g0.scaling_.detach(), g0.rotation_.detach(), 3,
                        float(cl.extent), bg)
 opts = {"cameras_extent": float(cl.extent), "seed": 7.0}
-if mode == "densify":
-    opts.update({"densify": 1.0, "densify_from_iter": 1.0, "densification_interval": 2.0, "densify_grad_threshold": 2e-5})
+if mode in ("densify", "densify_morton"):
+    opts.update({"densify": 1.0, "densify_from_iter": 1.0, "densification_interval": 2.0, "densify_grad_threshold": 2e-5,
+                 "morton_reindex": 1.0 if mode == "densify_morton" else 0.0})
 ops.trainer_set_options(h, opts)
 # every collective of the step is issued by the C++ host from here on (host/src/keyframe_batch_exchange.cpp)
 ops.trainer_set_process_group(h, dist.group.WORLD.group_name, sys.argv[4] in ("factored", "packed", "packed_late"))
@@ -318,7 +319,7 @@ if sys.argv[4] in ("packed", "packed_late"):   # the view-factored exchange in i
 cam = cl.cameras[rank]
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 torch.manual_seed(100 + rank); gt = torch.rand(3, 32, 48)
-for _ in range(int(os.environ.get("GSR_TEST_ITERS", 3 if mode == "densify" else 2))):
+for _ in range(int(os.environ.get("GSR_TEST_ITERS", 3 if mode in ("densify", "densify_morton") else 2))):
     ops.trainer_train_one_iteration(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), 2 * math.atan(cam.tanfovx),
                                     2 * math.atan(cam.tanfovy), cam.H, cam.W, gt, torch.ones(3, 32, 48))
 out = {n: p.detach().numpy() for n, p in zip(["xyz","features","opacity","scaling","rotation"], ops.trainer_params(h))}
@@ -396,6 +397,17 @@ np.savez(os.path.join(sys.argv[3], f"densify{rank}.npz"), info=np.array([ts.last
     r0 = np.load(py / "rank0.npz")
     for k in ("xyz", "features", "opacity", "scaling", "rotation"):
         assert np.allclose(r0[k], ranks[0][k], rtol=1e-4, atol=1e-5), k
+    # ... and with the Z-order layout (morton_reindex): every rank permutes alike -- identical replicas, the same decisions; the iteration
+    # behind the densification then sums in another row order, so the rows are compared as sorted sets with a float tolerance
+    ranks = [{k: r[k].copy() for k in r.files} for r in ranks]   # (the next launch writes the same files)
+    zr = _launch_cpp(tmp_path, emu, 2, 29557, "factored", "densify_morton")
+    for k in ("xyz", "features", "opacity", "scaling", "rotation"):
+        assert np.array_equal(zr[0][k], zr[1][k]), f"replicas diverged on {k} (Z-order layout)"
+    assert np.array_equal(zr[0]["densify"], ranks[0]["densify"])
+    key = lambda r: np.lexsort(np.round(r["xyz"].astype(np.float64), 4).T[::-1])
+    a, b = ranks[0], zr[0]
+    for k in ("xyz", "opacity", "scaling", "rotation", "features"):
+        assert np.allclose(a[k][key(a)], b[k][key(b)], rtol=1e-4, atol=1e-5), k
 
 
 def test_densify_and_prune_keeps_model_consistent(emu):
