@@ -334,7 +334,7 @@ def replica_checksum(torch, dist, tensors, dev, backend):
     return bool(torch.equal(lo, hi)), [int(x) for x in h.cpu()]
 
 
-def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window, morton_reindex=False):
+def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window, morton_reindex=False, persistent_workspace=True):
     """BASELINE config C5's SHAPE on one GPU (`--mapper-loop`, opt-in): 4 M Gaussians @ 752x480, the fused train step cycling
     through EIGHT keyframes, and the map maintenance of GaussianMapper::trainForOneIteration / run (src/gaussian_mapper.cpp:614-774,
     371-542) on its schedule: increasePcd of 5 k new map points every 10 iterations (a new keyframe's points, :854,955),
@@ -351,7 +351,8 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window, morton_
     h = ops.trainer_create(t(cl.xyz), t(feats), t(cl.opacity), t(cl.scaling), t(cl.rotation), 3, float(cl.extent), bg)
     ops.trainer_set_options(h, {"lazy_sh_adam_window": float(sh_adam_window), "densify": 1.0, "cameras_extent": float(cl.extent),
                                 "seed": float(seed), "densify_from_iter": 0.0, "densification_interval": 100.0,
-                                "opacity_reset_interval": 150.0, "active_sh_degree": 2.0, "morton_reindex": 1.0 if morton_reindex else 0.0})
+                                "opacity_reset_interval": 150.0, "active_sh_degree": 2.0, "morton_reindex": 1.0 if morton_reindex else 0.0,
+                                "persistent_workspace": 1.0 if persistent_workspace else 0.0})
     kfs, gts = [], []
     gen = torch.Generator(device="cpu").manual_seed(4321 + seed)
     for c in cams:
@@ -433,7 +434,10 @@ def mapper_loop_leg(torch, dev, ops, scene, steps, seed, sh_adam_window, morton_
             "slowest_plain_steps": [{"iteration": it, "ms": round(ms, 3)} for ms, it in plain_steps[:10]], "events": events,
             "stage_ms_median_of_a_plain_step": {k: round(float(np.median(v)), 4) for k, v in stage.items()},
             "stage_note": "16 plain steps behind the timed loop with the stage events on: after 300 training-lr steps the synthetic scene has "
-                          "inflated (DESIGN.md section 7) -- the instance-bound stages (emit_instances, tile_sort) carry ~3x the instances of step 1", "gaussians_start": P, "gaussians_end": P_end,
+                          "inflated (DESIGN.md section 7) -- the instance-bound stages (emit_instances, tile_sort) carry ~3x the instances of step 1", "gaussians_start": P, "gaussians_end": P_end, "persistent_workspace": bool(persistent_workspace),
+            "device_memory_MB": {"allocated_peak": int(torch.cuda.max_memory_allocated() // 2**20), "reserved_peak": int(torch.cuda.max_memory_reserved() // 2**20),
+                                 "reserved_at_end": int(torch.cuda.memory_reserved() // 2**20),
+                                 "allocator_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
             "learning_rates": "training", "sh_degree": "2, then 3 from iteration 200 (oneUpShDegree)",
             "schedule": "increasePcd(5 k) every 10 iterations, densifyAndPrune every 100, resetOpacity every 150, oneUpShDegree at 200",
             "note": "one HIP event per iteration; an iteration's time includes the maintenance calls that follow its optimizer step"}
@@ -487,6 +491,9 @@ def main():
                          "measures faster on this node (auto)")
     ap.add_argument("--median-steps", type=int, default=100, help="steps of the per-step-event leg (protocol.median_*)")
     ap.add_argument("--dump-steps", action="store_true", help="protocol.step_ms: the per-step times of that leg (debugging)")
+    ap.add_argument("--no-persistent-workspace", action="store_true",
+                    help="TrainStep allocates the rasterizer's three scratch buffers per call, as the reference's resizeFunctional does, "
+                         "instead of keeping them across iterations (RasterWorkspace): the A/B handle of the main leg and of --mapper-loop")
     ap.add_argument("--morton-reindex", action="store_true",
                     help="densify_run / mapper-loop legs: densifyAndPrune lays the new set out along a Z-order curve (GaussianModel::morton_reindex_; "
                          "include/gsr.h: gsr_densify_gather_args.morton_scratch) -- the same Gaussians in another row order")
@@ -543,7 +550,7 @@ def main():
         import build_host
         torch.ops.load_library(build_host.build("hip"))
         print(json.dumps({"mapper_loop": mapper_loop_leg(torch, dev, torch.ops.photoslam_amd, scene, args.mapper_loop_steps, args.seed,
-                                                         args.sh_adam_window, args.morton_reindex)}), flush=True)
+                                                         args.sh_adam_window, args.morton_reindex, not args.no_persistent_workspace)}), flush=True)
         return
 
     cfg = scene.CONFIGS[args.config]
@@ -597,7 +604,8 @@ def main():
         handle = ops.trainer_create(g.xyz_.detach(), g.features_.detach(), g.opacity_.detach(), g.scaling_.detach(),
                                     g.rotation_.detach(), 3, float(cl.extent), bg)
         ops.trainer_set_options(handle, {"lazy_sh_adam_window": float(args.sh_adam_window),
-                                         "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0})
+                                         "fused_geom_adam": 0.0 if args.no_fused_geom_adam else 1.0,
+                                         "persistent_workspace": 0.0 if args.no_persistent_workspace else 1.0})
         # GSR_BENCH_PY_EXCHANGE=1: the collectives issued from Python around the C++ pieces (the round-2 arrangement, kept for
         # comparison); default: the C++ host drives the exchange itself on the c10d process group (keyframe_batch_exchange.cpp)
         # (GSR_BENCH_CPP_EXCHANGE=1 keeps the C++ exchange on a backend other than RCCL: the two-ranks-on-one-GPU functional check)

@@ -41,6 +41,9 @@ class GaussianRasterizationSettings:
     # extension (GSR_CULL_EMPTY_TILES, include/gsr.h): instances of tiles in which no pixel can blend the Gaussian are dropped
     # in front of the tile sort -- same image, same gradients, shorter internal lists
     cull_empty_tiles_: bool = False
+    # extension: rasterize_points.RasterWorkspace -- the caller's persistent scratch buffers (None = fresh buffers per call, as the
+    # reference)
+    workspace_: object = None
 
 
 class GaussianRasterizerFunction(torch.autograd.Function):
@@ -52,7 +55,8 @@ class GaussianRasterizerFunction(torch.autograd.Function):
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = rp.RasterizeGaussiansCUDA(
             s.bg_, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier_, cov3Ds_precomp,
             s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_, s.image_height_, s.image_width_, sh, s.sh_degree_,
-            s.campos_, s.prefiltered_, s.raw_params_ | (8 if s.cull_empty_tiles_ else 0), s.sh_adam_)   # sh_adam_: lazy mode brings visible rows up to date first
+            s.campos_, s.prefiltered_, s.raw_params_ | (8 if s.cull_empty_tiles_ else 0), s.sh_adam_,   # sh_adam_: lazy mode brings visible rows up to date first
+            s.workspace_)
         ctx.set_materialize_grads(False)   # (no zero tensor for the unused gradient of `radii`)
         ctx.num_rendered = num_rendered
         ctx.raster_settings = s

@@ -36,7 +36,7 @@ class GaussianRenderer:
     @staticmethod
     def render(viewpoint_camera, image_height, image_width, pc, pipe, bg_color, override_color=None,
                scaling_modifier=1.0, use_override_color=False, fuse_activations=True, sh_grad_view=None, sh_adam=None, view_stats=None,
-               geom_adam=None, training_outputs_only=False, cull_empty_tiles=False):
+               geom_adam=None, training_outputs_only=False, cull_empty_tiles=False, workspace=None):
         """returns (render, viewspace_points, visibility_filter, radii)
 
         fuse_activations (extension; False = the reference data flow): hand the raw opacity / scaling / rotation
@@ -67,7 +67,7 @@ class GaussianRenderer:
             viewpoint_camera.camera_center_, False, raw,
             sh_grad_view if sh_in_rasterizer else None, sh_adam if sh_in_rasterizer else None, view_stats,
             geom_adam if raw == 7 else None, bool((geom_adam is not None or training_outputs_only) and raw == 7),
-            cull_empty_tiles_=bool(cull_empty_tiles))
+            cull_empty_tiles_=bool(cull_empty_tiles), workspace_=workspace)
         rasterizer = GaussianRasterizer(raster_settings)
         means3D = pc.getXYZ()
         means2D = screenspace_points

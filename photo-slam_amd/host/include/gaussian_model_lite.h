@@ -7,6 +7,8 @@
 #include <torch/torch.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
+#include "rasterize_points.h"   // RasterWorkspace
+
 #include <array>
 #include <cmath>
 #include <map>
@@ -265,6 +267,10 @@ public:
 	// are options of THIS object -- a SLAM process that links the library decides per TrainStep -- and the environment variables
 	// of the bench sessions (GSR_CULL_EMPTY_TILES, GSR_EARLY_GATHER, GSR_LAZY_SLICE_EARLY, GSR_SH_ADAM_SIDE_STREAM) only override.
 	bool cull_empty_tiles_ = false;   // instances of tiles no pixel of which can blend the Gaussian leave the list (a wash on MI355X)
+	// the rasterizer's three scratch buffers, kept across iterations and grown with headroom (rasterize_points.h: RasterWorkspace);
+	// persistent_workspace_ = false: fresh buffers per call, as the reference's resizeFunctional
+	bool persistent_workspace_ = true;
+	RasterWorkspace workspace_;
 	bool early_gather_ = true;        // the exchange's all-gather waits for the colour gradients only, not for the whole backward pass
 	// The view-factored exchange in its PACKED form (include/gsr.h: gsr_pack_color_view): every rank sends only the rows its
 	// view sees -- 11.7 MB instead of 24 MB per rank and link at 2 M Gaussians.  The ranks agree on the message capacity by

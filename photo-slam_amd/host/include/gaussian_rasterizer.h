@@ -87,6 +87,9 @@ struct GaussianRasterizationExtensions {
 	// GSR_CULL_EMPTY_TILES (include/gsr.h): instances of tiles in which no pixel can blend the Gaussian are dropped in front of
 	// the tile sort -- the same image and the same gradients from shorter internal lists
 	bool cull_empty_tiles_ = false;
+	// persistent scratch buffers of a caller that renders iteration after iteration (rasterize_points.h: RasterWorkspace; the
+	// caller owns it and keeps it alive until the backward pass has run); nullptr = fresh buffers per call, as the reference
+	RasterWorkspace* workspace_ = nullptr;
 };
 
 class GaussianRasterizerFunctionEx : public torch::autograd::Function<GaussianRasterizerFunctionEx> {

@@ -42,7 +42,8 @@ public:
 	    ShAdamStep sh_adam = ShAdamStep() /* extension: GaussianRasterizationExtensions::sh_adam_ */,
 	    std::vector<torch::Tensor> view_stats = {} /* extension: GaussianRasterizationExtensions::view_stats_ */,
 	    GeomAdamStep geom_adam = GeomAdamStep() /* extension: GaussianRasterizationExtensions::geom_adam_ */,
-	    bool cull_empty_tiles = false /* extension: GaussianRasterizationExtensions::cull_empty_tiles_ */)
+	    bool cull_empty_tiles = false /* extension: GaussianRasterizationExtensions::cull_empty_tiles_ */,
+	    RasterWorkspace* workspace = nullptr /* extension: GaussianRasterizationExtensions::workspace_ */)
 	{
 		// fuse_activations (extension): hand the raw opacity_/scaling_/rotation_ leaves to the rasterizer, which applies
 		// sigmoid / exp / normalize and their chain rule in-kernel (include/gsr.h raw_params)
@@ -67,6 +68,7 @@ public:
 		if (sh_in_rasterizer) ext.sh_grad_view_ = sh_grad_view;
 		if (sh_in_rasterizer) ext.sh_adam_ = sh_adam;
 		ext.view_stats_ = view_stats;
+		ext.workspace_ = workspace;
 		// (the same image and gradients either way; off by default: measured a wash, DESIGN.md section 10.  The caller's
 		// argument decides; the environment variable GSR_CULL_EMPTY_TILES=0/1, when set, overrides it -- an A/B handle)
 		static const int cull_env = [] { const char* e = std::getenv("GSR_CULL_EMPTY_TILES"); return (e && *e) ? (e[0] == '1' ? 1 : 0) : -1; }();

@@ -52,14 +52,25 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
     const bool prefiltered, const int raw_params);
-// ... and the lazy SH Adam state (only consulted when sh_adam.row_step is defined; `sh` is then updated in place)
+// Persistent scratch for a caller that renders iteration after iteration (TrainStep): the three byte buffers of the rasterizer
+// (the reference allocates them per call, src/rasterize_points.cu:71-76, and returns them).  They grow with 50 % headroom and
+// never shrink.  The binning buffer's size follows the instance count, which changes with every step of a training run: per-call
+// allocations of ever-new sizes leave the caching allocator with a trail of blocks none of which fits the next request
+// (measured over 300 mapper iterations at 4 M Gaussians: 46 GB reserved for 10 GB in use against 15 GB with the workspace, and
+// every new largest size is a hipMalloc of a gigabyte -- up to 45 ms on the pool's boxes, profiles/r06_w*).
+struct RasterWorkspace {
+	torch::Tensor geom, binning, img;
+};
+
+// ... and the lazy SH Adam state (only consulted when sh_adam.row_step is defined; `sh` is then updated in place); workspace:
+// nullptr = fresh buffers per call, as the reference
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> RasterizeGaussiansCUDA(
     const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
     const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
     const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam);
+    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam, RasterWorkspace* workspace = nullptr);
 
 // Extension, optimizer-in-backward for xyz / opacity / scaling / rotation (gsr_geom_adam of include/gsr.h): when param is
 // filled (four entries each, in that order), backward applies this Adam step to the four tensors IN PLACE instead of computing

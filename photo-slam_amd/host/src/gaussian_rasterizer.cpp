@@ -21,7 +21,7 @@ torch::autograd::tensor_list forward_impl(torch::autograd::AutogradContext* ctx,
 	                                cov3Ds_precomp, s.viewmatrix_, s.projmatrix_, s.tanfovx_, s.tanfovy_,
 	                                s.image_height_, s.image_width_, sh, s.sh_degree_, s.campos_, s.prefiltered_,
 	                                e.raw_params_ | (e.cull_empty_tiles_ ? 8 /* GSR_CULL_EMPTY_TILES, include/gsr.h */ : 0),
-	                                e.sh_adam_ /* lazy mode: visible rows are brought up to date first */);
+	                                e.sh_adam_ /* lazy mode: visible rows are brought up to date first */, e.workspace_);
 	// (no zero tensor for the unused gradient of `radii`: autograd would otherwise fill P ints per backward)
 	ctx->set_materialize_grads(false);
 	ctx->saved_data["num_rendered"] = std::get<0>(r);

@@ -170,6 +170,7 @@ void trainer_set_options(int64_t h, c10::Dict<std::string, double> o)
 		else if (k == "fused_geom_adam") t->fused_geom_adam_ = v != 0.0;
 		else if (k == "active_sh_degree") t->gaussians_->active_sh_degree_ = std::min((int)v, t->gaussians_->max_sh_degree_);
 		else if (k == "cull_empty_tiles") t->cull_empty_tiles_ = v != 0.0;
+		else if (k == "persistent_workspace") t->persistent_workspace_ = v != 0.0;
 		else if (k == "early_gather") t->early_gather_ = v != 0.0;
 		else if (k == "packed_exchange") t->packed_exchange_ = v != 0.0;
 		else if (k == "pack_in_backward") t->pack_in_backward_ = v != 0.0;

@@ -21,6 +21,19 @@ char* resize_tensor(void* ctx, size_t bytes)
 	return reinterpret_cast<char*>(t->data_ptr());
 }
 
+// a RasterWorkspace buffer (rasterize_points.h): kept when large enough, replaced by one with 50 % headroom otherwise (a new
+// allocation, not resize_: the old content is of no use and would be copied)
+char* grow_tensor(void* ctx, size_t bytes)
+{
+	auto* t = static_cast<torch::Tensor*>(ctx);
+	if (static_cast<size_t>(t->numel()) < bytes) {
+		const auto opts = t->options();
+		*t = torch::Tensor();   // (released first: the two never have to coexist)
+		*t = torch::empty({static_cast<int64_t>(bytes + bytes / 2)}, opts);
+	}
+	return reinterpret_cast<char*>(t->data_ptr());
+}
+
 void* current_stream(const torch::Tensor& t)
 {
 #ifndef GSR_HOST_NO_HIP
@@ -129,7 +142,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
     const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const int image_height,
     const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam)
+    const bool prefiltered, const int raw_params, const ShAdamStep& sh_adam, RasterWorkspace* workspace)
 {
 	if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
 		AT_ERROR("means3D must have dimensions (num_points, 3)");
@@ -145,6 +158,16 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 	torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
 	torch::Tensor binningBuffer = torch::empty({0}, byte_opts);
 	torch::Tensor imgBuffer = torch::empty({0}, byte_opts);
+	// (a persistent workspace: its buffers are used in place and returned; a buffer of another device or type starts over)
+	torch::Tensor* bufs[3] = {&geomBuffer, &binningBuffer, &imgBuffer};
+	if (workspace) {
+		torch::Tensor* ws[3] = {&workspace->geom, &workspace->binning, &workspace->img};
+		for (int i = 0; i < 3; i++) {
+			if (!ws[i]->defined() || ws[i]->device() != means3D.device() || ws[i]->scalar_type() != torch::kByte) *ws[i] = torch::empty({0}, byte_opts);
+			bufs[i] = ws[i];
+		}
+	}
+	const gsr_alloc_fn take = workspace ? grow_tensor : resize_tensor;
 
 	int rendered = 0;
 	if (P != 0) {
@@ -184,11 +207,9 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
 			fill_sh_adam(sh_adam, const_cast<float*>(a.shs), adam, lazy);
 			a.sh_adam = &adam;
 		}
-		check(gsr_forward(&a, resize_tensor, &geomBuffer, resize_tensor, &binningBuffer, resize_tensor, &imgBuffer,
-		                  current_stream(means3D), &rendered),
-		      "RasterizeGaussiansCUDA");
+		check(gsr_forward(&a, take, bufs[0], take, bufs[1], take, bufs[2], current_stream(means3D), &rendered), "RasterizeGaussiansCUDA");
 	}
-	return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer);
+	return std::make_tuple(rendered, out_color, radii, *bufs[0], *bufs[1], *bufs[2]);
 }
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,

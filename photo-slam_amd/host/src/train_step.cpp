@@ -336,7 +336,7 @@ torch::Tensor TrainStep::renderAndBackward(std::shared_ptr<GaussianKeyframe> kf,
 	g->in_lazy_step_ = lazy;
 	auto pkg = GaussianRenderer::render(kf, kf->image_height_, kf->image_width_, g, pipe, background_, override_color,
 	                                    1.0f, false, /*fuse_activations=*/true, sh_grad_view_, sh_adam, view_stats, geom_adam,
-	                                    cull_empty_tiles_);
+	                                    cull_empty_tiles_, persistent_workspace_ ? &workspace_ : nullptr);
 	g->in_lazy_step_ = false;
 	if (factored_exchange_ && packed_this_step_) beginCountExchange();   // (the forward pass has left this view's visible count)
 	if (prepacked_this_step_) planPackedView(std::get<3>(pkg));

@@ -64,9 +64,30 @@ def _resize_functional(t):
     return capi.ALLOC_FN(fn)
 
 
+class RasterWorkspace:
+    """Persistent scratch for a caller that renders iteration after iteration (TrainStep; RasterWorkspace of the C++ host's
+    rasterize_points.h): the rasterizer's three byte buffers, which the reference allocates per call (src/rasterize_points.cu:71-76).
+    They grow with 50 % headroom and never shrink.  The binning buffer follows the instance count, which changes with every step
+    of a training run: per-call allocations of ever-new sizes leave the caching allocator with a trail of blocks none of which
+    fits the next request (46 GB reserved for 10 GB in use after 300 mapper iterations, against 15 GB; every new largest size is a
+    hipMalloc of a gigabyte: up to 45 ms on the pool's boxes)."""
+
+    def __init__(self):
+        self.bufs = [None, None, None]   # geometry, binning, image
+
+    def taker(self, i, dev):
+        def fn(_ctx, nbytes):
+            b = self.bufs[i]
+            if b is None or b.device != dev or b.numel() < int(nbytes):
+                self.bufs[i] = b = None   # (released first: the two never have to coexist)
+                self.bufs[i] = b = torch.empty((int(nbytes) + int(nbytes) // 2,), dtype=torch.uint8, device=dev)
+            return b.data_ptr()
+        return capi.ALLOC_FN(fn)
+
+
 def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                           prefiltered, raw_params=0, sh_adam=None):
+                           prefiltered, raw_params=0, sh_adam=None, workspace=None):
     """raw_params (extension, default 0 = reference contract): GSR_RAW_* mask -- opacity / scales / rotations are the
     model's raw parameters and are activated in-kernel (include/gsr.h).
     sh_adam (extension, default None): the dict RasterizeGaussiansBackwardCUDA takes; only its lazy mode (row_step set,
@@ -107,11 +128,16 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
             adam, adam_keep = capi.make_sh_adam(sh, sh_adam)
             keep.append(adam_keep)
             a.sh_adam = C.cast(C.pointer(adam), C.c_void_p)
-        cbs = [_resize_functional(b) for b in (geomBuffer, binningBuffer, imgBuffer)]
+        if workspace is not None:   # (extension: the caller's persistent buffers, used in place and returned)
+            cbs = [workspace.taker(i, dev) for i in range(3)]
+        else:
+            cbs = [_resize_functional(b) for b in (geomBuffer, binningBuffer, imgBuffer)]
         n = C.c_int(0)
         st = lib.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream_ptr(means3D), C.byref(n))
         capi.check(lib, st, "RasterizeGaussiansCUDA")
         rendered = n.value
+        if workspace is not None:
+            geomBuffer, binningBuffer, imgBuffer = workspace.bufs
     return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer
 
 

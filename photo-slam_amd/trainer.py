@@ -208,6 +208,11 @@ class TrainStep:
     def __init__(self, gaussians, opt, pipe, background, world_size=1, cameras_extent=None, densify=False,
                  densify_min_opacity=0.005, prune_big_point_after_iter=30000, seed=0, factored_exchange=True, fused_sh_adam=True,
                  lazy_sh_adam_window=32, fused_geom_adam=True, cull_empty_tiles=False):
+        # the rasterizer's scratch buffers, kept across iterations and grown with headroom (rasterize_points.RasterWorkspace);
+        # persistent_workspace_ = False: fresh buffers per call, as the reference's resizeFunctional
+        from . import rasterize_points as rp
+        self.persistent_workspace_ = True
+        self.workspace_ = rp.RasterWorkspace()
         self.cull_empty_tiles_ = bool(cull_empty_tiles)   # option of this object; GSR_CULL_EMPTY_TILES only overrides (gaussian_renderer.py)
         self.gaussians_, self.opt_, self.pipe_, self.background_ = gaussians, opt, pipe, background
         self.cameras_extent_ = cameras_extent if cameras_extent is not None else gaussians.spatial_lr_scale_
@@ -299,7 +304,7 @@ class TrainStep:
                 viewpoint_cam, viewpoint_cam.image_height_, viewpoint_cam.image_width_, g, self.pipe_, self.background_,
                 sh_grad_view=sh_view, sh_adam=fwd_adam, view_stats=view_stats, geom_adam=geom_adam,
                 training_outputs_only=True,   # the statistics are fused (or over): nobody reads the viewspace gradient
-                cull_empty_tiles=self.cull_empty_tiles_)
+                cull_empty_tiles=self.cull_empty_tiles_, workspace=self.workspace_ if self.persistent_workspace_ else None)
         finally:
             g._in_lazy_step = False
         # :692-698  masked L1 + lambda * (1 - SSIM), fused with its gradient (csrc/train_ops.hip)

@@ -573,3 +573,65 @@ def test_morton_reindex_is_a_permutation_of_the_reference_order(emu):
         outs.append((rows(ops.trainer_params(h), ops.trainer_moments(h), ops.trainer_exist_since_iter(h)), ops.trainer_params(h)[0].detach().clone(), info))
         ops.trainer_destroy(h)
     assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][0], outs[1][0]) and step(outs[1][1]) < 0.4 * step(outs[0][1])
+
+
+def test_persistent_workspace_changes_no_result_and_is_reused(emu):
+    """TrainStep keeps the rasterizer's three scratch buffers across iterations (RasterWorkspace: grown with 50 % headroom, never
+    shrunk) instead of allocating them per call as the reference's resizeFunctional does (src/rasterize_points.cu:28-34,71-76):
+    the same parameters bit for bit, the same buffers from iteration to iteration, both hosts; views of different sizes share them."""
+    import math
+    cl, _, kfs = _setup(P=400, n_views=2)
+    torch.manual_seed(1)
+    gt = torch.rand(3, 32, 48)
+
+    def py_run(persistent):
+        g = GaussianModel.from_cloud(cl, device="cpu")
+        g.trainingSetup(GaussianOptimizationParams())
+        ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+        ts.persistent_workspace_ = persistent
+        ptrs = []
+        for i in range(4):
+            ts.trainForOneIteration(kfs[i % 2], gt, torch.ones(3, 32, 48))
+            ptrs.append([None if b is None else (b.data_ptr(), b.numel()) for b in ts.workspace_.bufs])
+        return [p.detach().clone() for p in g.params()], ptrs
+    (p1, ptr1), (p0, ptr0) = py_run(True), py_run(False)
+    for a, b in zip(p1, p0):
+        assert torch.equal(a, b)
+    assert ptr0[-1] == [None, None, None]
+    assert all(x is not None for x in ptr1[0])
+    # the geometry and image buffers never move (same P, same H x W); the binning buffer moves only when it has to grow
+    assert [p[0] for p in ptr1] == [ptr1[0][0]] * 4 and [p[2] for p in ptr1] == [ptr1[0][2]] * 4
+    assert all(b[1][1] >= a[1][1] for a, b in zip(ptr1, ptr1[1:])) and len({p[1] for p in ptr1}) <= 2
+    # a larger view grows the buffers once, a smaller one fits them
+    g = GaussianModel.from_cloud(cl, device="cpu")
+    g.trainingSetup(GaussianOptimizationParams())
+    ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+    big = GaussianKeyframe.from_camera(scene.make_cloud(400, 96, 64, 40.0, 40.0, seed=3, scale_k=0.35).cameras[0], "cpu")
+    ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+    small_img = ts.workspace_.bufs[2].numel()
+    ts.trainForOneIteration(big, torch.rand(3, 64, 96), torch.ones(3, 64, 96))
+    grown = [b.numel() for b in ts.workspace_.bufs]
+    assert grown[2] > small_img
+    ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+    assert [b.numel() for b in ts.workspace_.bufs] == grown
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_cpp_host import load_host
+    ops = load_host("emu")
+    outs = []
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for persistent in (1.0, 0.0):
+        g0 = GaussianModel.from_cloud(cl, device="cpu")
+        h = ops.trainer_create(g0.xyz_.detach(), g0.features_.detach(), g0.opacity_.detach(), g0.scaling_.detach(), g0.rotation_.detach(), 3,
+                               float(cl.extent), torch.zeros(3))
+        ops.trainer_set_options(h, {"persistent_workspace": persistent})
+        for i in range(4):
+            cam = cl.cameras[i % 2]
+            ops.trainer_train_one_iteration(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), 2 * math.atan(cam.tanfovx),
+                                            2 * math.atan(cam.tanfovy), cam.H, cam.W, gt, torch.ones(3, 32, 48))
+        outs.append([p.detach().clone() for p in ops.trainer_params(h)])
+        ops.trainer_destroy(h)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], p1):   # ... and the two hosts agree as they do without it
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)

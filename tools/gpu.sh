@@ -202,7 +202,7 @@ import json; d=json.load(open('$f')); print('$cfg dp 1 rank ${arg:-factored}', d
             grep '^{"metric"' $OUT/share_${n}_$form.log > $f
             python -c "
 import json; d=json.load(open('$f')); print('C2 $n ranks one GPU gloo', d['n_gpus'], d['ms_per_step'], d['rccl'], 'replicas_identical', d.get('replicas_identical'), d.get('exposed_communication'), 'per_rank', len(d.get('per_rank') or []))" || tail -20 $OUT/share_err.log ;;
-    mapper) timeout 900 python bench.py --mapper-loop $( [ "$arg" = morton ] && echo --morton-reindex ) > $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json 2>$OUT/mapper_err.log; cut -c1-700 $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json; tail -3 $OUT/mapper_err.log ;;   # mapper | mapper:morton
+    mapper) timeout 900 python bench.py --mapper-loop $( [ "$arg" = morton ] && echo --morton-reindex ) $( [ "$arg" = percall ] && echo --no-persistent-workspace ) > $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json 2>$OUT/mapper_err.log; cut -c1-700 $OUT/mapper_loop_C5$( [ -n "$arg" ] && echo _$arg ).json; tail -3 $OUT/mapper_err.log ;;   # mapper | mapper:morton | mapper:percall (the rasterizer's scratch buffers allocated per call, as the reference)
     densify) # the stated-config leg alone (250 steps, densify every 100, training learning rates): the reference's row order, then morton_reindex
             timeout 600 python bench.py --steps 5 --warmup 2 --median-steps 0 --no-cpu-baseline --no-knn-leg --dropin-steps 0 --no-config-legs --no-sq-probe > $OUT/densify_run_C3.json 2>>$OUT/bench_err.log
             python -c "
