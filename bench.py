@@ -726,20 +726,20 @@ def main():
     def timed(steps, read_dominant=False):
         """EXACTLY `steps` steps between barrier + synchronize; max over ranks.  Returns (seconds, dominant-kernel ms list)."""
         dom = []
-        import gc
-        gc.collect()
-        gc.disable()     # (a generation-2 collection of the interpreter inside a 20-step window is a 2 ms step: 7 % of the window)
         barrier()
         t0 = time.perf_counter()
+        stamps = []
         for _ in range(steps):
             one_step()
             if read_dominant:
                 v = capi.profile_read(lib)["blend_bwd"]      # waits only for events already recorded this step
                 if v >= 0:
                     dom.append(v)
+            stamps.append(time.perf_counter())
         barrier()
         el = time.perf_counter() - t0
-        gc.enable()
+        if os.environ.get("GSR_BENCH_STAMPS"):
+            print("STAMPS", [round((b - a) * 1e3, 3) for a, b in zip([t0] + stamps, stamps + [t0 + el])], file=sys.stderr)
         if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -784,6 +784,12 @@ def main():
     # untimed, so that the timed region does a steady state's work per step
     lazy_dp = dp and factored and ops is not None
     priming = max(0, (args.sh_adam_window if (not (dp or args.raster_only) or lazy_dp) else 0) - args.warmup)
+    # (the interpreter's garbage collector stays out of the window: a generation-2 collection inside 20 steps is a 2 ms step.  It runs
+    # HERE, in front of the warm-up steps -- a collection right in front of the window idles the device for tens of ms, and the first
+    # dozen steps behind such a pause run 5-10 % slow: measured with GSR_BENCH_STAMPS=1, profiles/r06_y)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(priming + args.warmup):
         one_step()
     # Timed region: HIP events only around the backward blend, the dominant kernel (gsr_profile_enable(2)): every event
@@ -791,6 +797,7 @@ def main():
     capi.profile_enable(lib, 2)
     capi.host_wait_stats(lib)                       # (reset)
     elapsed, dom_ms = timed(args.steps, read_dominant=True)
+    gc.enable()
     # how long the host was blocked in the forward pass's one synchronisation: a host that runs ahead of the device waits there
     # for most of a step; near zero = the device waits for the host (include/gsr.h: gsr_host_wait_stats)
     host_wait_us, host_waits = capi.host_wait_stats(lib)
