@@ -600,6 +600,34 @@ class GaussianModel:
         self.denom_.copy_(old_stats[1][keep])
         self.max_radii2D_.copy_(old_stats[2][keep])
 
+    def reorderAlongZCurve(self):
+        """The whole model -- parameters, Adam moments, statistics, exist_since_iter_ -- laid out along a Z-order curve of the positions
+        (what morton_reindex_ does inside densifyAndPrune, on request: a map that no longer densifies keeps growing at its end through
+        increasePcd).  The same Gaussians with the same values; returns perm with new row r = old row perm[r].  The permutation is
+        read off the gather itself: exist_since_iter_ travels through it as the row number."""
+        P = self.xyz_.shape[0]
+        dev = self.xyz_.device
+        if P == 0:
+            return torch.empty(0, dtype=torch.long, device=dev)
+        old_stats = (self.xyz_gradient_accum_, self.denom_, self.max_radii2D_)
+        old_exist = self.exist_since_iter_
+        self.exist_since_iter_ = torch.arange(P, dtype=torch.int32, device=dev)
+        none = torch.zeros(P, dtype=torch.uint8, device=dev)
+
+        def select(a):
+            a.prune_mask = none.data_ptr()
+            return none
+        self._compact(select, morton_reindex=True)
+        perm = self.exist_since_iter_.long()   # (a copy: exist_since_iter_ is a view into the arena)
+        self.xyz_gradient_accum_.copy_(old_stats[0][perm])
+        self.denom_.copy_(old_stats[1][perm])
+        self.max_radii2D_.copy_(old_stats[2][perm])
+        if old_exist is not None:
+            self.exist_since_iter_.copy_(old_exist[perm])
+        else:
+            self.exist_since_iter_ = None
+        return perm
+
     def densifyAndPrune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
         """:795-815 (densifyAndClone :763-793, densifyAndSplit :716-761 with N = 2, prunePoints :588-642) in one rebuild."""
         P = self.xyz_.shape[0]

@@ -84,6 +84,8 @@ public:
 	void resetOpacity();
 	bool intended_opacity_reset_ = false;   // see resetOpacity(): false = the reference as shipped
 	void prunePoints(torch::Tensor& mask);
+	// the whole model laid out along a Z-order curve of the positions (gaussian_model_densify.cpp); returns the permutation
+	torch::Tensor reorderAlongZCurve();
 	struct DensifyResult {
 		int64_t cloned = 0, split = 0, pruned = 0, points = 0;
 	};

@@ -410,6 +410,32 @@ void GaussianModel::prunePoints(torch::Tensor& mask)
 	max_radii2D_.copy_(old_max.index({keep}));
 }
 
+// The whole model -- parameters, Adam moments, statistics, exist_since_iter_ -- laid out along a Z-order curve of the positions (what
+// morton_reindex_ does inside densifyAndPrune, on request: a map that no longer densifies keeps growing at its end through
+// increasePcd).  The same Gaussians with the same values; returns perm with new row r = old row perm[r].  The permutation is read
+// off the gather itself: exist_since_iter_ travels through it as the row number.
+torch::Tensor GaussianModel::reorderAlongZCurve()
+{
+	torch::NoGradGuard ng;
+	const int64_t P = xyz_.size(0);
+	const auto iopt = xyz_.options().dtype(torch::kInt32).requires_grad(false);
+	if (P == 0) return torch::empty({0}, iopt.dtype(torch::kInt64));
+	auto old_accum = xyz_gradient_accum_, old_denom = denom_, old_max = max_radii2D_, old_exist = exist_since_iter_;
+	const bool had_exist = old_exist.defined() && old_exist.numel() == P;
+	exist_since_iter_ = torch::arange(P, iopt);
+	auto none = torch::zeros({P}, iopt.dtype(torch::kUInt8));
+	gsr_densify_select_args sel{};
+	sel.prune_mask = none.data_ptr<uint8_t>();
+	compact(sel, c10::nullopt, /*morton_reindex=*/true);
+	auto perm = exist_since_iter_.to(torch::kInt64);   // (a copy: exist_since_iter_ is a view into the arena)
+	xyz_gradient_accum_.copy_(old_accum.index({perm}));
+	denom_.copy_(old_denom.index({perm}));
+	max_radii2D_.copy_(old_max.index({perm}));
+	if (had_exist) exist_since_iter_.copy_(old_exist.index({perm}));
+	else exist_since_iter_ = torch::Tensor();
+	return perm;
+}
+
 // src/gaussian_model.cpp:795-815 with densifyAndClone (:763-793), densifyAndSplit (:716-761, N = 2) and the final
 // prunePoints (:805-813) folded into one rebuild.
 GaussianModel::DensifyResult GaussianModel::densifyAndPrune(float max_grad, float min_opacity, float extent,

@@ -204,6 +204,7 @@ std::vector<int64_t> trainer_densify_and_prune(int64_t h, double max_grad, doubl
 	                            make_generator(g->xyz_.device(), seed));
 	return {r.cloned, r.split, r.pruned, r.points};
 }
+torch::Tensor trainer_reorder_along_z_curve(int64_t h) { return get(h)->gaussians_->reorderAlongZCurve(); }
 std::vector<int64_t> trainer_last_densify(int64_t h)
 {
 	auto r = get(h)->last_densify_;
@@ -420,6 +421,7 @@ TORCH_LIBRARY(photoslam_amd, m)
 	m.def("trainer_create_from_pcd", &trainer_create_from_pcd);
 	m.def("trainer_set_options", &trainer_set_options);
 	m.def("trainer_densify_and_prune", &trainer_densify_and_prune);
+	m.def("trainer_reorder_along_z_curve", &trainer_reorder_along_z_curve);
 	m.def("trainer_last_densify", &trainer_last_densify);
 	m.def("trainer_save_ply", &trainer_save_ply);
 	m.def("trainer_create_from_ply", &trainer_create_from_ply);

@@ -635,3 +635,65 @@ def test_persistent_workspace_changes_no_result_and_is_reused(emu):
         assert torch.equal(a, b)
     for a, b in zip(outs[0], p1):   # ... and the two hosts agree as they do without it
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_reorder_along_z_curve_permutes_the_whole_model(emu):
+    """GaussianModel::reorderAlongZCurve (both hosts): parameters, both Adam moments, the three statistics arrays and
+    exist_since_iter_ are the old rows at perm -- bit for bit --, neighbouring rows are neighbours in space, training continues,
+    and the image of a view is the same up to the order of equal depths."""
+    import math
+    cl, _, kfs = _setup(P=1500)
+    torch.manual_seed(0)
+    gt = torch.rand(3, 32, 48)
+    g = GaussianModel.from_cloud(cl, device="cpu")
+    g.trainingSetup(GaussianOptimizationParams())
+    ts = TrainStep(g, GaussianOptimizationParams(), GaussianPipelineParams(), torch.zeros(3))
+    for _ in range(3):
+        ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48))
+    g.exist_since_iter_ = torch.arange(1500, dtype=torch.int32) * 3 + 1
+    before = dict(params=[p.detach().clone() for p in g.params()], mom=[[t.clone() for t in g.optimizer_.moments(p)] for p in g.params()],
+                  stats=[g.xyz_gradient_accum_.clone(), g.denom_.clone(), g.max_radii2D_.clone()], exist=g.exist_since_iter_.clone())
+    img0 = GaussianRenderer.render(kfs[0], 32, 48, g, GaussianPipelineParams(), torch.zeros(3))[0].detach().clone()
+    perm = g.reorderAlongZCurve()
+    assert perm.dtype == torch.long and torch.equal(torch.sort(perm).values, torch.arange(1500))
+    for p, old in zip(g.params(), before["params"]):
+        assert torch.equal(p.detach(), old[perm])
+    for p, (m0, v0) in zip(g.params(), before["mom"]):
+        m, v = g.optimizer_.moments(p)
+        assert torch.equal(m, m0[perm]) and torch.equal(v, v0[perm])
+    for a, b in zip((g.xyz_gradient_accum_, g.denom_, g.max_radii2D_), before["stats"]):
+        assert torch.equal(a, b[perm])
+    assert torch.equal(g.exist_since_iter_, before["exist"][perm]) and g.denom_.abs().sum() > 0
+    step = lambda x: float((x[1:] - x[:-1]).norm(dim=1).mean())
+    assert step(g.xyz_.detach()) < 0.4 * step(before["params"][0])
+    img1 = GaussianRenderer.render(kfs[0], 32, 48, g, GaussianPipelineParams(), torch.zeros(3))[0].detach()
+    assert (img1 - img0).abs().max() < 1e-5
+    assert torch.isfinite(ts.trainForOneIteration(kfs[0], gt, torch.ones(3, 32, 48)))
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_cpp_host import load_host
+    ops = load_host("emu")
+    g0 = GaussianModel.from_cloud(cl, device="cpu")
+    h = ops.trainer_create(g0.xyz_.detach(), g0.features_.detach(), g0.opacity_.detach(), g0.scaling_.detach(), g0.rotation_.detach(), 3,
+                           float(cl.extent), torch.zeros(3))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cam = cl.cameras[0]
+    for _ in range(3):
+        ops.trainer_train_one_iteration(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), 2 * math.atan(cam.tanfovx),
+                                        2 * math.atan(cam.tanfovy), cam.H, cam.W, gt, torch.ones(3, 32, 48))
+    ops.trainer_set_exist_since_iter(h, torch.arange(1500, dtype=torch.int32) * 3 + 1)
+    p0 = [p.detach().clone() for p in ops.trainer_params(h)]
+    m0 = [m.clone() for m in ops.trainer_moments(h)]
+    s0 = [s.clone() for s in ops.trainer_stats(h)]
+    perm_c = ops.trainer_reorder_along_z_curve(h)
+    assert torch.equal(perm_c, perm)   # (the same positions after the same three iterations would be too strict: the hosts agree to 1e-5)  # noqa
+    for a, b in zip(ops.trainer_params(h), p0):
+        assert torch.equal(a.detach(), b[perm_c])
+    for a, b in zip(ops.trainer_moments(h), m0):
+        assert torch.equal(a, b[perm_c])
+    for a, b in zip(ops.trainer_stats(h), s0):
+        assert torch.equal(a, b[perm_c])
+    assert torch.equal(ops.trainer_exist_since_iter(h), (torch.arange(1500, dtype=torch.int32) * 3 + 1)[perm_c])
+    ops.trainer_train_one_iteration(h, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos), 2 * math.atan(cam.tanfovx),
+                                    2 * math.atan(cam.tanfovy), cam.H, cam.W, gt, torch.ones(3, 32, 48))
+    ops.trainer_destroy(h)
