@@ -46,6 +46,8 @@ def load(lib_path=None):
         return _libs[path]
     L = C.CDLL(path)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.gsr_stage_tile_depth_sort.restype = i32
+    L.gsr_stage_tile_depth_sort.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.gsr_view_geometry.restype = i32
     L.gsr_view_geometry.argtypes = [vp, i32, C.POINTER(GeometryView)]
     L.gsr_view_binning.restype = i32

@@ -68,4 +68,11 @@ int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_i
 	return launch_radix_sort(keys_in, values_in, kp, vp, kq, vq, n, begin_bit, end_bit, sc, stream, &kres, &vres);
 }
 
+int gsr_stage_tile_depth_sort(const uint32_t* ranges, int tiles, const uint32_t* depth_key, uint32_t* point_list, uint32_t* spare_keys,
+                              uint32_t* spare_values, uint32_t* spare_words, void* stream)
+{
+	return launch_tile_depth_sort(reinterpret_cast<const uint2*>(ranges), tiles, depth_key, point_list, spare_keys, spare_values, spare_words,
+	                              (hipStream_t)stream);
+}
+
 }  // extern "C"

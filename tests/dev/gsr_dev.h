@@ -56,6 +56,12 @@ size_t gsr_sort_scratch_bytes(int n);
 int gsr_stage_radix_sort_pairs(const uint32_t* keys_in, const uint32_t* values_in, uint32_t* keys_out, uint32_t* values_out,
                                int n, int begin_bit, int end_bit, char* scratch, void* stream);
 
+/* The per-tile depth sort of the tile-first binning arrangement (csrc/tile_depth_sort.hip): list t = point_list[ranges[t].x ..
+ * ranges[t].y) is sorted in place by depth_key[id], stable (equal keys keep their order).  spare_keys / spare_values /
+ * spare_words: three arrays of as many words as point_list (scratch of the lists beyond 2 048 entries). */
+int gsr_stage_tile_depth_sort(const uint32_t* ranges /* [tiles][2] */, int tiles, const uint32_t* depth_key, uint32_t* point_list,
+                              uint32_t* spare_keys, uint32_t* spare_values, uint32_t* spare_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

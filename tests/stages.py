@@ -45,6 +45,21 @@ def radix_sort_pairs(lib_path, dev, keys, values, begin_bit, end_bit):
     return k_out.cpu().numpy().view(np.uint32), v_out.cpu().numpy().view(np.uint32)
 
 
+def tile_depth_sort(lib_path, dev, lengths, depth_key, point_list):
+    """the per-tile depth sort (tile_depth_sort.hip) on lists of the given lengths laid end to end in point_list"""
+    lib = devapi.load(lib_path)
+    ends = np.cumsum(np.asarray(lengths, np.int64))
+    ranges = np.stack([ends - np.asarray(lengths, np.int64), ends], 1).astype(np.uint32)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.uint32).view(np.int32)).to(dev)
+    r, k, pl = to(ranges), to(depth_key), to(point_list)
+    n = int(point_list.shape[0])
+    spare = [torch.full((n + 64,), -1, dtype=torch.int32, device=dev) for _ in range(3)]
+    st = lib.gsr_stage_tile_depth_sort(r.data_ptr(), int(len(lengths)), k.data_ptr(), pl.data_ptr(), spare[0].data_ptr(), spare[1].data_ptr(),
+                                       spare[2].data_ptr(), _stream(dev))
+    capi.check(capi.load(lib_path), st, "gsr_stage_tile_depth_sort")
+    return pl.cpu().numpy().view(np.uint32)
+
+
 def reference_sort(keys, values, begin_bit, end_bit):
     """what a stable sort on the bit field [begin_bit, end_bit) must produce"""
     mask = np.uint64((1 << (end_bit - begin_bit)) - 1)

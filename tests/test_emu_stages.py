@@ -317,3 +317,34 @@ def test_backward_extension_errors(emu_lib_path):
             rp.shGradFromViews(torch.zeros(120, 3), views[:, 120, :], torch.zeros(2, 120, 6)[:, :, ::2], 3, 16, 0.5)
         finally:
             rp._LIB_OVERRIDE = None
+
+
+def tile_depth_sort_case(lib_path, dev, seed=0, big=10_000):
+    """csrc/tile_depth_sort.hip at the sizes where its paths change: lists of 0, 1, 2, 63 ... 65, 2 047 ... 2 049 (registers + LDS up to
+    2 048 entries, chunks of 2 048 beyond), 4 095 ... 4 097 and one long list; keys that are all equal, two-valued, differ only in the
+    high or only in the low bits, already sorted, reversed, and random -- against a stable argsort of every list."""
+    rng = np.random.default_rng(seed)
+    lengths = [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, big, 0, 3]
+    P = 50_000
+    kinds = ("random", "equal", "two", "high", "low", "sorted", "reversed")
+    for kind in kinds:
+        key = {"random": lambda: rng.integers(0, 2**32, P, dtype=np.uint64),
+               "equal": lambda: np.full(P, 0x3F800000, np.uint64),
+               "two": lambda: np.where(rng.random(P) < 0.5, 0x40000000, 0x3F000000).astype(np.uint64),
+               "high": lambda: rng.integers(0, 256, P, dtype=np.uint64) << np.uint64(24),
+               "low": lambda: np.uint64(0x3F800000) + rng.integers(0, 300, P, dtype=np.uint64),
+               "sorted": lambda: np.arange(P, dtype=np.uint64) * np.uint64(7919),
+               "reversed": lambda: np.uint64(0xFFFFFFF0) - np.arange(P, dtype=np.uint64) * np.uint64(7919)}[kind]().astype(np.uint32)
+        # ids in ascending order inside a list, as the stable tile sort delivers them (any ids: the kernel only gathers their keys)
+        lists = [np.sort(rng.choice(P, n, replace=n > P)) for n in lengths]
+        pl = np.concatenate(lists).astype(np.uint32)
+        got = stages.tile_depth_sort(lib_path, dev, lengths, key, pl)
+        at = 0
+        for n, ids in zip(lengths, lists):
+            want = ids[np.argsort(key[ids], kind="stable")]
+            assert np.array_equal(got[at:at + n], want), (kind, n)
+            at += n
+
+
+def test_tile_depth_sort_at_its_path_boundaries(emu_lib_path):
+    tile_depth_sort_case(emu_lib_path, torch.device("cpu"), big=5000)

@@ -66,3 +66,8 @@ def test_mark_visible(oracle, dev):
     cam = cl.cameras[0]
     got = stages.mark_visible(None, dev, cl.xyz, cam.viewmatrix, cam.projmatrix)
     assert np.array_equal(got, oracle.mark_visible(cl.xyz, cam.viewmatrix, cam.projmatrix))
+
+
+def test_tile_depth_sort_at_its_path_boundaries(dev):
+    from test_emu_stages import tile_depth_sort_case
+    tile_depth_sort_case(None, dev, seed=1, big=300_000)
