@@ -1,8 +1,8 @@
 // rasterize_points.h -- LibTorch boundary of the MI355X rasterizer.  RasterizeGaussiansCUDA, RasterizeGaussiansBackwardCUDA and
 // markVisible are declared with EXACTLY the parameter lists of the reference's include/rasterize_points.h:18-65: the
 // same mangled symbols, so an object compiled against the reference header links against libphotoslam_host.so
-// (tests/test_reference_link.py does that).  The extensions of this repository are separate OVERLOADS with extra,
-// non-defaulted parameters.  On a ROCm build of LibTorch torch::kCUDA *is* the HIP device.
+// (tests/test_reference_link.py does that).  The extensions of this repository are separate OVERLOADS with extra
+// parameters (only the last one, the workspace of the longest overload, has a default).  On a ROCm build of LibTorch torch::kCUDA *is* the HIP device.
 // Implementation: src/rasterize_points.cpp on top of the C-ABI in include/gsr.h (libgsr_hip.so).
 #pragma once
 #include <torch/torch.h>
